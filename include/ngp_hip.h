@@ -1,0 +1,134 @@
+/*
+ * ngp_hip.h -- C ABI of libngp_hip.so: the MI355X (gfx950) Instant-NGP training hot path.
+ *
+ * This is the drop-in boundary under the Python surface of the reference's `modules/` package
+ * (taichi-dev/taichi-nerfs).  Every entry point replaces ONE Taichi kernel launch of the reference;
+ * the reference file:line each one stands in for is cited next to it.  The reference binds its kernels
+ * through Taichi's torch zero-copy interop (tensor -> raw device pointer); the binding a maintainer adds
+ * instead is the ctypes stub shown in INTEGRATION.md (it is what taichi-nerfs_amd/ngp_hip/lib.py does).
+ *
+ * Conventions
+ *   - plain C: raw DEVICE pointers + explicit sizes; no torch types; no allocation; no host sync
+ *     (the only exception is ngp_march_train_total, which is an explicit D2H read).
+ *   - every function returns 0 on success, or the negated hipError_t of the failing launch.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).
+ *   - all geometric data is f32, `rays_a` is i32, alive/ray indices are i64 -- as in the reference.
+ *   - arrays are dense row-major ("contiguous" in torch terms); the reference wrappers call
+ *     .contiguous() before every launch (hash_encoder.py:283, volume_train.py:188, rendering.py:34).
+ */
+#ifndef NGP_HIP_H
+#define NGP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NGP_MAX_LEVELS 16
+#define NGP_ABI_VERSION 1
+
+/* Multiresolution level table.  Built ONCE on the host (ngp_hash_levels_init) in the arithmetic of
+ * modules/hash_encoder.py:183-205 + modules/utils.py:19-42 (f64 sizes) and of the in-kernel
+ * grid_scale/grid_resolution (hash_encoder.py:73-80, f32) and handed to every hash kernel by value, so
+ * the CPU oracle and the HIP kernels index with the very same numbers. */
+typedef struct ngp_hash_levels {
+    int32_t  n_levels;                 /* L, <= NGP_MAX_LEVELS                                  */
+    int32_t  n_features;               /* F, features per entry (2)                             */
+    int32_t  begin_fast_hash_level;    /* first level that uses the xor-prime hash              */
+    int32_t  total_entries;            /* sum of map_size                                       */
+    float    scale[NGP_MAX_LEVELS];    /* base*exp(l*log_b)-1, f32                              */
+    uint32_t resolution[NGP_MAX_LEVELS]; /* ceil(scale)+1                                       */
+    uint32_t map_size[NGP_MAX_LEVELS]; /* entries in level l                                    */
+    uint32_t offset[NGP_MAX_LEVELS];   /* first entry of level l                                */
+} ngp_hash_levels;
+
+int ngp_abi_version(void);
+
+/* Host-only helper: fills `lv` like HashEncoder.__init__ (hash_encoder.py:183-205). Returns 0. */
+int ngp_hash_levels_init(ngp_hash_levels* lv, double max_params, int levels, double base_res,
+                         double max_res, int features);
+
+/* ---- a-1  ray_aabb_intersect (modules/intersection.py:8-37) ---------------------------------- */
+int ngp_ray_aabb(const float* rays_o, const float* rays_d, float scale, int n_rays,
+                 float* hits_t /*[n,2]*/, void* stream);
+
+/* ---- a-2  raymarching_train_kernel (modules/ray_march.py:8-123) ------------------------------
+ * The reference's single kernel (count pass, two global atomics per ray, write pass) is split into
+ * three deterministic launches:
+ *   count : one lane per ray walks the f32 orbit once, stores every emitted (t,dt) into the ray's
+ *           private staging row stage[r*max_samples + k] and its sample count into counts[r];
+ *   scan  : exclusive prefix sum over counts -> rays_a[r] = (r, start, count) IN RAY ORDER and
+ *           total[0] = number of samples (replaces counter[0]/counter[1] atomics, ray_march.py:76-81);
+ *   write : sample-parallel expansion of the staged (t,dt) into xyzs/dirs/deltas/ts.            */
+int ngp_march_train_count(const float* rays_o, const float* rays_d, const float* hits_t,
+                          const uint8_t* density_bitfield, const float* noise,
+                          int cascades, int grid_size, float scale, float exp_step_factor,
+                          int max_samples, int n_rays,
+                          float* stage /*[n*max_samples,2] (t,dt)*/, int32_t* counts /*[n]*/,
+                          void* stream);
+int ngp_march_train_scan(const int32_t* counts, int n_rays, int32_t* rays_a /*[n,3]*/,
+                         int32_t* total /*[1]*/, void* stream);
+int ngp_march_train_write(const float* rays_o, const float* rays_d, const int32_t* rays_a,
+                          const float* stage, int max_samples, int n_rays,
+                          float* xyzs, float* dirs, float* deltas, float* ts, void* stream);
+
+/* ---- a-3  raymarching_test_kernel (modules/ray_march.py:197-268) ----------------------------- */
+int ngp_march_test(const float* rays_o, const float* rays_d, float* hits_t /*in-out*/,
+                   const int64_t* alive_indices, const uint8_t* density_bitfield,
+                   int cascades, int grid_size, float scale, float exp_step_factor,
+                   int max_samples, int n_alive,
+                   int64_t* ray_indices, uint8_t* valid_mask, float* deltas, float* ts,
+                   int32_t* samples_counter, void* stream);
+
+/* ---- a-4  hash_encoder_kernel fp32 + its autodiff backward (modules/hash_encoder.py:89-143,269) */
+int ngp_hash_fwd_f32(const float* xyzs /*[n,3] in [0,1]*/, const float* table,
+                     const ngp_hash_levels* lv, int n, float* out /*[n, L*F]*/, void* stream);
+/* dtable must be zero-filled by the caller (or hold a gradient to accumulate into). */
+int ngp_hash_bwd_f32(const float* xyzs, const float* dout /*[n, L*F]*/,
+                     const ngp_hash_levels* lv, int n, float* dtable, void* stream);
+
+/* ---- a-5  half2 encoder fwd / explicit bwd (modules/hash_encoder_half.py:112-161,164-213) ----
+ * table/out/dout/dtable are IEEE binary16 pairs (uint16_t storage). */
+int ngp_hash_fwd_f16(const float* xyzs, const uint16_t* table, const ngp_hash_levels* lv, int n,
+                     uint16_t* out /*[n, L, 2]*/, void* stream);
+int ngp_hash_bwd_f16(const float* xyzs, const uint16_t* dout, const ngp_hash_levels* lv, int n,
+                     uint16_t* dtable /*[entries,2] f16*/, void* stream);
+
+/* ---- a-6  dir_encoder (modules/spherical_harmonics.py:7-42) + analytic backward -------------- */
+int ngp_sh16_fwd(const float* dirs /*[n,3]*/, int n, float* out /*[n,16]*/, void* stream);
+int ngp_sh16_bwd(const float* dirs, const float* dout /*[n,16]*/, int n, float* ddirs /*[n,3]*/,
+                 void* stream);
+
+/* ---- a-7  volume_rendering_kernel + closed-form backward (modules/volume_train.py:6-48,160) ---
+ * rgbs_is_half selects fp16 (autocast) or fp32 `rgbs`; the gradient is written in the same dtype.
+ * Outputs are indexed by ray_idx = rays_a[n,0] like the reference. dL_dopacity / dL_ddepth / dL_dws may
+ * be NULL (== zeros); opacity/depth/rgb/ws are the forward outputs. */
+int ngp_composite_train_fwd(const float* sigmas, const void* rgbs, int rgbs_is_half,
+                            const float* deltas, const float* ts, const int32_t* rays_a,
+                            float T_threshold, int n_rays,
+                            int32_t* total_samples /*[n]*/, float* opacity, float* depth,
+                            float* rgb /*[n,3]*/, float* ws /*[S]*/, void* stream);
+int ngp_composite_train_bwd(const float* dL_dopacity, const float* dL_ddepth, const float* dL_drgb,
+                            const float* dL_dws, const float* sigmas, const void* rgbs,
+                            int rgbs_is_half, const float* deltas, const float* ts,
+                            const int32_t* rays_a, const float* opacity, const float* depth,
+                            const float* rgb, const float* ws, float T_threshold, int n_rays,
+                            float* dL_dsigmas, void* dL_drgbs, void* stream);
+
+/* ---- a-8  composite_test (modules/volume_render_test.py:4-54) -------------------------------- */
+int ngp_composite_test(const float* sigmas, const void* rgbs, int rgbs_is_half, const float* deltas,
+                       const float* ts, const int64_t* pack_info /*[n,2]*/,
+                       int64_t* alive_indices /*in-out*/, float T_threshold, int n_alive,
+                       float* opacity, float* depth, float* rgb, void* stream);
+
+/* ---- a-10 morton3D / morton3D_invert / packbits (modules/utils.py:120-169) -------------------- */
+int ngp_morton3d(const int32_t* coords /*[m,3]*/, int m, int32_t* indices, void* stream);
+int ngp_morton3d_invert(const int32_t* indices, int m, int32_t* coords /*[m,3]*/, void* stream);
+int ngp_packbits(const float* density_grid /*[8k]*/, float threshold, int n_bytes,
+                 uint8_t* bitfield, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NGP_HIP_H */

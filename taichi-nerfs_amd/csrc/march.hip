@@ -1,0 +1,331 @@
+// march.hip -- ray-AABB intersection and occupancy-grid ray marching for gfx950.
+//
+// Replaces modules/intersection.py:8-37 and modules/ray_march.py:8-123,197-268 of the reference.
+//
+// Design (not a translation of the Taichi launch shape):
+//   The reference marches every ray twice in one kernel and packs samples with two global atomics per ray.
+//   Here the orbit t_{k+1} = t_k + calc_dt(t_k) is recognised as independent of occupancy (occupied cells and
+//   the skip loop both advance by calc_dt), so the count kernel evaluates ORBIT_BATCH consecutive orbit points
+//   speculatively -- 8 independent bitfield loads in flight per lane instead of one dependent load per step --
+//   and then resolves the reference's "examined / skipped" logic over the batch in order.  Emitted (t, dt)
+//   pairs go to a per-ray staging row; a deterministic prefix sum replaces the atomics (rays_a in ray order);
+//   the expansion into xyzs/dirs/deltas/ts is a coalesced wave-per-ray kernel.  Samples are bit-identical to
+//   the reference's serial march (checked against the oracle).
+#include "ngp_device.h"
+
+namespace ngp {
+
+struct MarchParams {
+    int cascades, grid_size;
+    uint32_t grid_size3;
+    float grid_size_f, grid_size_inv, grid_max;   // G, 1/G, G-1
+    float scale, esf, dt_min, dt_max;
+};
+
+__host__ inline MarchParams make_march_params(int cascades, int grid_size, float scale, float esf) {
+    MarchParams p;
+    p.cascades = cascades;
+    p.grid_size = grid_size;
+    p.grid_size3 = (uint32_t)grid_size * (uint32_t)grid_size * (uint32_t)grid_size;
+    p.grid_size_f = (float)grid_size;
+    p.grid_size_inv = 1.0f / (float)grid_size;
+    p.grid_max = (float)grid_size - 1.0f;
+    p.scale = scale;
+    p.esf = esf;
+    p.dt_min = (float)(1.7320508075688772 / 1024);                       // utils.py:15
+    p.dt_max = (float)(1.7320508075688772 * 2) * scale / (float)grid_size;  // utils.py:16,56-57
+    return p;
+}
+
+struct CellProbe {
+    float xyz[3];
+    float nxyz[3];
+    float mip_bound;
+    uint32_t idx;
+};
+
+// ray_march.py:46-60 for one orbit point
+__device__ __forceinline__ void probe_cell(const MarchParams& p, const float o[3], const float d[3], float t, float dt,
+                                           CellProbe& c) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) c.xyz[k] = o[k] + t * d[k];
+    float mx = fmaxf(fmaxf(fabsf(c.xyz[0]), fabsf(c.xyz[1])), fabsf(c.xyz[2]));
+    int mip_pos = min(p.cascades - 1, max(0, frexp_bit(mx) + 1));                  // utils.py:78-84
+    int mip_dt = min(p.cascades - 1, max(0, frexp_bit(dt * p.grid_size_f)));       // utils.py:87-92
+    int mip = max(mip_pos, mip_dt);
+    c.mip_bound = fminf(ldexpf(1.0f, mip - 1), p.scale);
+    float mip_bound_inv = 1.0f / c.mip_bound;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float v = 0.5f * (c.xyz[k] * mip_bound_inv + 1.0f) * p.grid_size_f;
+        c.nxyz[k] = fminf(p.grid_max, fmaxf(0.0f, v));
+    }
+    c.idx = (uint32_t)mip * p.grid_size3 + morton3d(f2u_sat(c.nxyz[0]), f2u_sat(c.nxyz[1]), f2u_sat(c.nxyz[2]));
+}
+
+// ray_march.py:68-71: t_target of the skip taken from an empty cell
+__device__ __forceinline__ float skip_target(const MarchParams& p, const float d[3], const float d_inv[3], float t,
+                                             const CellProbe& c) {
+    float tmin = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float v = (((c.nxyz[k] + 0.5f + 0.5f * fsign(d[k])) * p.grid_size_inv * 2.0f - 1.0f) * c.mip_bound - c.xyz[k]) * d_inv[k];
+        tmin = k ? fminf(tmin, v) : v;
+    }
+    return t + fmaxf(0.0f, tmin);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// a-1  ray-AABB slab test, one lane per ray (intersection.py:22-37)
+// ------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) ray_aabb_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                        float scale, int n, float2* __restrict__ hits_t) {
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const float half_size = (scale - (-scale)) / 2.0f;
+    float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float o = rays_o[3 * r + k], d = rays_d[3 * r + k];
+        float inv_d = 1.0f / d;
+        float t_min = (0.0f - half_size - o) * inv_d;
+        float t_max = (0.0f + half_size - o) * inv_d;
+        float a = fminf(t_min, t_max), b = fmaxf(t_min, t_max);
+        t1 = k ? fmaxf(t1, a) : a;
+        t2 = k ? fminf(t2, b) : b;
+    }
+    hits_t[r] = (t2 > 0.0f) ? make_float2(fmaxf(t1, 0.01f), t2) : make_float2(-1.0f, -1.0f);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// a-2  training march, count + stage.  One lane per ray; ORBIT_BATCH orbit points per trip.
+// ------------------------------------------------------------------------------------------------------
+constexpr int ORBIT_BATCH = 8;
+
+__global__ void __launch_bounds__(64) march_count_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                         const float2* __restrict__ hits_t,
+                                                         const uint8_t* __restrict__ bits, const float* __restrict__ noise,
+                                                         MarchParams p, int max_samples, int n_rays,
+                                                         float2* __restrict__ stage, int32_t* __restrict__ counts) {
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rays) return;
+    float o[3], d[3], d_inv[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { o[k] = rays_o[3 * r + k]; d[k] = rays_d[3 * r + k]; d_inv[k] = 1.0f / d[k]; }
+    float2 h = hits_t[r];
+    float t1 = h.x;
+    const float t2 = h.y;
+    if (t1 >= 0.0f) t1 += calc_dt(t1, p.esf, p.dt_min, p.dt_max) * noise[r];       // ray_march.py:39-41
+    float t = t1;
+    int n = 0;
+    float t_target = -INFINITY;                 // orbit points below this are skipped, not examined
+    float2* row = stage + (size_t)r * (size_t)max_samples;
+    bool live = (0.0f <= t) && (t < t2) && (n < max_samples);                       // ray_march.py:46
+    while (live) {
+        float tb[ORBIT_BATCH], dtb[ORBIT_BATCH];
+        uint8_t ob[ORBIT_BATCH];
+        uint32_t ib[ORBIT_BATCH];
+        float tt = t;
+#pragma unroll
+        for (int u = 0; u < ORBIT_BATCH; ++u) {                                    // speculative: loads independent
+            float dt = calc_dt(tt, p.esf, p.dt_min, p.dt_max);
+            CellProbe c;
+            probe_cell(p, o, d, tt, dt, c);
+            tb[u] = tt; dtb[u] = dt; ib[u] = c.idx;
+            ob[u] = bits[c.idx >> 3];
+            tt += dt;
+        }
+#pragma unroll
+        for (int u = 0; u < ORBIT_BATCH; ++u) {
+            if (!live) break;
+            float tu = tb[u];
+            if (!(tu < t2)) { live = false; break; }
+            if (tu < t_target) continue;                                           // inside a skip (ray_march.py:73-74)
+            if (ob[u] & (1u << (ib[u] & 7u))) {                                     // ray_march.py:61-65
+                row[n] = make_float2(tu, dtb[u]);
+                n += 1;
+                t_target = -INFINITY;
+                if (n >= max_samples) live = false;
+            } else {                                                               // ray_march.py:66-72
+                CellProbe c;
+                probe_cell(p, o, d, tu, dtb[u], c);
+                t_target = skip_target(p, d, d_inv, tu, c);
+            }
+        }
+        t = tt;
+    }
+    counts[r] = n;
+}
+
+// exclusive prefix sum over per-ray counts -> rays_a (ray order) + total.  One 1024-thread block, chunked.
+__global__ void __launch_bounds__(1024) march_scan_kernel(const int32_t* __restrict__ counts, int n_rays,
+                                                          int32_t* __restrict__ rays_a, int32_t* __restrict__ total) {
+    __shared__ int wave_tot[16];
+    __shared__ int carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < n_rays; base += 1024) {
+        int i = base + tid;
+        int c = (i < n_rays) ? counts[i] : 0;
+        int inc = wave_scan_add_i(c, lane);
+        if (lane == 63) wave_tot[wv] = inc;
+        __syncthreads();
+        int carry = carry_s;
+        int woff = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) woff += (w < wv) ? wave_tot[w] : 0;
+        int start = carry + woff + inc - c;
+        if (i < n_rays) { rays_a[3 * i] = i; rays_a[3 * i + 1] = start; rays_a[3 * i + 2] = c; }
+        __syncthreads();
+        if (tid == 1023) carry_s = start + c;
+        __syncthreads();
+    }
+    if (tid == 0) total[0] = carry_s;
+}
+
+// expansion: one wave per ray, lanes stride over the ray's staged samples (coalesced stores)
+__global__ void __launch_bounds__(256) march_write_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                          const int32_t* __restrict__ rays_a, const float2* __restrict__ stage,
+                                                          int max_samples, int n_rays, float* __restrict__ xyzs,
+                                                          float* __restrict__ dirs, float* __restrict__ deltas,
+                                                          float* __restrict__ ts) {
+    int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (r >= n_rays) return;
+    const int lane = lane_id();
+    const int start = rays_a[3 * r + 1], cnt = rays_a[3 * r + 2];
+    if (cnt == 0) return;
+    float o[3], d[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { o[k] = rays_o[3 * r + k]; d[k] = rays_d[3 * r + k]; }
+    const float2* row = stage + (size_t)r * (size_t)max_samples;
+    for (int k = lane; k < cnt; k += NGP_WAVE) {
+        float2 s = row[k];
+        size_t g = (size_t)start + k;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            xyzs[3 * g + a] = o[a] + s.x * d[a];                                   // ray_march.py:88
+            dirs[3 * g + a] = d[a];
+        }
+        ts[g] = s.x;
+        deltas[g] = s.y;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// a-3  test-time march (ray_march.py:216-268): <= max_samples per alive ray per call, resumes via hits_t.
+// Same speculative orbit batching; slot layout n*max_samples+s like the reference.
+// ------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) march_test_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                        float* __restrict__ hits_t, const int64_t* __restrict__ alive,
+                                                        const uint8_t* __restrict__ bits, MarchParams p, int max_samples,
+                                                        int n_alive, int64_t* __restrict__ ray_indices,
+                                                        uint8_t* __restrict__ valid_mask, float* __restrict__ deltas,
+                                                        float* __restrict__ ts, int32_t* __restrict__ samples_counter) {
+    int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= n_alive) return;
+    const int64_t r = alive[n];
+    float o[3], d[3], d_inv[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { o[k] = rays_o[3 * r + k]; d[k] = rays_d[3 * r + k]; d_inv[k] = 1.0f / d[k]; }
+    float t = hits_t[2 * r];
+    const float t2 = hits_t[2 * r + 1];
+    int s = 0;
+    const size_t base = (size_t)n * (size_t)max_samples;
+    float t_target = -INFINITY;
+    float t_resume = t;
+    bool wrote = false;
+    bool live = (0.0f < t) && (t < t2) && (s < max_samples);                        // :230 (strict 0 < t)
+    while (live) {
+        float tb[ORBIT_BATCH], dtb[ORBIT_BATCH];
+        uint8_t ob[ORBIT_BATCH];
+        uint32_t ib[ORBIT_BATCH];
+        float tt = t;
+#pragma unroll
+        for (int u = 0; u < ORBIT_BATCH; ++u) {
+            float dt = calc_dt(tt, p.esf, p.dt_min, p.dt_max);
+            CellProbe c;
+            probe_cell(p, o, d, tt, dt, c);
+            tb[u] = tt; dtb[u] = dt; ib[u] = c.idx;
+            ob[u] = bits[c.idx >> 3];
+            tt += dt;
+        }
+#pragma unroll
+        for (int u = 0; u < ORBIT_BATCH; ++u) {
+            if (!live) break;
+            float tu = tb[u];
+            if (!(tu < t2)) { live = false; break; }
+            if (tu < t_target) continue;
+            if (ob[u] & (1u << (ib[u] & 7u))) {                                     // :250-258
+                size_t i = base + s;
+                ray_indices[i] = r; valid_mask[i] = 1; ts[i] = tu; deltas[i] = dtb[u];
+                t_resume = tu + dtb[u]; wrote = true;
+                s += 1;
+                t_target = -INFINITY;
+                if (s >= max_samples) live = false;
+            } else {
+                CellProbe c;
+                probe_cell(p, o, d, tu, dtb[u], c);
+                t_target = skip_target(p, d, d_inv, tu, c);
+            }
+        }
+        t = tt;
+    }
+    if (wrote) hits_t[2 * r] = t_resume;                                            // :257
+    samples_counter[n] = s;                                                         // :268
+}
+
+}  // namespace ngp
+
+using namespace ngp;
+
+extern "C" {
+
+int ngp_ray_aabb(const float* rays_o, const float* rays_d, float scale, int n_rays, float* hits_t, void* stream) {
+    if (n_rays <= 0) return 0;
+    hipLaunchKernelGGL(ray_aabb_kernel, dim3((n_rays + 255) / 256), dim3(256), 0, (hipStream_t)stream, rays_o, rays_d, scale,
+                       n_rays, (float2*)hits_t);
+    NGP_LAUNCH_CHECK();
+    return 0;
+}
+
+int ngp_march_train_count(const float* rays_o, const float* rays_d, const float* hits_t, const uint8_t* density_bitfield,
+                          const float* noise, int cascades, int grid_size, float scale, float exp_step_factor,
+                          int max_samples, int n_rays, float* stage, int32_t* counts, void* stream) {
+    if (n_rays <= 0) return 0;
+    MarchParams p = make_march_params(cascades, grid_size, scale, exp_step_factor);
+    hipLaunchKernelGGL(march_count_kernel, dim3((n_rays + 63) / 64), dim3(64), 0, (hipStream_t)stream, rays_o, rays_d,
+                       (const float2*)hits_t, density_bitfield, noise, p, max_samples, n_rays, (float2*)stage, counts);
+    NGP_LAUNCH_CHECK();
+    return 0;
+}
+
+int ngp_march_train_scan(const int32_t* counts, int n_rays, int32_t* rays_a, int32_t* total, void* stream) {
+    hipLaunchKernelGGL(march_scan_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, counts, n_rays, rays_a, total);
+    NGP_LAUNCH_CHECK();
+    return 0;
+}
+
+int ngp_march_train_write(const float* rays_o, const float* rays_d, const int32_t* rays_a, const float* stage,
+                          int max_samples, int n_rays, float* xyzs, float* dirs, float* deltas, float* ts, void* stream) {
+    if (n_rays <= 0) return 0;
+    hipLaunchKernelGGL(march_write_kernel, dim3((n_rays + 3) / 4), dim3(256), 0, (hipStream_t)stream, rays_o, rays_d, rays_a,
+                       (const float2*)stage, max_samples, n_rays, xyzs, dirs, deltas, ts);
+    NGP_LAUNCH_CHECK();
+    return 0;
+}
+
+int ngp_march_test(const float* rays_o, const float* rays_d, float* hits_t, const int64_t* alive_indices,
+                   const uint8_t* density_bitfield, int cascades, int grid_size, float scale, float exp_step_factor,
+                   int max_samples, int n_alive, int64_t* ray_indices, uint8_t* valid_mask, float* deltas, float* ts,
+                   int32_t* samples_counter, void* stream) {
+    if (n_alive <= 0) return 0;
+    MarchParams p = make_march_params(cascades, grid_size, scale, exp_step_factor);
+    hipLaunchKernelGGL(march_test_kernel, dim3((n_alive + 63) / 64), dim3(64), 0, (hipStream_t)stream, rays_o, rays_d, hits_t,
+                       alive_indices, density_bitfield, p, max_samples, n_alive, ray_indices, valid_mask, deltas, ts,
+                       samples_counter);
+    NGP_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,111 @@
+// ngp_device.h -- device-side helpers shared by the gfx950 kernels of libngp_hip.so.
+//
+// Everything on the bit-exact paths (ray orbit, Morton / bitfield indexing, hash-grid corner indices and
+// trilinear weights) is written as separate IEEE binary32 multiplies and adds; the library is compiled with
+// -ffp-contract=off so the compiler never fuses them, and explicit fmaf() is used only where a kernel is
+// tolerance-checked instead of bit-checked.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/ngp_hip.h"
+
+#define NGP_WAVE 64
+
+#define NGP_LAUNCH_CHECK()                                   \
+    do {                                                     \
+        hipError_t e__ = hipGetLastError();                  \
+        if (e__ != hipSuccess) return -(int)e__;             \
+    } while (0)
+
+namespace ngp {
+
+__device__ __forceinline__ uint32_t f2u_bits(float x) { return __float_as_uint(x); }
+__device__ __forceinline__ float u2f_bits(uint32_t u) { return __uint_as_float(u); }
+
+// f32 -> u32 truncating, saturating cast (v_cvt_u32_f32 semantics; NaN/negative -> 0).
+__device__ __forceinline__ uint32_t f2u_sat(float v) {
+    if (!(v > 0.0f)) return 0u;
+    if (v >= 4294967296.0f) return 0xffffffffu;
+    return (uint32_t)v;
+}
+
+// modules/utils.py:54-57
+__device__ __forceinline__ float calc_dt(float t, float esf, float dt_min, float dt_max) {
+    return fminf(dt_max, fmaxf(dt_min, t * esf));
+}
+
+// modules/utils.py:60-75 (differs from C frexp on exact powers of two)
+__device__ __forceinline__ int frexp_bit(float x) {
+    int exponent = 0;
+    if (x != 0.0f) {
+        uint32_t bits = f2u_bits(x);
+        exponent = (int)((bits & 0x7f800000u) >> 23) - 127;
+        float frac = u2f_bits((bits & 0x7fffffu) | 0x3f800000u);
+        if (frac > 1.0f) exponent += 1;   // the frac < 0.5 branch of the reference can never fire
+    }
+    return exponent;
+}
+
+// modules/utils.py:95-107
+__device__ __forceinline__ uint32_t expand_bits(uint32_t v) {
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+__device__ __forceinline__ uint32_t morton3d(uint32_t x, uint32_t y, uint32_t z) {
+    return expand_bits(x) | (expand_bits(y) << 1) | (expand_bits(z) << 2);
+}
+// modules/utils.py:110-117
+__device__ __forceinline__ int32_t morton3d_invert1(uint32_t x) {
+    x = x & 0x49249249u;
+    x = (x | (x >> 2)) & 0xc30c30c3u;
+    x = (x | (x >> 4)) & 0x0f00f00fu;
+    x = (x | (x >> 8)) & 0xff0000ffu;
+    x = (x | (x >> 16)) & 0x0000ffffu;
+    return (int32_t)x;
+}
+
+__device__ __forceinline__ float fsign(float x) { return (float)((x > 0.0f) - (x < 0.0f)); }
+
+// ---- wave64 primitives -------------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & (NGP_WAVE - 1)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, NGP_WAVE);
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, NGP_WAVE);
+    return v;
+}
+// inclusive scans across the 64 lanes (Kogge-Stone)
+__device__ __forceinline__ float wave_scan_mul(float v, int lane) {
+#pragma unroll
+    for (int d = 1; d < NGP_WAVE; d <<= 1) {
+        float o = __shfl_up(v, d, NGP_WAVE);
+        if (lane >= d) v *= o;
+    }
+    return v;
+}
+__device__ __forceinline__ float wave_scan_add(float v, int lane) {
+#pragma unroll
+    for (int d = 1; d < NGP_WAVE; d <<= 1) {
+        float o = __shfl_up(v, d, NGP_WAVE);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+__device__ __forceinline__ int wave_scan_add_i(int v, int lane) {
+#pragma unroll
+    for (int d = 1; d < NGP_WAVE; d <<= 1) {
+        int o = __shfl_up(v, d, NGP_WAVE);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+}  // namespace ngp

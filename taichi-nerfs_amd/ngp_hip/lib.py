@@ -1,0 +1,121 @@
+"""ctypes binding of libngp_hip.so (C ABI declared in include/ngp_hip.h).
+
+This is the binding a maintainer of the reference would add in place of Taichi's torch interop: every
+`@ti.kernel` launch in the reference's modules/*.py becomes one call through this table with
+`tensor.data_ptr()` + the current torch stream.  There is NO fallback: if the shared library is missing or
+fails to load, `load()` raises -- the product path never routes through a CPU implementation.
+"""
+import ctypes
+import os
+import shutil
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+PKG_ROOT = os.path.dirname(_HERE)
+CSRC = os.path.join(PKG_ROOT, "csrc")
+INCLUDE = os.path.join(os.path.dirname(PKG_ROOT), "include")
+LIB_PATH = os.path.join(CSRC, "libngp_hip.so")
+SOURCES = ["march.hip", "hash_grid.hip", "composite.hip", "sh_grid.hip", "mlp.hip", "optim.hip"]
+HEADERS = ["ngp_device.h"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+
+NGP_MAX_LEVELS = 16
+
+
+class HashLevels(ctypes.Structure):
+    """Mirror of `ngp_hash_levels` (include/ngp_hip.h)."""
+    _fields_ = [
+        ("n_levels", ctypes.c_int32),
+        ("n_features", ctypes.c_int32),
+        ("begin_fast_hash_level", ctypes.c_int32),
+        ("total_entries", ctypes.c_int32),
+        ("scale", ctypes.c_float * NGP_MAX_LEVELS),
+        ("resolution", ctypes.c_uint32 * NGP_MAX_LEVELS),
+        ("map_size", ctypes.c_uint32 * NGP_MAX_LEVELS),
+        ("offset", ctypes.c_uint32 * NGP_MAX_LEVELS),
+    ]
+
+
+def _sources():
+    return [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+
+
+def needs_build():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = _sources() + [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(INCLUDE, "ngp_hip.h")]
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build(force=False, verbose=False):
+    """Cross-compile every HIP source for gfx950 into the in-tree libngp_hip.so (works without a GPU)."""
+    if not force and not needs_build():
+        return LIB_PATH
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        raise RuntimeError("hipcc not found: cannot build libngp_hip.so")
+    tmp = LIB_PATH + ".tmp.%d" % os.getpid()
+    cmd = [hipcc] + HIPCC_FLAGS + ["-o", tmp] + _sources()
+    if verbose:
+        print(" ".join(cmd))
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
+    os.replace(tmp, LIB_PATH)
+    return LIB_PATH
+
+
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+_F = ctypes.c_float
+_LV = ctypes.POINTER(HashLevels)
+
+# name -> argtypes (restype is always int); must list every symbol include/ngp_hip.h declares
+SIGNATURES = {
+    "ngp_abi_version": [],
+    "ngp_hash_levels_init": [_LV, ctypes.c_double, _I, ctypes.c_double, ctypes.c_double, _I],
+    "ngp_ray_aabb": [_P, _P, _F, _I, _P, _P],
+    "ngp_march_train_count": [_P, _P, _P, _P, _P, _I, _I, _F, _F, _I, _I, _P, _P, _P],
+    "ngp_march_train_scan": [_P, _I, _P, _P, _P],
+    "ngp_march_train_write": [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P],
+    "ngp_march_test": [_P, _P, _P, _P, _P, _I, _I, _F, _F, _I, _I, _P, _P, _P, _P, _P, _P],
+    "ngp_hash_fwd_f32": [_P, _P, _LV, _I, _P, _P],
+    "ngp_hash_bwd_f32": [_P, _P, _LV, _I, _P, _P],
+    "ngp_hash_fwd_f16": [_P, _P, _LV, _I, _P, _P],
+    "ngp_hash_bwd_f16": [_P, _P, _LV, _I, _P, _P],
+    "ngp_sh16_fwd": [_P, _I, _P, _P],
+    "ngp_sh16_bwd": [_P, _P, _I, _P, _P],
+    "ngp_composite_train_fwd": [_P, _P, _I, _P, _P, _P, _F, _I, _P, _P, _P, _P, _P, _P],
+    "ngp_composite_train_bwd": [_P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _F, _I, _P, _P, _P],
+    "ngp_composite_test": [_P, _P, _I, _P, _P, _P, _P, _F, _I, _P, _P, _P, _P],
+    "ngp_morton3d": [_P, _I, _P, _P],
+    "ngp_morton3d_invert": [_P, _I, _P, _P],
+    "ngp_packbits": [_P, _F, _I, _P, _P],
+}
+
+_lib = None
+
+
+def load():
+    """Load libngp_hip.so (after torch, so both share torch's libamdhip64.so.7) and type every entry point."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    import torch  # noqa: F401  (must be imported first: the HIP runtime SONAME is then already resolved)
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "libngp_hip.so is not built (%s). Run `python __graft_entry__.py` or "
+            "`python -c 'import __graft_entry__ as g; g.build()'`. There is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)     # AttributeError here = header/library mismatch: fail loudly
+        fn.argtypes = argtypes
+        fn.restype = ctypes.c_int
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError("%s failed with code %d (negated hipError_t, or -1 for bad arguments)" % (what, rc))

@@ -1,0 +1,241 @@
+"""Tensor-level launchers over the C ABI: allocate outputs with torch, pass raw device pointers + the current
+torch HIP stream.  No autograd here (that lives in modules/), no CPU path: every function requires device
+tensors and raises otherwise."""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import lib as _lib_mod
+from .lib import HashLevels, check
+
+
+def _lib():
+    return _lib_mod.load()
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _dev(t, dtype=None, name="tensor"):
+    if not t.is_cuda:
+        raise RuntimeError("%s must live on the GPU: libngp_hip has no CPU path (got device %s)" % (name, t.device))
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise ValueError("%s must be contiguous" % name)
+    return t
+
+
+def make_levels(max_params, levels, base_res, max_res, features):
+    """ngp_hash_levels table (host struct) -- HashEncoder.__init__ arithmetic (hash_encoder.py:183-205)."""
+    lv = HashLevels()
+    check(_lib().ngp_hash_levels_init(ctypes.byref(lv), float(max_params), int(levels), float(base_res), float(max_res),
+                                      int(features)), "ngp_hash_levels_init")
+    return lv
+
+
+# ---------------------------------------------------------------------------------------------------- a-1
+def ray_aabb(rays_o, rays_d, scale):
+    _dev(rays_o, torch.float32, "rays_o"); _dev(rays_d, torch.float32, "rays_d")
+    n = rays_o.shape[0]
+    hits_t = torch.empty(n, 2, device=rays_o.device, dtype=torch.float32)
+    check(_lib().ngp_ray_aabb(_ptr(rays_o), _ptr(rays_d), float(scale), n, _ptr(hits_t), _stream()), "ngp_ray_aabb")
+    return hits_t
+
+
+# ---------------------------------------------------------------------------------------------------- a-2
+class MarchArena:
+    """Per-device staging rows for the training march: [n_rays * max_samples] (t, dt) pairs.
+
+    Worst case like the reference's N*1024 torch.empty buffers (ray_march.py:144-168) but allocated once and
+    reused; only the rows/entries actually emitted are ever touched (288 GB of HBM makes the reservation free)."""
+    _cache = {}
+
+    @classmethod
+    def get(cls, device, n_rays, max_samples):
+        key = (device.index if device.index is not None else torch.cuda.current_device())
+        need = n_rays * max_samples
+        cur = cls._cache.get(key)
+        if cur is None or cur.shape[0] < need:
+            cur = torch.empty(need, 2, device=device, dtype=torch.float32)
+            cls._cache[key] = cur
+        return cur
+
+
+def march_train(rays_o, rays_d, hits_t, density_bitfield, noise, cascades, scale, exp_step_factor, grid_size, max_samples):
+    """count -> scan -> (one D2H read of the total, like ray_march.py:187-192) -> write."""
+    _dev(rays_o, torch.float32, "rays_o"); _dev(rays_d, torch.float32, "rays_d"); _dev(hits_t, torch.float32, "hits_t")
+    _dev(density_bitfield, torch.uint8, "density_bitfield"); _dev(noise, torch.float32, "noise")
+    n = rays_o.shape[0]
+    dev = rays_o.device
+    L = _lib()
+    stage = MarchArena.get(dev, n, int(max_samples))
+    counts = torch.empty(n, device=dev, dtype=torch.int32)
+    rays_a = torch.empty(n, 3, device=dev, dtype=torch.int32)
+    total = torch.zeros(1, device=dev, dtype=torch.int32)
+    st = _stream()
+    check(L.ngp_march_train_count(_ptr(rays_o), _ptr(rays_d), _ptr(hits_t), _ptr(density_bitfield), _ptr(noise),
+                                  int(cascades), int(grid_size), float(scale), float(exp_step_factor), int(max_samples), n,
+                                  _ptr(stage), _ptr(counts), st), "ngp_march_train_count")
+    check(L.ngp_march_train_scan(_ptr(counts), n, _ptr(rays_a), _ptr(total), st), "ngp_march_train_scan")
+    S = int(total.item())
+    xyzs = torch.empty(S, 3, device=dev, dtype=torch.float32)
+    dirs = torch.empty(S, 3, device=dev, dtype=torch.float32)
+    deltas = torch.empty(S, device=dev, dtype=torch.float32)
+    ts = torch.empty(S, device=dev, dtype=torch.float32)
+    if S > 0:
+        check(L.ngp_march_train_write(_ptr(rays_o), _ptr(rays_d), _ptr(rays_a), _ptr(stage), int(max_samples), n,
+                                      _ptr(xyzs), _ptr(dirs), _ptr(deltas), _ptr(ts), st), "ngp_march_train_write")
+    return rays_a, xyzs, dirs, deltas, ts, total[0]
+
+
+# ---------------------------------------------------------------------------------------------------- a-3
+def march_test(rays_o, rays_d, hits_t, alive_indices, density_bitfield, cascades, scale, exp_step_factor, grid_size,
+               max_samples):
+    _dev(rays_o, torch.float32, "rays_o"); _dev(rays_d, torch.float32, "rays_d"); _dev(hits_t, torch.float32, "hits_t")
+    _dev(alive_indices, torch.int64, "alive_indices"); _dev(density_bitfield, torch.uint8, "density_bitfield")
+    n = alive_indices.shape[0]
+    dev = rays_o.device
+    ray_indices = torch.empty(n * max_samples, device=dev, dtype=torch.int64)
+    valid_mask = torch.zeros(n * max_samples, device=dev, dtype=torch.uint8)
+    deltas = torch.empty(n * max_samples, device=dev, dtype=torch.float32)
+    ts = torch.empty(n * max_samples, device=dev, dtype=torch.float32)
+    samples_counter = torch.empty(n, device=dev, dtype=torch.int32)
+    check(_lib().ngp_march_test(_ptr(rays_o), _ptr(rays_d), _ptr(hits_t), _ptr(alive_indices), _ptr(density_bitfield),
+                                int(cascades), int(grid_size), float(scale), float(exp_step_factor), int(max_samples), n,
+                                _ptr(ray_indices), _ptr(valid_mask), _ptr(deltas), _ptr(ts), _ptr(samples_counter), _stream()),
+          "ngp_march_test")
+    return ray_indices, valid_mask, deltas, ts, samples_counter
+
+
+# ---------------------------------------------------------------------------------------------------- a-4/5
+def hash_fwd_f32(xyzs, table, lv):
+    _dev(xyzs, torch.float32, "xyzs"); _dev(table, torch.float32, "hash_table")
+    n = xyzs.shape[0]
+    out = torch.empty(n, lv.n_levels * lv.n_features, device=xyzs.device, dtype=torch.float32)
+    check(_lib().ngp_hash_fwd_f32(_ptr(xyzs), _ptr(table), ctypes.byref(lv), n, _ptr(out), _stream()), "ngp_hash_fwd_f32")
+    return out
+
+
+def hash_bwd_f32(xyzs, dout, lv, dtable):
+    _dev(xyzs, torch.float32, "xyzs"); _dev(dout, torch.float32, "dout"); _dev(dtable, torch.float32, "dtable")
+    check(_lib().ngp_hash_bwd_f32(_ptr(xyzs), _ptr(dout), ctypes.byref(lv), xyzs.shape[0], _ptr(dtable), _stream()),
+          "ngp_hash_bwd_f32")
+    return dtable
+
+
+def hash_fwd_f16(xyzs, table_h, lv):
+    _dev(xyzs, torch.float32, "xyzs"); _dev(table_h, torch.float16, "hash_table(f16)")
+    n = xyzs.shape[0]
+    out = torch.empty(n, lv.n_levels, lv.n_features, device=xyzs.device, dtype=torch.float16)
+    check(_lib().ngp_hash_fwd_f16(_ptr(xyzs), _ptr(table_h), ctypes.byref(lv), n, _ptr(out), _stream()), "ngp_hash_fwd_f16")
+    return out
+
+
+def hash_bwd_f16(xyzs, dout_h, lv, dtable_h):
+    _dev(xyzs, torch.float32, "xyzs"); _dev(dout_h, torch.float16, "dout"); _dev(dtable_h, torch.float16, "dtable")
+    check(_lib().ngp_hash_bwd_f16(_ptr(xyzs), _ptr(dout_h), ctypes.byref(lv), xyzs.shape[0], _ptr(dtable_h), _stream()),
+          "ngp_hash_bwd_f16")
+    return dtable_h
+
+
+# ---------------------------------------------------------------------------------------------------- a-6
+def sh16_fwd(dirs):
+    _dev(dirs, torch.float32, "dirs")
+    out = torch.empty(dirs.shape[0], 16, device=dirs.device, dtype=torch.float32)
+    check(_lib().ngp_sh16_fwd(_ptr(dirs), dirs.shape[0], _ptr(out), _stream()), "ngp_sh16_fwd")
+    return out
+
+
+def sh16_bwd(dirs, dout):
+    _dev(dirs, torch.float32, "dirs"); _dev(dout, torch.float32, "dout")
+    ddirs = torch.empty_like(dirs)
+    check(_lib().ngp_sh16_bwd(_ptr(dirs), _ptr(dout), dirs.shape[0], _ptr(ddirs), _stream()), "ngp_sh16_bwd")
+    return ddirs
+
+
+# ---------------------------------------------------------------------------------------------------- a-7
+def _rgb_kind(rgbs):
+    if rgbs.dtype == torch.float16:
+        return 1
+    if rgbs.dtype == torch.float32:
+        return 0
+    raise TypeError("rgbs must be float16 or float32, got %s" % rgbs.dtype)
+
+
+def composite_train_fwd(sigmas, rgbs, deltas, ts, rays_a, T_threshold):
+    _dev(sigmas, torch.float32, "sigmas"); _dev(rgbs, None, "rgbs"); _dev(deltas, torch.float32, "deltas")
+    _dev(ts, torch.float32, "ts"); _dev(rays_a, torch.int32, "rays_a")
+    n = rays_a.shape[0]
+    dev = rays_a.device
+    total_samples = torch.empty(n, device=dev, dtype=torch.int32)
+    opacity = torch.empty(n, device=dev, dtype=torch.float32)
+    depth = torch.empty(n, device=dev, dtype=torch.float32)
+    rgb = torch.empty(n, 3, device=dev, dtype=torch.float32)
+    ws = torch.empty_like(sigmas)
+    check(_lib().ngp_composite_train_fwd(_ptr(sigmas), _ptr(rgbs), _rgb_kind(rgbs), _ptr(deltas), _ptr(ts), _ptr(rays_a),
+                                         float(T_threshold), n, _ptr(total_samples), _ptr(opacity), _ptr(depth), _ptr(rgb),
+                                         _ptr(ws), _stream()), "ngp_composite_train_fwd")
+    return total_samples, opacity, depth, rgb, ws
+
+
+def composite_train_bwd(dL_dopacity, dL_ddepth, dL_drgb, dL_dws, sigmas, rgbs, deltas, ts, rays_a, opacity, depth, rgb, ws,
+                        T_threshold):
+    n = rays_a.shape[0]
+    for name, t in (("dL_dopacity", dL_dopacity), ("dL_ddepth", dL_ddepth), ("dL_drgb", dL_drgb), ("dL_dws", dL_dws)):
+        if t is not None:
+            _dev(t, torch.float32, name)
+    d_sigmas = torch.empty_like(sigmas)
+    d_rgbs = torch.empty_like(rgbs)
+    check(_lib().ngp_composite_train_bwd(_ptr(dL_dopacity), _ptr(dL_ddepth), _ptr(dL_drgb), _ptr(dL_dws), _ptr(sigmas),
+                                         _ptr(rgbs), _rgb_kind(rgbs), _ptr(deltas), _ptr(ts), _ptr(rays_a), _ptr(opacity),
+                                         _ptr(depth), _ptr(rgb), _ptr(ws), float(T_threshold), n, _ptr(d_sigmas), _ptr(d_rgbs),
+                                         _stream()), "ngp_composite_train_bwd")
+    return d_sigmas, d_rgbs
+
+
+# ---------------------------------------------------------------------------------------------------- a-8
+def composite_test(sigmas, rgbs, deltas, ts, pack_info, alive_indices, T_threshold, opacity, depth, rgb):
+    _dev(sigmas, torch.float32, "sigmas"); _dev(rgbs, None, "rgbs"); _dev(deltas, torch.float32, "deltas")
+    _dev(ts, torch.float32, "ts"); _dev(pack_info, torch.int64, "pack_info"); _dev(alive_indices, torch.int64, "alive_indices")
+    _dev(opacity, torch.float32, "opacity"); _dev(depth, torch.float32, "depth"); _dev(rgb, torch.float32, "rgb")
+    check(_lib().ngp_composite_test(_ptr(sigmas), _ptr(rgbs), _rgb_kind(rgbs), _ptr(deltas), _ptr(ts), _ptr(pack_info),
+                                    _ptr(alive_indices), float(T_threshold), alive_indices.shape[0], _ptr(opacity), _ptr(depth),
+                                    _ptr(rgb), _stream()), "ngp_composite_test")
+
+
+# ---------------------------------------------------------------------------------------------------- a-10
+def morton3d(coords):
+    _dev(coords, torch.int32, "coords")
+    out = torch.empty(coords.shape[0], device=coords.device, dtype=torch.int32)
+    check(_lib().ngp_morton3d(_ptr(coords), coords.shape[0], _ptr(out), _stream()), "ngp_morton3d")
+    return out
+
+
+def morton3d_invert(indices):
+    _dev(indices, torch.int32, "indices")
+    out = torch.empty(indices.shape[0], 3, device=indices.device, dtype=torch.int32)
+    check(_lib().ngp_morton3d_invert(_ptr(indices), indices.shape[0], _ptr(out), _stream()), "ngp_morton3d_invert")
+    return out
+
+
+def packbits(density_grid, threshold, density_bitfield):
+    _dev(density_grid, torch.float32, "density_grid"); _dev(density_bitfield, torch.uint8, "density_bitfield")
+    n_bytes = density_bitfield.shape[0]
+    if density_grid.numel() != 8 * n_bytes:
+        raise ValueError("density_grid must hold 8 floats per bitfield byte")
+    check(_lib().ngp_packbits(_ptr(density_grid), float(threshold), n_bytes, _ptr(density_bitfield), _stream()), "ngp_packbits")
+    return density_bitfield
+
+
+def levels_to_numpy(lv):
+    """(scale, resolution, map_size, offset) as numpy arrays -- for tests and for the module buffers."""
+    L = lv.n_levels
+    return (np.array(lv.scale[:L], dtype=np.float32), np.array(lv.resolution[:L], dtype=np.uint32),
+            np.array(lv.map_size[:L], dtype=np.uint32), np.array(lv.offset[:L], dtype=np.uint32))

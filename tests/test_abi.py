@@ -1,0 +1,58 @@
+"""The C-ABI library builds for gfx950, loads, and exports exactly what include/ngp_hip.h declares
+(no compute calls: there is no GPU in the CPU test tier)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+
+def _declared():
+    hdr = open(os.path.join(ROOT, "include", "ngp_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\bint\s+(ngp_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_header_symbols_exported(hip_lib):
+    from ngp_hip import lib
+    names = _declared()
+    assert len(names) >= 19
+    for n in names:
+        assert hasattr(hip_lib, n), "libngp_hip.so does not export %s" % n
+    assert sorted(lib.SIGNATURES) == names, "ngp_hip/lib.py binds a different symbol set than the header declares"
+    assert hip_lib.ngp_abi_version() == 1
+
+
+def test_struct_layout_matches_header():
+    from ngp_hip.lib import HashLevels
+    assert ctypes.sizeof(HashLevels) == 16 + 4 * 16 * 4
+
+
+def test_ops_refuse_cpu_tensors(hip_lib):
+    """The product path has no CPU fallback: host tensors are rejected loudly."""
+    import torch
+    from ngp_hip import ops
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops.ray_aabb(torch.zeros(4, 3), torch.ones(4, 3), 0.5)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops.sh16_fwd(torch.zeros(4, 3))
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from ngp_hip import lib
+    monkeypatch.setattr(lib, "_lib", None)
+    monkeypatch.setattr(lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        lib.load()
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "taichi-nerfs_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dp, f)).read()
+                assert "oracle" not in src.replace("the CPU oracle", "").replace("against the oracle", "") \
+                    .replace("the oracle", ""), "%s mentions the oracle" % f
