@@ -84,7 +84,7 @@ def cpu_baseline(bits, seconds):
     from ngp_hip import synthetic
     ora.build()
     cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    torch.set_num_threads(min(cores, 32))         # tiny GEMMs: more threads only add contention
     n = 1024
     lv = ora.make_levels(2**19, 16, 16, 1024, 2)
     rng = np.random.default_rng(0)
@@ -94,6 +94,7 @@ def cpu_baseline(bits, seconds):
     for t in w:
         t.requires_grad_(True)
     target = torch.rand(n, 3)
+    dtable = np.zeros(lv.total_entries * 2, np.float32)
     done, t0, samples = 0, time.perf_counter(), 0
     it = 0
     while True:
@@ -115,7 +116,8 @@ def cpu_baseline(bits, seconds):
         ds, dc = ora.composite_train_bwd(g_op, None, g_rgb, None, sigma.detach().numpy(), rgbs.detach().numpy(), deltas, ts,
                                          rays_a, 1e-4)
         torch.autograd.backward([sigma, rgbs], [torch.from_numpy(ds), torch.from_numpy(dc)])
-        ora.hash_bwd_f32(x01, enc.grad.numpy(), lv)
+        dtable.fill(0.0)
+        ora.hash_bwd_f32_atomic(x01, enc.grad.numpy(), lv, dtable)
         for t in w:
             t.grad = None
         done += n; samples += S; it += 1

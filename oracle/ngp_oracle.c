@@ -368,6 +368,24 @@ ORA_API void ora_hash_bwd_f32(const float* xyzs, const float* dout, const ngp_ha
     }
 }
 
+/* Throughput variant used ONLY by bench.py's cpu_baseline leg: parallel over samples with omp atomics
+ * (summation order is then nondeterministic, like the reference's atomic_add on the CUDA/CPU backends). */
+ORA_API void ora_hash_bwd_f32_atomic(const float* xyzs, const float* dout, const ngp_hash_levels* lv, int n, float* dtable) {
+    const int L = lv->n_levels, F = lv->n_features;
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; ++i)
+        for (int level = 0; level < L; ++level) {
+            uint32_t idx[8]; float w[8];
+            hash_corners(xyzs + 3 * i, lv, level, idx, w);
+            for (int c = 0; c < 8; ++c)
+                for (int f = 0; f < F; ++f) {
+                    float v = w[c] * dout[(size_t)i * L * F + level * F + f];
+#pragma omp atomic
+                    dtable[(size_t)idx[c] * F + f] += v;
+                }
+        }
+}
+
 /* ------------------------------------------------------------------------------------------------
  * a-5  half encoder -- modules/hash_encoder_half.py:112-161 (fwd), :164-213 (bwd)
  * table/out are (f16,f16) pairs; pos/scale/w are f32; accumulate in f16 (:159).

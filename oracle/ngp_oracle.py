@@ -138,6 +138,14 @@ def hash_bwd_f32(xyzs, dout, lv):
     return dtable
 
 
+def hash_bwd_f32_atomic(xyzs, dout, lv, dtable):
+    """cpu_baseline-only throughput variant (omp atomics); accumulates into the caller's dtable."""
+    x, g = _f32(xyzs), _f32(dout)
+    assert dtable.dtype == np.float32 and dtable.flags.c_contiguous
+    lib().ora_hash_bwd_f32_atomic(_p(x), _p(g), ctypes.byref(lv), x.shape[0], _p(dtable))
+    return dtable
+
+
 def hash_fwd_f16(xyzs, table_h, lv):
     x = _f32(xyzs)
     t = np.ascontiguousarray(table_h, dtype=np.float16).view(np.uint16).reshape(-1)

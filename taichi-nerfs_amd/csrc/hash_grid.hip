@@ -127,6 +127,7 @@ __global__ void __launch_bounds__(256) hash_fwd_f32_kernel(const float* __restri
 }
 
 // ---- fp32 backward: dtable[idx*F+f] += w * dout -----------------------------------------------------
+// Generic-F fallback: one lane per (sample, level), F*8 independent atomics.
 template <int F>
 __global__ void __launch_bounds__(256) hash_bwd_f32_kernel(const float* __restrict__ xyzs, const float* __restrict__ dout,
                                                            ngp_hash_levels lv, int n, float* __restrict__ dtable) {
@@ -149,6 +150,84 @@ __global__ void __launch_bounds__(256) hash_bwd_f32_kernel(const float* __restri
         for (int ci = 0; ci < 8; ++ci)
 #pragma unroll
             for (int f = 0; f < F; ++f) unsafeAtomicAdd(dtable + (size_t)c.idx[ci] * F + f, c.w[ci] * g[f]);
+    }
+}
+
+// F = 2 fast path, shaped by what the MI355X atomic pipeline charges for (profiles/microbench/atomics2.hip):
+// a float atomic instruction costs one request per DISTINCT 64-byte line it touches (~21 G lines/s chip-wide),
+// adjacent lanes on one line are free, and duplicate addresses inside an instruction are NOT merged.
+//   * lane quad = (sample, x-corner bit, feature): the four lanes of a quad hit (e, f0) (e, f1) (e', f0) (e', f1)
+//     where e' is the x-neighbour entry -- adjacent (dense levels) or e^small-mask (xor hash) -- so the quad lands
+//     on one 64-B line 7 times out of 8: ~4 line requests per (sample, level) instead of 16 scattered atomics.
+//   * one wave = 16 consecutive samples x one level; consecutive samples of a ray sit in the same cell on the
+//     coarse/mid levels, so equal-cell runs are summed with a segmented wave scan and only the last lane of a
+//     run issues atomics (removes the in-instruction duplicates and ~60 % of all requests).
+// Summation order differs from a serial loop: tolerance-checked against the oracle (float atomics are
+// order-nondeterministic in the reference too).
+__global__ void __launch_bounds__(256) hash_bwd_f32x2_kernel(const float* __restrict__ xyzs, const float* __restrict__ dout,
+                                                             ngp_hash_levels lv, int n, float* __restrict__ dtable) {
+    __shared__ LevelLDS L;
+    load_levels(lv, L);
+    const int nl = lv.n_levels, bfhl = lv.begin_fast_hash_level;
+    const int lane = threadIdx.x & 63;
+    const int s_in = lane >> 2, xb = (lane >> 1) & 1, f = lane & 1;
+    const int n_tiles = (n + 15) >> 4;
+    const int waves_per_block = blockDim.x >> 6;
+    for (int tile = blockIdx.x * waves_per_block + (threadIdx.x >> 6); tile < n_tiles; tile += gridDim.x * waves_per_block) {
+        const int i = tile * 16 + s_in;
+        const bool valid = i < n;
+        float x = 0.f, y = 0.f, z = 0.f;
+        if (valid) { x = xyzs[3 * (size_t)i]; y = xyzs[3 * (size_t)i + 1]; z = xyzs[3 * (size_t)i + 2]; }
+        for (int level = 0; level < nl; ++level) {
+            const float g = valid ? dout[(size_t)i * (nl * 2) + level * 2 + f] : 0.0f;
+            const float scale = L.scale[level];
+            const uint32_t res = L.res[level], size = L.size[level], mode = L.mode[level];
+            const float px = x * scale + 0.5f, py = y * scale + 0.5f, pz = z * scale + 0.5f;
+            const uint32_t cx = f2u_sat(floorf(px)), cy = f2u_sat(floorf(py)), cz = f2u_sat(floorf(pz));
+            const float fx = px - (float)cx, fy = py - (float)cy, fz = pz - (float)cz;
+            // run structure: head = first sample of the tile or a different cell than the previous sample
+            const uint32_t pcx = __shfl_up(cx, 4, 64), pcy = __shfl_up(cy, 4, 64), pcz = __shfl_up(cz, 4, 64);
+            const int pvalid = __shfl_up((int)valid, 4, 64);
+            bool head = (s_in == 0) || !valid || !pvalid || cx != pcx || cy != pcy || cz != pcz;
+            const int nhead = __shfl_down((int)head, 4, 64);
+            const bool tail = valid && ((s_in == 15) || nhead);
+            const float wx = xb ? fx : 1.0f - fx;
+            const uint32_t gx = cx + (uint32_t)xb;
+            float v[4];
+            uint32_t e[4];
+            const bool dense = level < bfhl;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {              // k = (z bit, y bit)
+                const int yb = k & 1, zb = k >> 1;
+                const float w = (1.0f * wx) * (yb ? fy : 1.0f - fy) * (zb ? fz : 1.0f - fz);   // same product order as fwd
+                const uint32_t gy = cy + (uint32_t)yb, gz = cz + (uint32_t)zb;
+                uint32_t h = dense ? (gx + gy * res + gz * res * res) : (gx ^ (gy * 2654435761u) ^ (gz * 805459861u));
+                if (mode == 1u) h &= (size - 1u);
+                else if (mode == 0u) { if (h >= size) { h -= size; if (h >= size) h %= size; } }
+                else h = h % size;
+                e[k] = L.offset[level] + h;
+                v[k] = w * g;
+            }
+            // segmented inclusive scan over samples (lane distance 4 = one sample)
+            bool hf = head;
+#pragma unroll
+            for (int d = 4; d < 64; d <<= 1) {
+                const int hup = __shfl_up((int)hf, d, 64);
+                float vup[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) vup[k] = __shfl_up(v[k], d, 64);
+                if (lane >= d && !hf) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] += vup[k];
+                    hf = hup != 0;
+                }
+            }
+            if (tail) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (v[k] != 0.0f) unsafeAtomicAdd(dtable + (size_t)e[k] * 2 + f, v[k]);
+            }
+        }
     }
 }
 
@@ -244,7 +323,12 @@ int ngp_hash_bwd_f32(const float* xyzs, const float* dout, const ngp_hash_levels
     hipStream_t s = (hipStream_t)stream;
     switch (lv->n_features) {
         case 1: hipLaunchKernelGGL(hash_bwd_f32_kernel<1>, dim3(grid), dim3(256), 0, s, xyzs, dout, *lv, n, dtable); break;
-        case 2: hipLaunchKernelGGL(hash_bwd_f32_kernel<2>, dim3(grid), dim3(256), 0, s, xyzs, dout, *lv, n, dtable); break;
+        case 2: {
+            const int tiles = (n + 15) / 16;
+            const int g2 = tiles < 4 ? 1 : (tiles / 4 < 8192 ? (tiles + 3) / 4 : 8192);
+            hipLaunchKernelGGL(hash_bwd_f32x2_kernel, dim3(g2), dim3(256), 0, s, xyzs, dout, *lv, n, dtable);
+            break;
+        }
         case 4: hipLaunchKernelGGL(hash_bwd_f32_kernel<4>, dim3(grid), dim3(256), 0, s, xyzs, dout, *lv, n, dtable); break;
         case 8: hipLaunchKernelGGL(hash_bwd_f32_kernel<8>, dim3(grid), dim3(256), 0, s, xyzs, dout, *lv, n, dtable); break;
         default: return -1;

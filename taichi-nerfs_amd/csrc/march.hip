@@ -5,9 +5,9 @@
 // Design (not a translation of the Taichi launch shape):
 //   The reference marches every ray twice in one kernel and packs samples with two global atomics per ray.
 //   Here the orbit t_{k+1} = t_k + calc_dt(t_k) is recognised as independent of occupancy (occupied cells and
-//   the skip loop both advance by calc_dt), so the count kernel evaluates ORBIT_BATCH consecutive orbit points
-//   speculatively -- 8 independent bitfield loads in flight per lane instead of one dependent load per step --
-//   and then resolves the reference's "examined / skipped" logic over the batch in order.  Emitted (t, dt)
+//   the skip loop both advance by calc_dt), so the count kernel probes a batch of consecutive orbit points
+//   speculatively -- 16 lanes per ray, one orbit point each, all bitfield loads independent -- and then
+//   resolves the reference's "examined / skipped" logic over the batch in order.  Emitted (t, dt)
 //   pairs go to a per-ray staging row; a deterministic prefix sum replaces the atomics (rays_a in ray order);
 //   the expansion into xyzs/dirs/deltas/ts is a coalesced wave-per-ray kernel.  Samples are bit-identical to
 //   the reference's serial march (checked against the oracle).
@@ -98,63 +98,77 @@ __global__ void __launch_bounds__(256) ray_aabb_kernel(const float* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------------
-// a-2  training march, count + stage.  One lane per ray; ORBIT_BATCH orbit points per trip.
+// a-2  training march, count + stage.
+// MARCH_GROUP lanes cooperate on one ray: the orbit t_{k+1} = t_k + calc_dt(t_k) does not depend on occupancy, so
+// the 16 lanes of a group probe 16 consecutive orbit points at once (cell index, bitfield byte, skip target), park
+// the results in LDS, and every lane then replays the reference's examined / skipped / emitted logic over the 16
+// points from LDS broadcasts (same address for the whole group: conflict-free).  8192 rays give 2048 waves instead of
+// the 128 single-lane-per-ray waves that left 7/8 of the SIMDs idle and each ray with a ~2000-instruction serial
+// chain per 8 steps.
 // ------------------------------------------------------------------------------------------------------
-constexpr int ORBIT_BATCH = 8;
+constexpr int MARCH_GROUP = 16;
+constexpr int ORBIT_BATCH = 8;      // used by the test-time kernel (one lane per ray)
 
 __global__ void __launch_bounds__(64) march_count_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
-                                                         const float2* __restrict__ hits_t,
-                                                         const uint8_t* __restrict__ bits, const float* __restrict__ noise,
-                                                         MarchParams p, int max_samples, int n_rays,
-                                                         float2* __restrict__ stage, int32_t* __restrict__ counts) {
-    int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_rays) return;
+                                                          const float2* __restrict__ hits_t,
+                                                          const uint8_t* __restrict__ bits, const float* __restrict__ noise,
+                                                          MarchParams p, int max_samples, int n_rays,
+                                                          float2* __restrict__ stage, int32_t* __restrict__ counts) {
+    constexpr int G = MARCH_GROUP;
+    constexpr int GROUPS = 64 / G;                          // one wave per block: the barriers below are wave-local
+    __shared__ float4 pts[GROUPS][G];                       // (t, dt, skip target, occupied)
+    const int grp = threadIdx.x / G, sub = threadIdx.x % G;
+    const int r = blockIdx.x * GROUPS + grp;
+    const bool has_ray = r < n_rays;
+    const int rr = has_ray ? r : 0;
     float o[3], d[3], d_inv[3];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { o[k] = rays_o[3 * r + k]; d[k] = rays_d[3 * r + k]; d_inv[k] = 1.0f / d[k]; }
-    float2 h = hits_t[r];
+    for (int k = 0; k < 3; ++k) { o[k] = rays_o[3 * rr + k]; d[k] = rays_d[3 * rr + k]; d_inv[k] = 1.0f / d[k]; }
+    const float2 h = hits_t[rr];
     float t1 = h.x;
     const float t2 = h.y;
-    if (t1 >= 0.0f) t1 += calc_dt(t1, p.esf, p.dt_min, p.dt_max) * noise[r];       // ray_march.py:39-41
-    float t = t1;
-    int n = 0;
-    float t_target = -INFINITY;                 // orbit points below this are skipped, not examined
-    float2* row = stage + (size_t)r * (size_t)max_samples;
-    bool live = (0.0f <= t) && (t < t2) && (n < max_samples);                       // ray_march.py:46
-    while (live) {
-        float tb[ORBIT_BATCH], dtb[ORBIT_BATCH];
-        uint8_t ob[ORBIT_BATCH];
-        uint32_t ib[ORBIT_BATCH];
-        float tt = t;
+    if (t1 >= 0.0f) t1 += calc_dt(t1, p.esf, p.dt_min, p.dt_max) * noise[rr];      // ray_march.py:39-41
+    float t = t1;                                    // group-uniform: first orbit point of the current batch
+    int n = 0;                                       // group-uniform: samples emitted so far
+    float t_target = -INFINITY;                      // group-uniform: orbit points below this are skipped
+    float2* row = stage + (size_t)rr * (size_t)max_samples;
+    bool live = has_ray && (0.0f <= t) && (t < t2) && (n < max_samples);             // ray_march.py:46
+    while (__any(live)) {
+        // lane `sub` walks `sub` steps along the orbit from the batch base (exact f32 adds, no closed form)
+        float tu = t;
+        for (int k = 0; k < G - 1; ++k)
+            if (k < sub) tu += calc_dt(tu, p.esf, p.dt_min, p.dt_max);
+        const float dtu = calc_dt(tu, p.esf, p.dt_min, p.dt_max);
+        CellProbe c;
+        probe_cell(p, o, d, tu, dtu, c);
+        const bool occ = live && ((bits[c.idx >> 3] >> (c.idx & 7u)) & 1u);           // ray_march.py:60-61
+        const float targ = skip_target(p, d, d_inv, tu, c);                          // ray_march.py:68-71
+        pts[grp][sub] = make_float4(tu, dtu, targ, occ ? 1.0f : 0.0f);
+        __syncthreads();
+        const float t_next_batch = pts[grp][G - 1].x + pts[grp][G - 1].y;
+        int my_slot = -1;
 #pragma unroll
-        for (int u = 0; u < ORBIT_BATCH; ++u) {                                    // speculative: loads independent
-            float dt = calc_dt(tt, p.esf, p.dt_min, p.dt_max);
-            CellProbe c;
-            probe_cell(p, o, d, tt, dt, c);
-            tb[u] = tt; dtb[u] = dt; ib[u] = c.idx;
-            ob[u] = bits[c.idx >> 3];
-            tt += dt;
-        }
-#pragma unroll
-        for (int u = 0; u < ORBIT_BATCH; ++u) {
-            if (!live) break;
-            float tu = tb[u];
-            if (!(tu < t2)) { live = false; break; }
-            if (tu < t_target) continue;                                           // inside a skip (ray_march.py:73-74)
-            if (ob[u] & (1u << (ib[u] & 7u))) {                                     // ray_march.py:61-65
-                row[n] = make_float2(tu, dtb[u]);
-                n += 1;
-                t_target = -INFINITY;
-                if (n >= max_samples) live = false;
-            } else {                                                               // ray_march.py:66-72
-                CellProbe c;
-                probe_cell(p, o, d, tu, dtb[u], c);
-                t_target = skip_target(p, d, d_inv, tu, c);
+        for (int u = 0; u < G; ++u) {
+            const float4 q = pts[grp][u];
+            if (live) {
+                if (!(q.x < t2)) live = false;                                       // loop head, ray_march.py:46
+                else if (!(q.x < t_target)) {                                        // examined (not inside a skip)
+                    if (q.w != 0.0f) {                                               // occupied: emit, ray_march.py:63-65
+                        if (u == sub) my_slot = n;
+                        n += 1;
+                        t_target = -INFINITY;
+                        if (n >= max_samples) live = false;
+                    } else {
+                        t_target = q.z;                                              // empty: skip, ray_march.py:66-74
+                    }
+                }
             }
         }
-        t = tt;
+        if (my_slot >= 0) row[my_slot] = make_float2(tu, dtu);
+        t = t_next_batch;
+        __syncthreads();
     }
-    counts[r] = n;
+    if (has_ray && sub == 0) counts[r] = n;
 }
 
 // exclusive prefix sum over per-ray counts -> rays_a (ray order) + total.  One 1024-thread block, chunked.
@@ -294,7 +308,7 @@ int ngp_march_train_count(const float* rays_o, const float* rays_d, const float*
                           int max_samples, int n_rays, float* stage, int32_t* counts, void* stream) {
     if (n_rays <= 0) return 0;
     MarchParams p = make_march_params(cascades, grid_size, scale, exp_step_factor);
-    hipLaunchKernelGGL(march_count_kernel, dim3((n_rays + 63) / 64), dim3(64), 0, (hipStream_t)stream, rays_o, rays_d,
+    hipLaunchKernelGGL(march_count_kernel, dim3((n_rays + 64 / MARCH_GROUP - 1) / (64 / MARCH_GROUP)), dim3(64), 0, (hipStream_t)stream, rays_o, rays_d,
                        (const float2*)hits_t, density_bitfield, noise, p, max_samples, n_rays, (float2*)stage, counts);
     NGP_LAUNCH_CHECK();
     return 0;
