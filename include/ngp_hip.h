@@ -122,6 +122,22 @@ int ngp_composite_test(const float* sigmas, const void* rgbs, int rgbs_is_half, 
                        int64_t* alive_indices /*in-out*/, float T_threshold, int n_alive,
                        float* opacity, float* depth, float* rgb, void* stream);
 
+/* ---- a-9  the two MLPs + TruncExp + direction glue, fused (modules/networks.py:18-30,111-132,136-166,293-380
+ * under torch.autocast(fp16), train.py:177).  Default architecture only: xyz_encoder 32->64->16, rgb_net
+ * [SH16|h16]->64->64->3, bias-free.  Weights are the fp32 master tensors in nn.Linear layout [out][in];
+ * ngp_mlp_pack rounds them to fp16 and lays them out as MFMA fragments (ngp_mlp_wpack_halfs() uint16 elements).
+ *   fwd : enc [n,32] f32 (hash-grid output), dirs [n,3] f32 (raw ray directions; normalisation, (d+1)/2 and SH16
+ *         happen inside) -> sigmas [n] f32, rgbs [n,3] f16.  dirs == NULL or rgbs == NULL: density only.
+ *   bwd : recomputes the forward, consumes dL/dsigmas [n] f32 and dL/drgbs [n,3] f16, writes dL/denc [n,32] f32 and
+ *         ACCUMULATES the weight gradients into dW [9408] f32 = W1|W2|W3|W4|W5 row-major (caller zero-fills). */
+int ngp_mlp_wpack_halfs(void);
+int ngp_mlp_pack(const float* W1, const float* W2, const float* W3, const float* W4, const float* W5,
+                 uint16_t* wpack, void* stream);
+int ngp_mlp_fwd(const float* enc, const float* dirs, const uint16_t* wpack, int n, float* sigmas,
+                uint16_t* rgbs, void* stream);
+int ngp_mlp_bwd(const float* enc, const float* dirs, const uint16_t* wpack, const float* dsigmas,
+                const uint16_t* drgbs, int n, float* d_enc, float* dW, void* stream);
+
 /* ---- a-10 morton3D / morton3D_invert / packbits (modules/utils.py:120-169) -------------------- */
 int ngp_morton3d(const int32_t* coords /*[m,3]*/, int m, int32_t* indices, void* stream);
 int ngp_morton3d_invert(const int32_t* indices, int m, int32_t* coords /*[m,3]*/, void* stream);

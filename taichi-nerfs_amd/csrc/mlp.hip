@@ -1,0 +1,486 @@
+// mlp.hip -- the fused tiny-MLP (density + colour heads) of Instant-NGP on gfx950 matrix cores.
+//
+// Replaces, for the default architecture of the reference (modules/networks.py:111-132,136-166,293-380 under
+// torch.autocast(fp16), train.py:177):
+//     xyz_encoder : 32 -> 64 (ReLU) -> 16            sigma = exp(h[0])                (TruncExp, networks.py:18-30)
+//     dir path    : d/|d| -> (d+1)/2 -> SH16                                          (networks.py:162-163)
+//     rgb_net     : [SH16 | h16] -> 64 (ReLU) -> 64 (ReLU) -> 3 (Sigmoid)
+// i.e. 5 forward + 10 backward hipBLASLt GEMMs and ~25 elementwise launches per step in the reference's formulation.
+//
+// Formulation: D[out_feature][sample] = W[out][k] * X[k][sample] with v_mfma_f32_16x16x32_f16, so that a wave owns
+// 16-sample column tiles and the activations of one layer feed the next layer's B operand straight from the
+// accumulator registers: lane (n = lane&15, g = lane>>4) of a D tile holds rows 4g..4g+3 of column n, and the B
+// operand wants 8 k-values of column n per lane, so two D tiles (rows 4g+r of features [32s,32s+16) and
+// [32s+16,32s+32)) ARE one K=32 B fragment if the weight fragment's k-order is permuted to match
+// (chain(s,g,j) = 32s + 16(j>>2) + 4g + (j&3)).  The permutation is paid once, in the weight packer.
+// Activations never touch LDS or HBM in the forward pass; fp16 rounding points are the ones autocast produces
+// (every Linear output is fp16, accumulation fp32).
+//
+// Backward recomputes the forward per tile (cheaper than storing 0.68 KB/sample of activations), propagates
+// dX = W^T dZ through the same register-chaining trick, and forms the weight gradients dW = dZ X^T with the sample
+// index as K: that needs [feature][sample] fragments, so dZ and X of one layer at a time are transposed through a
+// 10 KB per-wave LDS tile.  dW accumulates in registers across the wave's whole persistent loop (fp32), is reduced
+// across the block's waves with LDS float atomics and leaves the block as line-coalesced global atomics.
+//
+// Numerics are tolerance-checked against an fp32 torch restatement and against torch's own autocast path
+// (tests/test_gpu_mlp.py); bf16/fp16 MFMA is used because this is the one genuine dense contraction on the path.
+#include "ngp_device.h"
+
+namespace ngp {
+
+typedef _Float16 half_t;
+typedef half_t half8 __attribute__((ext_vector_type(8)));
+typedef half_t half4 __attribute__((ext_vector_type(4)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+#define NGP_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
+
+constexpr int N_FWD_FRAGS = 20;
+constexpr int N_ALL_FRAGS = 42;
+// fragment ids inside the packed weight image
+constexpr int F_W1 = 0;    // [mt]        4
+constexpr int F_W2 = 4;    // [s]         2
+constexpr int F_W3 = 6;    // [mt]        4
+constexpr int F_W4 = 10;   // [mt*2+s]    8
+constexpr int F_W5 = 18;   // [s]         2
+constexpr int B_W5T = 20;  // [mt]        4
+constexpr int B_W4T = 24;  // [mt*2+s]    8
+constexpr int B_W3T = 32;  // [s]         2
+constexpr int B_W2T = 34;  // [mt]        4
+constexpr int B_W1T = 38;  // [mt*2+s]    4
+
+__device__ __forceinline__ int chain_k(int s, int g, int j) { return 32 * s + 16 * (j >> 2) + 4 * g + (j & 3); }
+
+// One thread per (fragment, lane, slot): gathers the fp32 master weight, rounds to fp16 (what autocast's
+// weight.to(fp16) does) and stores it where the MFMA A operand of that lane wants it.
+__global__ void __launch_bounds__(256) mlp_pack_kernel(const float* __restrict__ W1, const float* __restrict__ W2,
+                                                       const float* __restrict__ W3, const float* __restrict__ W4,
+                                                       const float* __restrict__ W5, half_t* __restrict__ wpack) {
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= N_ALL_FRAGS * 64 * 8) return;
+    const int j = tid & 7, lane = (tid >> 3) & 63, frag = tid >> 9;
+    const int i = lane & 15, g = lane >> 4;
+    float v = 0.0f;
+    if (frag < F_W2) {                                  // W1 [64][32], plain k
+        const int mt = frag - F_W1;
+        v = W1[(16 * mt + i) * 32 + 8 * g + j];
+    } else if (frag < F_W3) {                           // W2 [16][64], chained over a1
+        const int s = frag - F_W2;
+        v = W2[i * 64 + chain_k(s, g, j)];
+    } else if (frag < F_W4) {                           // W3 [64][32], k = [SH(4g+j) | 16 + h(4g+j-4)]
+        const int mt = frag - F_W3;
+        const int k = (j < 4) ? (4 * g + j) : (16 + 4 * g + (j - 4));
+        v = W3[(16 * mt + i) * 32 + k];
+    } else if (frag < F_W5) {                           // W4 [64][64], chained over a3
+        const int mt = (frag - F_W4) >> 1, s = (frag - F_W4) & 1;
+        v = W4[(16 * mt + i) * 64 + chain_k(s, g, j)];
+    } else if (frag < B_W5T) {                          // W5 [3][64] (rows >= 3 are padding), chained over a4
+        const int s = frag - F_W5;
+        v = (i < 3) ? W5[i * 64 + chain_k(s, g, j)] : 0.0f;
+    } else if (frag < B_W4T) {                          // W5^T: rows = a4 features, k = dz5 (slot j<4 <-> 4g+j)
+        const int mt = frag - B_W5T;
+        const int k = 4 * g + j;
+        v = (j < 4 && k < 3) ? W5[k * 64 + 16 * mt + i] : 0.0f;
+    } else if (frag < B_W3T) {                          // W4^T: rows = a3 features, k = dz4 chained
+        const int mt = (frag - B_W4T) >> 1, s = (frag - B_W4T) & 1;
+        v = W4[chain_k(s, g, j) * 64 + 16 * mt + i];
+    } else if (frag < B_W2T) {                          // W3^T restricted to the h inputs (16..31), k = dz3 chained
+        const int s = frag - B_W3T;
+        v = W3[chain_k(s, g, j) * 32 + 16 + i];
+    } else if (frag < B_W1T) {                          // W2^T: rows = a1 features, k = dh (slot j<4 <-> 4g+j)
+        const int mt = frag - B_W2T;
+        v = (j < 4) ? W2[(4 * g + j) * 64 + 16 * mt + i] : 0.0f;
+    } else {                                            // W1^T: rows = enc features, k = dz1 chained
+        const int mt = (frag - B_W1T) >> 1, s = (frag - B_W1T) & 1;
+        v = W1[chain_k(s, g, j) * 32 + 16 * mt + i];
+    }
+    wpack[tid] = (half_t)v;
+}
+
+// ---- per-lane helpers -------------------------------------------------------------------------------------
+__device__ __forceinline__ half4 relu_h4(const floatx4& d) {
+    half4 r;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { half_t h = (half_t)d[k]; r[k] = h > (half_t)0 ? h : (half_t)0; }
+    return r;
+}
+__device__ __forceinline__ half4 to_h4(const floatx4& d) {
+    half4 r;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r[k] = (half_t)d[k];
+    return r;
+}
+__device__ __forceinline__ half8 cat_h4(const half4& a, const half4& b) {
+    half8 r;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { r[k] = a[k]; r[4 + k] = b[k]; }
+    return r;
+}
+__device__ __forceinline__ half4 mask_h4(const floatx4& d, const half4& act) {   // dz = (act > 0) ? f16(d) : 0
+    half4 r;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r[k] = act[k] > (half_t)0 ? (half_t)d[k] : (half_t)0;
+    return r;
+}
+
+// SH coefficients 4g..4g+3 of the encoded direction (x,y,z) = (d/|d| + 1)/2, spherical_harmonics.py:27-42
+__device__ __forceinline__ half4 sh_quad(int g, float x, float y, float z) {
+    const float xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;
+    float a, b, c, d;
+    if (g == 0) {
+        a = 0.28209479177387814f; b = -0.48860251190291987f * y; c = 0.48860251190291987f * z; d = -0.48860251190291987f * x;
+    } else if (g == 1) {
+        a = 1.0925484305920792f * xy; b = -1.0925484305920792f * yz; c = 0.94617469575755997f * z2 - 0.31539156525251999f;
+        d = -1.0925484305920792f * xz;
+    } else if (g == 2) {
+        a = 0.54627421529603959f * x2 - 0.54627421529603959f * y2; b = 0.59004358992664352f * y * (-3.0f * x2 + y2);
+        c = 2.8906114426405538f * xy * z; d = 0.45704579946446572f * y * (1.0f - 5.0f * z2);
+    } else {
+        a = 0.3731763325901154f * z * (5.0f * z2 - 3.0f); b = 0.45704579946446572f * x * (1.0f - 5.0f * z2);
+        c = 1.4453057213202769f * z * (x2 - y2); d = 0.59004358992664352f * x * (-x2 + 3.0f * y2);
+    }
+    half4 r;
+    r[0] = (half_t)a; r[1] = (half_t)b; r[2] = (half_t)c; r[3] = (half_t)d;
+    return r;
+}
+
+struct TileFwd {            // everything the backward needs from the recomputed forward of one 16-sample tile
+    half8 b_enc;            // layer-1 B operand (enc features 8g..8g+7)
+    half4 a1[4];            // relu(L1), D layout (feature 16mt+4g+r)
+    half4 h;                // L2 output (feature 4g+r)
+    half8 b_in3;            // [SH(4g..4g+3) | h(4g..4g+3)]
+    half4 a3[4], a4[4];
+    half4 rgb;              // sigmoid(L5) rows 4g+r (only g==0, r<3 meaningful)
+    float sigma;            // exp(h0), valid on g==0 lanes
+};
+
+__device__ __forceinline__ const half8& wfrag(const half8* __restrict__ wl, int id, int lane) { return wl[id * 64 + lane]; }
+
+// forward of one tile; wl = packed weight image in LDS
+template <bool COLOR>
+__device__ __forceinline__ void tile_forward(const half8* __restrict__ wl, int lane, int g, const float* __restrict__ enc_row,
+                                             float dx, float dy, float dz, bool valid, TileFwd& t) {
+    const floatx4 zero = {0.f, 0.f, 0.f, 0.f};
+    if (valid) {
+        const float4 e0 = *reinterpret_cast<const float4*>(enc_row + 8 * g);
+        const float4 e1 = *reinterpret_cast<const float4*>(enc_row + 8 * g + 4);
+        t.b_enc[0] = (half_t)e0.x; t.b_enc[1] = (half_t)e0.y; t.b_enc[2] = (half_t)e0.z; t.b_enc[3] = (half_t)e0.w;
+        t.b_enc[4] = (half_t)e1.x; t.b_enc[5] = (half_t)e1.y; t.b_enc[6] = (half_t)e1.z; t.b_enc[7] = (half_t)e1.w;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t.b_enc[k] = (half_t)0;
+    }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) t.a1[mt] = relu_h4(NGP_MFMA(wfrag(wl, F_W1 + mt, lane), t.b_enc, zero));
+    floatx4 d2 = NGP_MFMA(wfrag(wl, F_W2 + 0, lane), cat_h4(t.a1[0], t.a1[1]), zero);
+    d2 = NGP_MFMA(wfrag(wl, F_W2 + 1, lane), cat_h4(t.a1[2], t.a1[3]), d2);
+    t.h = to_h4(d2);
+    t.sigma = expf((float)t.h[0]);                                         // TruncExp forward, fp32
+    if (COLOR) {
+        const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);       // d / ||d||, networks.py:162
+        const float x = (dx * inv + 1.0f) / 2.0f, y = (dy * inv + 1.0f) / 2.0f, z = (dz * inv + 1.0f) / 2.0f;   // :163
+        t.b_in3 = cat_h4(sh_quad(g, x, y, z), t.h);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) t.a3[mt] = relu_h4(NGP_MFMA(wfrag(wl, F_W3 + mt, lane), t.b_in3, zero));
+        const half8 b30 = cat_h4(t.a3[0], t.a3[1]), b31 = cat_h4(t.a3[2], t.a3[3]);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            floatx4 d4 = NGP_MFMA(wfrag(wl, F_W4 + 2 * mt, lane), b30, zero);
+            d4 = NGP_MFMA(wfrag(wl, F_W4 + 2 * mt + 1, lane), b31, d4);
+            t.a4[mt] = relu_h4(d4);
+        }
+        floatx4 d5 = NGP_MFMA(wfrag(wl, F_W5 + 0, lane), cat_h4(t.a4[0], t.a4[1]), zero);
+        d5 = NGP_MFMA(wfrag(wl, F_W5 + 1, lane), cat_h4(t.a4[2], t.a4[3]), d5);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float c = (float)(half_t)d5[r];                          // Linear output is fp16
+            t.rgb[r] = (half_t)(1.0f / (1.0f + expf(-c)));                 // nn.Sigmoid on an fp16 tensor
+        }
+    }
+}
+
+__device__ __forceinline__ void load_wpack(const half_t* __restrict__ wpack, half8* __restrict__ wl, int n_frags) {
+    const uint4* src = reinterpret_cast<const uint4*>(wpack);
+    uint4* dst = reinterpret_cast<uint4*>(wl);
+    for (int k = threadIdx.x; k < n_frags * 64; k += blockDim.x) dst[k] = src[k];
+    __syncthreads();
+}
+
+// ---- forward kernel: persistent waves, 32 samples (two interleaved 16-sample tiles) per trip ------------------
+template <bool COLOR>
+__global__ void __launch_bounds__(256) mlp_fwd_kernel(const float* __restrict__ enc, const float* __restrict__ dirs,
+                                                      const half_t* __restrict__ wpack, int S, float* __restrict__ sigmas,
+                                                      half_t* __restrict__ rgbs) {
+    __shared__ half8 wl[N_FWD_FRAGS * 64];
+    load_wpack(wpack, wl, COLOR ? N_FWD_FRAGS : F_W3);
+    const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
+    const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), n_waves = gridDim.x * (blockDim.x >> 6);
+    const int n_iter = (S + 31) >> 5;
+    for (int it = wave; it < n_iter; it += n_waves) {
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const int smp = it * 32 + 2 * n + tt;
+            const bool valid = smp < S;
+            float dx = 0.f, dy = 0.f, dz = 1.f;
+            if (COLOR && valid) { dx = dirs[3 * (size_t)smp]; dy = dirs[3 * (size_t)smp + 1]; dz = dirs[3 * (size_t)smp + 2]; }
+            TileFwd t;
+            tile_forward<COLOR>(wl, lane, g, enc + (size_t)smp * 32, dx, dy, dz, valid, t);
+            if (valid && g == 0) {
+                sigmas[smp] = t.sigma;
+                if (COLOR) { rgbs[3 * (size_t)smp] = t.rgb[0]; rgbs[3 * (size_t)smp + 1] = t.rgb[1]; rgbs[3 * (size_t)smp + 2] = t.rgb[2]; }
+            }
+        }
+    }
+}
+
+// ---- backward kernel ------------------------------------------------------------------------------------------
+constexpr int T_STRIDE = 20;              // uint32 per transposed row: 16 sample pairs + 4 pad (80 B rows: conflict-free b128 reads)
+constexpr int T_ROWS = 128;               // dZ rows [0,64) + X rows [64,128)
+constexpr int N_W = 2048 + 1024 + 2048 + 4096 + 192;    // 9408 weights
+constexpr int OFF_W1 = 0, OFF_W2 = 2048, OFF_W3 = 3072, OFF_W4 = 5120, OFF_W5 = 9216;
+
+__device__ __forceinline__ uint32_t pack2(half_t a, half_t b) {
+    return (uint32_t)__builtin_bit_cast(unsigned short, a) | ((uint32_t)__builtin_bit_cast(unsigned short, b) << 16);
+}
+
+// write a D-layout quantity (feature 16mt+4g+r, r=0..3) of both tiles into transposed rows [row0 + feature]
+__device__ __forceinline__ void t_store_d(uint32_t* T, int row0, int mt, int g, int n, const half4& v0, const half4& v1) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) T[(row0 + 16 * mt + 4 * g + r) * T_STRIDE + n] = pack2(v0[r], v1[r]);
+}
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ half8 t_load(const uint32_t* T, int row, int g) {
+    const u32x4 v = *reinterpret_cast<const u32x4*>(T + row * T_STRIDE + 4 * g);   // samples 8g..8g+7 of `row`
+    return __builtin_bit_cast(half8, v);
+}
+__device__ __forceinline__ void wave_lds_fence() {      // same-wave LDS ops retire in order; this only pins the compiler
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+}
+
+__global__ void __launch_bounds__(256, 1) mlp_bwd_kernel(const float* __restrict__ enc, const float* __restrict__ dirs,
+                                                         const half_t* __restrict__ wpack, const float* __restrict__ dsigmas,
+                                                         const half_t* __restrict__ drgbs, int S, float* __restrict__ d_enc,
+                                                         float* __restrict__ dW /*[N_W], pre-zeroed or accumulating*/) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[N_ALL_FRAGS * 64 * 16 + 4 * T_ROWS * T_STRIDE * 4];
+    half8* wl = reinterpret_cast<half8*>(smem);
+    load_wpack(wpack, wl, N_ALL_FRAGS);
+    const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
+    uint32_t* T = reinterpret_cast<uint32_t*>(smem + N_ALL_FRAGS * 64 * 16) + wv * (T_ROWS * T_STRIDE);
+    const int wave = blockIdx.x * (blockDim.x >> 6) + wv, n_waves = gridDim.x * (blockDim.x >> 6);
+    const int n_iter = (S + 31) >> 5;
+    const floatx4 zero = {0.f, 0.f, 0.f, 0.f};
+    const half4 hzero = {(half_t)0, (half_t)0, (half_t)0, (half_t)0};
+
+    floatx4 acc1[4][2], acc2[4], acc3[4][2], acc4[4][4], acc5[4];       // dW tiles: [out tile][in tile]
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        acc2[a] = zero; acc5[a] = zero;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) { acc1[a][b] = zero; acc3[a][b] = zero; }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc4[a][b] = zero;
+    }
+
+    for (int it = wave; it < n_iter; it += n_waves) {
+        TileFwd t[2];
+        half4 dz5[2], dz4[2][4], dz3[2][4], dz2[2], dz1[2][4];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const int smp = it * 32 + 2 * n + tt;
+            const bool valid = smp < S;
+            float dx = 0.f, dy = 0.f, dzz = 1.f;
+            if (valid) { dx = dirs[3 * (size_t)smp]; dy = dirs[3 * (size_t)smp + 1]; dzz = dirs[3 * (size_t)smp + 2]; }
+            tile_forward<true>(wl, lane, g, enc + (size_t)smp * 32, dx, dy, dzz, valid, t[tt]);
+            // ---- upstream gradients (loss-scaled by GradScaler, like the fp16 grads torch would see) ----
+            dz5[tt] = hzero;
+            float dsig = 0.0f;
+            if (valid && g == 0) {
+                dsig = dsigmas[smp];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const float y = (float)t[tt].rgb[r];
+                    dz5[tt][r] = (half_t)((float)drgbs[3 * (size_t)smp + r] * ((1.0f - y) * y));      // sigmoid_backward
+                }
+            }
+            const half8 b_dz5 = cat_h4(dz5[tt], hzero);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+                dz4[tt][mt] = mask_h4(NGP_MFMA(wfrag(wl, B_W5T + mt, lane), b_dz5, zero), t[tt].a4[mt]);
+            const half8 b40 = cat_h4(dz4[tt][0], dz4[tt][1]), b41 = cat_h4(dz4[tt][2], dz4[tt][3]);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                floatx4 d = NGP_MFMA(wfrag(wl, B_W4T + 2 * mt, lane), b40, zero);
+                d = NGP_MFMA(wfrag(wl, B_W4T + 2 * mt + 1, lane), b41, d);
+                dz3[tt][mt] = mask_h4(d, t[tt].a3[mt]);
+            }
+            floatx4 dh = NGP_MFMA(wfrag(wl, B_W3T + 0, lane), cat_h4(dz3[tt][0], dz3[tt][1]), zero);
+            dh = NGP_MFMA(wfrag(wl, B_W3T + 1, lane), cat_h4(dz3[tt][2], dz3[tt][3]), dh);
+            dz2[tt] = to_h4(dh);
+            if (g == 0) {                                                     // TruncExp backward, networks.py:28-30
+                const float h0 = (float)t[tt].h[0];
+                const half_t gs = (half_t)(dsig * expf(fminf(fmaxf(h0, -15.0f), 15.0f)));
+                dz2[tt][0] = (half_t)((float)dz2[tt][0] + (float)gs);
+            }
+            const half8 b_dz2 = cat_h4(dz2[tt], hzero);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+                dz1[tt][mt] = mask_h4(NGP_MFMA(wfrag(wl, B_W2T + mt, lane), b_dz2, zero), t[tt].a1[mt]);
+            const half8 b10 = cat_h4(dz1[tt][0], dz1[tt][1]), b11 = cat_h4(dz1[tt][2], dz1[tt][3]);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                floatx4 d = NGP_MFMA(wfrag(wl, B_W1T + 2 * mt, lane), b10, zero);
+                d = NGP_MFMA(wfrag(wl, B_W1T + 2 * mt + 1, lane), b11, d);
+                if (valid) *reinterpret_cast<float4*>(d_enc + (size_t)smp * 32 + 16 * mt + 4 * g) = make_float4(d[0], d[1], d[2], d[3]);
+            }
+        }
+        // ---- weight gradients: one layer at a time through the per-wave transposed LDS tile ----
+        // layer 5: dZ5 [16 rows] x a4 [64 rows]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) T[(4 * g + r) * T_STRIDE + n] = pack2(dz5[0][r], dz5[1][r]);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) t_store_d(T, 64, mt, g, n, t[0].a4[mt], t[1].a4[mt]);
+        wave_lds_fence();
+        {
+            const half8 a = t_load(T, n, g);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc5[nt] = NGP_MFMA(a, t_load(T, 64 + 16 * nt + n, g), acc5[nt]);
+        }
+        wave_lds_fence();
+        // layer 4: dZ4 [64] x a3 [64]
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) { t_store_d(T, 0, mt, g, n, dz4[0][mt], dz4[1][mt]); t_store_d(T, 64, mt, g, n, t[0].a3[mt], t[1].a3[mt]); }
+        wave_lds_fence();
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const half8 a = t_load(T, 16 * mt + n, g);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc4[mt][nt] = NGP_MFMA(a, t_load(T, 64 + 16 * nt + n, g), acc4[mt][nt]);
+        }
+        wave_lds_fence();
+        // layer 3: dZ3 [64] x in3 [32 rows: SH 0..15 | h 16..31]
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) t_store_d(T, 0, mt, g, n, dz3[0][mt], dz3[1][mt]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int row = (j < 4) ? (4 * g + j) : (16 + 4 * g + (j - 4));
+            T[(64 + row) * T_STRIDE + n] = pack2(t[0].b_in3[j], t[1].b_in3[j]);
+        }
+        wave_lds_fence();
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const half8 a = t_load(T, 16 * mt + n, g);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) acc3[mt][nt] = NGP_MFMA(a, t_load(T, 64 + 16 * nt + n, g), acc3[mt][nt]);
+        }
+        wave_lds_fence();
+        // layer 2: dZ2 [16] x a1 [64]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) T[(4 * g + r) * T_STRIDE + n] = pack2(dz2[0][r], dz2[1][r]);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) t_store_d(T, 64, mt, g, n, t[0].a1[mt], t[1].a1[mt]);
+        wave_lds_fence();
+        {
+            const half8 a = t_load(T, n, g);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc2[nt] = NGP_MFMA(a, t_load(T, 64 + 16 * nt + n, g), acc2[nt]);
+        }
+        wave_lds_fence();
+        // layer 1: dZ1 [64] x enc [32]
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) t_store_d(T, 0, mt, g, n, dz1[0][mt], dz1[1][mt]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) T[(64 + 8 * g + j) * T_STRIDE + n] = pack2(t[0].b_enc[j], t[1].b_enc[j]);
+        wave_lds_fence();
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const half8 a = t_load(T, 16 * mt + n, g);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) acc1[mt][nt] = NGP_MFMA(a, t_load(T, 64 + 16 * nt + n, g), acc1[mt][nt]);
+        }
+        wave_lds_fence();
+    }
+
+    // ---- block reduction of dW through LDS float atomics, then line-coalesced global atomics ----
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);                       // reuses the weight image (>= N_W floats)
+    for (int k = threadIdx.x; k < N_W; k += blockDim.x) red[k] = 0.0f;
+    __syncthreads();
+    // D layout of a dW tile: row (out) = 16mt + 4g + r, col (in) = 16nt + n
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int o = 16 * mt + 4 * g + r;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                atomicAdd(&red[OFF_W1 + o * 32 + 16 * nt + n], acc1[mt][nt][r]);
+                atomicAdd(&red[OFF_W3 + o * 32 + 16 * nt + n], acc3[mt][nt][r]);
+            }
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) atomicAdd(&red[OFF_W4 + o * 64 + 16 * nt + n], acc4[mt][nt][r]);
+        }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int o = 4 * g + r;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            atomicAdd(&red[OFF_W2 + o * 64 + 16 * nt + n], acc2[nt][r]);
+            if (o < 3) atomicAdd(&red[OFF_W5 + o * 64 + 16 * nt + n], acc5[nt][r]);
+        }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < N_W; k += blockDim.x) {
+        const float v = red[k];
+        if (v != 0.0f) unsafeAtomicAdd(dW + k, v);
+    }
+}
+
+}  // namespace ngp
+
+using namespace ngp;
+
+extern "C" {
+
+int ngp_mlp_wpack_halfs(void) { return N_ALL_FRAGS * 64 * 8; }
+
+int ngp_mlp_pack(const float* W1, const float* W2, const float* W3, const float* W4, const float* W5, uint16_t* wpack, void* stream) {
+    const int total = N_ALL_FRAGS * 64 * 8;
+    hipLaunchKernelGGL(mlp_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, W1, W2, W3, W4, W5,
+                       (half_t*)wpack);
+    NGP_LAUNCH_CHECK();
+    return 0;
+}
+
+static inline int mlp_grid(int S) {
+    const int iters = (S + 31) / 32;
+    int blocks = (iters + 3) / 4;
+    if (blocks > 512) blocks = 512;
+    return blocks < 1 ? 1 : blocks;
+}
+
+int ngp_mlp_fwd(const float* enc, const float* dirs, const uint16_t* wpack, int n, float* sigmas, uint16_t* rgbs, void* stream) {
+    if (n <= 0) return 0;
+    if (dirs && rgbs)
+        hipLaunchKernelGGL(mlp_fwd_kernel<true>, dim3(mlp_grid(n)), dim3(256), 0, (hipStream_t)stream, enc, dirs,
+                           (const half_t*)wpack, n, sigmas, (half_t*)rgbs);
+    else
+        hipLaunchKernelGGL(mlp_fwd_kernel<false>, dim3(mlp_grid(n)), dim3(256), 0, (hipStream_t)stream, enc, (const float*)nullptr,
+                           (const half_t*)wpack, n, sigmas, (half_t*)nullptr);
+    NGP_LAUNCH_CHECK();
+    return 0;
+}
+
+int ngp_mlp_bwd(const float* enc, const float* dirs, const uint16_t* wpack, const float* dsigmas, const uint16_t* drgbs, int n,
+                float* d_enc, float* dW, void* stream) {
+    if (n <= 0) return 0;
+    int blocks = ((n + 31) / 32 + 3) / 4;
+    if (blocks > 256) blocks = 256;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(mlp_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, enc, dirs, (const half_t*)wpack, dsigmas,
+                       (const half_t*)drgbs, n, d_enc, dW);
+    NGP_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

@@ -9,6 +9,9 @@ import numpy as np
 import torch
 from torch import nn
 
+import os
+
+from ngp_hip import ops as _ops
 from .rendering import NEAR_DISTANCE
 from .spherical_harmonics import DirEncoder
 from .utils import morton3D, morton3D_invert, packbits
@@ -29,6 +32,31 @@ class TruncExp(torch.autograd.Function):
     def backward(ctx, g):
         (x,) = ctx.saved_tensors
         return g * torch.exp(x.clamp(-15, 15))
+
+
+class _FusedShade(torch.autograd.Function):
+    """xyz_encoder + TruncExp + direction normalisation + SH16 + rgb_net in one MFMA kernel each way
+    (ngp_mlp_fwd / ngp_mlp_bwd).  Numerically this is the autocast(fp16) formulation of reference
+    networks.py:136-166: fp16 operands and layer outputs, fp32 accumulation, fp32 exp."""
+
+    @staticmethod
+    def forward(ctx, enc, dirs, w1, w2, w3, w4, w5):
+        wpack = _ops.mlp_pack((w1, w2, w3, w4, w5))
+        sigmas, rgbs = _ops.mlp_fwd(enc, dirs, wpack)
+        ctx.save_for_backward(enc, dirs, wpack)
+        ctx.set_materialize_grads(False)
+        return sigmas, rgbs
+
+    @staticmethod
+    def backward(ctx, g_sigmas, g_rgbs):
+        enc, dirs, wpack = ctx.saved_tensors
+        n = enc.shape[0]
+        g_sigmas = torch.zeros(n, device=enc.device) if g_sigmas is None else g_sigmas.contiguous().float()
+        g_rgbs = torch.zeros(n, 3, device=enc.device, dtype=torch.float16) if g_rgbs is None \
+            else g_rgbs.contiguous().to(torch.float16)
+        d_enc, dW = _ops.mlp_bwd(enc, dirs, wpack, g_sigmas, g_rgbs)
+        grads = [g.view(shape) for g, shape in zip(dW.split(_ops.MLP_SPLITS), _ops.MLP_SHAPES)]
+        return (d_enc, None, *grads)
 
 
 def _cell_coords(grid_size):
@@ -76,17 +104,36 @@ class NGP(nn.Module):
                            net_depth=rgb_net_depth, net_width=rgb_net_width, bias_enabled=False,
                            output_activation=nn.Sigmoid())
         self.render_func = VolumeRenderer()
+        # the fused MFMA MLP covers exactly the default architecture; anything else runs the torch layers
+        self.use_fused_mlp = (os.environ.get("NGP_FUSED_MLP", "1") != "0" and self.pos_encoder.out_dim == 32
+                              and xyz_net_width == 64 and xyz_net_depth == 1 and xyz_net_out_dim == 16
+                              and rgb_net_depth == 2 and rgb_net_width == 64)
+
+    def _mlp_weights(self):
+        return (self.xyz_encoder.hidden_layers[0].weight, self.xyz_encoder.output_layer.weight,
+                self.rgb_net.hidden_layers[0].weight, self.rgb_net.hidden_layers[1].weight, self.rgb_net.output_layer.weight)
+
+    def _fused_ok(self, x):
+        """Fused path = the fp16-autocast numerics of the reference's training/eval loops (train.py:177,250)."""
+        return self.use_fused_mlp and x.is_cuda and torch.is_autocast_enabled()
 
     # ------------------------------------------------------------------------------------------ shading
     def density(self, x, return_feat=False):
         """x: [N,3] in [-scale, scale] -> sigmas [N] (and the 16-wide geometry feature)."""
         x = (x - self.xyz_min) / (self.xyz_max - self.xyz_min)
+        if not return_feat and not torch.is_grad_enabled() and self._fused_ok(x):
+            enc = self.pos_encoder(x).float().contiguous()
+            return _ops.mlp_density(enc, _ops.mlp_pack(self._mlp_weights()))
         h = self.xyz_encoder(self.pos_encoder(x))
         sigmas = TruncExp.apply(h[:, 0])
         return (sigmas, h) if return_feat else sigmas
 
     def forward(self, x, d):
         """x: [N,3] positions, d: [N,3] directions -> (sigmas [N], rgbs [N,3])."""
+        if self._fused_ok(x):
+            x01 = (x - self.xyz_min) / (self.xyz_max - self.xyz_min)
+            enc = self.pos_encoder(x01).float().contiguous()
+            return _FusedShade.apply(enc, d.contiguous().float(), *self._mlp_weights())
         sigmas, h = self.density(x, return_feat=True)
         d = d / torch.norm(d, dim=1, keepdim=True)
         sh = self.dir_encoder((d + 1) / 2)

@@ -89,6 +89,10 @@ SIGNATURES = {
     "ngp_composite_train_fwd": [_P, _P, _I, _P, _P, _P, _F, _I, _P, _P, _P, _P, _P, _P],
     "ngp_composite_train_bwd": [_P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _F, _I, _P, _P, _P],
     "ngp_composite_test": [_P, _P, _I, _P, _P, _P, _P, _F, _I, _P, _P, _P, _P],
+    "ngp_mlp_wpack_halfs": [],
+    "ngp_mlp_pack": [_P, _P, _P, _P, _P, _P, _P],
+    "ngp_mlp_fwd": [_P, _P, _P, _I, _P, _P, _P],
+    "ngp_mlp_bwd": [_P, _P, _P, _P, _P, _I, _P, _P, _P],
     "ngp_morton3d": [_P, _I, _P, _P],
     "ngp_morton3d_invert": [_P, _I, _P, _P],
     "ngp_packbits": [_P, _F, _I, _P, _P],

@@ -210,6 +210,56 @@ def composite_test(sigmas, rgbs, deltas, ts, pack_info, alive_indices, T_thresho
                                     _ptr(rgb), _stream()), "ngp_composite_test")
 
 
+# ---------------------------------------------------------------------------------------------------- a-9
+MLP_N_WEIGHTS = 2048 + 1024 + 2048 + 4096 + 192
+MLP_SPLITS = (2048, 1024, 2048, 4096, 192)
+MLP_SHAPES = ((64, 32), (16, 64), (64, 32), (64, 64), (3, 64))
+
+
+def mlp_pack(weights):
+    """weights: the five fp32 nn.Linear weight tensors (W1 [64,32], W2 [16,64], W3 [64,32], W4 [64,64], W5 [3,64])
+    -> fp16 MFMA-fragment image consumed by mlp_fwd / mlp_bwd."""
+    ws = []
+    for w, shape in zip(weights, MLP_SHAPES):
+        if tuple(w.shape) != shape:
+            raise ValueError("fused MLP needs the default architecture; got weight shape %s, want %s" % (tuple(w.shape), shape))
+        ws.append(_dev(w.detach().contiguous(), torch.float32, "mlp weight"))
+    wpack = torch.empty(_lib().ngp_mlp_wpack_halfs(), device=ws[0].device, dtype=torch.float16)
+    check(_lib().ngp_mlp_pack(*[_ptr(w) for w in ws], _ptr(wpack), _stream()), "ngp_mlp_pack")
+    return wpack
+
+
+def mlp_fwd(enc, dirs, wpack):
+    """enc [n,32] f32, dirs [n,3] f32 (raw directions) -> (sigmas [n] f32, rgbs [n,3] f16)."""
+    _dev(enc, torch.float32, "enc"); _dev(dirs, torch.float32, "dirs"); _dev(wpack, torch.float16, "wpack")
+    n = enc.shape[0]
+    sigmas = torch.empty(n, device=enc.device, dtype=torch.float32)
+    rgbs = torch.empty(n, 3, device=enc.device, dtype=torch.float16)
+    check(_lib().ngp_mlp_fwd(_ptr(enc), _ptr(dirs), _ptr(wpack), n, _ptr(sigmas), _ptr(rgbs), _stream()), "ngp_mlp_fwd")
+    return sigmas, rgbs
+
+
+def mlp_density(enc, wpack):
+    """density head only: enc [n,32] f32 -> sigmas [n] f32."""
+    _dev(enc, torch.float32, "enc"); _dev(wpack, torch.float16, "wpack")
+    n = enc.shape[0]
+    sigmas = torch.empty(n, device=enc.device, dtype=torch.float32)
+    check(_lib().ngp_mlp_fwd(_ptr(enc), _ptr(None), _ptr(wpack), n, _ptr(sigmas), _ptr(None), _stream()), "ngp_mlp_fwd")
+    return sigmas
+
+
+def mlp_bwd(enc, dirs, wpack, dsigmas, drgbs):
+    """-> (d_enc [n,32] f32, dW [9408] f32 flat = W1|W2|W3|W4|W5)."""
+    _dev(enc, torch.float32, "enc"); _dev(dirs, torch.float32, "dirs"); _dev(wpack, torch.float16, "wpack")
+    _dev(dsigmas, torch.float32, "dsigmas"); _dev(drgbs, torch.float16, "drgbs")
+    n = enc.shape[0]
+    d_enc = torch.empty_like(enc)
+    dW = torch.zeros(MLP_N_WEIGHTS, device=enc.device, dtype=torch.float32)
+    check(_lib().ngp_mlp_bwd(_ptr(enc), _ptr(dirs), _ptr(wpack), _ptr(dsigmas), _ptr(drgbs), n, _ptr(d_enc), _ptr(dW), _stream()),
+          "ngp_mlp_bwd")
+    return d_enc, dW
+
+
 # ---------------------------------------------------------------------------------------------------- a-10
 def morton3d(coords):
     _dev(coords, torch.int32, "coords")
