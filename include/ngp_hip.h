@@ -88,6 +88,14 @@ int ngp_hash_fwd_f32(const float* xyzs /*[n,3] in [0,1]*/, const float* table,
 int ngp_hash_bwd_f32(const float* xyzs, const float* dout /*[n, L*F]*/,
                      const ngp_hash_levels* lv, int n, float* dtable, void* stream);
 
+/* Sync-free forms used by the fused training step: the sample count is read ON THE DEVICE from n_dev[0] (the
+ * `total` written by ngp_march_train_scan; NULL = use n_max), buffers are sized for n_max, and `normalize` fuses the
+ * caller-side position normalisation (x - lo) / (hi - lo) of modules/networks.py:144 (same two f32 operations). */
+int ngp_hash_fwd_f32_ex(const float* xyzs, const float* table, const ngp_hash_levels* lv, int n_max,
+                        const int32_t* n_dev, int normalize, float lo, float hi, float* out, void* stream);
+int ngp_hash_bwd_f32_ex(const float* xyzs, const float* dout, const ngp_hash_levels* lv, int n_max,
+                        const int32_t* n_dev, int normalize, float lo, float hi, float* dtable, void* stream);
+
 /* ---- a-5  half2 encoder fwd / explicit bwd (modules/hash_encoder_half.py:112-161,164-213) ----
  * table/out/dout/dtable are IEEE binary16 pairs (uint16_t storage). */
 int ngp_hash_fwd_f16(const float* xyzs, const uint16_t* table, const ngp_hash_levels* lv, int n,
@@ -137,6 +145,11 @@ int ngp_mlp_fwd(const float* enc, const float* dirs, const uint16_t* wpack, int 
                 uint16_t* rgbs, void* stream);
 int ngp_mlp_bwd(const float* enc, const float* dirs, const uint16_t* wpack, const float* dsigmas,
                 const uint16_t* drgbs, int n, float* d_enc, float* dW, void* stream);
+
+int ngp_mlp_fwd_ex(const float* enc, const float* dirs, const uint16_t* wpack, int n_max, const int32_t* n_dev,
+                   float* sigmas, uint16_t* rgbs, void* stream);
+int ngp_mlp_bwd_ex(const float* enc, const float* dirs, const uint16_t* wpack, const float* dsigmas,
+                   const uint16_t* drgbs, int n_max, const int32_t* n_dev, float* d_enc, float* dW, void* stream);
 
 /* ---- a-10 morton3D / morton3D_invert / packbits (modules/utils.py:120-169) -------------------- */
 int ngp_morton3d(const int32_t* coords /*[m,3]*/, int m, int32_t* indices, void* stream);

@@ -85,17 +85,26 @@ __device__ __forceinline__ void corners(const LevelLDS& L, int level, int bfhl, 
 }
 
 // ---- fp32 forward -----------------------------------------------------------------------------------
+struct XyzNorm {            // optional fused (x - lo) / (hi - lo) of reference networks.py:144 (same two f32 ops)
+    int enabled;
+    float lo, hi;
+};
+__device__ __forceinline__ float norm01(const XyzNorm& nm, float v) { return nm.enabled ? (v - nm.lo) / (nm.hi - nm.lo) : v; }
+
 template <int F>
 __global__ void __launch_bounds__(256) hash_fwd_f32_kernel(const float* __restrict__ xyzs, const float* __restrict__ table,
-                                                           ngp_hash_levels lv, int n, float* __restrict__ out) {
+                                                           ngp_hash_levels lv, int n, const int32_t* __restrict__ n_dev,
+                                                           XyzNorm nm, float* __restrict__ out) {
     __shared__ LevelLDS L;
     load_levels(lv, L);
+    if (n_dev) n = min(n, *n_dev);
     const int nl = lv.n_levels;
     const long long total = (long long)n * nl;
     for (long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x; gid < total;
          gid += (long long)gridDim.x * blockDim.x) {
         const int i = (int)(gid / nl), level = (int)(gid - (long long)i * nl);
-        const float x = xyzs[3 * (size_t)i], y = xyzs[3 * (size_t)i + 1], z = xyzs[3 * (size_t)i + 2];
+        const float x = norm01(nm, xyzs[3 * (size_t)i]), y = norm01(nm, xyzs[3 * (size_t)i + 1]),
+                    z = norm01(nm, xyzs[3 * (size_t)i + 2]);
         Corners c;
         corners<false>(L, level, lv.begin_fast_hash_level, x, y, z, c);
         float v[8][F];
@@ -130,9 +139,11 @@ __global__ void __launch_bounds__(256) hash_fwd_f32_kernel(const float* __restri
 // Generic-F fallback: one lane per (sample, level), F*8 independent atomics.
 template <int F>
 __global__ void __launch_bounds__(256) hash_bwd_f32_kernel(const float* __restrict__ xyzs, const float* __restrict__ dout,
-                                                           ngp_hash_levels lv, int n, float* __restrict__ dtable) {
+                                                           ngp_hash_levels lv, int n, const int32_t* __restrict__ n_dev,
+                                                           XyzNorm nm, float* __restrict__ dtable) {
     __shared__ LevelLDS L;
     load_levels(lv, L);
+    if (n_dev) n = min(n, *n_dev);
     const int nl = lv.n_levels;
     const long long total = (long long)n * nl;
     for (long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x; gid < total;
@@ -143,7 +154,8 @@ __global__ void __launch_bounds__(256) hash_bwd_f32_kernel(const float* __restri
 #pragma unroll
         for (int f = 0; f < F; ++f) { g[f] = dout[(size_t)gid * F + f]; any |= (g[f] != 0.0f); }
         if (!any) continue;            // samples behind early termination carry exact-zero gradients
-        const float x = xyzs[3 * (size_t)i], y = xyzs[3 * (size_t)i + 1], z = xyzs[3 * (size_t)i + 2];
+        const float x = norm01(nm, xyzs[3 * (size_t)i]), y = norm01(nm, xyzs[3 * (size_t)i + 1]),
+                    z = norm01(nm, xyzs[3 * (size_t)i + 2]);
         Corners c;
         corners<false>(L, level, lv.begin_fast_hash_level, x, y, z, c);
 #pragma unroll
@@ -165,9 +177,11 @@ __global__ void __launch_bounds__(256) hash_bwd_f32_kernel(const float* __restri
 // Summation order differs from a serial loop: tolerance-checked against the oracle (float atomics are
 // order-nondeterministic in the reference too).
 __global__ void __launch_bounds__(256) hash_bwd_f32x2_kernel(const float* __restrict__ xyzs, const float* __restrict__ dout,
-                                                             ngp_hash_levels lv, int n, float* __restrict__ dtable) {
+                                                             ngp_hash_levels lv, int n, const int32_t* __restrict__ n_dev,
+                                                             XyzNorm nm, float* __restrict__ dtable) {
     __shared__ LevelLDS L;
     load_levels(lv, L);
+    if (n_dev) n = min(n, *n_dev);
     const int nl = lv.n_levels, bfhl = lv.begin_fast_hash_level;
     const int lane = threadIdx.x & 63;
     const int s_in = lane >> 2, xb = (lane >> 1) & 1, f = lane & 1;
@@ -177,7 +191,7 @@ __global__ void __launch_bounds__(256) hash_bwd_f32x2_kernel(const float* __rest
         const int i = tile * 16 + s_in;
         const bool valid = i < n;
         float x = 0.f, y = 0.f, z = 0.f;
-        if (valid) { x = xyzs[3 * (size_t)i]; y = xyzs[3 * (size_t)i + 1]; z = xyzs[3 * (size_t)i + 2]; }
+        if (valid) { x = norm01(nm, xyzs[3 * (size_t)i]); y = norm01(nm, xyzs[3 * (size_t)i + 1]); z = norm01(nm, xyzs[3 * (size_t)i + 2]); }
         for (int level = 0; level < nl; ++level) {
             const float g = valid ? dout[(size_t)i * (nl * 2) + level * 2 + f] : 0.0f;
             const float scale = L.scale[level];
@@ -300,16 +314,45 @@ extern "C" {
 
 int ngp_abi_version(void) { return NGP_ABI_VERSION; }
 
-int ngp_hash_fwd_f32(const float* xyzs, const float* table, const ngp_hash_levels* lv, int n, float* out, void* stream) {
-    if (n <= 0) return 0;
+int ngp_hash_fwd_f32_ex(const float* xyzs, const float* table, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev,
+                        int normalize, float lo, float hi, float* out, void* stream) {
+    if (n_max <= 0) return 0;
     if (lv->n_levels < 1 || lv->n_levels > NGP_MAX_LEVELS) return -1;
-    const int grid = grid_for((long long)n * lv->n_levels, 256);
+    const int grid = grid_for((long long)n_max * lv->n_levels, 256);
     hipStream_t s = (hipStream_t)stream;
+    const XyzNorm nm = {normalize, lo, hi};
     switch (lv->n_features) {
-        case 1: hipLaunchKernelGGL(hash_fwd_f32_kernel<1>, dim3(grid), dim3(256), 0, s, xyzs, table, *lv, n, out); break;
-        case 2: hipLaunchKernelGGL(hash_fwd_f32_kernel<2>, dim3(grid), dim3(256), 0, s, xyzs, table, *lv, n, out); break;
-        case 4: hipLaunchKernelGGL(hash_fwd_f32_kernel<4>, dim3(grid), dim3(256), 0, s, xyzs, table, *lv, n, out); break;
-        case 8: hipLaunchKernelGGL(hash_fwd_f32_kernel<8>, dim3(grid), dim3(256), 0, s, xyzs, table, *lv, n, out); break;
+        case 1: hipLaunchKernelGGL(hash_fwd_f32_kernel<1>, dim3(grid), dim3(256), 0, s, xyzs, table, *lv, n_max, n_dev, nm, out); break;
+        case 2: hipLaunchKernelGGL(hash_fwd_f32_kernel<2>, dim3(grid), dim3(256), 0, s, xyzs, table, *lv, n_max, n_dev, nm, out); break;
+        case 4: hipLaunchKernelGGL(hash_fwd_f32_kernel<4>, dim3(grid), dim3(256), 0, s, xyzs, table, *lv, n_max, n_dev, nm, out); break;
+        case 8: hipLaunchKernelGGL(hash_fwd_f32_kernel<8>, dim3(grid), dim3(256), 0, s, xyzs, table, *lv, n_max, n_dev, nm, out); break;
+        default: return -1;
+    }
+    NGP_LAUNCH_CHECK();
+    return 0;
+}
+
+int ngp_hash_fwd_f32(const float* xyzs, const float* table, const ngp_hash_levels* lv, int n, float* out, void* stream) {
+    return ngp_hash_fwd_f32_ex(xyzs, table, lv, n, nullptr, 0, 0.0f, 1.0f, out, stream);
+}
+
+int ngp_hash_bwd_f32_ex(const float* xyzs, const float* dout, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev,
+                        int normalize, float lo, float hi, float* dtable, void* stream) {
+    if (n_max <= 0) return 0;
+    if (lv->n_levels < 1 || lv->n_levels > NGP_MAX_LEVELS) return -1;
+    const int grid = grid_for((long long)n_max * lv->n_levels, 256);
+    hipStream_t s = (hipStream_t)stream;
+    const XyzNorm nm = {normalize, lo, hi};
+    switch (lv->n_features) {
+        case 1: hipLaunchKernelGGL(hash_bwd_f32_kernel<1>, dim3(grid), dim3(256), 0, s, xyzs, dout, *lv, n_max, n_dev, nm, dtable); break;
+        case 2: {
+            const int tiles = (n_max + 15) / 16;
+            const int g2 = tiles < 4 ? 1 : (tiles / 4 < 8192 ? (tiles + 3) / 4 : 8192);
+            hipLaunchKernelGGL(hash_bwd_f32x2_kernel, dim3(g2), dim3(256), 0, s, xyzs, dout, *lv, n_max, n_dev, nm, dtable);
+            break;
+        }
+        case 4: hipLaunchKernelGGL(hash_bwd_f32_kernel<4>, dim3(grid), dim3(256), 0, s, xyzs, dout, *lv, n_max, n_dev, nm, dtable); break;
+        case 8: hipLaunchKernelGGL(hash_bwd_f32_kernel<8>, dim3(grid), dim3(256), 0, s, xyzs, dout, *lv, n_max, n_dev, nm, dtable); break;
         default: return -1;
     }
     NGP_LAUNCH_CHECK();
@@ -317,24 +360,7 @@ int ngp_hash_fwd_f32(const float* xyzs, const float* table, const ngp_hash_level
 }
 
 int ngp_hash_bwd_f32(const float* xyzs, const float* dout, const ngp_hash_levels* lv, int n, float* dtable, void* stream) {
-    if (n <= 0) return 0;
-    if (lv->n_levels < 1 || lv->n_levels > NGP_MAX_LEVELS) return -1;
-    const int grid = grid_for((long long)n * lv->n_levels, 256);
-    hipStream_t s = (hipStream_t)stream;
-    switch (lv->n_features) {
-        case 1: hipLaunchKernelGGL(hash_bwd_f32_kernel<1>, dim3(grid), dim3(256), 0, s, xyzs, dout, *lv, n, dtable); break;
-        case 2: {
-            const int tiles = (n + 15) / 16;
-            const int g2 = tiles < 4 ? 1 : (tiles / 4 < 8192 ? (tiles + 3) / 4 : 8192);
-            hipLaunchKernelGGL(hash_bwd_f32x2_kernel, dim3(g2), dim3(256), 0, s, xyzs, dout, *lv, n, dtable);
-            break;
-        }
-        case 4: hipLaunchKernelGGL(hash_bwd_f32_kernel<4>, dim3(grid), dim3(256), 0, s, xyzs, dout, *lv, n, dtable); break;
-        case 8: hipLaunchKernelGGL(hash_bwd_f32_kernel<8>, dim3(grid), dim3(256), 0, s, xyzs, dout, *lv, n, dtable); break;
-        default: return -1;
-    }
-    NGP_LAUNCH_CHECK();
-    return 0;
+    return ngp_hash_bwd_f32_ex(xyzs, dout, lv, n, nullptr, 0, 0.0f, 1.0f, dtable, stream);
 }
 
 int ngp_hash_fwd_f16(const float* xyzs, const uint16_t* table, const ngp_hash_levels* lv, int n, uint16_t* out, void* stream) {

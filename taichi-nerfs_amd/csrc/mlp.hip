@@ -209,9 +209,11 @@ __device__ __forceinline__ void load_wpack(const half_t* __restrict__ wpack, hal
 // ---- forward kernel: persistent waves, 32 samples (two interleaved 16-sample tiles) per trip ------------------
 template <bool COLOR>
 __global__ void __launch_bounds__(256) mlp_fwd_kernel(const float* __restrict__ enc, const float* __restrict__ dirs,
-                                                      const half_t* __restrict__ wpack, int S, float* __restrict__ sigmas,
+                                                      const half_t* __restrict__ wpack, int S,
+                                                      const int32_t* __restrict__ n_dev, float* __restrict__ sigmas,
                                                       half_t* __restrict__ rgbs) {
     __shared__ half8 wl[N_FWD_FRAGS * 64];
+    if (n_dev) S = min(S, *n_dev);
     load_wpack(wpack, wl, COLOR ? N_FWD_FRAGS : F_W3);
     const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
     const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), n_waves = gridDim.x * (blockDim.x >> 6);
@@ -260,9 +262,11 @@ __device__ __forceinline__ void wave_lds_fence() {      // same-wave LDS ops ret
 
 __global__ void __launch_bounds__(256, 1) mlp_bwd_kernel(const float* __restrict__ enc, const float* __restrict__ dirs,
                                                          const half_t* __restrict__ wpack, const float* __restrict__ dsigmas,
-                                                         const half_t* __restrict__ drgbs, int S, float* __restrict__ d_enc,
+                                                         const half_t* __restrict__ drgbs, int S,
+                                                         const int32_t* __restrict__ n_dev, float* __restrict__ d_enc,
                                                          float* __restrict__ dW /*[N_W], pre-zeroed or accumulating*/) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[N_ALL_FRAGS * 64 * 16 + 4 * T_ROWS * T_STRIDE * 4];
+    if (n_dev) S = min(S, *n_dev);
     half8* wl = reinterpret_cast<half8*>(smem);
     load_wpack(wpack, wl, N_ALL_FRAGS);
     const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
@@ -459,28 +463,38 @@ static inline int mlp_grid(int S) {
     return blocks < 1 ? 1 : blocks;
 }
 
-int ngp_mlp_fwd(const float* enc, const float* dirs, const uint16_t* wpack, int n, float* sigmas, uint16_t* rgbs, void* stream) {
-    if (n <= 0) return 0;
+int ngp_mlp_fwd_ex(const float* enc, const float* dirs, const uint16_t* wpack, int n_max, const int32_t* n_dev, float* sigmas,
+                   uint16_t* rgbs, void* stream) {
+    if (n_max <= 0) return 0;
     if (dirs && rgbs)
-        hipLaunchKernelGGL(mlp_fwd_kernel<true>, dim3(mlp_grid(n)), dim3(256), 0, (hipStream_t)stream, enc, dirs,
-                           (const half_t*)wpack, n, sigmas, (half_t*)rgbs);
+        hipLaunchKernelGGL(mlp_fwd_kernel<true>, dim3(mlp_grid(n_max)), dim3(256), 0, (hipStream_t)stream, enc, dirs,
+                           (const half_t*)wpack, n_max, n_dev, sigmas, (half_t*)rgbs);
     else
-        hipLaunchKernelGGL(mlp_fwd_kernel<false>, dim3(mlp_grid(n)), dim3(256), 0, (hipStream_t)stream, enc, (const float*)nullptr,
-                           (const half_t*)wpack, n, sigmas, (half_t*)nullptr);
+        hipLaunchKernelGGL(mlp_fwd_kernel<false>, dim3(mlp_grid(n_max)), dim3(256), 0, (hipStream_t)stream, enc,
+                           (const float*)nullptr, (const half_t*)wpack, n_max, n_dev, sigmas, (half_t*)nullptr);
+    NGP_LAUNCH_CHECK();
+    return 0;
+}
+
+int ngp_mlp_fwd(const float* enc, const float* dirs, const uint16_t* wpack, int n, float* sigmas, uint16_t* rgbs, void* stream) {
+    return ngp_mlp_fwd_ex(enc, dirs, wpack, n, nullptr, sigmas, rgbs, stream);
+}
+
+int ngp_mlp_bwd_ex(const float* enc, const float* dirs, const uint16_t* wpack, const float* dsigmas, const uint16_t* drgbs,
+                   int n_max, const int32_t* n_dev, float* d_enc, float* dW, void* stream) {
+    if (n_max <= 0) return 0;
+    int blocks = ((n_max + 31) / 32 + 3) / 4;
+    if (blocks > 256) blocks = 256;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(mlp_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, enc, dirs, (const half_t*)wpack, dsigmas,
+                       (const half_t*)drgbs, n_max, n_dev, d_enc, dW);
     NGP_LAUNCH_CHECK();
     return 0;
 }
 
 int ngp_mlp_bwd(const float* enc, const float* dirs, const uint16_t* wpack, const float* dsigmas, const uint16_t* drgbs, int n,
                 float* d_enc, float* dW, void* stream) {
-    if (n <= 0) return 0;
-    int blocks = ((n + 31) / 32 + 3) / 4;
-    if (blocks > 256) blocks = 256;
-    if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(mlp_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, enc, dirs, (const half_t*)wpack, dsigmas,
-                       (const half_t*)drgbs, n, d_enc, dW);
-    NGP_LAUNCH_CHECK();
-    return 0;
+    return ngp_mlp_bwd_ex(enc, dirs, wpack, dsigmas, drgbs, n, nullptr, d_enc, dW, stream);
 }
 
 }  // extern "C"

@@ -74,6 +74,7 @@ class NGP(nn.Module):
                  rgb_net_width: int = 64):
         super().__init__()
         self.scale = scale
+        self.half_opt = bool(half_opt)
         self.register_buffer('center', torch.zeros(1, 3))
         self.register_buffer('xyz_min', -torch.ones(1, 3) * scale)
         self.register_buffer('xyz_max', torch.ones(1, 3) * scale)
@@ -112,6 +113,11 @@ class NGP(nn.Module):
     def _mlp_weights(self):
         return (self.xyz_encoder.hidden_layers[0].weight, self.xyz_encoder.output_layer.weight,
                 self.rgb_net.hidden_layers[0].weight, self.rgb_net.hidden_layers[1].weight, self.rgb_net.output_layer.weight)
+
+    def fused_train_ok(self, rays):
+        """Whole-render fusion (ngp_hip/fused.py): fp32 hash table + default MLPs + autocast(fp16) numerics."""
+        return (self._fused_ok(rays) and torch.is_grad_enabled() and not self.half_opt
+                and os.environ.get("NGP_FUSED_RENDER", "1") != "0")
 
     def _fused_ok(self, x):
         """Fused path = the fp16-autocast numerics of the reference's training/eval loops (train.py:177,250)."""

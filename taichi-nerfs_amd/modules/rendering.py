@@ -59,6 +59,19 @@ def _render_rays_test(model, rays_o, rays_d, hits_t, exp_step_factor, T_threshol
 
 def _render_rays_train(model, rays_o, rays_d, hits_t, exp_step_factor, T_threshold):
     """march (occupancy-skipping, jittered) -> shade -> differentiable front-to-back compositing."""
+    if getattr(model, 'fused_train_ok', None) is not None and model.fused_train_ok(rays_o):
+        # one autograd node, no host sync; deltas / ts / ws come back padded to the N*MAX_SAMPLES arena
+        # (only rows [0, rm_samples) are live -- rays_a addresses them exactly like the reference)
+        from ngp_hip.fused import FusedTrainRender, RenderConfig
+        cfg = RenderConfig(model, exp_step_factor, T_threshold, MAX_SAMPLES)
+        rgb, opacity, depth, ws, rm_samples, vr_samples, rays_a = FusedTrainRender.apply(
+            rays_o.contiguous().float(), rays_d.contiguous().float(), hits_t, model.pos_encoder.hash_table,
+            *model._mlp_weights(), cfg)
+        rgb = rgb + _background(exp_step_factor, rays_o.device) * (1 - opacity)[:, None]
+        from ngp_hip.fused import TrainArena
+        A = TrainArena.get(rays_o.device, rays_o.shape[0], MAX_SAMPLES)
+        return {'deltas': A.deltas, 'ts': A.ts, 'rm_samples': rm_samples, 'vr_samples': vr_samples, 'opacity': opacity,
+                'depth': depth, 'rgb': rgb, 'ws': ws, 'rays_a': rays_a}
     rays_a, xyzs, dirs, deltas, ts, rm_samples = raymarching_train(
         rays_o, rays_d, hits_t, model.density_bitfield, model.cascades, model.scale, exp_step_factor, model.grid_size,
         MAX_SAMPLES)

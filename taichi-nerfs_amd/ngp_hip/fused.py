@@ -1,0 +1,139 @@
+"""The whole training render (reference modules/rendering.py:161-228 + modules/networks.py:152-166) as ONE autograd
+node over the C ABI, with no host synchronisation and no per-step allocation.
+
+  forward : march (count / scan / write) -> hash-grid encode (position normalisation fused) -> fused MFMA
+            MLP -> front-to-back compositing
+  backward: compositing backward -> fused MLP backward (recompute) -> hash-grid scatter-add
+
+The reference reads the sample total back to the host every step to slice its N*1024 worst-case buffers
+(ray_march.py:187-192).  Here the worst case lives in a persistent arena (N*max_samples rows; 288 GB of HBM make the
+reservation free), every kernel reads the live count from device memory, and nothing in the step waits for the GPU:
+the step can be replayed from a hipGraph (ngp_hip/graph.py)."""
+import ctypes
+
+import torch
+
+from . import lib as _lib_mod
+from .lib import check
+from .ops import MLP_N_WEIGHTS, MLP_SHAPES, MLP_SPLITS, _ptr, _stream
+
+
+class TrainArena:
+    """Capacity-sized, reused buffers of one (device, n_rays, max_samples) training configuration."""
+    _cache = {}
+
+    def __init__(self, device, n_rays, max_samples):
+        cap = n_rays * max_samples
+        f32 = dict(device=device, dtype=torch.float32)
+        self.cap, self.n_rays, self.max_samples = cap, n_rays, max_samples
+        self.stage = torch.empty(cap, 2, **f32)
+        self.counts = torch.empty(n_rays, device=device, dtype=torch.int32)
+        self.xyzs = torch.empty(cap, 3, **f32)
+        self.dirs = torch.empty(cap, 3, **f32)
+        self.deltas = torch.empty(cap, **f32)
+        self.ts = torch.empty(cap, **f32)
+        self.enc = torch.empty(cap, 32, **f32)
+        self.sigmas = torch.empty(cap, **f32)
+        self.rgbs = torch.empty(cap, 3, device=device, dtype=torch.float16)
+        self.ws = torch.empty(cap, **f32)
+        self.d_sigmas = torch.empty(cap, **f32)
+        self.d_rgbs = torch.empty(cap, 3, device=device, dtype=torch.float16)
+        self.d_enc = torch.empty(cap, 32, **f32)
+        self.wpack = torch.empty(_lib_mod.load().ngp_mlp_wpack_halfs(), device=device, dtype=torch.float16)
+
+    @classmethod
+    def get(cls, device, n_rays, max_samples):
+        key = (device.index if device.index is not None else torch.cuda.current_device(), n_rays, max_samples)
+        a = cls._cache.get(key)
+        if a is None:
+            a = cls._cache[key] = TrainArena(device, n_rays, max_samples)
+        return a
+
+
+class FusedTrainRender(torch.autograd.Function):
+    """(rays_o, rays_d, hits_t, hash_table, W1..W5) -> (rgb[N,3], opacity[N], depth[N], ws[cap], rm_samples, vr_samples, rays_a).
+    Differentiable w.r.t. the hash table and the five MLP weights."""
+
+    @staticmethod
+    def forward(ctx, rays_o, rays_d, hits_t, table, w1, w2, w3, w4, w5, cfg):
+        L = _lib_mod.load()
+        dev = rays_o.device
+        n = rays_o.shape[0]
+        st = _stream()
+        A = TrainArena.get(dev, n, cfg.max_samples)
+        i32 = dict(device=dev, dtype=torch.int32)
+        f32 = dict(device=dev, dtype=torch.float32)
+        rays_a = torch.empty(n, 3, **i32)
+        total = torch.empty(1, **i32)
+        noise = torch.rand(n, **f32)                                            # ray_march.py:138
+        check(L.ngp_march_train_count(_ptr(rays_o), _ptr(rays_d), _ptr(hits_t), _ptr(cfg.bitfield), _ptr(noise), cfg.cascades,
+                                      cfg.grid_size, cfg.scale, cfg.exp_step_factor, cfg.max_samples, n, _ptr(A.stage),
+                                      _ptr(A.counts), st), "ngp_march_train_count")
+        check(L.ngp_march_train_scan(_ptr(A.counts), n, _ptr(rays_a), _ptr(total), st), "ngp_march_train_scan")
+        check(L.ngp_march_train_write(_ptr(rays_o), _ptr(rays_d), _ptr(rays_a), _ptr(A.stage), cfg.max_samples, n,
+                                      _ptr(A.xyzs), _ptr(A.dirs), _ptr(A.deltas), _ptr(A.ts), st), "ngp_march_train_write")
+        check(L.ngp_hash_fwd_f32_ex(_ptr(A.xyzs), _ptr(table), ctypes.byref(cfg.levels), A.cap, _ptr(total), 1, cfg.lo, cfg.hi,
+                                    _ptr(A.enc), st), "ngp_hash_fwd_f32_ex")
+        check(L.ngp_mlp_pack(_ptr(w1), _ptr(w2), _ptr(w3), _ptr(w4), _ptr(w5), _ptr(A.wpack), st), "ngp_mlp_pack")
+        check(L.ngp_mlp_fwd_ex(_ptr(A.enc), _ptr(A.dirs), _ptr(A.wpack), A.cap, _ptr(total), _ptr(A.sigmas), _ptr(A.rgbs), st),
+              "ngp_mlp_fwd_ex")
+        vr_per_ray = torch.empty(n, **i32)
+        opacity = torch.empty(n, **f32)
+        depth = torch.empty(n, **f32)
+        rgb = torch.empty(n, 3, **f32)
+        check(L.ngp_composite_train_fwd(_ptr(A.sigmas), _ptr(A.rgbs), 1, _ptr(A.deltas), _ptr(A.ts), _ptr(rays_a),
+                                        cfg.T_threshold, n, _ptr(vr_per_ray), _ptr(opacity), _ptr(depth), _ptr(rgb), _ptr(A.ws),
+                                        st), "ngp_composite_train_fwd")
+        ctx.cfg, ctx.arena, ctx.table_numel = cfg, A, table.numel()
+        ctx.save_for_backward(rays_a, total, opacity, depth, rgb)
+        ctx.set_materialize_grads(False)
+        rm = total[0]
+        vr = vr_per_ray.sum()
+        ctx.mark_non_differentiable(rm, vr, rays_a)
+        return rgb, opacity, depth, A.ws, rm, vr, rays_a
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_opacity, g_depth, g_ws, _g_rm, _g_vr, _g_ra):
+        L = _lib_mod.load()
+        rays_a, total, opacity, depth, rgb = ctx.saved_tensors
+        cfg, A = ctx.cfg, ctx.arena
+        dev = rgb.device
+        n = rays_a.shape[0]
+        st = _stream()
+
+        def f32(g):
+            return None if g is None else g.contiguous().float()
+
+        g_rgb = f32(g_rgb)
+        if g_rgb is None:
+            g_rgb = torch.zeros(n, 3, device=dev, dtype=torch.float32)
+        g_opacity, g_depth, g_ws = f32(g_opacity), f32(g_depth), f32(g_ws)
+        check(L.ngp_composite_train_bwd(_ptr(g_opacity), _ptr(g_depth), _ptr(g_rgb), _ptr(g_ws), _ptr(A.sigmas), _ptr(A.rgbs), 1,
+                                        _ptr(A.deltas), _ptr(A.ts), _ptr(rays_a), _ptr(opacity), _ptr(depth), _ptr(rgb),
+                                        _ptr(A.ws), cfg.T_threshold, n, _ptr(A.d_sigmas), _ptr(A.d_rgbs), st),
+              "ngp_composite_train_bwd")
+        dW = torch.zeros(MLP_N_WEIGHTS, device=dev, dtype=torch.float32)
+        check(L.ngp_mlp_bwd_ex(_ptr(A.enc), _ptr(A.dirs), _ptr(A.wpack), _ptr(A.d_sigmas), _ptr(A.d_rgbs), A.cap, _ptr(total),
+                               _ptr(A.d_enc), _ptr(dW), st), "ngp_mlp_bwd_ex")
+        dtable = torch.zeros(ctx.table_numel, device=dev, dtype=torch.float32)
+        check(L.ngp_hash_bwd_f32_ex(_ptr(A.xyzs), _ptr(A.d_enc), ctypes.byref(cfg.levels), A.cap, _ptr(total), 1, cfg.lo, cfg.hi,
+                                    _ptr(dtable), st), "ngp_hash_bwd_f32_ex")
+        grads = [g.view(shape) for g, shape in zip(dW.split(MLP_SPLITS), MLP_SHAPES)]
+        return (None, None, None, dtable, *grads, None)
+
+
+class RenderConfig:
+    """Scalars + handles the fused step needs from the model (captured once per call; plain Python values so a
+    captured hipGraph bakes them in)."""
+
+    def __init__(self, model, exp_step_factor, T_threshold, max_samples):
+        self.scale = float(model.scale)
+        self.cascades = int(model.cascades)
+        self.grid_size = int(model.grid_size)
+        self.exp_step_factor = float(exp_step_factor)
+        self.T_threshold = float(T_threshold)
+        self.max_samples = int(max_samples)
+        self.bitfield = model.density_bitfield
+        self.levels = model.pos_encoder.levels_struct
+        self.lo = -float(model.scale)            # xyz_min / xyz_max of reference networks.py:57-58
+        self.hi = float(model.scale)
