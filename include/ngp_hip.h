@@ -93,8 +93,11 @@ int ngp_hash_bwd_f32(const float* xyzs, const float* dout /*[n, L*F]*/,
  * caller-side position normalisation (x - lo) / (hi - lo) of modules/networks.py:144 (same two f32 operations). */
 int ngp_hash_fwd_f32_ex(const float* xyzs, const float* table, const ngp_hash_levels* lv, int n_max,
                         const int32_t* n_dev, int normalize, float lo, float hi, float* out, void* stream);
+/* found_inf (nullable): set to 1 when a non-finite incoming gradient is seen -- GradScaler's inf/nan check
+ * (train.py:199) done where the data passes instead of in an extra pass over the 45.7 MB gradient. */
 int ngp_hash_bwd_f32_ex(const float* xyzs, const float* dout, const ngp_hash_levels* lv, int n_max,
-                        const int32_t* n_dev, int normalize, float lo, float hi, float* dtable, void* stream);
+                        const int32_t* n_dev, int normalize, float lo, float hi, float* dtable,
+                        int32_t* found_inf, void* stream);
 
 /* ---- a-5  half2 encoder fwd / explicit bwd (modules/hash_encoder_half.py:112-161,164-213) ----
  * table/out/dout/dtable are IEEE binary16 pairs (uint16_t storage). */
@@ -149,7 +152,21 @@ int ngp_mlp_bwd(const float* enc, const float* dirs, const uint16_t* wpack, cons
 int ngp_mlp_fwd_ex(const float* enc, const float* dirs, const uint16_t* wpack, int n_max, const int32_t* n_dev,
                    float* sigmas, uint16_t* rgbs, void* stream);
 int ngp_mlp_bwd_ex(const float* enc, const float* dirs, const uint16_t* wpack, const float* dsigmas,
-                   const uint16_t* drgbs, int n_max, const int32_t* n_dev, float* d_enc, float* dW, void* stream);
+                   const uint16_t* drgbs, int n_max, const int32_t* n_dev, float* d_enc, float* dW,
+                   int32_t* found_inf, void* stream);
+
+/* ---- f-2  device-resident optimisation-step epilogue (reference train.py:193-201: mse_loss, GradScaler,
+ * Adam(eps=1e-15), CosineAnnealingLR, zero_grad) -- see csrc/optim.hip.
+ * state_f[8] f32: [0] loss scale, [1] 1/scale of this step, [2] lr, [3] 1-beta1^t, [4] sqrt(1-beta2^t), [5] last loss
+ * state_i[8] i32: [0] iteration, [1] optimizer steps taken, [2] growth tracker, [3] found_inf (set by the backward
+ *                 kernels, consumed + cleared by the prologue), [4] skip flag of this step, [5] skipped steps so far */
+int ngp_mse_loss_grad(const float* rgb, const float* opacity, const float* target, float bg, int n_rays,
+                      float* state_f, float* g_rgb, float* g_opacity, void* stream);
+int ngp_train_prologue(float* state_f, int32_t* state_i, float lr0, float eta_min, int t_max, float beta1,
+                       float beta2, float growth, float backoff, int growth_interval, void* stream);
+/* p, g, m, v: n floats each (n % 4 == 0, 16-byte aligned); g is unscaled on the fly and zero-filled. */
+int ngp_adam_step(float* p, float* g, float* m, float* v, long long n, const float* state_f,
+                  const int32_t* state_i, float beta1, float beta2, float eps, void* stream);
 
 /* ---- a-10 morton3D / morton3D_invert / packbits (modules/utils.py:120-169) -------------------- */
 int ngp_morton3d(const int32_t* coords /*[m,3]*/, int m, int32_t* indices, void* stream);

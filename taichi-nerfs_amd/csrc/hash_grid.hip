@@ -178,7 +178,8 @@ __global__ void __launch_bounds__(256) hash_bwd_f32_kernel(const float* __restri
 // order-nondeterministic in the reference too).
 __global__ void __launch_bounds__(256) hash_bwd_f32x2_kernel(const float* __restrict__ xyzs, const float* __restrict__ dout,
                                                              ngp_hash_levels lv, int n, const int32_t* __restrict__ n_dev,
-                                                             XyzNorm nm, float* __restrict__ dtable) {
+                                                             XyzNorm nm, float* __restrict__ dtable,
+                                                             int32_t* __restrict__ found_inf) {
     __shared__ LevelLDS L;
     load_levels(lv, L);
     if (n_dev) n = min(n, *n_dev);
@@ -194,6 +195,7 @@ __global__ void __launch_bounds__(256) hash_bwd_f32x2_kernel(const float* __rest
         if (valid) { x = norm01(nm, xyzs[3 * (size_t)i]); y = norm01(nm, xyzs[3 * (size_t)i + 1]); z = norm01(nm, xyzs[3 * (size_t)i + 2]); }
         for (int level = 0; level < nl; ++level) {
             const float g = valid ? dout[(size_t)i * (nl * 2) + level * 2 + f] : 0.0f;
+            if (found_inf && !isfinite(g)) *found_inf = 1;          // GradScaler's inf/nan check, done where the data passes
             const float scale = L.scale[level];
             const uint32_t res = L.res[level], size = L.size[level], mode = L.mode[level];
             const float px = x * scale + 0.5f, py = y * scale + 0.5f, pz = z * scale + 0.5f;
@@ -337,7 +339,7 @@ int ngp_hash_fwd_f32(const float* xyzs, const float* table, const ngp_hash_level
 }
 
 int ngp_hash_bwd_f32_ex(const float* xyzs, const float* dout, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev,
-                        int normalize, float lo, float hi, float* dtable, void* stream) {
+                        int normalize, float lo, float hi, float* dtable, int32_t* found_inf, void* stream) {
     if (n_max <= 0) return 0;
     if (lv->n_levels < 1 || lv->n_levels > NGP_MAX_LEVELS) return -1;
     const int grid = grid_for((long long)n_max * lv->n_levels, 256);
@@ -348,7 +350,7 @@ int ngp_hash_bwd_f32_ex(const float* xyzs, const float* dout, const ngp_hash_lev
         case 2: {
             const int tiles = (n_max + 15) / 16;
             const int g2 = tiles < 4 ? 1 : (tiles / 4 < 8192 ? (tiles + 3) / 4 : 8192);
-            hipLaunchKernelGGL(hash_bwd_f32x2_kernel, dim3(g2), dim3(256), 0, s, xyzs, dout, *lv, n_max, n_dev, nm, dtable);
+            hipLaunchKernelGGL(hash_bwd_f32x2_kernel, dim3(g2), dim3(256), 0, s, xyzs, dout, *lv, n_max, n_dev, nm, dtable, found_inf);
             break;
         }
         case 4: hipLaunchKernelGGL(hash_bwd_f32_kernel<4>, dim3(grid), dim3(256), 0, s, xyzs, dout, *lv, n_max, n_dev, nm, dtable); break;
@@ -360,7 +362,7 @@ int ngp_hash_bwd_f32_ex(const float* xyzs, const float* dout, const ngp_hash_lev
 }
 
 int ngp_hash_bwd_f32(const float* xyzs, const float* dout, const ngp_hash_levels* lv, int n, float* dtable, void* stream) {
-    return ngp_hash_bwd_f32_ex(xyzs, dout, lv, n, nullptr, 0, 0.0f, 1.0f, dtable, stream);
+    return ngp_hash_bwd_f32_ex(xyzs, dout, lv, n, nullptr, 0, 0.0f, 1.0f, dtable, nullptr, stream);
 }
 
 int ngp_hash_fwd_f16(const float* xyzs, const uint16_t* table, const ngp_hash_levels* lv, int n, uint16_t* out, void* stream) {

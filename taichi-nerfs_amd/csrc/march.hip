@@ -109,11 +109,12 @@ __global__ void __launch_bounds__(256) ray_aabb_kernel(const float* __restrict__
 constexpr int MARCH_GROUP = 16;
 constexpr int ORBIT_BATCH = 8;      // used by the test-time kernel (one lane per ray)
 
+template <bool CONST_DT>
 __global__ void __launch_bounds__(64) march_count_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
-                                                          const float2* __restrict__ hits_t,
-                                                          const uint8_t* __restrict__ bits, const float* __restrict__ noise,
-                                                          MarchParams p, int max_samples, int n_rays,
-                                                          float2* __restrict__ stage, int32_t* __restrict__ counts) {
+                                                         const float2* __restrict__ hits_t,
+                                                         const uint8_t* __restrict__ bits, const float* __restrict__ noise,
+                                                         MarchParams p, int max_samples, int n_rays,
+                                                         float2* __restrict__ stage, int32_t* __restrict__ counts) {
     constexpr int G = MARCH_GROUP;
     constexpr int GROUPS = 64 / G;                          // one wave per block: the barriers below are wave-local
     __shared__ float4 pts[GROUPS][G];                       // (t, dt, skip target, occupied)
@@ -127,6 +128,7 @@ __global__ void __launch_bounds__(64) march_count_kernel(const float* __restrict
     const float2 h = hits_t[rr];
     float t1 = h.x;
     const float t2 = h.y;
+    const float dt_c = calc_dt(0.0f, p.esf, p.dt_min, p.dt_max);                    // the step when exp_step_factor == 0
     if (t1 >= 0.0f) t1 += calc_dt(t1, p.esf, p.dt_min, p.dt_max) * noise[rr];      // ray_march.py:39-41
     float t = t1;                                    // group-uniform: first orbit point of the current batch
     int n = 0;                                       // group-uniform: samples emitted so far
@@ -136,37 +138,58 @@ __global__ void __launch_bounds__(64) march_count_kernel(const float* __restrict
     while (__any(live)) {
         // lane `sub` walks `sub` steps along the orbit from the batch base (exact f32 adds, no closed form)
         float tu = t;
-        for (int k = 0; k < G - 1; ++k)
-            if (k < sub) tu += calc_dt(tu, p.esf, p.dt_min, p.dt_max);
-        const float dtu = calc_dt(tu, p.esf, p.dt_min, p.dt_max);
+        if (CONST_DT) {
+#pragma unroll
+            for (int k = 0; k < G - 1; ++k) tu = (k < sub) ? tu + dt_c : tu;
+        } else {
+            for (int k = 0; k < G - 1; ++k)
+                if (k < sub) tu += calc_dt(tu, p.esf, p.dt_min, p.dt_max);
+        }
+        const float dtu = CONST_DT ? dt_c : calc_dt(tu, p.esf, p.dt_min, p.dt_max);
+        const float t_after = tu + dtu;
         CellProbe c;
         probe_cell(p, o, d, tu, dtu, c);
         const bool occ = live && ((bits[c.idx >> 3] >> (c.idx & 7u)) & 1u);           // ray_march.py:60-61
         const float targ = skip_target(p, d, d_inv, tu, c);                          // ray_march.py:68-71
-        pts[grp][sub] = make_float4(tu, dtu, targ, occ ? 1.0f : 0.0f);
-        __syncthreads();
-        const float t_next_batch = pts[grp][G - 1].x + pts[grp][G - 1].y;
-        int my_slot = -1;
-#pragma unroll
-        for (int u = 0; u < G; ++u) {
-            const float4 q = pts[grp][u];
+        // Fast path: a batch with no occupied point and no skip that reaches past the next orbit point cannot emit,
+        // and leaves behind a skip target that is already behind the next batch -- no need to replay it.
+        const unsigned long long interesting = __ballot(live && (occ || targ > t_after));
+        const float t_last = __shfl(tu, (grp + 1) * G - 1, 64), targ_last = __shfl(targ, (grp + 1) * G - 1, 64);
+        const float t_next_batch = __shfl(t_after, (grp + 1) * G - 1, 64);
+        const bool need = ((interesting >> (grp * G)) & ((1ull << G) - 1ull)) != 0ull;
+        if (!need) {
             if (live) {
-                if (!(q.x < t2)) live = false;                                       // loop head, ray_march.py:46
-                else if (!(q.x < t_target)) {                                        // examined (not inside a skip)
-                    if (q.w != 0.0f) {                                               // occupied: emit, ray_march.py:63-65
-                        if (u == sub) my_slot = n;
-                        n += 1;
-                        t_target = -INFINITY;
-                        if (n >= max_samples) live = false;
-                    } else {
-                        t_target = q.z;                                              // empty: skip, ray_march.py:66-74
+                if (!(t_last < t2)) live = false;                                    // the orbit left the box inside this batch
+                t_target = fmaxf(t_target, targ_last);
+            }
+        }
+        if (interesting != 0ull) {
+            pts[grp][sub] = make_float4(tu, dtu, targ, occ ? 1.0f : 0.0f);
+            __syncthreads();
+            int my_slot = -1;
+            if (need) {
+#pragma unroll
+                for (int u = 0; u < G; ++u) {
+                    const float4 q = pts[grp][u];
+                    if (live) {
+                        if (!(q.x < t2)) live = false;                               // loop head, ray_march.py:46
+                        else if (!(q.x < t_target)) {                                // examined (not inside a skip)
+                            if (q.w != 0.0f) {                                       // occupied: emit, ray_march.py:63-65
+                                if (u == sub) my_slot = n;
+                                n += 1;
+                                t_target = -INFINITY;
+                                if (n >= max_samples) live = false;
+                            } else {
+                                t_target = q.z;                                      // empty: skip, ray_march.py:66-74
+                            }
+                        }
                     }
                 }
             }
+            if (my_slot >= 0) row[my_slot] = make_float2(tu, dtu);
+            __syncthreads();
         }
-        if (my_slot >= 0) row[my_slot] = make_float2(tu, dtu);
         t = t_next_batch;
-        __syncthreads();
     }
     if (has_ray && sub == 0) counts[r] = n;
 }
@@ -308,8 +331,13 @@ int ngp_march_train_count(const float* rays_o, const float* rays_d, const float*
                           int max_samples, int n_rays, float* stage, int32_t* counts, void* stream) {
     if (n_rays <= 0) return 0;
     MarchParams p = make_march_params(cascades, grid_size, scale, exp_step_factor);
-    hipLaunchKernelGGL(march_count_kernel, dim3((n_rays + 64 / MARCH_GROUP - 1) / (64 / MARCH_GROUP)), dim3(64), 0, (hipStream_t)stream, rays_o, rays_d,
-                       (const float2*)hits_t, density_bitfield, noise, p, max_samples, n_rays, (float2*)stage, counts);
+    const dim3 grid((n_rays + 64 / MARCH_GROUP - 1) / (64 / MARCH_GROUP));
+    if (exp_step_factor == 0.0f)
+        hipLaunchKernelGGL(march_count_kernel<true>, grid, dim3(64), 0, (hipStream_t)stream, rays_o, rays_d,
+                           (const float2*)hits_t, density_bitfield, noise, p, max_samples, n_rays, (float2*)stage, counts);
+    else
+        hipLaunchKernelGGL(march_count_kernel<false>, grid, dim3(64), 0, (hipStream_t)stream, rays_o, rays_d,
+                           (const float2*)hits_t, density_bitfield, noise, p, max_samples, n_rays, (float2*)stage, counts);
     NGP_LAUNCH_CHECK();
     return 0;
 }

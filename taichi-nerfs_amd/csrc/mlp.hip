@@ -264,7 +264,8 @@ __global__ void __launch_bounds__(256, 1) mlp_bwd_kernel(const float* __restrict
                                                          const half_t* __restrict__ wpack, const float* __restrict__ dsigmas,
                                                          const half_t* __restrict__ drgbs, int S,
                                                          const int32_t* __restrict__ n_dev, float* __restrict__ d_enc,
-                                                         float* __restrict__ dW /*[N_W], pre-zeroed or accumulating*/) {
+                                                         float* __restrict__ dW /*[N_W], pre-zeroed or accumulating*/,
+                                                         int32_t* __restrict__ found_inf) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[N_ALL_FRAGS * 64 * 16 + 4 * T_ROWS * T_STRIDE * 4];
     if (n_dev) S = min(S, *n_dev);
     half8* wl = reinterpret_cast<half8*>(smem);
@@ -437,6 +438,7 @@ __global__ void __launch_bounds__(256, 1) mlp_bwd_kernel(const float* __restrict
     for (int k = threadIdx.x; k < N_W; k += blockDim.x) {
         const float v = red[k];
         if (v != 0.0f) unsafeAtomicAdd(dW + k, v);
+        if (found_inf && !isfinite(v)) *found_inf = 1;
     }
 }
 
@@ -481,20 +483,20 @@ int ngp_mlp_fwd(const float* enc, const float* dirs, const uint16_t* wpack, int 
 }
 
 int ngp_mlp_bwd_ex(const float* enc, const float* dirs, const uint16_t* wpack, const float* dsigmas, const uint16_t* drgbs,
-                   int n_max, const int32_t* n_dev, float* d_enc, float* dW, void* stream) {
+                   int n_max, const int32_t* n_dev, float* d_enc, float* dW, int32_t* found_inf, void* stream) {
     if (n_max <= 0) return 0;
     int blocks = ((n_max + 31) / 32 + 3) / 4;
     if (blocks > 256) blocks = 256;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(mlp_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, enc, dirs, (const half_t*)wpack, dsigmas,
-                       (const half_t*)drgbs, n_max, n_dev, d_enc, dW);
+                       (const half_t*)drgbs, n_max, n_dev, d_enc, dW, found_inf);
     NGP_LAUNCH_CHECK();
     return 0;
 }
 
 int ngp_mlp_bwd(const float* enc, const float* dirs, const uint16_t* wpack, const float* dsigmas, const uint16_t* drgbs, int n,
                 float* d_enc, float* dW, void* stream) {
-    return ngp_mlp_bwd_ex(enc, dirs, wpack, dsigmas, drgbs, n, nullptr, d_enc, dW, stream);
+    return ngp_mlp_bwd_ex(enc, dirs, wpack, dsigmas, drgbs, n, nullptr, d_enc, dW, nullptr, stream);
 }
 
 }  // extern "C"

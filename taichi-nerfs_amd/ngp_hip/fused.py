@@ -114,10 +114,10 @@ class FusedTrainRender(torch.autograd.Function):
               "ngp_composite_train_bwd")
         dW = torch.zeros(MLP_N_WEIGHTS, device=dev, dtype=torch.float32)
         check(L.ngp_mlp_bwd_ex(_ptr(A.enc), _ptr(A.dirs), _ptr(A.wpack), _ptr(A.d_sigmas), _ptr(A.d_rgbs), A.cap, _ptr(total),
-                               _ptr(A.d_enc), _ptr(dW), st), "ngp_mlp_bwd_ex")
+                               _ptr(A.d_enc), _ptr(dW), _ptr(None), st), "ngp_mlp_bwd_ex")
         dtable = torch.zeros(ctx.table_numel, device=dev, dtype=torch.float32)
         check(L.ngp_hash_bwd_f32_ex(_ptr(A.xyzs), _ptr(A.d_enc), ctypes.byref(cfg.levels), A.cap, _ptr(total), 1, cfg.lo, cfg.hi,
-                                    _ptr(dtable), st), "ngp_hash_bwd_f32_ex")
+                                    _ptr(dtable), _ptr(None), st), "ngp_hash_bwd_f32_ex")
         grads = [g.view(shape) for g, shape in zip(dW.split(MLP_SPLITS), MLP_SHAPES)]
         return (None, None, None, dtable, *grads, None)
 
