@@ -38,6 +38,10 @@ def parse():
     ap.add_argument("--regime", default="lego", choices=["lego", "random50", "ones"],
                     help="occupancy bitfield: trained-Lego fixture (steady state), seeded 50%% (initialisation), all-ones")
     ap.add_argument("--half", action="store_true", help="half2 hash encoder (BASELINE C5)")
+    ap.add_argument("--path", default="trainer", choices=["trainer", "modules"],
+                    help="trainer: ngp_hip.trainer.FusedTrainer (device-resident step); modules: the reference's loop shape "
+                         "(render() through modules/ + torch Adam + torch GradScaler)")
+    ap.add_argument("--graph", action="store_true", help="replay the trainer step from a captured hipGraph (1 GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -152,6 +156,7 @@ def main():
     timer = KernelTimer()
     timer.wrap(ops, "hash_fwd_f32", lambda xyzs, table, lv: xyzs.shape[0])
     timer.wrap(ops, "hash_bwd_f32", lambda xyzs, dout, lv, dtable: xyzs.shape[0])
+    use_trainer = args.path == "trainer" and not args.half
 
     torch.manual_seed(23)                       # identical replicas on every rank (train.py:39-42 uses 23)
     np.random.seed(23)
@@ -166,10 +171,15 @@ def main():
     bits = torch.from_numpy(bits_np).to(dev)
     model.density_bitfield.copy_(bits)
 
-    opt = torch.optim.Adam(model.parameters(), 1e-2, eps=1e-15, fused=True)
-    sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, 20000, 1e-2 / 30)
-    scaler = torch.amp.GradScaler("cuda", init_scale=2.0**16 if args.half else 2.0**19)
-    reducer = GradReducer(model, world) if world > 1 else None
+    trainer = None
+    if use_trainer:
+        from ngp_hip.trainer import FusedTrainer
+        trainer = FusedTrainer(model, lr=1e-2, max_steps=20000, init_scale=2.0**19, world_size=world)
+    else:
+        opt = torch.optim.Adam(model.parameters(), 1e-2, eps=1e-15, fused=True)
+        sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, 20000, 1e-2 / 30)
+        scaler = torch.amp.GradScaler("cuda", init_scale=2.0**16 if args.half else 2.0**19)
+        reducer = GradReducer(model, world) if world > 1 else None
 
     # a pool of synthetic batches resident in HBM before the timed region (rank-dependent shards of one stream)
     n_pool = 8
@@ -181,7 +191,38 @@ def main():
 
     state = {"rm": 0, "vr": 0}
 
+    # the hash-grid launches of the trainer go straight through the C ABI: time them by wrapping the library entries
+    hash_events = {"hash_fwd_f32": [], "hash_bwd_f32": []}
+    if use_trainer:
+        L = lib.load()
+
+        def wrap_entry(name, key):
+            raw = getattr(L, name)
+
+            def timed(*a):
+                if not timer.enabled:
+                    return raw(*a)
+                e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+                e0.record(); rc = raw(*a); e1.record()
+                hash_events[key].append((e0, e1))
+                return rc
+            setattr(L, name, timed)
+        if not args.graph:
+            wrap_entry("ngp_hash_fwd_f32_ex", "hash_fwd_f32")
+            wrap_entry("ngp_hash_bwd_f32_ex", "hash_bwd_f32")
+
+    def trainer_step(i):
+        rays_o, rays_d, target = pool[i % n_pool]
+        if i % 16 == 0:
+            trainer.update_density_grid(0.01 * MAX_SAMPLES / 3**0.5, warmup=False)
+            model.density_bitfield.copy_(bits)          # see the comment in step() below
+        out = trainer.step(rays_o, rays_d, target)
+        state["rm"] += out["rm_samples"][0]
+        state["vr"] += out["vr_per_ray"].sum()
+
     def step(i):
+        if use_trainer:
+            return trainer_step(i)
         rays_o, rays_d, target = pool[i % n_pool]
         with torch.autocast(device_type="cuda", dtype=torch.float16):
             if i % 16 == 0:
@@ -209,7 +250,9 @@ def main():
 
     for i in range(args.warmup):
         step(i)
-    state = {"rm": 0, "vr": 0}
+    if use_trainer and args.graph and world == 1:
+        trainer.capture(args.rays)
+    state["rm"] = 0; state["vr"] = 0
     timer.enabled = True
     fence()
     t0 = time.perf_counter()
@@ -227,14 +270,23 @@ def main():
     total_rays = args.rays * world * args.steps
     if rank == 0:
         ks = timer.summary()
-        dom = max(ks, key=lambda k: ks[k]["total_ms"]) if ks else None
+        if use_trainer:
+            # trainer launches are sized for the arena; the live sample count per step is rm_samples
+            avg_units = rm / max(args.steps, 1)
+            for key, evs in hash_events.items():
+                if evs:
+                    ms = [e0.elapsed_time(e1) for e0, e1 in evs]
+                    ks[key + "(train)"] = {"launches": len(ms), "avg_ms": float(np.mean(ms)), "total_ms": float(np.sum(ms)),
+                                           "avg_units": float(avg_units)}
+        dom = max((k for k in ks if k.split("(")[0] in BYTES_PER_SAMPLE), key=lambda k: ks[k]["total_ms"], default=None)
         roof = None
         if dom is not None:
             k = ks[dom]
-            ach = BYTES_PER_SAMPLE[dom] * k["avg_units"] / (k["avg_ms"] * 1e-3) / 1e9
+            bps = BYTES_PER_SAMPLE[dom.split("(")[0]]
+            ach = bps * k["avg_units"] / (k["avg_ms"] * 1e-3) / 1e9
             roof = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                    "bytes_per_sample": BYTES_PER_SAMPLE[dom], "avg_samples_per_launch": k["avg_units"],
+                    "bytes_per_sample": bps, "avg_samples_per_launch": k["avg_units"],
                     "avg_launch_ms": k["avg_ms"], "launches": k["launches"]}
         out = {
             "metric": "training rays/sec", "value": total_rays / elapsed, "unit": "rays/s", "n_gpus": world,
@@ -246,7 +298,8 @@ def main():
                                    "(fwd+bwd+GradScaler+Adam, grid update every 16 steps)" % (
                                        "/C4" if world > 1 else "", args.rays, "f16" if args.half else "f32", args.regime),
                        "rays_per_gpu": args.rays, "global_batch": args.rays * world,
-                       "parallelism": "ray-sharded dp%d, RCCL all-reduce of %s" % (world, "grads") if world > 1 else "single GPU"},
+                       "parallelism": "ray-sharded dp%d, RCCL all-reduce of %s" % (world, "grads") if world > 1 else "single GPU",
+                       "path": ("FusedTrainer" + ("+hipGraph" if args.graph else "")) if use_trainer else "modules+torch.optim"},
             "samples_per_sec": rm / elapsed, "rm_samples_per_ray": rm / total_rays * world, "vr_samples_per_ray": vr / total_rays * world,
             "kernels": ks, "roofline": roof,
         }

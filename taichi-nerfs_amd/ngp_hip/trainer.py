@@ -1,0 +1,190 @@
+"""FusedTrainer -- one Instant-NGP optimisation step as a fixed sequence of ~18 kernel launches, no host sync.
+
+It performs exactly what the reference's training iteration does (train.py:168-201) for the default model:
+    rays -> render (march, hash encode, MLPs, composite) -> MSE vs target -> backward -> GradScaler -> Adam(eps=1e-15)
+    -> CosineAnnealingLR
+but every piece is a libngp_hip kernel working on persistent buffers:
+  * gradients are accumulated by the backward kernels straight into persistent buffers (no per-step 45.7 MB
+    allocation + memset, no autograd graph), and are unscaled + zeroed inside the Adam pass;
+  * the inf/nan check, loss-scale growth/backoff, learning rate and bias corrections live in a tiny device-side state
+    (ngp_train_prologue), so nothing is read back;
+  * with world_size > 1 each rank renders its own ray shard and the two gradient buffers (+ the inf flag) are
+    all-reduced over RCCL before the optimizer kernels -- the only exchange step.
+The step can be captured into a hipGraph (`capture()`), after which `step()` is a graph replay.
+
+The reference's own loop (torch.optim.Adam + torch GradScaler + autograd through modules/) keeps working on the
+drop-in operators; this class is the MI355X-native fast path that bench.py measures."""
+import ctypes
+import math
+
+import torch
+import torch.distributed as dist
+
+from . import lib as _lib_mod
+from .fused import RenderConfig, TrainArena
+from .lib import check
+from .ops import MLP_N_WEIGHTS, _ptr, _stream
+
+_SF_LOSS_SCALE, _SF_LOSS = 0, 5
+_SI_ITER, _SI_OPT_STEP, _SI_FOUND_INF, _SI_SKIPPED = 0, 1, 3, 5
+
+
+class FusedTrainer:
+
+    def __init__(self, model, lr=1e-2, betas=(0.9, 0.999), eps=1e-15, max_steps=20000, eta_min=None, init_scale=2.0**19,
+                 growth_factor=2.0, backoff_factor=0.5, growth_interval=2000, exp_step_factor=0.0, T_threshold=1e-4,
+                 max_samples=1024, process_group=None, world_size=None):
+        if not model.use_fused_mlp or model.half_opt:
+            raise ValueError("FusedTrainer needs the default architecture with the fp32 hash table")
+        self.model = model
+        self.L = _lib_mod.load()
+        dev = model.pos_encoder.hash_table.device
+        if dev.type != "cuda":
+            raise RuntimeError("FusedTrainer needs the model on a GPU (libngp_hip has no CPU path)")
+        self.dev = dev
+        self.lr0, self.eta_min = float(lr), float(lr / 30 if eta_min is None else eta_min)
+        self.t_max = int(max_steps)
+        self.beta1, self.beta2, self.eps = float(betas[0]), float(betas[1]), float(eps)
+        self.growth, self.backoff, self.growth_interval = float(growth_factor), float(backoff_factor), int(growth_interval)
+        self.exp_step_factor, self.T_threshold, self.max_samples = float(exp_step_factor), float(T_threshold), int(max_samples)
+        self.bg = 1.0 if exp_step_factor == 0 else 0.0                    # rendering.py:219-226
+        self.group = process_group
+        self.world = world_size if world_size is not None else (dist.get_world_size(process_group) if dist.is_initialized() else 1)
+
+        # the five MLP weights become views of one flat buffer so their gradient is the kernel's flat dW
+        ws = list(model._mlp_weights())
+        flat = torch.cat([w.detach().reshape(-1) for w in ws]).contiguous()
+        assert flat.numel() == MLP_N_WEIGHTS
+        off = 0
+        for w in ws:
+            n = w.numel()
+            w.data = flat[off:off + n].view_as(w)
+            off += n
+        self.mlp_flat = flat
+        self.table = model.pos_encoder.hash_table.data
+        f32 = dict(device=dev, dtype=torch.float32)
+        self.table_grad = torch.zeros_like(self.table)
+        self.mlp_grad = torch.zeros(MLP_N_WEIGHTS, **f32)
+        self.table_m, self.table_v = torch.zeros_like(self.table), torch.zeros_like(self.table)
+        self.mlp_m, self.mlp_v = torch.zeros(MLP_N_WEIGHTS, **f32), torch.zeros(MLP_N_WEIGHTS, **f32)
+        self.state_f = torch.zeros(8, **f32)
+        self.state_i = torch.zeros(8, device=dev, dtype=torch.int32)
+        self.state_f[_SF_LOSS_SCALE] = float(init_scale)
+        self._graph = None
+        self._static = None
+        self.stats = {}
+
+    # ------------------------------------------------------------------------------------------------ one step
+    def _launch(self, rays_o, rays_d, target):
+        L, m, st = self.L, self.model, _stream()
+        n = rays_o.shape[0]
+        dev = self.dev
+        cfg = RenderConfig(m, self.exp_step_factor, self.T_threshold, self.max_samples)
+        A = TrainArena.get(dev, n, self.max_samples)
+        i32 = dict(device=dev, dtype=torch.int32)
+        f32 = dict(device=dev, dtype=torch.float32)
+        hits_t = torch.empty(n, 2, **f32)
+        rays_a = torch.empty(n, 3, **i32)
+        total = torch.empty(1, **i32)
+        vr_per_ray = torch.empty(n, **i32)
+        opacity, depth, rgb = torch.empty(n, **f32), torch.empty(n, **f32), torch.empty(n, 3, **f32)
+        g_rgb, g_op = torch.empty(n, 3, **f32), torch.empty(n, **f32)
+        noise = torch.rand(n, **f32)                                                        # ray_march.py:138
+        ws = self.model._mlp_weights()
+        check(L.ngp_ray_aabb(_ptr(rays_o), _ptr(rays_d), cfg.scale, n, _ptr(hits_t), st), "ngp_ray_aabb")
+        check(L.ngp_march_train_count(_ptr(rays_o), _ptr(rays_d), _ptr(hits_t), _ptr(cfg.bitfield), _ptr(noise), cfg.cascades,
+                                      cfg.grid_size, cfg.scale, cfg.exp_step_factor, cfg.max_samples, n, _ptr(A.stage),
+                                      _ptr(A.counts), st), "ngp_march_train_count")
+        check(L.ngp_march_train_scan(_ptr(A.counts), n, _ptr(rays_a), _ptr(total), st), "ngp_march_train_scan")
+        check(L.ngp_march_train_write(_ptr(rays_o), _ptr(rays_d), _ptr(rays_a), _ptr(A.stage), cfg.max_samples, n,
+                                      _ptr(A.xyzs), _ptr(A.dirs), _ptr(A.deltas), _ptr(A.ts), st), "ngp_march_train_write")
+        check(L.ngp_hash_fwd_f32_ex(_ptr(A.xyzs), _ptr(self.table), ctypes.byref(cfg.levels), A.cap, _ptr(total), 1, cfg.lo,
+                                    cfg.hi, _ptr(A.enc), st), "ngp_hash_fwd_f32_ex")
+        check(L.ngp_mlp_pack(*[_ptr(w) for w in ws], _ptr(A.wpack), st), "ngp_mlp_pack")
+        check(L.ngp_mlp_fwd_ex(_ptr(A.enc), _ptr(A.dirs), _ptr(A.wpack), A.cap, _ptr(total), _ptr(A.sigmas), _ptr(A.rgbs), st),
+              "ngp_mlp_fwd_ex")
+        check(L.ngp_composite_train_fwd(_ptr(A.sigmas), _ptr(A.rgbs), 1, _ptr(A.deltas), _ptr(A.ts), _ptr(rays_a),
+                                        cfg.T_threshold, n, _ptr(vr_per_ray), _ptr(opacity), _ptr(depth), _ptr(rgb), _ptr(A.ws),
+                                        st), "ngp_composite_train_fwd")
+        check(L.ngp_mse_loss_grad(_ptr(rgb), _ptr(opacity), _ptr(target), self.bg, n, _ptr(self.state_f), _ptr(g_rgb), _ptr(g_op),
+                                  st), "ngp_mse_loss_grad")
+        check(L.ngp_composite_train_bwd(_ptr(g_op), _ptr(None), _ptr(g_rgb), _ptr(None), _ptr(A.sigmas), _ptr(A.rgbs), 1,
+                                        _ptr(A.deltas), _ptr(A.ts), _ptr(rays_a), _ptr(opacity), _ptr(depth), _ptr(rgb),
+                                        _ptr(A.ws), cfg.T_threshold, n, _ptr(A.d_sigmas), _ptr(A.d_rgbs), st),
+              "ngp_composite_train_bwd")
+        found = ctypes.c_void_p(self.state_i.data_ptr() + 4 * _SI_FOUND_INF)
+        check(L.ngp_mlp_bwd_ex(_ptr(A.enc), _ptr(A.dirs), _ptr(A.wpack), _ptr(A.d_sigmas), _ptr(A.d_rgbs), A.cap, _ptr(total),
+                               _ptr(A.d_enc), _ptr(self.mlp_grad), found, st), "ngp_mlp_bwd_ex")
+        check(L.ngp_hash_bwd_f32_ex(_ptr(A.xyzs), _ptr(A.d_enc), ctypes.byref(cfg.levels), A.cap, _ptr(total), 1, cfg.lo, cfg.hi,
+                                    _ptr(self.table_grad), found, st), "ngp_hash_bwd_f32_ex")
+        if self.world > 1:
+            self._all_reduce()
+        check(L.ngp_train_prologue(_ptr(self.state_f), _ptr(self.state_i), self.lr0, self.eta_min, self.t_max, self.beta1,
+                                   self.beta2, self.growth, self.backoff, self.growth_interval, st), "ngp_train_prologue")
+        check(L.ngp_adam_step(_ptr(self.table), _ptr(self.table_grad), _ptr(self.table_m), _ptr(self.table_v),
+                              self.table.numel(), _ptr(self.state_f), _ptr(self.state_i), self.beta1, self.beta2, self.eps, st),
+              "ngp_adam_step")
+        check(L.ngp_adam_step(_ptr(self.mlp_flat), _ptr(self.mlp_grad), _ptr(self.mlp_m), _ptr(self.mlp_v), MLP_N_WEIGHTS,
+                              _ptr(self.state_f), _ptr(self.state_i), self.beta1, self.beta2, self.eps, st), "ngp_adam_step")
+        return {"rm_samples": total, "vr_per_ray": vr_per_ray, "rgb": rgb, "opacity": opacity, "depth": depth, "rays_a": rays_a}
+
+    def _all_reduce(self):
+        """Average the gradients of the ray shards (MSE is a mean over the local shard) and OR the inf flags."""
+        avg = dist.get_backend(self.group) == "nccl"
+        for g in (self.table_grad, self.mlp_grad):
+            if avg:
+                dist.all_reduce(g, op=dist.ReduceOp.AVG, group=self.group)
+            else:
+                dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
+                g.div_(self.world)
+        dist.all_reduce(self.state_i[_SI_FOUND_INF:_SI_FOUND_INF + 1], op=dist.ReduceOp.MAX, group=self.group)
+
+    def step(self, rays_o, rays_d, target):
+        """rays_o, rays_d, target: [N,3] float32 device tensors (this rank's shard).  Returns the per-step outputs
+        (device tensors; nothing is synchronised)."""
+        if self._graph is not None:
+            so, sd, stg = self._static
+            so.copy_(rays_o); sd.copy_(rays_d); stg.copy_(target)
+            self._graph.replay()
+            return self.stats
+        self.stats = self._launch(rays_o.contiguous().float(), rays_d.contiguous().float(), target.contiguous().float())
+        return self.stats
+
+    def capture(self, n_rays):
+        """Capture one step into a hipGraph (single-GPU; the RCCL path stays eager).  Subsequent step() calls copy the
+        batch into static buffers and replay."""
+        if self.world > 1:
+            raise RuntimeError("graph capture is only wired for the single-GPU step")
+        f32 = dict(device=self.dev, dtype=torch.float32)
+        so, sd, stg = torch.zeros(n_rays, 3, **f32), torch.ones(n_rays, 3, **f32), torch.zeros(n_rays, 3, **f32)
+        TrainArena.get(self.dev, n_rays, self.max_samples)                 # allocate the arena outside the graph pool
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                                       # warm-up on a side stream (torch graph rule)
+            for _ in range(2):
+                self._launch(so, sd, stg)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.stats = self._launch(so, sd, stg)
+        self._graph, self._static = g, (so, sd, stg)
+        return g
+
+    # ------------------------------------------------------------------------------------------------ bookkeeping
+    def update_density_grid(self, density_threshold, warmup=False, **kw):
+        with torch.autocast(device_type="cuda", dtype=torch.float16):
+            self.model.update_density_grid(density_threshold, warmup=warmup, **kw)
+
+    def last_loss(self):
+        return float(self.state_f[_SF_LOSS].item())                         # host sync: logging only
+
+    def loss_scale(self):
+        return float(self.state_f[_SF_LOSS_SCALE].item())
+
+    def counters(self):
+        s = self.state_i.tolist()
+        return {"iter": s[_SI_ITER], "opt_steps": s[_SI_OPT_STEP], "skipped": s[_SI_SKIPPED]}
+
+    def lr_at(self, it):
+        return self.eta_min + (self.lr0 - self.eta_min) * 0.5 * (1 + math.cos(math.pi * min(it, self.t_max) / self.t_max))
