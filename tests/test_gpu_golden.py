@@ -1,0 +1,97 @@
+"""The HIP kernels (through the C ABI) directly against the reference-executed golden vectors (tests/golden/ref_*.npz,
+made by oracle/gen_golden.py from the reference's own kernel source)."""
+import numpy as np
+import pytest
+import torch
+
+from test_golden import G, beq, golden_table
+from ngp_hip import ops, synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def test_ray_aabb_golden(hip_lib):
+    g = G("ref_ray_aabb.npz")
+    for scale in (0.5, 16.0):
+        assert beq(ops.ray_aabb(dev(g["rays_o"]), dev(g["rays_d"]), scale).cpu().numpy(), g["hits_%g" % scale])
+
+
+@pytest.mark.parametrize("name,cascades,scale,esf,max_samples", [("ref_march_lego.npz", 1, 0.5, 0.0, 1024),
+                                                                  ("ref_march_garden.npz", 6, 16.0, 1.0 / 256, 64)])
+def test_march_train_golden(hip_lib, lego_bitfield, name, cascades, scale, esf, max_samples):
+    g = G(name)
+    bits = lego_bitfield if cascades == 1 else synthetic.ball_slab_bitfield(6, 16.0, seed=int(g["bitfield_seed"]))
+    r = ops.march_train(dev(g["rays_o"]), dev(g["rays_d"]), dev(g["hits_t"]), dev(bits), dev(g["noise"]), cascades, scale, esf,
+                        128, max_samples)
+    assert int(r[5]) == int(g["total"]) and np.array_equal(r[0].cpu().numpy(), g["rays_a"])
+    assert beq(r[4].cpu().numpy(), g["ts"]) and beq(r[3].cpu().numpy(), g["deltas"])
+    assert beq(r[1].cpu().numpy(), g["xyzs"]) and beq(r[2].cpu().numpy(), g["dirs"])
+
+
+def test_march_test_golden(hip_lib, lego_bitfield):
+    g = G("ref_march_test.npz")
+    hits = ops.ray_aabb(dev(g["rays_o"]), dev(g["rays_d"]), 0.5)
+    for k in range(2):
+        n_step = int(g["r%d_n_step" % k])
+        r_idx, valid, deltas, ts, cnt = ops.march_test(dev(g["rays_o"]), dev(g["rays_d"]), hits, dev(g["alive"]), dev(lego_bitfield),
+                                                       1, 0.5, 0.0, 128, n_step)
+        m = g["r%d_valid" % k].astype(bool)
+        assert np.array_equal(valid.cpu().numpy(), g["r%d_valid" % k]) and np.array_equal(cnt.cpu().numpy(), g["r%d_counter" % k])
+        assert np.array_equal(r_idx.cpu().numpy()[m], g["r%d_ray_indices" % k][m])
+        assert beq(ts.cpu().numpy()[m], g["r%d_ts" % k][m]) and beq(deltas.cpu().numpy()[m], g["r%d_deltas" % k][m])
+        assert beq(hits.cpu().numpy(), g["r%d_hits" % k])
+
+
+@pytest.mark.parametrize("tag", ["c2", "c3"])
+def test_hash_f32_golden(hip_lib, tag):
+    g = G("ref_hash_f32_%s.npz" % tag)
+    lv = ops.make_levels(2**19, 16, 16.0, float(g["max_res"]), 2)
+    for l in range(16):
+        lv.scale[l] = float(g["scale_used"][l])          # the scales the reference kernel evaluated (see test_golden.py)
+    out = ops.hash_fwd_f32(dev(g["xyzs"]), dev(golden_table(int(g["total_param_size"]))), lv)
+    assert beq(out.cpu().numpy(), g["out"])
+
+
+def test_hash_f16_golden(hip_lib):
+    g = G("ref_hash_f16.npz")
+    lv = ops.make_levels(2**19, 16, 16.0, 1024.0, 2)
+    for l in range(16):
+        lv.scale[l] = float(g["scale_used"][l])
+    table_h = golden_table(int(g["total_entries"]) * 2, -0.1, 0.1).astype(np.float16).reshape(-1, 2)
+    out = ops.hash_fwd_f16(dev(g["xyzs"]), dev(table_h), lv).cpu().numpy()
+    diff = np.abs(out.astype(np.float32) - g["out"].astype(np.float32))
+    assert (diff == 0).mean() > 0.97 and diff.max() <= 2.5e-4
+    grad = torch.zeros(table_h.shape[0], 2, device="cuda", dtype=torch.float16)
+    ops.hash_bwd_f16(dev(g["xyzs"]), dev(g["dout"]), lv, grad)
+    np.testing.assert_allclose(grad.float().cpu().numpy()[g["grad_rows"]], g["grad_vals"].astype(np.float32), rtol=2e-2, atol=2e-5)
+
+
+def test_sh16_and_grid_utils_golden(hip_lib):
+    g = G("ref_sh16.npz")
+    assert beq(ops.sh16_fwd(dev(g["dirs"])).cpu().numpy(), g["out"])
+    g = G("ref_grid_utils.npz")
+    assert np.array_equal(ops.morton3d(dev(g["coords"])).cpu().numpy(), g["morton"])
+    assert np.array_equal(ops.morton3d_invert(dev(g["morton"])).cpu().numpy(), g["inverted"])
+    out = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    ops.packbits(dev(g["grid"]), float(g["threshold"]), out)
+    assert np.array_equal(out.cpu().numpy(), g["bitfield"])
+
+
+def test_composites_golden(hip_lib):
+    g = G("ref_composite_train.npz")
+    tot, op, dep, rgb, ws = ops.composite_train_fwd(dev(g["sigmas"]), dev(g["rgbs"]), dev(g["deltas"]), dev(g["ts"]), dev(g["rays_a"]),
+                                                    1e-4)
+    assert np.abs(tot.cpu().numpy() - g["total_samples"]).max() <= 1
+    np.testing.assert_allclose(op.cpu().numpy(), g["opacity"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(rgb.cpu().numpy(), g["rgb"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(dep.cpu().numpy(), g["depth"], rtol=1e-5, atol=1e-6)
+    g = G("ref_composite_test.npz")
+    alive, op, dep, rgb = dev(g["alive_in"]), dev(g["opacity_in"]), dev(g["depth_in"]), dev(g["rgb_in"])
+    ops.composite_test(dev(g["sigmas"]), dev(g["rgbs"]), dev(g["deltas"]), dev(g["ts"]), dev(g["pack_info"]), alive, 1e-4, op, dep, rgb)
+    assert np.array_equal(alive.cpu().numpy(), g["alive_out"])
+    np.testing.assert_allclose(rgb.cpu().numpy(), g["rgb_out"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(op.cpu().numpy(), g["opacity_out"], rtol=1e-5, atol=1e-6)
