@@ -19,8 +19,9 @@
 // Backward recomputes the forward per tile (cheaper than storing 0.68 KB/sample of activations), propagates
 // dX = W^T dZ through the same register-chaining trick, and forms the weight gradients dW = dZ X^T with the sample
 // index as K: that needs [feature][sample] fragments, so dZ and X of one layer at a time are transposed through a
-// 10 KB per-wave LDS tile.  dW accumulates in registers across the wave's whole persistent loop (fp32), is reduced
-// across the block's waves with LDS float atomics and leaves the block as line-coalesced global atomics.
+// 10 KB LDS tile per 32-sample group.  The 40 dW output tiles are distributed over the 16 waves of a block (each wave
+// sums ITS tiles over all the block's samples), accumulate in fp32 registers across the whole persistent loop and leave the block
+// as line-coalesced global atomics -- no cross-wave reduction.
 //
 // Numerics are tolerance-checked against an fp32 torch restatement and against torch's own autocast path
 // (tests/test_gpu_mlp.py); bf16/fp16 MFMA is used because this is the one genuine dense contraction on the path.
@@ -260,186 +261,258 @@ __device__ __forceinline__ void wave_lds_fence() {      // same-wave LDS ops ret
     asm volatile("" ::: "memory");
 }
 
-__global__ void __launch_bounds__(256, 1) mlp_bwd_kernel(const float* __restrict__ enc, const float* __restrict__ dirs,
-                                                         const half_t* __restrict__ wpack, const float* __restrict__ dsigmas,
-                                                         const half_t* __restrict__ drgbs, int S,
-                                                         const int32_t* __restrict__ n_dev, float* __restrict__ d_enc,
-                                                         float* __restrict__ dW /*[N_W], pre-zeroed or accumulating*/,
-                                                         int32_t* __restrict__ found_inf) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[N_ALL_FRAGS * 64 * 16 + 4 * T_ROWS * T_STRIDE * 4];
+// Block = 12 waves (3 per SIMD, <= 168 registers each).  Every wave runs the data path (forward recompute + dX chain)
+// of ONE 16-sample tile; waves 2k and 2k+1 interleave their samples into one 32-sample group k (sample = 32 it + 2n +
+// (wave & 1)) so that a group's transposed tile has K = 32.  The 40 dW output tiles (16x16 each) are DISTRIBUTED over
+// the 12 waves (3-4 tiles = 12-16 accumulator registers per wave instead of 160 in a wave-private scheme), and each wave
+// accumulates its tiles over the transposed dZ / X tiles of all 6 groups (K = 192 samples per round).  One layer at a
+// time: 6 x 10 KB of LDS tiles, two block barriers per layer.  A block's waves own disjoint dW tiles, so nothing is
+// reduced across waves at the end.
+constexpr int BW = 12;                     // waves per block
+constexpr int BG = BW / 2;                 // 32-sample groups per round
+constexpr int T_STRIDE_H = 2 * T_STRIDE;   // the same 80-byte rows, addressed in halfs
+
+struct BwdIn {                             // prefetched per-round inputs of one lane
+    float4 e0, e1;                         // enc features 8g..8g+7
+    float dx, dy, dz, dsig;
+    half_t drgb[3];
+};
+
+__device__ __forceinline__ void bwd_prefetch(BwdIn& in, const float* __restrict__ enc, const float* __restrict__ dirs,
+                                             const float* __restrict__ dsigmas, const half_t* __restrict__ drgbs, int smp, int S,
+                                             int g) {
+    in.e0 = in.e1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    in.dx = 0.f; in.dy = 0.f; in.dz = 1.f; in.dsig = 0.f;
+    in.drgb[0] = in.drgb[1] = in.drgb[2] = (half_t)0;
+    if (smp < S) {
+        const float* row = enc + (size_t)smp * 32 + 8 * g;
+        in.e0 = *reinterpret_cast<const float4*>(row);
+        in.e1 = *reinterpret_cast<const float4*>(row + 4);
+        in.dx = dirs[3 * (size_t)smp]; in.dy = dirs[3 * (size_t)smp + 1]; in.dz = dirs[3 * (size_t)smp + 2];
+        if (g == 0) {
+            in.dsig = dsigmas[smp];
+            in.drgb[0] = drgbs[3 * (size_t)smp]; in.drgb[1] = drgbs[3 * (size_t)smp + 1]; in.drgb[2] = drgbs[3 * (size_t)smp + 2];
+        }
+    }
+}
+
+// forward of one tile from prefetched registers
+__device__ __forceinline__ void tile_forward_regs(const half8* __restrict__ wl, int lane, int g, const float4& e0, const float4& e1,
+                                                  float dx, float dy, float dz, TileFwd& t) {
+    const floatx4 zero = {0.f, 0.f, 0.f, 0.f};
+    t.b_enc[0] = (half_t)e0.x; t.b_enc[1] = (half_t)e0.y; t.b_enc[2] = (half_t)e0.z; t.b_enc[3] = (half_t)e0.w;
+    t.b_enc[4] = (half_t)e1.x; t.b_enc[5] = (half_t)e1.y; t.b_enc[6] = (half_t)e1.z; t.b_enc[7] = (half_t)e1.w;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) t.a1[mt] = relu_h4(NGP_MFMA(wfrag(wl, F_W1 + mt, lane), t.b_enc, zero));
+    floatx4 d2 = NGP_MFMA(wfrag(wl, F_W2 + 0, lane), cat_h4(t.a1[0], t.a1[1]), zero);
+    d2 = NGP_MFMA(wfrag(wl, F_W2 + 1, lane), cat_h4(t.a1[2], t.a1[3]), d2);
+    t.h = to_h4(d2);
+    t.sigma = expf((float)t.h[0]);
+    const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+    const float x = (dx * inv + 1.0f) / 2.0f, y = (dy * inv + 1.0f) / 2.0f, z = (dz * inv + 1.0f) / 2.0f;
+    t.b_in3 = cat_h4(sh_quad(g, x, y, z), t.h);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) t.a3[mt] = relu_h4(NGP_MFMA(wfrag(wl, F_W3 + mt, lane), t.b_in3, zero));
+    const half8 b30 = cat_h4(t.a3[0], t.a3[1]), b31 = cat_h4(t.a3[2], t.a3[3]);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        floatx4 d4 = NGP_MFMA(wfrag(wl, F_W4 + 2 * mt, lane), b30, zero);
+        d4 = NGP_MFMA(wfrag(wl, F_W4 + 2 * mt + 1, lane), b31, d4);
+        t.a4[mt] = relu_h4(d4);
+    }
+    floatx4 d5 = NGP_MFMA(wfrag(wl, F_W5 + 0, lane), cat_h4(t.a4[0], t.a4[1]), zero);
+    d5 = NGP_MFMA(wfrag(wl, F_W5 + 1, lane), cat_h4(t.a4[2], t.a4[3]), d5);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float c = (float)(half_t)d5[r];
+        t.rgb[r] = (half_t)(1.0f / (1.0f + expf(-c)));
+    }
+}
+
+// transposed stores, one half per (feature row, sample): T16[row][2n + parity]
+__device__ __forceinline__ void th_store_d(half_t* T16, int row0, int mt, int g, int col, const half4& v) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) T16[(row0 + 16 * mt + 4 * g + r) * T_STRIDE_H + col] = v[r];
+}
+
+__global__ void __launch_bounds__(768) mlp_bwd_kernel(const float* __restrict__ enc, const float* __restrict__ dirs,
+                                                       const half_t* __restrict__ wpack, const float* __restrict__ dsigmas,
+                                                       const half_t* __restrict__ drgbs, int S,
+                                                       const int32_t* __restrict__ n_dev, float* __restrict__ d_enc,
+                                                       float* __restrict__ dW /*[N_W], pre-zeroed or accumulating*/,
+                                                       int32_t* __restrict__ found_inf) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[N_ALL_FRAGS * 64 * 16 + BG * T_ROWS * T_STRIDE * 4];
     if (n_dev) S = min(S, *n_dev);
     half8* wl = reinterpret_cast<half8*>(smem);
     load_wpack(wpack, wl, N_ALL_FRAGS);
     const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
-    uint32_t* T = reinterpret_cast<uint32_t*>(smem + N_ALL_FRAGS * 64 * 16) + wv * (T_ROWS * T_STRIDE);
-    const int wave = blockIdx.x * (blockDim.x >> 6) + wv, n_waves = gridDim.x * (blockDim.x >> 6);
+    const int grp = wv >> 1, par = wv & 1;
+    uint32_t* Tall = reinterpret_cast<uint32_t*>(smem + N_ALL_FRAGS * 64 * 16);
+    half_t* T16 = reinterpret_cast<half_t*>(Tall + grp * (T_ROWS * T_STRIDE));     // this wave pair's transposed tile
+    const int col = 2 * n + par;
     const int n_iter = (S + 31) >> 5;
+    const int n_round = (n_iter + BG - 1) / BG;
     const floatx4 zero = {0.f, 0.f, 0.f, 0.f};
     const half4 hzero = {(half_t)0, (half_t)0, (half_t)0, (half_t)0};
 
-    floatx4 acc1[4][2], acc2[4], acc3[4][2], acc4[4][4], acc5[4];       // dW tiles: [out tile][in tile]
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-        acc2[a] = zero; acc5[a] = zero;
-#pragma unroll
-        for (int b = 0; b < 2; ++b) { acc1[a][b] = zero; acc3[a][b] = zero; }
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc4[a][b] = zero;
-    }
+    // dW tile ownership (40 tiles of 16x16 over 12 waves):
+    //   waves 0..7  (w)    : L4 tiles (mt = w>>1, nt = 2(w&1), 2(w&1)+1) -> accA0/accA1 ;  L3 tile (mt = w>>1, nt = w&1) -> accB
+    //   waves 8..11 (v=w-8): L1 tiles (mt = v, nt = 0, 1)                -> accA0/accA1 ;  L2 tile (nt = v) -> accB ;
+    //                        L5 tile (nt = v) -> accC
+    floatx4 accA0 = zero, accA1 = zero, accB = zero, accC = zero;
+    const bool lo8 = wv < 8;
+    const int v4 = wv - 8;
+    const int mtA = lo8 ? (wv >> 1) : v4, ntA = lo8 ? 2 * (wv & 1) : 0;
 
-    for (int it = wave; it < n_iter; it += n_waves) {
-        TileFwd t[2];
-        half4 dz5[2], dz4[2][4], dz3[2][4], dz2[2], dz1[2][4];
+    for (int round = blockIdx.x; round < n_round; round += gridDim.x) {
+        const int smp = (round * BG + grp) * 32 + col;
+        BwdIn in;                     // 4 waves per SIMD hide this latency; a register prefetch would spill
+        bwd_prefetch(in, enc, dirs, dsigmas, drgbs, smp, S, g);
+        TileFwd t;
+        half4 dz5 = hzero, dz4[4], dz3[4], dz2, dz1[4];
+        tile_forward_regs(wl, lane, g, in.e0, in.e1, in.dx, in.dy, in.dz, t);
+        if (g == 0) {
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
-            const int smp = it * 32 + 2 * n + tt;
-            const bool valid = smp < S;
-            float dx = 0.f, dy = 0.f, dzz = 1.f;
-            if (valid) { dx = dirs[3 * (size_t)smp]; dy = dirs[3 * (size_t)smp + 1]; dzz = dirs[3 * (size_t)smp + 2]; }
-            tile_forward<true>(wl, lane, g, enc + (size_t)smp * 32, dx, dy, dzz, valid, t[tt]);
-            // ---- upstream gradients (loss-scaled by GradScaler, like the fp16 grads torch would see) ----
-            dz5[tt] = hzero;
-            float dsig = 0.0f;
-            if (valid && g == 0) {
-                dsig = dsigmas[smp];
-#pragma unroll
-                for (int r = 0; r < 3; ++r) {
-                    const float y = (float)t[tt].rgb[r];
-                    dz5[tt][r] = (half_t)((float)drgbs[3 * (size_t)smp + r] * ((1.0f - y) * y));      // sigmoid_backward
-                }
+            for (int r = 0; r < 3; ++r) {
+                const float y = (float)t.rgb[r];
+                dz5[r] = (half_t)((float)in.drgb[r] * ((1.0f - y) * y));                        // sigmoid_backward
             }
-            const half8 b_dz5 = cat_h4(dz5[tt], hzero);
+        }
+        {
+            const half8 b_dz5 = cat_h4(dz5, hzero);
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-                dz4[tt][mt] = mask_h4(NGP_MFMA(wfrag(wl, B_W5T + mt, lane), b_dz5, zero), t[tt].a4[mt]);
-            const half8 b40 = cat_h4(dz4[tt][0], dz4[tt][1]), b41 = cat_h4(dz4[tt][2], dz4[tt][3]);
+            for (int mt = 0; mt < 4; ++mt) dz4[mt] = mask_h4(NGP_MFMA(wfrag(wl, B_W5T + mt, lane), b_dz5, zero), t.a4[mt]);
+            __builtin_amdgcn_sched_barrier(0);
+            const half8 b40 = cat_h4(dz4[0], dz4[1]), b41 = cat_h4(dz4[2], dz4[3]);
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
                 floatx4 d = NGP_MFMA(wfrag(wl, B_W4T + 2 * mt, lane), b40, zero);
                 d = NGP_MFMA(wfrag(wl, B_W4T + 2 * mt + 1, lane), b41, d);
-                dz3[tt][mt] = mask_h4(d, t[tt].a3[mt]);
+                dz3[mt] = mask_h4(d, t.a3[mt]);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            floatx4 dh = NGP_MFMA(wfrag(wl, B_W3T + 0, lane), cat_h4(dz3[tt][0], dz3[tt][1]), zero);
-            dh = NGP_MFMA(wfrag(wl, B_W3T + 1, lane), cat_h4(dz3[tt][2], dz3[tt][3]), dh);
-            dz2[tt] = to_h4(dh);
+            floatx4 dh = NGP_MFMA(wfrag(wl, B_W3T + 0, lane), cat_h4(dz3[0], dz3[1]), zero);
+            dh = NGP_MFMA(wfrag(wl, B_W3T + 1, lane), cat_h4(dz3[2], dz3[3]), dh);
+            dz2 = to_h4(dh);
             if (g == 0) {                                                     // TruncExp backward, networks.py:28-30
-                const float h0 = (float)t[tt].h[0];
-                const half_t gs = (half_t)(dsig * expf(fminf(fmaxf(h0, -15.0f), 15.0f)));
-                dz2[tt][0] = (half_t)((float)dz2[tt][0] + (float)gs);
+                const float h0 = (float)t.h[0];
+                const half_t gs = (half_t)(in.dsig * expf(fminf(fmaxf(h0, -15.0f), 15.0f)));
+                dz2[0] = (half_t)((float)dz2[0] + (float)gs);
             }
-            const half8 b_dz2 = cat_h4(dz2[tt], hzero);
+            __builtin_amdgcn_sched_barrier(0);
+            const half8 b_dz2 = cat_h4(dz2, hzero);
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-                dz1[tt][mt] = mask_h4(NGP_MFMA(wfrag(wl, B_W2T + mt, lane), b_dz2, zero), t[tt].a1[mt]);
-            const half8 b10 = cat_h4(dz1[tt][0], dz1[tt][1]), b11 = cat_h4(dz1[tt][2], dz1[tt][3]);
+            for (int mt = 0; mt < 4; ++mt) dz1[mt] = mask_h4(NGP_MFMA(wfrag(wl, B_W2T + mt, lane), b_dz2, zero), t.a1[mt]);
+            __builtin_amdgcn_sched_barrier(0);
+            const half8 b10 = cat_h4(dz1[0], dz1[1]), b11 = cat_h4(dz1[2], dz1[3]);
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
                 floatx4 d = NGP_MFMA(wfrag(wl, B_W1T + 2 * mt, lane), b10, zero);
                 d = NGP_MFMA(wfrag(wl, B_W1T + 2 * mt + 1, lane), b11, d);
-                if (valid) *reinterpret_cast<float4*>(d_enc + (size_t)smp * 32 + 16 * mt + 4 * g) = make_float4(d[0], d[1], d[2], d[3]);
+                if (smp < S) *reinterpret_cast<float4*>(d_enc + (size_t)smp * 32 + 16 * mt + 4 * g) = make_float4(d[0], d[1], d[2], d[3]);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
-        // ---- weight gradients: one layer at a time through the per-wave transposed LDS tile ----
-        // layer 5: dZ5 [16 rows] x a4 [64 rows]
+
+        // ---- weight gradients, one layer at a time: every wave publishes its dZ / X columns, then accumulates ITS dW
+        //      tiles over the tiles of all BG groups ----
+        // layer 5: dZ5 [16] x a4 [64]      (owners: waves 8..11)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) T[(4 * g + r) * T_STRIDE + n] = pack2(dz5[0][r], dz5[1][r]);
+        for (int r = 0; r < 4; ++r) T16[(4 * g + r) * T_STRIDE_H + col] = dz5[r];
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) t_store_d(T, 64, mt, g, n, t[0].a4[mt], t[1].a4[mt]);
-        wave_lds_fence();
-        {
-            const half8 a = t_load(T, n, g);
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) acc5[nt] = NGP_MFMA(a, t_load(T, 64 + 16 * nt + n, g), acc5[nt]);
+        for (int mt = 0; mt < 4; ++mt) th_store_d(T16, 64, mt, g, col, t.a4[mt]);
+        __syncthreads();
+        if (!lo8) {
+#pragma unroll 2
+            for (int k = 0; k < BG; ++k) {
+                const uint32_t* Tk = Tall + k * (T_ROWS * T_STRIDE);
+                accC = NGP_MFMA(t_load(Tk, n, g), t_load(Tk, 64 + 16 * v4 + n, g), accC);
+            }
         }
-        wave_lds_fence();
-        // layer 4: dZ4 [64] x a3 [64]
+        __syncthreads();
+        // layer 4: dZ4 [64] x a3 [64]      (owners: waves 0..7, two tiles each)
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) { t_store_d(T, 0, mt, g, n, dz4[0][mt], dz4[1][mt]); t_store_d(T, 64, mt, g, n, t[0].a3[mt], t[1].a3[mt]); }
-        wave_lds_fence();
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            const half8 a = t_load(T, 16 * mt + n, g);
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) acc4[mt][nt] = NGP_MFMA(a, t_load(T, 64 + 16 * nt + n, g), acc4[mt][nt]);
+        for (int mt = 0; mt < 4; ++mt) { th_store_d(T16, 0, mt, g, col, dz4[mt]); th_store_d(T16, 64, mt, g, col, t.a3[mt]); }
+        __syncthreads();
+        if (lo8) {
+#pragma unroll 2
+            for (int k = 0; k < BG; ++k) {
+                const uint32_t* Tk = Tall + k * (T_ROWS * T_STRIDE);
+                const half8 a = t_load(Tk, 16 * mtA + n, g);
+                accA0 = NGP_MFMA(a, t_load(Tk, 64 + 16 * ntA + n, g), accA0);
+                accA1 = NGP_MFMA(a, t_load(Tk, 64 + 16 * (ntA + 1) + n, g), accA1);
+            }
         }
-        wave_lds_fence();
-        // layer 3: dZ3 [64] x in3 [32 rows: SH 0..15 | h 16..31]
+        __syncthreads();
+        // layer 3: dZ3 [64] x in3 [32]     (owners: waves 0..7)
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) t_store_d(T, 0, mt, g, n, dz3[0][mt], dz3[1][mt]);
+        for (int mt = 0; mt < 4; ++mt) th_store_d(T16, 0, mt, g, col, dz3[mt]);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int row = (j < 4) ? (4 * g + j) : (16 + 4 * g + (j - 4));
-            T[(64 + row) * T_STRIDE + n] = pack2(t[0].b_in3[j], t[1].b_in3[j]);
+            T16[(64 + row) * T_STRIDE_H + col] = t.b_in3[j];
         }
-        wave_lds_fence();
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            const half8 a = t_load(T, 16 * mt + n, g);
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) acc3[mt][nt] = NGP_MFMA(a, t_load(T, 64 + 16 * nt + n, g), acc3[mt][nt]);
+        __syncthreads();
+        if (lo8) {
+#pragma unroll 2
+            for (int k = 0; k < BG; ++k) {
+                const uint32_t* Tk = Tall + k * (T_ROWS * T_STRIDE);
+                accB = NGP_MFMA(t_load(Tk, 16 * (wv >> 1) + n, g), t_load(Tk, 64 + 16 * (wv & 1) + n, g), accB);
+            }
         }
-        wave_lds_fence();
-        // layer 2: dZ2 [16] x a1 [64]
+        __syncthreads();
+        // layer 2: dZ2 [16] x a1 [64]      (owners: waves 8..11)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) T[(4 * g + r) * T_STRIDE + n] = pack2(dz2[0][r], dz2[1][r]);
+        for (int r = 0; r < 4; ++r) T16[(4 * g + r) * T_STRIDE_H + col] = dz2[r];
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) t_store_d(T, 64, mt, g, n, t[0].a1[mt], t[1].a1[mt]);
-        wave_lds_fence();
-        {
-            const half8 a = t_load(T, n, g);
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) acc2[nt] = NGP_MFMA(a, t_load(T, 64 + 16 * nt + n, g), acc2[nt]);
+        for (int mt = 0; mt < 4; ++mt) th_store_d(T16, 64, mt, g, col, t.a1[mt]);
+        __syncthreads();
+        if (!lo8) {
+#pragma unroll 2
+            for (int k = 0; k < BG; ++k) {
+                const uint32_t* Tk = Tall + k * (T_ROWS * T_STRIDE);
+                accB = NGP_MFMA(t_load(Tk, n, g), t_load(Tk, 64 + 16 * v4 + n, g), accB);
+            }
         }
-        wave_lds_fence();
-        // layer 1: dZ1 [64] x enc [32]
+        __syncthreads();
+        // layer 1: dZ1 [64] x enc [32]     (owners: waves 8..11, two tiles each)
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) t_store_d(T, 0, mt, g, n, dz1[0][mt], dz1[1][mt]);
+        for (int mt = 0; mt < 4; ++mt) th_store_d(T16, 0, mt, g, col, dz1[mt]);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) T[(64 + 8 * g + j) * T_STRIDE + n] = pack2(t[0].b_enc[j], t[1].b_enc[j]);
-        wave_lds_fence();
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            const half8 a = t_load(T, 16 * mt + n, g);
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) acc1[mt][nt] = NGP_MFMA(a, t_load(T, 64 + 16 * nt + n, g), acc1[mt][nt]);
+        for (int j = 0; j < 8; ++j) T16[(64 + 8 * g + j) * T_STRIDE_H + col] = t.b_enc[j];
+        __syncthreads();
+        if (!lo8) {
+#pragma unroll 2
+            for (int k = 0; k < BG; ++k) {
+                const uint32_t* Tk = Tall + k * (T_ROWS * T_STRIDE);
+                const half8 a = t_load(Tk, 16 * mtA + n, g);
+                accA0 = NGP_MFMA(a, t_load(Tk, 64 + n, g), accA0);
+                accA1 = NGP_MFMA(a, t_load(Tk, 64 + 16 + n, g), accA1);
+            }
         }
-        wave_lds_fence();
+        __syncthreads();
     }
 
-    // ---- block reduction of dW through LDS float atomics, then line-coalesced global atomics ----
-    __syncthreads();
-    float* red = reinterpret_cast<float*>(smem);                       // reuses the weight image (>= N_W floats)
-    for (int k = threadIdx.x; k < N_W; k += blockDim.x) red[k] = 0.0f;
-    __syncthreads();
-    // D layout of a dW tile: row (out) = 16mt + 4g + r, col (in) = 16nt + n
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int o = 16 * mt + 4 * g + r;
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                atomicAdd(&red[OFF_W1 + o * 32 + 16 * nt + n], acc1[mt][nt][r]);
-                atomicAdd(&red[OFF_W3 + o * 32 + 16 * nt + n], acc3[mt][nt][r]);
-            }
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) atomicAdd(&red[OFF_W4 + o * 64 + 16 * nt + n], acc4[mt][nt][r]);
-        }
+    // ---- each wave owns its dW tiles outright: line-coalesced global atomics straight from the accumulators ----
+    // D layout of a dW tile: row (out) = 16 mt + 4g + r, col (in) = 16 nt + n
+    bool bad = false;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int o = 4 * g + r;
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            atomicAdd(&red[OFF_W2 + o * 64 + 16 * nt + n], acc2[nt][r]);
-            if (o < 3) atomicAdd(&red[OFF_W5 + o * 64 + 16 * nt + n], acc5[nt][r]);
+        const int o = 16 * mtA + 4 * g + r, o2 = 4 * g + r;
+        const float a0 = accA0[r], a1 = accA1[r], b = accB[r], c = accC[r];
+        if (lo8) {
+            if (a0 != 0.0f) unsafeAtomicAdd(dW + OFF_W4 + o * 64 + 16 * ntA + n, a0);
+            if (a1 != 0.0f) unsafeAtomicAdd(dW + OFF_W4 + o * 64 + 16 * (ntA + 1) + n, a1);
+            if (b != 0.0f) unsafeAtomicAdd(dW + OFF_W3 + o * 32 + 16 * (wv & 1) + n, b);
+        } else {
+            if (a0 != 0.0f) unsafeAtomicAdd(dW + OFF_W1 + o * 32 + n, a0);
+            if (a1 != 0.0f) unsafeAtomicAdd(dW + OFF_W1 + o * 32 + 16 + n, a1);
+            if (b != 0.0f) unsafeAtomicAdd(dW + OFF_W2 + o2 * 64 + 16 * v4 + n, b);
+            if (o2 < 3 && c != 0.0f) unsafeAtomicAdd(dW + OFF_W5 + o2 * 64 + 16 * v4 + n, c);
         }
+        bad |= !isfinite(a0) || !isfinite(a1) || !isfinite(b) || !isfinite(c);
     }
-    __syncthreads();
-    for (int k = threadIdx.x; k < N_W; k += blockDim.x) {
-        const float v = red[k];
-        if (v != 0.0f) unsafeAtomicAdd(dW + k, v);
-        if (found_inf && !isfinite(v)) *found_inf = 1;
-    }
+    if (found_inf && bad) *found_inf = 1;
 }
 
 }  // namespace ngp
@@ -461,7 +534,7 @@ int ngp_mlp_pack(const float* W1, const float* W2, const float* W3, const float*
 static inline int mlp_grid(int S) {
     const int iters = (S + 31) / 32;
     int blocks = (iters + 3) / 4;
-    if (blocks > 512) blocks = 512;
+    if (blocks > 2048) blocks = 2048;
     return blocks < 1 ? 1 : blocks;
 }
 
@@ -485,10 +558,10 @@ int ngp_mlp_fwd(const float* enc, const float* dirs, const uint16_t* wpack, int 
 int ngp_mlp_bwd_ex(const float* enc, const float* dirs, const uint16_t* wpack, const float* dsigmas, const uint16_t* drgbs,
                    int n_max, const int32_t* n_dev, float* d_enc, float* dW, int32_t* found_inf, void* stream) {
     if (n_max <= 0) return 0;
-    int blocks = ((n_max + 31) / 32 + 3) / 4;
-    if (blocks > 256) blocks = 256;
+    int blocks = ((n_max + 31) / 32 + BG - 1) / BG;
+    if (blocks > 256) blocks = 256;                       // one 12-wave block per CU: 3 waves per SIMD
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(mlp_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, enc, dirs, (const half_t*)wpack, dsigmas,
+    hipLaunchKernelGGL(mlp_bwd_kernel, dim3(blocks), dim3(64 * BW), 0, (hipStream_t)stream, enc, dirs, (const half_t*)wpack, dsigmas,
                        (const half_t*)drgbs, n_max, n_dev, d_enc, dW, found_inf);
     NGP_LAUNCH_CHECK();
     return 0;
