@@ -174,6 +174,14 @@ int ngp_morton3d_invert(const int32_t* indices, int m, int32_t* coords /*[m,3]*/
 int ngp_packbits(const float* density_grid /*[8k]*/, float threshold, int n_bytes,
                  uint8_t* bitfield, void* stream);
 
+/* ---- f-1  distortion loss (modules/distortion.py:15-119): per-ray loss[N] (indexed by ray_idx) and the inclusive
+ * scans the backward needs; backward writes dL/dws for the live samples addressed by rays_a. */
+int ngp_distortion_fwd(const float* ws, const float* deltas, const float* ts, const int32_t* rays_a, int n_rays,
+                       float* loss, float* ws_inc, float* wts_inc, void* stream);
+int ngp_distortion_bwd(const float* dL_dloss, const float* ws, const float* deltas, const float* ts,
+                       const float* ws_inc, const float* wts_inc, const int32_t* rays_a, int n_rays,
+                       float* dL_dws, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -284,6 +284,27 @@ def packbits(density_grid, threshold, density_bitfield):
     return density_bitfield
 
 
+# ---------------------------------------------------------------------------------------------------- f-1
+def distortion_fwd(ws, deltas, ts, rays_a):
+    _dev(ws, torch.float32, "ws"); _dev(deltas, torch.float32, "deltas"); _dev(ts, torch.float32, "ts")
+    _dev(rays_a, torch.int32, "rays_a")
+    n = rays_a.shape[0]
+    loss = torch.zeros(n, device=ws.device, dtype=torch.float32)
+    ws_inc = torch.empty_like(ws)
+    wts_inc = torch.empty_like(ws)
+    check(_lib().ngp_distortion_fwd(_ptr(ws), _ptr(deltas), _ptr(ts), _ptr(rays_a), n, _ptr(loss), _ptr(ws_inc), _ptr(wts_inc),
+                                    _stream()), "ngp_distortion_fwd")
+    return loss, ws_inc, wts_inc
+
+
+def distortion_bwd(dL_dloss, ws, deltas, ts, ws_inc, wts_inc, rays_a):
+    _dev(dL_dloss, torch.float32, "dL_dloss")
+    dL_dws = torch.zeros_like(ws)
+    check(_lib().ngp_distortion_bwd(_ptr(dL_dloss), _ptr(ws), _ptr(deltas), _ptr(ts), _ptr(ws_inc), _ptr(wts_inc), _ptr(rays_a),
+                                    rays_a.shape[0], _ptr(dL_dws), _stream()), "ngp_distortion_bwd")
+    return dL_dws
+
+
 def levels_to_numpy(lv):
     """(scale, resolution, map_size, offset) as numpy arrays -- for tests and for the module buffers."""
     L = lv.n_levels

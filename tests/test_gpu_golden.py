@@ -95,3 +95,30 @@ def test_composites_golden(hip_lib):
     assert np.array_equal(alive.cpu().numpy(), g["alive_out"])
     np.testing.assert_allclose(rgb.cpu().numpy(), g["rgb_out"], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(op.cpu().numpy(), g["opacity_out"], rtol=1e-5, atol=1e-6)
+
+
+def test_distortion_golden_and_oracle(hip_lib, oracle):
+    g = G("ref_distortion.npz")
+    loss, wi, wti = ops.distortion_fwd(dev(g["ws"]), dev(g["deltas"]), dev(g["ts"]), dev(g["rays_a"]))
+    np.testing.assert_allclose(loss.cpu().numpy(), g["loss"], rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(wi.cpu().numpy(), g["ws_inc"], rtol=1e-5, atol=1e-8)
+    dws = ops.distortion_bwd(dev(g["dL_dloss"]), dev(g["ws"]), dev(g["deltas"]), dev(g["ts"]), wi, wti, dev(g["rays_a"]))
+    np.testing.assert_allclose(dws.cpu().numpy(), g["dL_dws"], rtol=1e-4, atol=1e-7)
+    # larger seeded case against the oracle, through the autograd Function of modules/distortion.py
+    from modules.distortion import distortion_loss
+    rng = np.random.default_rng(0)
+    counts = rng.integers(0, 300, 2000).astype(np.int32)
+    starts = np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(np.int32)
+    rays_a = np.stack([rng.permutation(2000).astype(np.int32), starts, counts], -1)
+    S = int(counts.sum())
+    ws = (rng.random(S, dtype=np.float32) * 0.05).astype(np.float32)
+    deltas = np.full(S, 0.0017, np.float32)
+    ts = (np.sort(rng.random(S, dtype=np.float32)) + 0.3).astype(np.float32)
+    ref_loss, ref_wi, ref_wti = oracle.distortion_fwd(ws, deltas, ts, rays_a)
+    w = dev(ws).requires_grad_(True)
+    out = distortion_loss({"ws": w, "deltas": dev(deltas), "ts": dev(ts), "rays_a": dev(rays_a)})
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref_loss, rtol=2e-4, atol=1e-6)
+    gl = rng.standard_normal(2000).astype(np.float32)
+    out.backward(dev(gl))
+    ref_dws = oracle.distortion_bwd(gl, deltas, ws, ts, ref_wi, ref_wti, rays_a)
+    np.testing.assert_allclose(w.grad.cpu().numpy(), ref_dws, rtol=2e-3, atol=2e-5 * np.abs(ref_dws).max())
