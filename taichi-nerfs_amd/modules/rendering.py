@@ -17,7 +17,8 @@ def _background(exp_step_factor, device):
 
 def render(model, rays_o, rays_d, test_time=False, exp_step_factor=0, T_threshold=1e-4, max_samples=MAX_SAMPLES):
     """rays_o, rays_d: [N,3].  Returns the reference's result dictionary (rgb, depth, opacity, ...)."""
-    hits_t = ray_aabb_intersection(rays_o.contiguous(), rays_d.contiguous(), model.scale)
+    rays_o, rays_d = rays_o.contiguous().float(), rays_d.contiguous().float()      # geometry is fp32 (ray_utils.py:50)
+    hits_t = ray_aabb_intersection(rays_o, rays_d, model.scale)
     if test_time:
         return _render_rays_test(model, rays_o, rays_d, hits_t, exp_step_factor, T_threshold, max_samples)
     return _render_rays_train(model, rays_o, rays_d, hits_t, exp_step_factor, T_threshold)
