@@ -25,8 +25,18 @@ import torch.distributed as dist  # noqa: E402
 import torch.nn.functional as F  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
-# algorithmic bytes per live sample, fp32 table, L=16, F=2
+MFMA_PEAK_TFLOPS = 2500.0      # dense fp16/bf16 MFMA
+# algorithmic bytes / FLOPs per unit of work (fp32 table, L=16, F=2)
 BYTES_PER_SAMPLE = {"hash_fwd_f32": 12 + 1024 + 128, "hash_bwd_f32": 12 + 128 + 1024 + 1024}
+# kernel (C-ABI entry) -> (key, bound, work per unit, unit, which argument is the unit count)
+TRAINER_KERNELS = {
+    "ngp_march_train_count_ex": ("march_count", "hbm", 24 + 8 + 4 + 12, "ray"),      # + 8 B per staged sample, added below
+    "ngp_hash_fwd_f32_ex": ("hash_fwd_f32", "hbm", 12 + 1024 + 128, "sample"),
+    "ngp_mlp_fwd_ex": ("mlp_fwd", "mfma", 18816, "sample"),
+    "ngp_mlp_bwd_ex": ("mlp_bwd", "mfma", 37632, "sample"),
+    "ngp_hash_bwd_f32_ex": ("hash_bwd_f32", "hbm", 12 + 128 + 1024 + 1024, "sample"),
+    "ngp_adam_step": ("adam", "hbm", 32, "param"),
+}
 
 
 def parse():
@@ -42,6 +52,8 @@ def parse():
                     help="trainer: ngp_hip.trainer.FusedTrainer (device-resident step); modules: the reference's loop shape "
                          "(render() through modules/ + torch Adam + torch GradScaler)")
     ap.add_argument("--graph", action="store_true", help="replay the trainer step from a captured hipGraph (1 GPU)")
+    ap.add_argument("--no-prefetch", dest="prefetch", action="store_false",
+                    help="do not march the next batch on a side stream underneath the current step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -191,32 +203,36 @@ def main():
 
     state = {"rm": 0, "vr": 0}
 
-    # the hash-grid launches of the trainer go straight through the C ABI: time them by wrapping the library entries
-    hash_events = {"hash_fwd_f32": [], "hash_bwd_f32": []}
-    if use_trainer:
+    # the trainer launches go straight through the C ABI: HIP events around the big kernels, on the launch stream
+    c_events = {}
+    # events are created up front (hipEventCreate inside the timed loop costs more than the kernels it would time)
+    event_pool = [torch.cuda.Event(enable_timing=True) for _ in range(2 * 8 * (args.steps + 2))] if use_trainer and not args.graph else []
+    if use_trainer and not args.graph:
         L = lib.load()
 
-        def wrap_entry(name, key):
+        def wrap_entry(name):
             raw = getattr(L, name)
 
             def timed(*a):
-                if not timer.enabled:
+                if not timer.enabled or not event_pool:
                     return raw(*a)
-                e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-                e0.record(); rc = raw(*a); e1.record()
-                hash_events[key].append((e0, e1))
+                e0, e1 = event_pool.pop(), event_pool.pop()
+                st = torch.cuda.current_stream()
+                e0.record(st); rc = raw(*a); e1.record(st)
+                c_events.setdefault(name, []).append((e0, e1, a))
                 return rc
             setattr(L, name, timed)
-        if not args.graph:
-            wrap_entry("ngp_hash_fwd_f32_ex", "hash_fwd_f32")
-            wrap_entry("ngp_hash_bwd_f32_ex", "hash_bwd_f32")
+        for name in TRAINER_KERNELS:
+            wrap_entry(name)
 
     def trainer_step(i):
         rays_o, rays_d, target = pool[i % n_pool]
         if i % 16 == 0:
             trainer.update_density_grid(0.01 * MAX_SAMPLES / 3**0.5, warmup=False)
             model.density_bitfield.copy_(bits)          # see the comment in step() below
-        out = trainer.step(rays_o, rays_d, target)
+        nxt = pool[(i + 1) % n_pool]
+        pre = (nxt[0], nxt[1]) if (args.prefetch and (i + 1) % 16 != 0) else None      # never across a grid update
+        out = trainer.step(rays_o, rays_d, target, prefetch=pre)
         state["rm"] += out["rm_samples"][0]
         state["vr"] += out["vr_per_ray"].sum()
 
@@ -270,24 +286,45 @@ def main():
     total_rays = args.rays * world * args.steps
     if rank == 0:
         ks = timer.summary()
+        rooflines = {}
         if use_trainer:
-            # trainer launches are sized for the arena; the live sample count per step is rm_samples
-            avg_units = rm / max(args.steps, 1)
-            for key, evs in hash_events.items():
-                if evs:
-                    ms = [e0.elapsed_time(e1) for e0, e1 in evs]
-                    ks[key + "(train)"] = {"launches": len(ms), "avg_ms": float(np.mean(ms)), "total_ms": float(np.sum(ms)),
-                                           "avg_units": float(avg_units)}
-        dom = max((k for k in ks if k.split("(")[0] in BYTES_PER_SAMPLE), key=lambda k: ks[k]["total_ms"], default=None)
-        roof = None
-        if dom is not None:
-            k = ks[dom]
-            bps = BYTES_PER_SAMPLE[dom.split("(")[0]]
-            ach = bps * k["avg_units"] / (k["avg_ms"] * 1e-3) / 1e9
-            roof = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                    "bytes_per_sample": bps, "avg_samples_per_launch": k["avg_units"],
-                    "avg_launch_ms": k["avg_ms"], "launches": k["launches"]}
+            live = rm / max(args.steps, 1)                     # live samples per step (launches are sized for the arena)
+            for name, evs in c_events.items():
+                key, bound, per_unit, unit = TRAINER_KERNELS[name]
+                if name == "ngp_adam_step":                    # two launches per step: keep the table pass (n = arg 4)
+                    evs = [e for e in evs if e[2][4] > 1000000]
+                    units = float(evs[0][2][4]) if evs else 0.0
+                elif unit == "ray":
+                    units = float(args.rays)
+                else:
+                    units = float(live)
+                ms = [e0.elapsed_time(e1) for e0, e1, _ in evs]
+                if not ms:
+                    continue
+                work = per_unit * units + (8 * live if key == "march_count" else 0)
+                ks[key] = {"launches": len(ms), "avg_ms": float(np.mean(ms)), "total_ms": float(np.sum(ms)), "avg_units": units}
+                ach = work / (np.mean(ms) * 1e-3) / (1e9 if bound == "hbm" else 1e12)
+                peak = HBM_PEAK_GBS if bound == "hbm" else MFMA_PEAK_TFLOPS
+                rooflines[key] = {"kernel": key, "bound": bound, "achieved": float(ach), "peak": peak,
+                                  "unit": "GB/s" if bound == "hbm" else "TFLOP/s", "frac": float(ach / peak),
+                                  "traffic": None, "work_per_unit": per_unit, "unit_of_work": unit, "avg_units_per_launch": units,
+                                  "avg_launch_ms": float(np.mean(ms)), "launches": len(ms)}
+        else:
+            for key, k in ks.items():
+                bps = BYTES_PER_SAMPLE[key]
+                ach = bps * k["avg_units"] / (k["avg_ms"] * 1e-3) / 1e9
+                rooflines[key] = {"kernel": key, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": ach / HBM_PEAK_GBS, "traffic": None, "work_per_unit": bps, "unit_of_work": "sample",
+                                  "avg_units_per_launch": k["avg_units"], "avg_launch_ms": k["avg_ms"], "launches": k["launches"]}
+        # PMC traffic (HBM bytes per launch) measured in separate rocprofv3 --pmc passes, see profiles/r01_pmc.json
+        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc.json")
+        if os.path.exists(pmc_path):
+            pmc = json.load(open(pmc_path))
+            for key, r in rooflines.items():
+                if key in pmc.get("kernels", {}):
+                    r["traffic"] = pmc["kernels"][key]["hbm_bytes_per_launch"]
+        dom = max(rooflines, key=lambda k: ks[k]["total_ms"], default=None)
+        roof = rooflines.get(dom)
         out = {
             "metric": "training rays/sec", "value": total_rays / elapsed, "unit": "rays/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -300,8 +337,8 @@ def main():
                        "rays_per_gpu": args.rays, "global_batch": args.rays * world,
                        "parallelism": "ray-sharded dp%d, RCCL all-reduce of %s" % (world, "grads") if world > 1 else "single GPU",
                        "path": ("FusedTrainer" + ("+hipGraph" if args.graph else "")) if use_trainer else "modules+torch.optim"},
-            "samples_per_sec": rm / elapsed, "rm_samples_per_ray": rm / total_rays * world, "vr_samples_per_ray": vr / total_rays * world,
-            "kernels": ks, "roofline": roof,
+            "samples_per_sec": rm * world / elapsed, "rm_samples_per_ray": rm / total_rays * world, "vr_samples_per_ray": vr / total_rays * world,
+            "kernels": ks, "roofline": roof, "rooflines": rooflines,
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(bits_np if args.regime == "lego" else np.load(golden)["density_bitfield"],

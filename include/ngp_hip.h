@@ -67,6 +67,15 @@ int ngp_march_train_count(const float* rays_o, const float* rays_d, const float*
                           int max_samples, int n_rays,
                           float* stage /*[n*max_samples,2] (t,dt)*/, int32_t* counts /*[n]*/,
                           void* stream);
+/* Optional acceleration of `count`: coarse[k] bit = any occupied cell among the 512 Morton codes of 8^3-cell block k
+ * (built by ngp_bitfield_coarsen whenever the bitfield changes; cascades*grid^3/512 bits).  Purely a shortcut for
+ * provably empty cells -- results are bit-identical with coarse == NULL. */
+int ngp_bitfield_coarsen(const uint8_t* density_bitfield, int cascades, int grid_size, uint32_t* coarse,
+                         void* stream);
+int ngp_march_train_count_ex(const float* rays_o, const float* rays_d, const float* hits_t,
+                             const uint8_t* density_bitfield, const uint32_t* coarse, const float* noise,
+                             int cascades, int grid_size, float scale, float exp_step_factor, int max_samples,
+                             int n_rays, float* stage, int32_t* counts, void* stream);
 int ngp_march_train_scan(const int32_t* counts, int n_rays, int32_t* rays_a /*[n,3]*/,
                          int32_t* total /*[1]*/, void* stream);
 int ngp_march_train_write(const float* rays_o, const float* rays_d, const int32_t* rays_a,

@@ -107,6 +107,7 @@ __global__ void __launch_bounds__(256) ray_aabb_kernel(const float* __restrict__
 // chain per 8 steps.
 // ------------------------------------------------------------------------------------------------------
 constexpr int MARCH_GROUP = 16;
+constexpr int MARCH_MAX_COARSE_WORDS = 1024;            // 32 768 coarse blocks: up to 8 cascades of a 128^3 grid
 constexpr int ORBIT_BATCH = 8;      // used by the test-time kernel (one lane per ray)
 
 template <bool CONST_DT>
@@ -114,10 +115,21 @@ __global__ void __launch_bounds__(64) march_count_kernel(const float* __restrict
                                                          const float2* __restrict__ hits_t,
                                                          const uint8_t* __restrict__ bits, const float* __restrict__ noise,
                                                          MarchParams p, int max_samples, int n_rays,
+                                                         const uint32_t* __restrict__ coarse /*nullable*/,
                                                          float2* __restrict__ stage, int32_t* __restrict__ counts) {
     constexpr int G = MARCH_GROUP;
     constexpr int GROUPS = 64 / G;                          // one wave per block: the barriers below are wave-local
     __shared__ float4 pts[GROUPS][G];                       // (t, dt, skip target, occupied)
+    // coarse occupancy: one bit per 8^3 block of cells == per 512 consecutive Morton codes (64 bitfield bytes).
+    // A clear bit proves the cell empty without touching the bitfield: most batches of a trained scene never issue a
+    // global load at all, which is what this latency-bound kernel is waiting on.
+    __shared__ uint32_t coarse_s[MARCH_MAX_COARSE_WORDS];
+    const int coarse_words = coarse ? (int)((p.grid_size3 >> 9) * (uint32_t)p.cascades + 31u) >> 5 : 0;
+    const bool use_coarse = coarse != nullptr && coarse_words <= MARCH_MAX_COARSE_WORDS;
+    if (use_coarse) {
+        for (int k = threadIdx.x; k < coarse_words; k += 64) coarse_s[k] = coarse[k];
+        __syncthreads();
+    }
     const int grp = threadIdx.x / G, sub = threadIdx.x % G;
     const int r = blockIdx.x * GROUPS + grp;
     const bool has_ray = r < n_rays;
@@ -149,7 +161,9 @@ __global__ void __launch_bounds__(64) march_count_kernel(const float* __restrict
         const float t_after = tu + dtu;
         CellProbe c;
         probe_cell(p, o, d, tu, dtu, c);
-        const bool occ = live && ((bits[c.idx >> 3] >> (c.idx & 7u)) & 1u);           // ray_march.py:60-61
+        bool occ = live;
+        if (use_coarse && occ) { const uint32_t cb = c.idx >> 9; occ = (coarse_s[cb >> 5] >> (cb & 31u)) & 1u; }
+        if (occ) occ = (bits[c.idx >> 3] >> (c.idx & 7u)) & 1u;                      // ray_march.py:60-61
         const float targ = skip_target(p, d, d_inv, tu, c);                          // ray_march.py:68-71
         // Fast path: a batch with no occupied point and no skip that reaches past the next orbit point cannot emit,
         // and leaves behind a skip target that is already behind the next batch -- no need to replay it.
@@ -192,6 +206,21 @@ __global__ void __launch_bounds__(64) march_count_kernel(const float* __restrict
         t = t_next_batch;
     }
     if (has_ray && sub == 0) counts[r] = n;
+}
+
+// coarse[k] bit = any occupied cell among Morton codes [512 k, 512 k + 512) = bitfield bytes [64 k, 64 k + 64)
+__global__ void __launch_bounds__(256) bitfield_coarsen_kernel(const uint4* __restrict__ bits16, int n_coarse,
+                                                               uint32_t* __restrict__ coarse) {
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;           // one lane per coarse block
+    bool any = false;
+    if (w < n_coarse) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const uint4 v = bits16[4 * (size_t)w + k]; any |= (v.x | v.y | v.z | v.w) != 0u; }
+    }
+    const unsigned long long m = __ballot(any);
+    const int lane = threadIdx.x & 63;
+    if (lane == 0 && w < n_coarse) coarse[w >> 5] = (uint32_t)m;
+    if (lane == 32 && w < n_coarse) coarse[w >> 5] = (uint32_t)(m >> 32);
 }
 
 // exclusive prefix sum over per-ray counts -> rays_a (ray order) + total.  One 1024-thread block, chunked.
@@ -326,18 +355,36 @@ int ngp_ray_aabb(const float* rays_o, const float* rays_d, float scale, int n_ra
     return 0;
 }
 
+int ngp_bitfield_coarsen(const uint8_t* density_bitfield, int cascades, int grid_size, uint32_t* coarse, void* stream) {
+    const long long cells = (long long)cascades * grid_size * grid_size * grid_size;
+    if (cells <= 0 || cells % 512 != 0) return -1;
+    const int n_coarse = (int)(cells / 512);
+    if (n_coarse % 32 != 0) return -1;
+    hipLaunchKernelGGL(bitfield_coarsen_kernel, dim3((n_coarse + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       (const uint4*)density_bitfield, n_coarse, coarse);
+    NGP_LAUNCH_CHECK();
+    return 0;
+}
+
 int ngp_march_train_count(const float* rays_o, const float* rays_d, const float* hits_t, const uint8_t* density_bitfield,
                           const float* noise, int cascades, int grid_size, float scale, float exp_step_factor,
                           int max_samples, int n_rays, float* stage, int32_t* counts, void* stream) {
+    return ngp_march_train_count_ex(rays_o, rays_d, hits_t, density_bitfield, nullptr, noise, cascades, grid_size, scale,
+                                    exp_step_factor, max_samples, n_rays, stage, counts, stream);
+}
+
+int ngp_march_train_count_ex(const float* rays_o, const float* rays_d, const float* hits_t, const uint8_t* density_bitfield,
+                             const uint32_t* coarse, const float* noise, int cascades, int grid_size, float scale,
+                             float exp_step_factor, int max_samples, int n_rays, float* stage, int32_t* counts, void* stream) {
     if (n_rays <= 0) return 0;
     MarchParams p = make_march_params(cascades, grid_size, scale, exp_step_factor);
     const dim3 grid((n_rays + 64 / MARCH_GROUP - 1) / (64 / MARCH_GROUP));
     if (exp_step_factor == 0.0f)
         hipLaunchKernelGGL(march_count_kernel<true>, grid, dim3(64), 0, (hipStream_t)stream, rays_o, rays_d,
-                           (const float2*)hits_t, density_bitfield, noise, p, max_samples, n_rays, (float2*)stage, counts);
+                           (const float2*)hits_t, density_bitfield, noise, p, max_samples, n_rays, coarse, (float2*)stage, counts);
     else
         hipLaunchKernelGGL(march_count_kernel<false>, grid, dim3(64), 0, (hipStream_t)stream, rays_o, rays_d,
-                           (const float2*)hits_t, density_bitfield, noise, p, max_samples, n_rays, (float2*)stage, counts);
+                           (const float2*)hits_t, density_bitfield, noise, p, max_samples, n_rays, coarse, (float2*)stage, counts);
     NGP_LAUNCH_CHECK();
     return 0;
 }

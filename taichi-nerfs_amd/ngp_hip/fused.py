@@ -40,6 +40,14 @@ class TrainArena:
         self.d_rgbs = torch.empty(cap, 3, device=device, dtype=torch.float16)
         self.d_enc = torch.empty(cap, 32, **f32)
         self.wpack = torch.empty(_lib_mod.load().ngp_mlp_wpack_halfs(), device=device, dtype=torch.float16)
+        self._coarse = {}
+
+    def coarse_for(self, cfg):
+        words = cfg.cascades * cfg.grid_size**3 // 512 // 32
+        buf = self._coarse.get(words)
+        if buf is None:
+            buf = self._coarse[words] = torch.empty(words, device=self.stage.device, dtype=torch.int32)
+        return buf
 
     @classmethod
     def get(cls, device, n_rays, max_samples):
@@ -66,9 +74,11 @@ class FusedTrainRender(torch.autograd.Function):
         rays_a = torch.empty(n, 3, **i32)
         total = torch.empty(1, **i32)
         noise = torch.rand(n, **f32)                                            # ray_march.py:138
-        check(L.ngp_march_train_count(_ptr(rays_o), _ptr(rays_d), _ptr(hits_t), _ptr(cfg.bitfield), _ptr(noise), cfg.cascades,
-                                      cfg.grid_size, cfg.scale, cfg.exp_step_factor, cfg.max_samples, n, _ptr(A.stage),
-                                      _ptr(A.counts), st), "ngp_march_train_count")
+        coarse = A.coarse_for(cfg)
+        check(L.ngp_bitfield_coarsen(_ptr(cfg.bitfield), cfg.cascades, cfg.grid_size, _ptr(coarse), st), "ngp_bitfield_coarsen")
+        check(L.ngp_march_train_count_ex(_ptr(rays_o), _ptr(rays_d), _ptr(hits_t), _ptr(cfg.bitfield), _ptr(coarse), _ptr(noise),
+                                         cfg.cascades, cfg.grid_size, cfg.scale, cfg.exp_step_factor, cfg.max_samples, n,
+                                         _ptr(A.stage), _ptr(A.counts), st), "ngp_march_train_count_ex")
         check(L.ngp_march_train_scan(_ptr(A.counts), n, _ptr(rays_a), _ptr(total), st), "ngp_march_train_scan")
         check(L.ngp_march_train_write(_ptr(rays_o), _ptr(rays_d), _ptr(rays_a), _ptr(A.stage), cfg.max_samples, n,
                                       _ptr(A.xyzs), _ptr(A.dirs), _ptr(A.deltas), _ptr(A.ts), st), "ngp_march_train_write")

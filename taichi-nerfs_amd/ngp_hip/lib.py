@@ -77,6 +77,8 @@ SIGNATURES = {
     "ngp_hash_levels_init": [_LV, ctypes.c_double, _I, ctypes.c_double, ctypes.c_double, _I],
     "ngp_ray_aabb": [_P, _P, _F, _I, _P, _P],
     "ngp_march_train_count": [_P, _P, _P, _P, _P, _I, _I, _F, _F, _I, _I, _P, _P, _P],
+    "ngp_bitfield_coarsen": [_P, _I, _I, _P, _P],
+    "ngp_march_train_count_ex": [_P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _I, _I, _P, _P, _P],
     "ngp_march_train_scan": [_P, _I, _P, _P, _P],
     "ngp_march_train_write": [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P],
     "ngp_march_test": [_P, _P, _P, _P, _P, _I, _I, _F, _F, _I, _I, _P, _P, _P, _P, _P, _P],

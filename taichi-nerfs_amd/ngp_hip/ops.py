@@ -68,6 +68,16 @@ class MarchArena:
         return cur
 
 
+def coarse_bitfield(density_bitfield, cascades, grid_size, out=None):
+    """One bit per 8^3-cell block (any cell occupied) -- the shortcut table of ngp_march_train_count_ex."""
+    words = int(cascades) * int(grid_size)**3 // 512 // 32
+    if out is None:
+        out = torch.empty(words, device=density_bitfield.device, dtype=torch.int32)
+    check(_lib().ngp_bitfield_coarsen(_ptr(density_bitfield), int(cascades), int(grid_size), _ptr(out), _stream()),
+          "ngp_bitfield_coarsen")
+    return out
+
+
 def march_train(rays_o, rays_d, hits_t, density_bitfield, noise, cascades, scale, exp_step_factor, grid_size, max_samples):
     """count -> scan -> (one D2H read of the total, like ray_march.py:187-192) -> write."""
     _dev(rays_o, torch.float32, "rays_o"); _dev(rays_d, torch.float32, "rays_d"); _dev(hits_t, torch.float32, "hits_t")
@@ -80,9 +90,10 @@ def march_train(rays_o, rays_d, hits_t, density_bitfield, noise, cascades, scale
     rays_a = torch.empty(n, 3, device=dev, dtype=torch.int32)
     total = torch.zeros(1, device=dev, dtype=torch.int32)
     st = _stream()
-    check(L.ngp_march_train_count(_ptr(rays_o), _ptr(rays_d), _ptr(hits_t), _ptr(density_bitfield), _ptr(noise),
-                                  int(cascades), int(grid_size), float(scale), float(exp_step_factor), int(max_samples), n,
-                                  _ptr(stage), _ptr(counts), st), "ngp_march_train_count")
+    coarse = coarse_bitfield(density_bitfield, cascades, grid_size)
+    check(L.ngp_march_train_count_ex(_ptr(rays_o), _ptr(rays_d), _ptr(hits_t), _ptr(density_bitfield), _ptr(coarse), _ptr(noise),
+                                     int(cascades), int(grid_size), float(scale), float(exp_step_factor), int(max_samples), n,
+                                     _ptr(stage), _ptr(counts), st), "ngp_march_train_count_ex")
     check(L.ngp_march_train_scan(_ptr(counts), n, _ptr(rays_a), _ptr(total), st), "ngp_march_train_scan")
     S = int(total.item())
     xyzs = torch.empty(S, 3, device=dev, dtype=torch.float32)

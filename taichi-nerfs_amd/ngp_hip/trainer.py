@@ -73,49 +73,102 @@ class FusedTrainer:
         self._graph = None
         self._static = None
         self.stats = {}
+        self._sets = {}
+        self._cur = 0
+        self._side = torch.cuda.Stream(device=dev)
 
     # ------------------------------------------------------------------------------------------------ one step
-    def _launch(self, rays_o, rays_d, target):
+    class _MarchSet:
+        """Outputs of one batch's march.  Two sets alternate so the NEXT batch can be marched on a side stream while
+        the current batch's encode / MLP / backward kernels (which read xyzs, dirs, deltas, ts) are still running."""
+
+        def __init__(self, dev, n, max_samples):
+            cap = n * max_samples
+            f32 = dict(device=dev, dtype=torch.float32)
+            self.n, self.cap = n, cap
+            self.stage = torch.empty(cap, 2, **f32)
+            self.counts = torch.empty(n, device=dev, dtype=torch.int32)
+            self.rays_a = torch.empty(n, 3, device=dev, dtype=torch.int32)
+            self.total = torch.zeros(1, device=dev, dtype=torch.int32)
+            self.hits_t = torch.empty(n, 2, **f32)
+            self.xyzs, self.dirs = torch.empty(cap, 3, **f32), torch.empty(cap, 3, **f32)
+            self.deltas, self.ts = torch.empty(cap, **f32), torch.empty(cap, **f32)
+            self.ready = None               # event recorded on the side stream when a prefetched march has finished
+            self.key = None                 # (data_ptr of rays_o, rays_d) the set was marched for
+
+    def _march_sets(self, n):
+        key = n
+        sets = self._sets.get(key)
+        if sets is None:
+            sets = self._sets[key] = [self._MarchSet(self.dev, n, self.max_samples) for _ in range(2)]
+        return sets
+
+    def _march(self, M, rays_o, rays_d, cfg, A):
+        """ray-AABB + count/scan/write into march set M on the CURRENT stream."""
+        L, st, n = self.L, _stream(), rays_o.shape[0]
+        noise = torch.rand(n, device=self.dev, dtype=torch.float32)                         # ray_march.py:138
+        check(L.ngp_ray_aabb(_ptr(rays_o), _ptr(rays_d), cfg.scale, n, _ptr(M.hits_t), st), "ngp_ray_aabb")
+        coarse = A.coarse_for(cfg)
+        check(L.ngp_bitfield_coarsen(_ptr(cfg.bitfield), cfg.cascades, cfg.grid_size, _ptr(coarse), st), "ngp_bitfield_coarsen")
+        check(L.ngp_march_train_count_ex(_ptr(rays_o), _ptr(rays_d), _ptr(M.hits_t), _ptr(cfg.bitfield), _ptr(coarse), _ptr(noise),
+                                         cfg.cascades, cfg.grid_size, cfg.scale, cfg.exp_step_factor, cfg.max_samples, n,
+                                         _ptr(M.stage), _ptr(M.counts), st), "ngp_march_train_count_ex")
+        check(L.ngp_march_train_scan(_ptr(M.counts), n, _ptr(M.rays_a), _ptr(M.total), st), "ngp_march_train_scan")
+        check(L.ngp_march_train_write(_ptr(rays_o), _ptr(rays_d), _ptr(M.rays_a), _ptr(M.stage), cfg.max_samples, n,
+                                      _ptr(M.xyzs), _ptr(M.dirs), _ptr(M.deltas), _ptr(M.ts), st), "ngp_march_train_write")
+        M.key = (rays_o.data_ptr(), rays_d.data_ptr())
+
+    def _launch(self, rays_o, rays_d, target, prefetch=None):
         L, m, st = self.L, self.model, _stream()
         n = rays_o.shape[0]
         dev = self.dev
         cfg = RenderConfig(m, self.exp_step_factor, self.T_threshold, self.max_samples)
         A = TrainArena.get(dev, n, self.max_samples)
+        sets = self._march_sets(n)
+        M = sets[self._cur]
+        if M.ready is not None and M.key == (rays_o.data_ptr(), rays_d.data_ptr()):
+            torch.cuda.current_stream().wait_event(M.ready)                 # this batch was marched ahead on the side stream
+        else:
+            self._march(M, rays_o, rays_d, cfg, A)
+        M.ready = None
+        if prefetch is not None and self._graph is None:
+            # software pipelining across steps: the march only depends on the rays and the occupancy bitfield, never on
+            # the weights, and it is latency-bound (few resident waves) -- run the NEXT batch's march on a side stream
+            # underneath this step's bandwidth-bound kernels.
+            nxt = sets[1 - self._cur]
+            start = torch.cuda.Event()
+            start.record()                                                  # everything that still reads `nxt` is before this
+            with torch.cuda.stream(self._side):
+                self._side.wait_event(start)
+                self._march(nxt, prefetch[0], prefetch[1], cfg, A)
+                nxt.ready = torch.cuda.Event()
+                nxt.ready.record(self._side)
+        self._cur = 1 - self._cur
         i32 = dict(device=dev, dtype=torch.int32)
         f32 = dict(device=dev, dtype=torch.float32)
-        hits_t = torch.empty(n, 2, **f32)
-        rays_a = torch.empty(n, 3, **i32)
-        total = torch.empty(1, **i32)
+        rays_a, total = M.rays_a, M.total
         vr_per_ray = torch.empty(n, **i32)
         opacity, depth, rgb = torch.empty(n, **f32), torch.empty(n, **f32), torch.empty(n, 3, **f32)
         g_rgb, g_op = torch.empty(n, 3, **f32), torch.empty(n, **f32)
-        noise = torch.rand(n, **f32)                                                        # ray_march.py:138
         ws = self.model._mlp_weights()
-        check(L.ngp_ray_aabb(_ptr(rays_o), _ptr(rays_d), cfg.scale, n, _ptr(hits_t), st), "ngp_ray_aabb")
-        check(L.ngp_march_train_count(_ptr(rays_o), _ptr(rays_d), _ptr(hits_t), _ptr(cfg.bitfield), _ptr(noise), cfg.cascades,
-                                      cfg.grid_size, cfg.scale, cfg.exp_step_factor, cfg.max_samples, n, _ptr(A.stage),
-                                      _ptr(A.counts), st), "ngp_march_train_count")
-        check(L.ngp_march_train_scan(_ptr(A.counts), n, _ptr(rays_a), _ptr(total), st), "ngp_march_train_scan")
-        check(L.ngp_march_train_write(_ptr(rays_o), _ptr(rays_d), _ptr(rays_a), _ptr(A.stage), cfg.max_samples, n,
-                                      _ptr(A.xyzs), _ptr(A.dirs), _ptr(A.deltas), _ptr(A.ts), st), "ngp_march_train_write")
-        check(L.ngp_hash_fwd_f32_ex(_ptr(A.xyzs), _ptr(self.table), ctypes.byref(cfg.levels), A.cap, _ptr(total), 1, cfg.lo,
+        check(L.ngp_hash_fwd_f32_ex(_ptr(M.xyzs), _ptr(self.table), ctypes.byref(cfg.levels), A.cap, _ptr(total), 1, cfg.lo,
                                     cfg.hi, _ptr(A.enc), st), "ngp_hash_fwd_f32_ex")
         check(L.ngp_mlp_pack(*[_ptr(w) for w in ws], _ptr(A.wpack), st), "ngp_mlp_pack")
-        check(L.ngp_mlp_fwd_ex(_ptr(A.enc), _ptr(A.dirs), _ptr(A.wpack), A.cap, _ptr(total), _ptr(A.sigmas), _ptr(A.rgbs), st),
+        check(L.ngp_mlp_fwd_ex(_ptr(A.enc), _ptr(M.dirs), _ptr(A.wpack), A.cap, _ptr(total), _ptr(A.sigmas), _ptr(A.rgbs), st),
               "ngp_mlp_fwd_ex")
-        check(L.ngp_composite_train_fwd(_ptr(A.sigmas), _ptr(A.rgbs), 1, _ptr(A.deltas), _ptr(A.ts), _ptr(rays_a),
+        check(L.ngp_composite_train_fwd(_ptr(A.sigmas), _ptr(A.rgbs), 1, _ptr(M.deltas), _ptr(M.ts), _ptr(rays_a),
                                         cfg.T_threshold, n, _ptr(vr_per_ray), _ptr(opacity), _ptr(depth), _ptr(rgb), _ptr(A.ws),
                                         st), "ngp_composite_train_fwd")
         check(L.ngp_mse_loss_grad(_ptr(rgb), _ptr(opacity), _ptr(target), self.bg, n, _ptr(self.state_f), _ptr(g_rgb), _ptr(g_op),
                                   st), "ngp_mse_loss_grad")
         check(L.ngp_composite_train_bwd(_ptr(g_op), _ptr(None), _ptr(g_rgb), _ptr(None), _ptr(A.sigmas), _ptr(A.rgbs), 1,
-                                        _ptr(A.deltas), _ptr(A.ts), _ptr(rays_a), _ptr(opacity), _ptr(depth), _ptr(rgb),
+                                        _ptr(M.deltas), _ptr(M.ts), _ptr(rays_a), _ptr(opacity), _ptr(depth), _ptr(rgb),
                                         _ptr(A.ws), cfg.T_threshold, n, _ptr(A.d_sigmas), _ptr(A.d_rgbs), st),
               "ngp_composite_train_bwd")
         found = ctypes.c_void_p(self.state_i.data_ptr() + 4 * _SI_FOUND_INF)
-        check(L.ngp_mlp_bwd_ex(_ptr(A.enc), _ptr(A.dirs), _ptr(A.wpack), _ptr(A.d_sigmas), _ptr(A.d_rgbs), A.cap, _ptr(total),
+        check(L.ngp_mlp_bwd_ex(_ptr(A.enc), _ptr(M.dirs), _ptr(A.wpack), _ptr(A.d_sigmas), _ptr(A.d_rgbs), A.cap, _ptr(total),
                                _ptr(A.d_enc), _ptr(self.mlp_grad), found, st), "ngp_mlp_bwd_ex")
-        check(L.ngp_hash_bwd_f32_ex(_ptr(A.xyzs), _ptr(A.d_enc), ctypes.byref(cfg.levels), A.cap, _ptr(total), 1, cfg.lo, cfg.hi,
+        check(L.ngp_hash_bwd_f32_ex(_ptr(M.xyzs), _ptr(A.d_enc), ctypes.byref(cfg.levels), A.cap, _ptr(total), 1, cfg.lo, cfg.hi,
                                     _ptr(self.table_grad), found, st), "ngp_hash_bwd_f32_ex")
         if self.world > 1:
             self._all_reduce()
@@ -126,7 +179,8 @@ class FusedTrainer:
               "ngp_adam_step")
         check(L.ngp_adam_step(_ptr(self.mlp_flat), _ptr(self.mlp_grad), _ptr(self.mlp_m), _ptr(self.mlp_v), MLP_N_WEIGHTS,
                               _ptr(self.state_f), _ptr(self.state_i), self.beta1, self.beta2, self.eps, st), "ngp_adam_step")
-        return {"rm_samples": total, "vr_per_ray": vr_per_ray, "rgb": rgb, "opacity": opacity, "depth": depth, "rays_a": rays_a}
+        return {"rm_samples": total, "vr_per_ray": vr_per_ray, "rgb": rgb, "opacity": opacity, "depth": depth, "rays_a": rays_a,
+                "deltas": M.deltas, "ts": M.ts}
 
     def _all_reduce(self):
         """Average the gradients of the ray shards (MSE is a mean over the local shard) and OR the inf flags."""
@@ -139,15 +193,20 @@ class FusedTrainer:
                 g.div_(self.world)
         dist.all_reduce(self.state_i[_SI_FOUND_INF:_SI_FOUND_INF + 1], op=dist.ReduceOp.MAX, group=self.group)
 
-    def step(self, rays_o, rays_d, target):
-        """rays_o, rays_d, target: [N,3] float32 device tensors (this rank's shard).  Returns the per-step outputs
-        (device tensors; nothing is synchronised)."""
+    def step(self, rays_o, rays_d, target, prefetch=None):
+        """rays_o, rays_d, target: [N,3] contiguous float32 device tensors (this rank's shard).  Returns the per-step
+        outputs (device tensors; nothing is synchronised).
+        prefetch=(next_rays_o, next_rays_d): the NEXT step's rays, if already known and if the occupancy grid will not be
+        updated in between -- their march then overlaps this step on a side stream (the tensors must stay alive and
+        unmodified until that next step() call, which must receive the very same tensors)."""
         if self._graph is not None:
             so, sd, stg = self._static
             so.copy_(rays_o); sd.copy_(rays_d); stg.copy_(target)
             self._graph.replay()
             return self.stats
-        self.stats = self._launch(rays_o.contiguous().float(), rays_d.contiguous().float(), target.contiguous().float())
+        if prefetch is not None:
+            prefetch = (prefetch[0].contiguous().float(), prefetch[1].contiguous().float())
+        self.stats = self._launch(rays_o.contiguous().float(), rays_d.contiguous().float(), target.contiguous().float(), prefetch)
         return self.stats
 
     def capture(self, n_rays):
