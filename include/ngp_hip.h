@@ -67,6 +67,7 @@ int ngp_march_train_count(const float* rays_o, const float* rays_d, const float*
                           int max_samples, int n_rays,
                           float* stage /*[n*max_samples,2] (t,dt)*/, int32_t* counts /*[n]*/,
                           void* stream);
+/* (hits_t may be NULL in the _ex form below: the slab test of ngp_ray_aabb is then evaluated inline.) */
 /* Optional acceleration of `count`: coarse[k] bit = any occupied cell among the 512 Morton codes of 8^3-cell block k
  * (built by ngp_bitfield_coarsen whenever the bitfield changes; cascades*grid^3/512 bits).  Purely a shortcut for
  * provably empty cells -- results are bit-identical with coarse == NULL. */
@@ -136,6 +137,15 @@ int ngp_composite_train_bwd(const float* dL_dopacity, const float* dL_ddepth, co
                             const float* rgb, const float* ws, float T_threshold, int n_rays,
                             float* dL_dsigmas, void* dL_drgbs, void* stream);
 
+/* Trainer fusion of composite forward + MSE gradient (train.py:193, white/black background blend of
+ * rendering.py:219-226) + composite backward: one wave per ray, two passes.  loss_scale points at state_f[0]; the
+ * per-ray squared error sum_c (rgb_final - target)^2 is written to sq_err[ray] (nullable) for logging. */
+int ngp_composite_train_fused(const float* sigmas, const void* rgbs, int rgbs_is_half, const float* deltas,
+                              const float* ts, const int32_t* rays_a, const float* target, float bg,
+                              const float* loss_scale, float T_threshold, int n_rays, int32_t* vr_per_ray,
+                              float* opacity, float* depth, float* rgb, float* ws, float* d_sigmas, void* d_rgbs,
+                              float* sq_err, void* stream);
+
 /* ---- a-8  composite_test (modules/volume_render_test.py:4-54) -------------------------------- */
 int ngp_composite_test(const float* sigmas, const void* rgbs, int rgbs_is_half, const float* deltas,
                        const float* ts, const int64_t* pack_info /*[n,2]*/,
@@ -176,6 +186,9 @@ int ngp_train_prologue(float* state_f, int32_t* state_i, float lr0, float eta_mi
 /* p, g, m, v: n floats each (n % 4 == 0, 16-byte aligned); g is unscaled on the fly and zero-filled. */
 int ngp_adam_step(float* p, float* g, float* m, float* v, long long n, const float* state_f,
                   const int32_t* state_i, float beta1, float beta2, float eps, void* stream);
+/* Adam on the 9 408 flat MLP weights (W1|W2|W3|W4|W5) + the fp16 fragment repack for the next step, one launch. */
+int ngp_adam_mlp_pack(float* p, float* g, float* m, float* v, const float* state_f, const int32_t* state_i,
+                      float beta1, float beta2, float eps, uint16_t* wpack, void* stream);
 
 /* ---- a-10 morton3D / morton3D_invert / packbits (modules/utils.py:120-169) -------------------- */
 int ngp_morton3d(const int32_t* coords /*[m,3]*/, int m, int32_t* indices, void* stream);
@@ -190,6 +203,23 @@ int ngp_distortion_fwd(const float* ws, const float* deltas, const float* ts, co
 int ngp_distortion_bwd(const float* dL_dloss, const float* ws, const float* deltas, const float* ts,
                        const float* ws_inc, const float* wts_inc, const int32_t* rays_a, int n_rays,
                        float* dL_dws, void* stream);
+
+/* ---- f-3  occupancy-grid update without host round trips (modules/networks.py:181-209,255-290).
+ * compact : list[0..count) = cells of ONE cascade with density > threshold (count must be zeroed by the caller)
+ * sample  : m uniform cells (u_cell [m,3] in [0,1)) + m picks from the list (u_pick [m]) -> Morton indices [2m] and jittered
+ *           world positions [2m,3] (u_jit [2m,3]); s = min(2^(c-1), scale), half_grid = s / grid_size
+ * all_cells: warm-up variant, cell i = Morton code i
+ * scatter : tmp[indices[i]] = sigmas[i] (indices == NULL: identity)
+ * merge   : grid = grid < 0 ? grid : max(grid*decay, tmp); stats[0] += sum, stats[1] += count of positive cells (zero stats first)
+ * pack    : bitfield bit = grid > min(stats[0]/stats[1], density_threshold) */
+int ngp_occ_compact(const float* density_grid, float threshold, int n_cells, int32_t* list, int32_t* count, void* stream);
+int ngp_occ_sample(const float* u_cell, const float* u_pick, const float* u_jit, const int32_t* list, const int32_t* count,
+                   int m, int grid_size, float s, float half_grid, int32_t* indices, float* xyzs, void* stream);
+int ngp_occ_all_cells(const float* u_jit, int n_cells, int grid_size, float s, float half_grid, float* xyzs, void* stream);
+int ngp_occ_scatter(const int32_t* indices, const float* sigmas, int n, float* tmp, void* stream);
+int ngp_occ_merge(float* density_grid, const float* tmp, float decay, int n, float* stats, void* stream);
+int ngp_occ_pack(const float* density_grid, const float* stats, float density_threshold, int n_bytes, uint8_t* bitfield,
+                 void* stream);
 
 #ifdef __cplusplus
 }

@@ -157,6 +157,99 @@ __global__ void __launch_bounds__(256) composite_bwd_kernel(const float* __restr
     }
 }
 
+// ---- trainer fusion: forward + MSE gradient + backward of one ray in one wave -----------------------------------
+// rgb_final = rgb + bg (1 - opacity) (rendering.py:219-226), loss = mean((rgb_final - target)^2) (train.py:193).  The
+// gradient of a ray's outputs only needs that ray's own radiance, so the three launches (composite fwd, loss, composite
+// bwd) collapse into one: pass 1 composites and leaves R/D/O in registers, pass 2 re-walks the ray (its samples are
+// still in L2) with the closed-form backward.  The per-ray squared error goes to sq_err[ray] (nullable) for logging.
+template <bool HALF>
+__global__ void __launch_bounds__(256) composite_train_fused_kernel(
+    const float* __restrict__ sigmas, const void* __restrict__ rgbs, const float* __restrict__ deltas, const float* __restrict__ ts,
+    const int32_t* __restrict__ rays_a, const float* __restrict__ target, float bg, const float* __restrict__ loss_scale, float thr,
+    int n_rays, int32_t* __restrict__ vr_per_ray, float* __restrict__ opacity, float* __restrict__ depth, float* __restrict__ rgb,
+    float* __restrict__ ws, float* __restrict__ d_sigmas, void* __restrict__ d_rgbs, float* __restrict__ sq_err) {
+    const int n = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (n >= n_rays) return;
+    const int lane = lane_id();
+    const int ray_idx = rays_a[3 * n], start = rays_a[3 * n + 1], N = rays_a[3 * n + 2];
+    // ---- pass 1: forward (same arithmetic as composite_fwd_kernel)
+    float T = 1.0f, r0 = 0.f, r1 = 0.f, r2 = 0.f, dep = 0.f, op = 0.f;
+    int cnt = 0;
+    for (int base = 0; base < N; base += NGP_WAVE) {
+        const int j = base + lane;
+        const bool valid = j < N;
+        const size_t s = (size_t)start + j;
+        if (!(T > thr)) { if (valid) ws[s] = 0.0f; continue; }
+        float a = 0.0f, tm = 0.0f, c[3] = {0.f, 0.f, 0.f};
+        if (valid) { a = 1.0f - expf(-sigmas[s] * deltas[s]); tm = ts[s]; load_rgb<HALF>(rgbs, s, c); }
+        const float incl = wave_scan_mul(1.0f - a, lane);
+        float excl = __shfl_up(incl, 1, NGP_WAVE);
+        if (lane == 0) excl = 1.0f;
+        const float Ts = T * excl;
+        const bool live = valid && (Ts > thr);
+        const float w = live ? a * Ts : 0.0f;
+        if (valid) ws[s] = w;
+        r0 += w * c[0]; r1 += w * c[1]; r2 += w * c[2]; dep += w * tm; op += w; cnt += live ? 1 : 0;
+        T = T * __shfl(incl, NGP_WAVE - 1, NGP_WAVE);
+    }
+    const float R0 = wave_sum(r0), R1 = wave_sum(r1), R2 = wave_sum(r2), D = wave_sum(dep), O = wave_sum(op);
+    cnt = wave_sum_i(cnt);
+    // ---- MSE gradient of this ray (loss-scaled, like GradScaler.scale(loss).backward())
+    const float k = 2.0f / (3.0f * (float)n_rays) * loss_scale[0];
+    const float b = bg * (1.0f - O);
+    const float e0 = (R0 + b) - target[3 * ray_idx], e1 = (R1 + b) - target[3 * ray_idx + 1], e2 = (R2 + b) - target[3 * ray_idx + 2];
+    const float gr0 = k * e0, gr1 = k * e1, gr2 = k * e2;
+    const float go = -bg * (gr0 + gr1 + gr2);
+    if (lane == 0) {
+        rgb[3 * ray_idx] = R0; rgb[3 * ray_idx + 1] = R1; rgb[3 * ray_idx + 2] = R2;
+        depth[ray_idx] = D; opacity[ray_idx] = O; vr_per_ray[ray_idx] = cnt;
+        // per-ray squared error for logging; summing it here would be 8192 same-address atomics (~12 ns each, measured:
+        // 100 us) -- the reader reduces this array instead
+        if (sq_err) sq_err[ray_idx] = e0 * e0 + e1 * e1 + e2 * e2;
+    }
+    // ---- pass 2: closed-form backward (composite_bwd_kernel with g_depth = g_ws = 0)
+    T = 1.0f;
+    float cr0 = 0.f, cr1 = 0.f, cr2 = 0.f;
+    for (int base = 0; base < N; base += NGP_WAVE) {
+        const int j = base + lane;
+        const bool valid = j < N;
+        const size_t s = (size_t)start + j;
+        if (!(T > thr)) {
+            if (valid) {
+                d_sigmas[s] = 0.0f;
+                if (HALF) { __half* p = (__half*)d_rgbs + 3 * s; p[0] = p[1] = p[2] = __float2half(0.0f); }
+                else { float* p = (float*)d_rgbs + 3 * s; p[0] = p[1] = p[2] = 0.0f; }
+            }
+            continue;
+        }
+        float a = 0.0f, dl = 0.0f, c[3] = {0.f, 0.f, 0.f};
+        if (valid) { dl = deltas[s]; a = 1.0f - expf(-sigmas[s] * dl); load_rgb<HALF>(rgbs, s, c); }
+        const float incl = wave_scan_mul(1.0f - a, lane);
+        float excl = __shfl_up(incl, 1, NGP_WAVE);
+        if (lane == 0) excl = 1.0f;
+        const float Ts = T * excl;
+        const bool live = valid && (Ts > thr);
+        const float w = live ? a * Ts : 0.0f;
+        const float Tp = Ts * (1.0f - a);
+        const float p0 = cr0 + wave_scan_add(w * c[0], lane), p1 = cr1 + wave_scan_add(w * c[1], lane),
+                    p2 = cr2 + wave_scan_add(w * c[2], lane);
+        if (valid) {
+            float ds = 0.0f, dc0 = 0.0f, dc1 = 0.0f, dc2 = 0.0f;
+            if (live) {
+                float acc = gr0 * (c[0] * Tp - (R0 - p0)) + gr1 * (c[1] * Tp - (R1 - p1)) + gr2 * (c[2] * Tp - (R2 - p2));
+                acc += go * (1.0f - O);
+                ds = dl * acc;
+                dc0 = gr0 * w; dc1 = gr1 * w; dc2 = gr2 * w;
+            }
+            d_sigmas[s] = ds;
+            if (HALF) { __half* p = (__half*)d_rgbs + 3 * s; p[0] = __float2half(dc0); p[1] = __float2half(dc1); p[2] = __float2half(dc2); }
+            else { float* p = (float*)d_rgbs + 3 * s; p[0] = dc0; p[1] = dc1; p[2] = dc2; }
+        }
+        cr0 = __shfl(p0, NGP_WAVE - 1, NGP_WAVE); cr1 = __shfl(p1, NGP_WAVE - 1, NGP_WAVE); cr2 = __shfl(p2, NGP_WAVE - 1, NGP_WAVE);
+        T = T * __shfl(incl, NGP_WAVE - 1, NGP_WAVE);
+    }
+}
+
 // ---- a-8 test-time compositing (volume_render_test.py:18-54): one lane per alive ray, serial over <= steps ----
 template <bool HALF>
 __global__ void __launch_bounds__(256) composite_test_kernel(const float* __restrict__ sigmas, const void* __restrict__ rgbs,
@@ -221,6 +314,22 @@ int ngp_composite_train_bwd(const float* dL_dopacity, const float* dL_ddepth, co
         hipLaunchKernelGGL(composite_bwd_kernel<false>, grid, block, 0, (hipStream_t)stream, dL_dopacity, dL_ddepth, dL_drgb,
                            dL_dws, sigmas, rgbs, deltas, ts, rays_a, opacity, depth, rgb, ws, T_threshold, n_rays, dL_dsigmas,
                            dL_drgbs);
+    NGP_LAUNCH_CHECK();
+    return 0;
+}
+
+int ngp_composite_train_fused(const float* sigmas, const void* rgbs, int rgbs_is_half, const float* deltas, const float* ts,
+                              const int32_t* rays_a, const float* target, float bg, const float* loss_scale, float T_threshold,
+                              int n_rays, int32_t* vr_per_ray, float* opacity, float* depth, float* rgb, float* ws,
+                              float* d_sigmas, void* d_rgbs, float* sq_err, void* stream) {
+    if (n_rays <= 0) return 0;
+    dim3 grid((n_rays + 3) / 4), block(256);
+    if (rgbs_is_half)
+        hipLaunchKernelGGL(composite_train_fused_kernel<true>, grid, block, 0, (hipStream_t)stream, sigmas, rgbs, deltas, ts, rays_a,
+                           target, bg, loss_scale, T_threshold, n_rays, vr_per_ray, opacity, depth, rgb, ws, d_sigmas, d_rgbs, sq_err);
+    else
+        hipLaunchKernelGGL(composite_train_fused_kernel<false>, grid, block, 0, (hipStream_t)stream, sigmas, rgbs, deltas, ts, rays_a,
+                           target, bg, loss_scale, T_threshold, n_rays, vr_per_ray, opacity, depth, rgb, ws, d_sigmas, d_rgbs, sq_err);
     NGP_LAUNCH_CHECK();
     return 0;
 }

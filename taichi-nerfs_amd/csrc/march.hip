@@ -137,7 +137,20 @@ __global__ void __launch_bounds__(64) march_count_kernel(const float* __restrict
     float o[3], d[3], d_inv[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) { o[k] = rays_o[3 * rr + k]; d[k] = rays_d[3 * rr + k]; d_inv[k] = 1.0f / d[k]; }
-    const float2 h = hits_t[rr];
+    float2 h;
+    if (hits_t) h = hits_t[rr];
+    else {                                            // fused ray-AABB slab test (intersection.py:22-37), same arithmetic
+        const float half_size = (p.scale - (-p.scale)) / 2.0f;
+        float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float t_min = (0.0f - half_size - o[k]) * d_inv[k], t_max = (0.0f + half_size - o[k]) * d_inv[k];
+            const float lo = fminf(t_min, t_max), hi = fmaxf(t_min, t_max);
+            a1 = k ? fmaxf(a1, lo) : lo;
+            a2 = k ? fminf(a2, hi) : hi;
+        }
+        h = (a2 > 0.0f) ? make_float2(fmaxf(a1, 0.01f), a2) : make_float2(-1.0f, -1.0f);
+    }
     float t1 = h.x;
     const float t2 = h.y;
     const float dt_c = calc_dt(0.0f, p.esf, p.dt_min, p.dt_max);                    // the step when exp_step_factor == 0

@@ -54,11 +54,8 @@ __device__ __forceinline__ int chain_k(int s, int g, int j) { return 32 * s + 16
 
 // One thread per (fragment, lane, slot): gathers the fp32 master weight, rounds to fp16 (what autocast's
 // weight.to(fp16) does) and stores it where the MFMA A operand of that lane wants it.
-__global__ void __launch_bounds__(256) mlp_pack_kernel(const float* __restrict__ W1, const float* __restrict__ W2,
-                                                       const float* __restrict__ W3, const float* __restrict__ W4,
-                                                       const float* __restrict__ W5, half_t* __restrict__ wpack) {
-    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (tid >= N_ALL_FRAGS * 64 * 8) return;
+__device__ __forceinline__ void pack_one(int tid, const float* W1, const float* W2, const float* W3, const float* W4,
+                                         const float* W5, half_t* wpack) {
     const int j = tid & 7, lane = (tid >> 3) & 63, frag = tid >> 9;
     const int i = lane & 15, g = lane >> 4;
     float v = 0.0f;
@@ -96,6 +93,37 @@ __global__ void __launch_bounds__(256) mlp_pack_kernel(const float* __restrict__
         v = W1[chain_k(s, g, j) * 32 + 16 * mt + i];
     }
     wpack[tid] = (half_t)v;
+}
+
+__global__ void __launch_bounds__(256) mlp_pack_kernel(const float* __restrict__ W1, const float* __restrict__ W2,
+                                                       const float* __restrict__ W3, const float* __restrict__ W4,
+                                                       const float* __restrict__ W5, half_t* __restrict__ wpack) {
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid < N_ALL_FRAGS * 64 * 8) pack_one(tid, W1, W2, W3, W4, W5, wpack);
+}
+
+// Trainer fusion: Adam on the 9 408 flat MLP weights (same arithmetic as optim.hip's adam_kernel, state layout in
+// include/ngp_hip.h) followed by the fp16 fragment repack for the next step, in ONE block -- replaces two launches.
+__global__ void __launch_bounds__(1024) adam_mlp_pack_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                             float* __restrict__ v, const float* __restrict__ sf,
+                                                             const int32_t* __restrict__ si, float beta1, float beta2, float eps,
+                                                             half_t* __restrict__ wpack) {
+    const bool skip = si[4] != 0;
+    const float inv_scale = sf[1], step_size = sf[2] / sf[3], bc2_sqrt = sf[4];
+    for (int i = threadIdx.x; i < 9408; i += blockDim.x) {
+        if (!skip) {
+            const float gr = g[i] * inv_scale;
+            const float mi = m[i] + (gr - m[i]) * (1.0f - beta1);
+            const float vi = v[i] * beta2 + gr * gr * (1.0f - beta2);
+            const float denom = sqrtf(vi) / bc2_sqrt + eps;
+            p[i] = p[i] - step_size * (mi / denom);
+            m[i] = mi; v[i] = vi;
+        }
+        g[i] = 0.0f;
+    }
+    __syncthreads();
+    for (int tid = threadIdx.x; tid < N_ALL_FRAGS * 64 * 8; tid += blockDim.x)
+        pack_one(tid, p, p + 2048, p + 3072, p + 5120, p + 9216, wpack);
 }
 
 // ---- per-lane helpers -------------------------------------------------------------------------------------
@@ -527,6 +555,14 @@ int ngp_mlp_pack(const float* W1, const float* W2, const float* W3, const float*
     const int total = N_ALL_FRAGS * 64 * 8;
     hipLaunchKernelGGL(mlp_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, W1, W2, W3, W4, W5,
                        (half_t*)wpack);
+    NGP_LAUNCH_CHECK();
+    return 0;
+}
+
+int ngp_adam_mlp_pack(float* p, float* g, float* m, float* v, const float* state_f, const int32_t* state_i, float beta1, float beta2,
+                      float eps, uint16_t* wpack, void* stream) {
+    hipLaunchKernelGGL(adam_mlp_pack_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, p, g, m, v, state_f, state_i, beta1, beta2,
+                       eps, (half_t*)wpack);
     NGP_LAUNCH_CHECK();
     return 0;
 }

@@ -1,0 +1,182 @@
+// occupancy.hip -- the occupancy-grid update of Instant-NGP as device-resident kernels for gfx950.
+//
+// Replaces the torch-op sequence of reference modules/networks.py:181-209 (sample_uniform_and_occupied_cells) and
+// :255-290 (update_density_grid): ~45 small launches, a torch.nonzero (host sync, dynamic shape) and a .item() (host sync)
+// every 16 training steps, during which the GPU idles.  Here the update is a fixed sequence of launches with no
+// read-back: the list of occupied cells is compacted on the device, sampled through its device-side count, the mean
+// density is reduced on the device and consumed by the packbits kernel from device memory.
+// The density evaluation in the middle reuses the hash-grid and fused-MLP kernels.
+#include "ngp_device.h"
+
+namespace ngp {
+
+// cells of one cascade with density > threshold -> list[0 .. count) (order unspecified; they are sampled uniformly)
+__global__ void __launch_bounds__(256) occ_compact_kernel(const float* __restrict__ grid, float thr, int n_cells,
+                                                          int32_t* __restrict__ list, int32_t* __restrict__ count) {
+    // every wave owns a contiguous chunk: count it, reserve its slice with ONE returning atomic (same-address atomics
+    // serialise at ~12 ns each: one per 64 cells cost 390 us for 128^3 cells), then write it
+    const int n_waves = gridDim.x * (blockDim.x >> 6);
+    const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int chunk = ((n_cells + n_waves - 1) / n_waves + 63) & ~63;
+    const int lo = wave * chunk, hi = min(lo + chunk, n_cells);
+    int mine = 0;
+    for (int i = lo + lane; i < hi; i += 64) mine += grid[i] > thr ? 1 : 0;                  // networks.py:198-199
+    const int total = wave_sum_i(mine);
+    int base = 0;
+    if (lane == 0 && total) base = atomicAdd(count, total);
+    base = __shfl(base, 0, 64);
+    for (int i0 = lo; i0 < hi; i0 += 64) {
+        const int i = i0 + lane;
+        const bool occ = i < hi && grid[i] > thr;
+        const unsigned long long m = __ballot(occ);
+        if (occ) list[base + __popcll(m & ((1ull << lane) - 1ull))] = i;
+        base += __popcll(m);
+    }
+}
+
+// M uniform cells + M cells drawn (with replacement) from the occupied list, their Morton indices and a jittered world
+// position inside each cell (networks.py:193-207, :270-275).  u: [2M,4] uniform [0,1) numbers (3 for the cell or the
+// list pick, reused as jitter source via the 4th..; see below).
+__global__ void __launch_bounds__(256) occ_sample_kernel(const float* __restrict__ u_cell /*[M,3]*/, const float* __restrict__ u_pick /*[M]*/,
+                                                         const float* __restrict__ u_jit /*[2M,3]*/, const int32_t* __restrict__ list,
+                                                         const int32_t* __restrict__ count, int M, int G, float s, float half_grid,
+                                                         int32_t* __restrict__ indices /*[2M]*/, float* __restrict__ xyzs /*[2M,3]*/) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 2 * M) return;
+    int cx, cy, cz, idx;
+    if (i < M) {                                                                   // torch.randint(grid_size, (M,3)) :193
+        cx = min((int)(u_cell[3 * i] * (float)G), G - 1);
+        cy = min((int)(u_cell[3 * i + 1] * (float)G), G - 1);
+        cz = min((int)(u_cell[3 * i + 2] * (float)G), G - 1);
+        idx = (int)morton3d((uint32_t)cx, (uint32_t)cy, (uint32_t)cz);             // :196
+    } else {
+        const int n_occ = *count;
+        if (n_occ > 0) {                                                           // :200-203
+            const int k = min((int)(u_pick[i - M] * (float)n_occ), n_occ - 1);
+            idx = list[k];
+        } else {
+            idx = 0;                                                               // torch: empty index list -> no cells; cell 0 is
+        }                                                                          // a harmless stand-in (only ever max-merged)
+        cx = morton3d_invert1((uint32_t)idx); cy = morton3d_invert1((uint32_t)idx >> 1); cz = morton3d_invert1((uint32_t)idx >> 2);
+    }
+    indices[i] = idx;
+    const int c[3] = {cx, cy, cz};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float base = ((float)c[k] / (float)(G - 1) * 2.0f - 1.0f) * (s - half_grid);      // :272-273
+        xyzs[3 * (size_t)i + k] = base + (u_jit[3 * (size_t)i + k] * 2.0f - 1.0f) * half_grid;  // :275
+    }
+}
+
+// warm-up variant: every cell, enumerated in Morton order (index i IS the Morton code)
+__global__ void __launch_bounds__(256) occ_all_cells_kernel(const float* __restrict__ u_jit /*[n,3]*/, int n_cells, int G, float s,
+                                                            float half_grid, float* __restrict__ xyzs) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_cells) return;
+    const int c[3] = {morton3d_invert1((uint32_t)i), morton3d_invert1((uint32_t)i >> 1), morton3d_invert1((uint32_t)i >> 2)};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float base = ((float)c[k] / (float)(G - 1) * 2.0f - 1.0f) * (s - half_grid);
+        xyzs[3 * (size_t)i + k] = base + (u_jit[3 * (size_t)i + k] * 2.0f - 1.0f) * half_grid;
+    }
+}
+
+// density_grid_tmp[indices] = sigmas (duplicates: any winner, like torch's index_put_ with repeated indices, :276)
+__global__ void __launch_bounds__(256) occ_scatter_kernel(const int32_t* __restrict__ indices, const float* __restrict__ sigmas, int n,
+                                                          float* __restrict__ tmp) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) tmp[indices ? indices[i] : i] = sigmas[i];
+}
+
+// grid = where(grid < 0, grid, max(grid*decay, tmp)) (:281-284) and the sum / count of the positive cells (:286)
+__global__ void __launch_bounds__(256) occ_merge_kernel(float* __restrict__ grid, const float* __restrict__ tmp, float decay, int n,
+                                                        float* __restrict__ stats /*[0] sum, [1] count*/) {
+    float sum = 0.f, cnt = 0.f;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        float g = grid[i];
+        if (!(g < 0.f)) g = fmaxf(g * decay, tmp[i]);
+        grid[i] = g;
+        if (g > 0.f) { sum += g; cnt += 1.f; }
+    }
+    sum = wave_sum(sum); cnt = wave_sum(cnt);
+    __shared__ float ps[4], pc[4];
+    if ((threadIdx.x & 63) == 0) { ps[threadIdx.x >> 6] = sum; pc[threadIdx.x >> 6] = cnt; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsafeAtomicAdd(stats, ps[0] + ps[1] + ps[2] + ps[3]);
+        unsafeAtomicAdd(stats + 1, pc[0] + pc[1] + pc[2] + pc[3]);
+    }
+}
+
+// packbits with threshold = min(mean density, density_threshold) read from device memory (:286-290)
+__global__ void __launch_bounds__(256) occ_pack_kernel(const float4* __restrict__ grid, const float* __restrict__ stats, float thr_max,
+                                                       int n_bytes, uint8_t* __restrict__ out) {
+    const float thr = fminf(stats[0] / stats[1], thr_max);
+    for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < n_bytes; n += gridDim.x * blockDim.x) {
+        const float4 a = grid[2 * (size_t)n], b = grid[2 * (size_t)n + 1];
+        uint32_t bits = 0;
+        bits |= (a.x > thr) ? 1u : 0u; bits |= (a.y > thr) ? 2u : 0u; bits |= (a.z > thr) ? 4u : 0u; bits |= (a.w > thr) ? 8u : 0u;
+        bits |= (b.x > thr) ? 16u : 0u; bits |= (b.y > thr) ? 32u : 0u; bits |= (b.z > thr) ? 64u : 0u; bits |= (b.w > thr) ? 128u : 0u;
+        out[n] = (uint8_t)bits;
+    }
+}
+
+}  // namespace ngp
+
+using namespace ngp;
+
+extern "C" {
+
+int ngp_occ_compact(const float* density_grid, float threshold, int n_cells, int32_t* list, int32_t* count, void* stream) {
+    if (n_cells <= 0) return 0;
+    int blocks = (n_cells + 255) / 256;
+    if (blocks > 128) blocks = 128;                          // 512 waves -> 512 reserving atomics
+    hipLaunchKernelGGL(occ_compact_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, density_grid, threshold, n_cells, list, count);
+    NGP_LAUNCH_CHECK();
+    return 0;
+}
+
+int ngp_occ_sample(const float* u_cell, const float* u_pick, const float* u_jit, const int32_t* list, const int32_t* count, int m,
+                   int grid_size, float s, float half_grid, int32_t* indices, float* xyzs, void* stream) {
+    if (m <= 0) return 0;
+    hipLaunchKernelGGL(occ_sample_kernel, dim3((2 * m + 255) / 256), dim3(256), 0, (hipStream_t)stream, u_cell, u_pick, u_jit, list,
+                       count, m, grid_size, s, half_grid, indices, xyzs);
+    NGP_LAUNCH_CHECK();
+    return 0;
+}
+
+int ngp_occ_all_cells(const float* u_jit, int n_cells, int grid_size, float s, float half_grid, float* xyzs, void* stream) {
+    if (n_cells <= 0) return 0;
+    hipLaunchKernelGGL(occ_all_cells_kernel, dim3((n_cells + 255) / 256), dim3(256), 0, (hipStream_t)stream, u_jit, n_cells, grid_size,
+                       s, half_grid, xyzs);
+    NGP_LAUNCH_CHECK();
+    return 0;
+}
+
+int ngp_occ_scatter(const int32_t* indices, const float* sigmas, int n, float* tmp, void* stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(occ_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, indices, sigmas, n, tmp);
+    NGP_LAUNCH_CHECK();
+    return 0;
+}
+
+int ngp_occ_merge(float* density_grid, const float* tmp, float decay, int n, float* stats, void* stream) {
+    if (n <= 0) return 0;
+    int blocks = (n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(occ_merge_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, density_grid, tmp, decay, n, stats);
+    NGP_LAUNCH_CHECK();
+    return 0;
+}
+
+int ngp_occ_pack(const float* density_grid, const float* stats, float density_threshold, int n_bytes, uint8_t* bitfield, void* stream) {
+    if (n_bytes <= 0) return 0;
+    int blocks = (n_bytes + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(occ_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float4*)density_grid, stats,
+                       density_threshold, n_bytes, bitfield);
+    NGP_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

@@ -13,7 +13,7 @@
 
 namespace ngp {
 
-enum { SF_LOSS_SCALE = 0, SF_INV_SCALE = 1, SF_LR = 2, SF_BC1 = 3, SF_BC2_SQRT = 4, SF_LOSS = 5 };
+enum { SF_LOSS_SCALE = 0, SF_INV_SCALE = 1, SF_LR = 2, SF_BC1 = 3, SF_BC2_SQRT = 4, SF_LOSS = 5, SF_LOSS_ACC = 6 };
 enum { SI_ITER = 0, SI_OPT_STEP = 1, SI_GROWTH = 2, SI_FOUND_INF = 3, SI_SKIP = 4, SI_SKIPPED_TOTAL = 5 };
 
 __global__ void train_prologue_kernel(float* __restrict__ sf, int32_t* __restrict__ si, float lr0, float eta_min, int t_max,

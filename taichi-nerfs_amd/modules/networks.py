@@ -203,6 +203,16 @@ class NGP(nn.Module):
 
     @torch.no_grad()
     def update_density_grid(self, density_threshold, warmup=False, decay=0.95, erode=False):
+        if (not erode and self.density_grid.is_cuda and self._fused_ok(self.density_grid) and not self.half_opt
+                and os.environ.get("NGP_FUSED_OCCUPANCY", "1") != "0"):
+            # same algorithm, device-resident (no torch.nonzero / .item() host round trips): ngp_hip/occupancy.py
+            upd = getattr(self, '_occ_updater', None)
+            if upd is None or upd.dev != self.density_grid.device:
+                from ngp_hip.occupancy import OccupancyUpdater
+                upd = self._occ_updater = OccupancyUpdater(self)
+            if not self.density_grid.is_contiguous():
+                self.density_grid = self.density_grid.contiguous()
+            return upd.update(density_threshold, warmup=warmup, decay=decay)
         fresh = torch.zeros_like(self.density_grid)
         cells = self.get_all_cells() if warmup else \
             self.sample_uniform_and_occupied_cells(self.grid_size**3 // 4, density_threshold)

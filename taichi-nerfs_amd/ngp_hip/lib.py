@@ -15,7 +15,7 @@ PKG_ROOT = os.path.dirname(_HERE)
 CSRC = os.path.join(PKG_ROOT, "csrc")
 INCLUDE = os.path.join(os.path.dirname(PKG_ROOT), "include")
 LIB_PATH = os.path.join(CSRC, "libngp_hip.so")
-SOURCES = ["march.hip", "hash_grid.hip", "composite.hip", "sh_grid.hip", "mlp.hip", "optim.hip", "distortion.hip"]
+SOURCES = ["march.hip", "hash_grid.hip", "composite.hip", "sh_grid.hip", "mlp.hip", "optim.hip", "distortion.hip", "occupancy.hip"]
 HEADERS = ["ngp_device.h"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
 
@@ -92,6 +92,7 @@ SIGNATURES = {
     "ngp_sh16_bwd": [_P, _P, _I, _P, _P],
     "ngp_composite_train_fwd": [_P, _P, _I, _P, _P, _P, _F, _I, _P, _P, _P, _P, _P, _P],
     "ngp_composite_train_bwd": [_P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _F, _I, _P, _P, _P],
+    "ngp_composite_train_fused": [_P, _P, _I, _P, _P, _P, _P, _F, _P, _F, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "ngp_composite_test": [_P, _P, _I, _P, _P, _P, _P, _F, _I, _P, _P, _P, _P],
     "ngp_mlp_wpack_halfs": [],
     "ngp_mlp_pack": [_P, _P, _P, _P, _P, _P, _P],
@@ -102,8 +103,15 @@ SIGNATURES = {
     "ngp_mse_loss_grad": [_P, _P, _P, _F, _I, _P, _P, _P, _P],
     "ngp_train_prologue": [_P, _P, _F, _F, _I, _F, _F, _F, _F, _I, _P],
     "ngp_adam_step": [_P, _P, _P, _P, ctypes.c_longlong, _P, _P, _F, _F, _F, _P],
+    "ngp_adam_mlp_pack": [_P, _P, _P, _P, _P, _P, _F, _F, _F, _P, _P],
     "ngp_distortion_fwd": [_P, _P, _P, _P, _I, _P, _P, _P, _P],
     "ngp_distortion_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P],
+    "ngp_occ_compact": [_P, _F, _I, _P, _P, _P],
+    "ngp_occ_sample": [_P, _P, _P, _P, _P, _I, _I, _F, _F, _P, _P, _P],
+    "ngp_occ_all_cells": [_P, _I, _I, _F, _F, _P, _P],
+    "ngp_occ_scatter": [_P, _P, _I, _P, _P],
+    "ngp_occ_merge": [_P, _P, _F, _I, _P, _P],
+    "ngp_occ_pack": [_P, _P, _F, _I, _P, _P],
     "ngp_morton3d": [_P, _I, _P, _P],
     "ngp_morton3d_invert": [_P, _I, _P, _P],
     "ngp_packbits": [_P, _F, _I, _P, _P],

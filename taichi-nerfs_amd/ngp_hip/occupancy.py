@@ -1,0 +1,76 @@
+"""Device-resident occupancy-grid update (reference modules/networks.py:181-209,255-290), no host round trips.
+
+Same algorithm as the reference (and as NGP.update_density_grid's torch formulation, which stays as the generic path):
+per cascade, either all cells (warm-up) or M = G^3/4 uniform cells + M cells drawn from the occupied set; a jittered point
+per cell; density there; decay/max merge; bitfield threshold = min(mean positive density, density_threshold)."""
+import ctypes
+
+import torch
+
+from . import lib as _lib_mod
+from .lib import check
+from .ops import _ptr, _stream
+
+
+class OccupancyUpdater:
+
+    def __init__(self, model):
+        self.model = model
+        self.L = _lib_mod.load()
+        G3 = model.grid_size**3
+        dev = model.density_grid.device
+        self.dev = dev
+        self.M = G3 // 4
+        n_max = max(G3, 2 * self.M)
+        f32 = dict(device=dev, dtype=torch.float32)
+        self.list = torch.empty(G3, device=dev, dtype=torch.int32)
+        self.count = torch.zeros(1, device=dev, dtype=torch.int32)
+        self.indices = torch.empty(2 * self.M, device=dev, dtype=torch.int32)
+        self.xyzs = torch.empty(n_max, 3, **f32)
+        self.enc = torch.empty(n_max, 32, **f32)
+        self.sigmas = torch.empty(n_max, **f32)
+        self.tmp = torch.empty(model.cascades, G3, **f32)
+        self.stats = torch.zeros(2, **f32)
+        self.wpack = torch.empty(self.L.ngp_mlp_wpack_halfs(), device=dev, dtype=torch.float16)
+
+    @torch.no_grad()
+    def update(self, density_threshold, warmup=False, decay=0.95):
+        m, L, st = self.model, self.L, _stream()
+        G, G3, C = m.grid_size, m.grid_size**3, m.cascades
+        grid = m.density_grid
+        if not grid.is_contiguous():
+            raise ValueError("density_grid must be contiguous")
+        lv = m.pos_encoder.levels_struct
+        ws = m._mlp_weights()
+        check(L.ngp_mlp_pack(*[_ptr(w) for w in ws], _ptr(self.wpack), st), "ngp_mlp_pack")
+        self.tmp.zero_()                                                       # density_grid_tmp = zeros_like, networks.py:261
+        lo, hi = -float(m.scale), float(m.scale)
+        for c in range(C):
+            s = min(2.0**(c - 1), float(m.scale))
+            hg = s / G
+            grid_c = grid[c]
+            tmp_c = self.tmp[c]
+            if warmup:
+                n = G3
+                u_jit = torch.rand(n, 3, device=self.dev)
+                check(L.ngp_occ_all_cells(_ptr(u_jit), n, G, s, hg, _ptr(self.xyzs), st), "ngp_occ_all_cells")
+                idx_ptr = _ptr(None)
+            else:
+                n = 2 * self.M
+                u = torch.rand(self.M * 4 + n * 3, device=self.dev)
+                u_cell, u_pick, u_jit = u[:self.M * 3], u[self.M * 3:self.M * 4], u[self.M * 4:]
+                self.count.zero_()
+                check(L.ngp_occ_compact(_ptr(grid_c), float(density_threshold), G3, _ptr(self.list), _ptr(self.count), st),
+                      "ngp_occ_compact")
+                check(L.ngp_occ_sample(_ptr(u_cell), _ptr(u_pick), _ptr(u_jit), _ptr(self.list), _ptr(self.count), self.M, G, s, hg,
+                                       _ptr(self.indices), _ptr(self.xyzs), st), "ngp_occ_sample")
+                idx_ptr = _ptr(self.indices)
+            check(L.ngp_hash_fwd_f32_ex(_ptr(self.xyzs), _ptr(m.pos_encoder.hash_table), ctypes.byref(lv), n, _ptr(None), 1, lo, hi,
+                                        _ptr(self.enc), st), "ngp_hash_fwd_f32_ex")
+            check(L.ngp_mlp_fwd_ex(_ptr(self.enc), _ptr(None), _ptr(self.wpack), n, _ptr(None), _ptr(self.sigmas), _ptr(None), st),
+                  "ngp_mlp_fwd_ex")
+            check(L.ngp_occ_scatter(idx_ptr, _ptr(self.sigmas), n, _ptr(tmp_c), st), "ngp_occ_scatter")
+        self.stats.zero_()
+        check(L.ngp_occ_merge(_ptr(grid), _ptr(self.tmp), float(decay), C * G3, _ptr(self.stats), st), "ngp_occ_merge")
+        check(L.ngp_occ_pack(_ptr(grid), _ptr(self.stats), float(density_threshold), C * G3 // 8, _ptr(m.density_bitfield), st),
+              "ngp_occ_pack")

@@ -76,6 +76,15 @@ class FusedTrainer:
         self._sets = {}
         self._cur = 0
         self._side = torch.cuda.Stream(device=dev)
+        self._coarse_ver = None
+        self.wpack = torch.empty(self.L.ngp_mlp_wpack_halfs(), device=dev, dtype=torch.float16)
+        self.repack()
+
+    def repack(self):
+        """Rebuild the fp16 MFMA weight image from the fp32 master weights (call after loading a checkpoint into the
+        model; the training step keeps it current by itself)."""
+        ws = self.model._mlp_weights()
+        check(self.L.ngp_mlp_pack(*[_ptr(w) for w in ws], _ptr(self.wpack), _stream()), "ngp_mlp_pack")
 
     # ------------------------------------------------------------------------------------------------ one step
     class _MarchSet:
@@ -103,16 +112,25 @@ class FusedTrainer:
             sets = self._sets[key] = [self._MarchSet(self.dev, n, self.max_samples) for _ in range(2)]
         return sets
 
+    def _coarse_bits(self, cfg, A):
+        """The 8^3-block occupancy shortcut table, rebuilt only when the bitfield tensor was written to (its torch version
+        counter moves on every in-place op, e.g. packbits / copy_)."""
+        coarse = A.coarse_for(cfg)
+        ver = (cfg.bitfield.data_ptr(), cfg.bitfield._version)
+        if self._coarse_ver != ver:
+            check(self.L.ngp_bitfield_coarsen(_ptr(cfg.bitfield), cfg.cascades, cfg.grid_size, _ptr(coarse), _stream()),
+                  "ngp_bitfield_coarsen")
+            self._coarse_ver = ver
+        return coarse
+
     def _march(self, M, rays_o, rays_d, cfg, A):
         """ray-AABB + count/scan/write into march set M on the CURRENT stream."""
         L, st, n = self.L, _stream(), rays_o.shape[0]
         noise = torch.rand(n, device=self.dev, dtype=torch.float32)                         # ray_march.py:138
-        check(L.ngp_ray_aabb(_ptr(rays_o), _ptr(rays_d), cfg.scale, n, _ptr(M.hits_t), st), "ngp_ray_aabb")
-        coarse = A.coarse_for(cfg)
-        check(L.ngp_bitfield_coarsen(_ptr(cfg.bitfield), cfg.cascades, cfg.grid_size, _ptr(coarse), st), "ngp_bitfield_coarsen")
-        check(L.ngp_march_train_count_ex(_ptr(rays_o), _ptr(rays_d), _ptr(M.hits_t), _ptr(cfg.bitfield), _ptr(coarse), _ptr(noise),
+        coarse = self._coarse_bits(cfg, A)
+        check(L.ngp_march_train_count_ex(_ptr(rays_o), _ptr(rays_d), _ptr(None), _ptr(cfg.bitfield), _ptr(coarse), _ptr(noise),
                                          cfg.cascades, cfg.grid_size, cfg.scale, cfg.exp_step_factor, cfg.max_samples, n,
-                                         _ptr(M.stage), _ptr(M.counts), st), "ngp_march_train_count_ex")
+                                         _ptr(M.stage), _ptr(M.counts), st), "ngp_march_train_count_ex")   # slab test inline
         check(L.ngp_march_train_scan(_ptr(M.counts), n, _ptr(M.rays_a), _ptr(M.total), st), "ngp_march_train_scan")
         check(L.ngp_march_train_write(_ptr(rays_o), _ptr(rays_d), _ptr(M.rays_a), _ptr(M.stage), cfg.max_samples, n,
                                       _ptr(M.xyzs), _ptr(M.dirs), _ptr(M.deltas), _ptr(M.ts), st), "ngp_march_train_write")
@@ -149,38 +167,33 @@ class FusedTrainer:
         rays_a, total = M.rays_a, M.total
         vr_per_ray = torch.empty(n, **i32)
         opacity, depth, rgb = torch.empty(n, **f32), torch.empty(n, **f32), torch.empty(n, 3, **f32)
-        g_rgb, g_op = torch.empty(n, 3, **f32), torch.empty(n, **f32)
-        ws = self.model._mlp_weights()
+        sf, si = self.state_f, self.state_i
+        sq_err = torch.empty(n, **f32)
+        found = ctypes.c_void_p(si.data_ptr() + 4 * _SI_FOUND_INF)
         check(L.ngp_hash_fwd_f32_ex(_ptr(M.xyzs), _ptr(self.table), ctypes.byref(cfg.levels), A.cap, _ptr(total), 1, cfg.lo,
                                     cfg.hi, _ptr(A.enc), st), "ngp_hash_fwd_f32_ex")
-        check(L.ngp_mlp_pack(*[_ptr(w) for w in ws], _ptr(A.wpack), st), "ngp_mlp_pack")
-        check(L.ngp_mlp_fwd_ex(_ptr(A.enc), _ptr(M.dirs), _ptr(A.wpack), A.cap, _ptr(total), _ptr(A.sigmas), _ptr(A.rgbs), st),
+        check(L.ngp_mlp_fwd_ex(_ptr(A.enc), _ptr(M.dirs), _ptr(self.wpack), A.cap, _ptr(total), _ptr(A.sigmas), _ptr(A.rgbs), st),
               "ngp_mlp_fwd_ex")
-        check(L.ngp_composite_train_fwd(_ptr(A.sigmas), _ptr(A.rgbs), 1, _ptr(M.deltas), _ptr(M.ts), _ptr(rays_a),
-                                        cfg.T_threshold, n, _ptr(vr_per_ray), _ptr(opacity), _ptr(depth), _ptr(rgb), _ptr(A.ws),
-                                        st), "ngp_composite_train_fwd")
-        check(L.ngp_mse_loss_grad(_ptr(rgb), _ptr(opacity), _ptr(target), self.bg, n, _ptr(self.state_f), _ptr(g_rgb), _ptr(g_op),
-                                  st), "ngp_mse_loss_grad")
-        check(L.ngp_composite_train_bwd(_ptr(g_op), _ptr(None), _ptr(g_rgb), _ptr(None), _ptr(A.sigmas), _ptr(A.rgbs), 1,
-                                        _ptr(M.deltas), _ptr(M.ts), _ptr(rays_a), _ptr(opacity), _ptr(depth), _ptr(rgb),
-                                        _ptr(A.ws), cfg.T_threshold, n, _ptr(A.d_sigmas), _ptr(A.d_rgbs), st),
-              "ngp_composite_train_bwd")
-        found = ctypes.c_void_p(self.state_i.data_ptr() + 4 * _SI_FOUND_INF)
-        check(L.ngp_mlp_bwd_ex(_ptr(A.enc), _ptr(M.dirs), _ptr(A.wpack), _ptr(A.d_sigmas), _ptr(A.d_rgbs), A.cap, _ptr(total),
+        # composite forward + MSE gradient + composite backward, one launch
+        check(L.ngp_composite_train_fused(_ptr(A.sigmas), _ptr(A.rgbs), 1, _ptr(M.deltas), _ptr(M.ts), _ptr(rays_a), _ptr(target),
+                                          self.bg, _ptr(sf), cfg.T_threshold, n, _ptr(vr_per_ray), _ptr(opacity), _ptr(depth),
+                                          _ptr(rgb), _ptr(A.ws), _ptr(A.d_sigmas), _ptr(A.d_rgbs), _ptr(sq_err), st),
+              "ngp_composite_train_fused")
+        check(L.ngp_mlp_bwd_ex(_ptr(A.enc), _ptr(M.dirs), _ptr(self.wpack), _ptr(A.d_sigmas), _ptr(A.d_rgbs), A.cap, _ptr(total),
                                _ptr(A.d_enc), _ptr(self.mlp_grad), found, st), "ngp_mlp_bwd_ex")
         check(L.ngp_hash_bwd_f32_ex(_ptr(M.xyzs), _ptr(A.d_enc), ctypes.byref(cfg.levels), A.cap, _ptr(total), 1, cfg.lo, cfg.hi,
                                     _ptr(self.table_grad), found, st), "ngp_hash_bwd_f32_ex")
         if self.world > 1:
             self._all_reduce()
-        check(L.ngp_train_prologue(_ptr(self.state_f), _ptr(self.state_i), self.lr0, self.eta_min, self.t_max, self.beta1,
+        check(L.ngp_train_prologue(_ptr(sf), _ptr(si), self.lr0, self.eta_min, self.t_max, self.beta1,
                                    self.beta2, self.growth, self.backoff, self.growth_interval, st), "ngp_train_prologue")
         check(L.ngp_adam_step(_ptr(self.table), _ptr(self.table_grad), _ptr(self.table_m), _ptr(self.table_v),
-                              self.table.numel(), _ptr(self.state_f), _ptr(self.state_i), self.beta1, self.beta2, self.eps, st),
-              "ngp_adam_step")
-        check(L.ngp_adam_step(_ptr(self.mlp_flat), _ptr(self.mlp_grad), _ptr(self.mlp_m), _ptr(self.mlp_v), MLP_N_WEIGHTS,
-                              _ptr(self.state_f), _ptr(self.state_i), self.beta1, self.beta2, self.eps, st), "ngp_adam_step")
+                              self.table.numel(), _ptr(sf), _ptr(si), self.beta1, self.beta2, self.eps, st), "ngp_adam_step")
+        # Adam on the MLP weights + the fp16 fragment repack the next step needs, one launch
+        check(L.ngp_adam_mlp_pack(_ptr(self.mlp_flat), _ptr(self.mlp_grad), _ptr(self.mlp_m), _ptr(self.mlp_v), _ptr(sf), _ptr(si),
+                                  self.beta1, self.beta2, self.eps, _ptr(self.wpack), st), "ngp_adam_mlp_pack")
         return {"rm_samples": total, "vr_per_ray": vr_per_ray, "rgb": rgb, "opacity": opacity, "depth": depth, "rays_a": rays_a,
-                "deltas": M.deltas, "ts": M.ts}
+                "deltas": M.deltas, "ts": M.ts, "sq_err": sq_err}
 
     def _all_reduce(self):
         """Average the gradients of the ray shards (MSE is a mean over the local shard) and OR the inf flags."""
@@ -236,7 +249,9 @@ class FusedTrainer:
             self.model.update_density_grid(density_threshold, warmup=warmup, **kw)
 
     def last_loss(self):
-        return float(self.state_f[_SF_LOSS].item())                         # host sync: logging only
+        """MSE of the last step (host sync: logging only)."""
+        se = self.stats.get("sq_err")
+        return float("nan") if se is None else float(se.sum().item()) / (3.0 * se.numel())
 
     def loss_scale(self):
         return float(self.state_f[_SF_LOSS_SCALE].item())
