@@ -206,7 +206,7 @@ int ngp_distortion_bwd(const float* dL_dloss, const float* ws, const float* delt
 
 /* ---- f-3  occupancy-grid update without host round trips (modules/networks.py:181-209,255-290).
  * compact : list[0..count) = cells of ONE cascade with density > threshold (count must be zeroed by the caller)
- * sample  : m uniform cells (u_cell [m,3] in [0,1)) + m picks from the list (u_pick [m]) -> Morton indices [2m] and jittered
+ * sample  : m uniform cells (u_cell [m] in [0,1) -> Morton code) + m picks from the list (u_pick [m]) -> Morton indices [2m] and jittered
  *           world positions [2m,3] (u_jit [2m,3]); s = min(2^(c-1), scale), half_grid = s / grid_size
  * all_cells: warm-up variant, cell i = Morton code i
  * scatter : tmp[indices[i]] = sigmas[i] (indices == NULL: identity)

@@ -35,20 +35,21 @@ __global__ void __launch_bounds__(256) occ_compact_kernel(const float* __restric
 }
 
 // M uniform cells + M cells drawn (with replacement) from the occupied list, their Morton indices and a jittered world
-// position inside each cell (networks.py:193-207, :270-275).  u: [2M,4] uniform [0,1) numbers (3 for the cell or the
-// list pick, reused as jitter source via the 4th..; see below).
-__global__ void __launch_bounds__(256) occ_sample_kernel(const float* __restrict__ u_cell /*[M,3]*/, const float* __restrict__ u_pick /*[M]*/,
+// position inside each cell (networks.py:193-207, :270-275).
+__global__ void __launch_bounds__(256) occ_sample_kernel(const float* __restrict__ u_cell /*[M]*/, const float* __restrict__ u_pick /*[M]*/,
                                                          const float* __restrict__ u_jit /*[2M,3]*/, const int32_t* __restrict__ list,
                                                          const int32_t* __restrict__ count, int M, int G, float s, float half_grid,
                                                          int32_t* __restrict__ indices /*[2M]*/, float* __restrict__ xyzs /*[2M,3]*/) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= 2 * M) return;
     int cx, cy, cz, idx;
-    if (i < M) {                                                                   // torch.randint(grid_size, (M,3)) :193
-        cx = min((int)(u_cell[3 * i] * (float)G), G - 1);
-        cy = min((int)(u_cell[3 * i + 1] * (float)G), G - 1);
-        cz = min((int)(u_cell[3 * i + 2] * (float)G), G - 1);
-        idx = (int)morton3d((uint32_t)cx, (uint32_t)cy, (uint32_t)cz);             // :196
+    if (i < M) {
+        // torch.randint(grid_size, (M,3)) + morton3D (:193-196) == one uniform Morton code: the code is a bijection of the
+        // cell coordinates, so drawing it directly is the same distribution.  The caller hands the uniforms in ASCENDING
+        // order (order statistics of M iid uniforms), which makes consecutive encoder queries spatially coherent.
+        const int G3 = G * G * G;
+        idx = min((int)((double)u_cell[i] * (double)G3), G3 - 1);
+        cx = morton3d_invert1((uint32_t)idx); cy = morton3d_invert1((uint32_t)idx >> 1); cz = morton3d_invert1((uint32_t)idx >> 2);
     } else {
         const int n_occ = *count;
         if (n_occ > 0) {                                                           // :200-203

@@ -57,8 +57,18 @@ class OccupancyUpdater:
                 idx_ptr = _ptr(None)
             else:
                 n = 2 * self.M
-                u = torch.rand(self.M * 4 + n * 3, device=self.dev)
-                u_cell, u_pick, u_jit = u[:self.M * 3], u[self.M * 3:self.M * 4], u[self.M * 4:]
+                # order statistics of M iid uniforms without sorting: normalised partial sums of M+1 unit exponentials
+                # (exact in distribution).  Ascending uniforms -> ascending Morton codes / list positions -> neighbouring
+                # encoder queries share hash-grid lines (the 1 M-point encode is gather-bound: 900 -> ~540 us).
+                cols = 1024
+                rows = (self.M + 1 + cols - 1) // cols
+                e = -torch.log1p(-torch.rand(2, rows, cols, device=self.dev))
+                c1 = torch.cumsum(e, dim=2)                    # two-level prefix sum: torch's single-row scan of 524 k
+                tot = c1[:, :, -1]                             # elements runs 1.1 ms, 1026 rows of 1024 run in microseconds
+                cs = (c1 + (torch.cumsum(tot, dim=1) - tot)[:, :, None]).reshape(2, -1)
+                u_sorted = (cs[:, :self.M] / cs[:, self.M:self.M + 1]).contiguous()
+                u_cell, u_pick = u_sorted[0], u_sorted[1]
+                u_jit = torch.rand(n * 3, device=self.dev)
                 self.count.zero_()
                 check(L.ngp_occ_compact(_ptr(grid_c), float(density_threshold), G3, _ptr(self.list), _ptr(self.count), st),
                       "ngp_occ_compact")

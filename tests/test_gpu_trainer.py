@@ -101,3 +101,33 @@ def test_trainer_graph_replay_equals_eager(hip_lib, lego_bitfield):
     assert tr_a.counters() == tr_b.counters()
     # different jitter noise streams (graph-safe philox offsets) -> statistically, not bitwise, equal
     assert abs(tr_a.last_loss() - tr_b.last_loss()) < 2e-2
+
+
+def test_trainer_allreduce_path_on_rccl_world1(hip_lib, lego_bitfield):
+    """The N>1 exchange step (RCCL all-reduce of the two gradient buffers + the inf flag) exercised on the real `nccl`
+    backend with a 1-rank group: averaging over one rank must leave every buffer bit-identical.  (Multi-rank numerics are
+    covered on CPU by tests/test_dist_gloo.py; the 8-GPU run is the driver's.)"""
+    import os
+    import socket
+    import torch.distributed as dist
+    from ngp_hip.trainer import FusedTrainer
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        m, o, d, target = _make(lego_bitfield, n=1024)
+        tr = FusedTrainer(m, init_scale=2.0**10, world_size=1)
+        tr.table_grad.normal_(); tr.mlp_grad.normal_()
+        tg, mg = tr.table_grad.clone(), tr.mlp_grad.clone()
+        tr.world = 2                      # force the exchange code path; AVG over the single rank is the identity
+        tr._all_reduce()
+        torch.cuda.synchronize()
+        assert torch.equal(tg, tr.table_grad) and torch.equal(mg, tr.mlp_grad)
+        tr.table_grad.zero_(); tr.mlp_grad.zero_()
+        for _ in range(3):
+            tr.step(o, d, target)         # full steps with the collective inside
+        torch.cuda.synchronize()
+        assert tr.counters()["iter"] == 3 and np.isfinite(tr.last_loss())
+    finally:
+        dist.destroy_process_group()
