@@ -314,7 +314,10 @@ def main():
                     elif unit == "n_arg":
                         units = float(a[3])
                     else:
-                        units = float(live)
+                        # _ex launches: device-side count (the live samples of the step) unless n_dev is NULL
+                        # (occupancy-update encodes: exact n = arg 3)
+                        n_dev = a[4] if name in ("ngp_hash_fwd_f32_ex", "ngp_mlp_fwd_ex") else None
+                        units = float(a[3]) if (n_dev is not None and getattr(n_dev, "value", 1) is None) else float(live)
                     work = per_unit * units + (8 * live if key == "march_count" else 0)
                     rec = agg.setdefault(key, [0, 0.0, 0.0, bound, per_unit, "sample" if unit == "n_arg" else unit, 0.0])
                     rec[0] += 1; rec[1] += e0.elapsed_time(e1); rec[2] += work; rec[6] += units

@@ -100,13 +100,17 @@ int ngp_hash_bwd_f32(const float* xyzs, const float* dout /*[n, L*F]*/,
 
 /* Sync-free forms used by the fused training step: the sample count is read ON THE DEVICE from n_dev[0] (the
  * `total` written by ngp_march_train_scan; NULL = use n_max), buffers are sized for n_max, and `normalize` fuses the
- * caller-side position normalisation (x - lo) / (hi - lo) of modules/networks.py:144 (same two f32 operations). */
+ * caller-side position normalisation (x - lo) / (hi - lo) of modules/networks.py:144 (same two f32 operations).
+ * enc_pairs = 1 (L = 16, F = 2 only) selects the PAIR-MAJOR encoding layout of the fused path:
+ *     enc[(p * n_max + i) * 4 + slot],  plane p = min(l, 15 - l),  slot = 2 * (l >= 8) + f
+ * i.e. eight [n_max, 4] planes, each written by the workgroups of one XCD (16 contiguous bytes per sample). */
 int ngp_hash_fwd_f32_ex(const float* xyzs, const float* table, const ngp_hash_levels* lv, int n_max,
-                        const int32_t* n_dev, int normalize, float lo, float hi, float* out, void* stream);
+                        const int32_t* n_dev, int normalize, float lo, float hi, int enc_pairs, float* out,
+                        void* stream);
 /* found_inf (nullable): set to 1 when a non-finite incoming gradient is seen -- GradScaler's inf/nan check
  * (train.py:199) done where the data passes instead of in an extra pass over the 45.7 MB gradient. */
 int ngp_hash_bwd_f32_ex(const float* xyzs, const float* dout, const ngp_hash_levels* lv, int n_max,
-                        const int32_t* n_dev, int normalize, float lo, float hi, float* dtable,
+                        const int32_t* n_dev, int normalize, float lo, float hi, int enc_pairs, float* dtable,
                         int32_t* found_inf, void* stream);
 
 /* ---- a-5  half2 encoder fwd / explicit bwd (modules/hash_encoder_half.py:112-161,164-213) ----
@@ -162,16 +166,16 @@ int ngp_composite_test(const float* sigmas, const void* rgbs, int rgbs_is_half, 
  *         ACCUMULATES the weight gradients into dW [9408] f32 = W1|W2|W3|W4|W5 row-major (caller zero-fills). */
 int ngp_mlp_wpack_halfs(void);
 int ngp_mlp_pack(const float* W1, const float* W2, const float* W3, const float* W4, const float* W5,
-                 uint16_t* wpack, void* stream);
+                 int enc_pairs, uint16_t* wpack, void* stream);      /* enc_pairs: which enc layout the image is for */
 int ngp_mlp_fwd(const float* enc, const float* dirs, const uint16_t* wpack, int n, float* sigmas,
                 uint16_t* rgbs, void* stream);
 int ngp_mlp_bwd(const float* enc, const float* dirs, const uint16_t* wpack, const float* dsigmas,
                 const uint16_t* drgbs, int n, float* d_enc, float* dW, void* stream);
 
 int ngp_mlp_fwd_ex(const float* enc, const float* dirs, const uint16_t* wpack, int n_max, const int32_t* n_dev,
-                   float* sigmas, uint16_t* rgbs, void* stream);
+                   int enc_pairs, float* sigmas, uint16_t* rgbs, void* stream);
 int ngp_mlp_bwd_ex(const float* enc, const float* dirs, const uint16_t* wpack, const float* dsigmas,
-                   const uint16_t* drgbs, int n_max, const int32_t* n_dev, float* d_enc, float* dW,
+                   const uint16_t* drgbs, int n_max, const int32_t* n_dev, int enc_pairs, float* d_enc, float* dW,
                    int32_t* found_inf, void* stream);
 
 /* ---- f-2  device-resident optimisation-step epilogue (reference train.py:193-201: mse_loss, GradScaler,
@@ -188,7 +192,7 @@ int ngp_adam_step(float* p, float* g, float* m, float* v, long long n, const flo
                   const int32_t* state_i, float beta1, float beta2, float eps, void* stream);
 /* Adam on the 9 408 flat MLP weights (W1|W2|W3|W4|W5) + the fp16 fragment repack for the next step, one launch. */
 int ngp_adam_mlp_pack(float* p, float* g, float* m, float* v, const float* state_f, const int32_t* state_i,
-                      float beta1, float beta2, float eps, uint16_t* wpack, void* stream);
+                      float beta1, float beta2, float eps, int enc_pairs, uint16_t* wpack, void* stream);
 
 /* ---- a-10 morton3D / morton3D_invert / packbits (modules/utils.py:120-169) -------------------- */
 int ngp_morton3d(const int32_t* coords /*[m,3]*/, int m, int32_t* indices, void* stream);

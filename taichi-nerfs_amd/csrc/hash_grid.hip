@@ -141,11 +141,15 @@ __global__ void __launch_bounds__(256) hash_fwd_f32_kernel(const float* __restri
 // Workgroups are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8; a speed assumption only), so block b
 // encodes the level pair (p, 15-p), p = b % 8: coarse + fine levels paired so every XCD owns a similar byte count.
 // Lanes (2s, 2s+1) of a block handle the two levels of sample s.  Output stays in the reference layout [n, 32].
+// enc_pairs = 1 writes the PAIR-MAJOR layout out[(pair * n_max + i) * 4 + which * 2 + f] (pair = min(l, 15-l), which = l >= 8):
+// every block then stores 16 contiguous bytes per sample instead of two 8-byte pieces of a 128-byte row shared with the
+// other seven XCDs (another 1.5x, same microbenchmark); the fused MLP kernels and the scatter-add consume that layout.
 __global__ void __launch_bounds__(256) hash_fwd_f32_xcd_kernel(const float* __restrict__ xyzs, const float* __restrict__ table,
                                                                ngp_hash_levels lv, int n, const int32_t* __restrict__ n_dev,
-                                                               XyzNorm nm, float* __restrict__ out) {
+                                                               XyzNorm nm, int enc_pairs, float* __restrict__ out) {
     __shared__ LevelLDS L;
     load_levels(lv, L);
+    const size_t plane = (size_t)n;                       // pair-major plane stride = buffer capacity
     if (n_dev) n = min(n, *n_dev);
     const int pair = blockIdx.x & 7, which = threadIdx.x & 1;
     const int level = which ? 15 - pair : pair;
@@ -161,7 +165,8 @@ __global__ void __launch_bounds__(256) hash_fwd_f32_xcd_kernel(const float* __re
         float a0 = 0.0f, a1 = 0.0f;
 #pragma unroll
         for (int ci = 0; ci < 8; ++ci) { a0 += c.w[ci] * v[ci].x; a1 += c.w[ci] * v[ci].y; }   // same order as the generic kernel
-        *reinterpret_cast<float2*>(out + (size_t)i * 32 + level * 2) = make_float2(a0, a1);
+        float* o = enc_pairs ? out + ((size_t)pair * plane + i) * 4 + which * 2 : out + (size_t)i * 32 + level * 2;
+        *reinterpret_cast<float2*>(o) = make_float2(a0, a1);
     }
 }
 
@@ -208,10 +213,11 @@ __global__ void __launch_bounds__(256) hash_bwd_f32_kernel(const float* __restri
 // order-nondeterministic in the reference too).
 __global__ void __launch_bounds__(256) hash_bwd_f32x2_kernel(const float* __restrict__ xyzs, const float* __restrict__ dout,
                                                              ngp_hash_levels lv, int n, const int32_t* __restrict__ n_dev,
-                                                             XyzNorm nm, float* __restrict__ dtable,
+                                                             XyzNorm nm, int enc_pairs, float* __restrict__ dtable,
                                                              int32_t* __restrict__ found_inf) {
     __shared__ LevelLDS L;
     load_levels(lv, L);
+    const size_t plane = (size_t)n;
     if (n_dev) n = min(n, *n_dev);
     const int nl = lv.n_levels, bfhl = lv.begin_fast_hash_level;
     const int lane = threadIdx.x & 63;
@@ -224,7 +230,9 @@ __global__ void __launch_bounds__(256) hash_bwd_f32x2_kernel(const float* __rest
         float x = 0.f, y = 0.f, z = 0.f;
         if (valid) { x = norm01(nm, xyzs[3 * (size_t)i]); y = norm01(nm, xyzs[3 * (size_t)i + 1]); z = norm01(nm, xyzs[3 * (size_t)i + 2]); }
         for (int level = 0; level < nl; ++level) {
-            const float g = valid ? dout[(size_t)i * (nl * 2) + level * 2 + f] : 0.0f;
+            const size_t gi = enc_pairs ? ((size_t)(level < 8 ? level : 15 - level) * plane + i) * 4 + (level < 8 ? 0 : 2) + f
+                                        : (size_t)i * (nl * 2) + level * 2 + f;
+            const float g = valid ? dout[gi] : 0.0f;
             if (found_inf && !isfinite(g)) *found_inf = 1;          // GradScaler's inf/nan check, done where the data passes
             const float scale = L.scale[level];
             const uint32_t res = L.res[level], size = L.size[level], mode = L.mode[level];
@@ -347,16 +355,17 @@ extern "C" {
 int ngp_abi_version(void) { return NGP_ABI_VERSION; }
 
 int ngp_hash_fwd_f32_ex(const float* xyzs, const float* table, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev,
-                        int normalize, float lo, float hi, float* out, void* stream) {
+                        int normalize, float lo, float hi, int enc_pairs, float* out, void* stream) {
     if (n_max <= 0) return 0;
     if (lv->n_levels < 1 || lv->n_levels > NGP_MAX_LEVELS) return -1;
     const int grid = grid_for((long long)n_max * lv->n_levels, 256);
     hipStream_t s = (hipStream_t)stream;
     const XyzNorm nm = {normalize, lo, hi};
-    if (lv->n_features == 2 && lv->n_levels == 16 && n_max >= 4096) {
+    if (enc_pairs && !(lv->n_features == 2 && lv->n_levels == 16)) return -1;
+    if (lv->n_features == 2 && lv->n_levels == 16 && (n_max >= 4096 || enc_pairs)) {
         int tiles = (n_max + 127) / 128;
         if (tiles > 512) tiles = 512;                       // 4096 blocks, tile-stride beyond
-        hipLaunchKernelGGL(hash_fwd_f32_xcd_kernel, dim3(8 * tiles), dim3(256), 0, s, xyzs, table, *lv, n_max, n_dev, nm, out);
+        hipLaunchKernelGGL(hash_fwd_f32_xcd_kernel, dim3(8 * tiles), dim3(256), 0, s, xyzs, table, *lv, n_max, n_dev, nm, enc_pairs, out);
         NGP_LAUNCH_CHECK();
         return 0;
     }
@@ -372,22 +381,23 @@ int ngp_hash_fwd_f32_ex(const float* xyzs, const float* table, const ngp_hash_le
 }
 
 int ngp_hash_fwd_f32(const float* xyzs, const float* table, const ngp_hash_levels* lv, int n, float* out, void* stream) {
-    return ngp_hash_fwd_f32_ex(xyzs, table, lv, n, nullptr, 0, 0.0f, 1.0f, out, stream);
+    return ngp_hash_fwd_f32_ex(xyzs, table, lv, n, nullptr, 0, 0.0f, 1.0f, 0, out, stream);
 }
 
 int ngp_hash_bwd_f32_ex(const float* xyzs, const float* dout, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev,
-                        int normalize, float lo, float hi, float* dtable, int32_t* found_inf, void* stream) {
+                        int normalize, float lo, float hi, int enc_pairs, float* dtable, int32_t* found_inf, void* stream) {
     if (n_max <= 0) return 0;
     if (lv->n_levels < 1 || lv->n_levels > NGP_MAX_LEVELS) return -1;
     const int grid = grid_for((long long)n_max * lv->n_levels, 256);
     hipStream_t s = (hipStream_t)stream;
     const XyzNorm nm = {normalize, lo, hi};
+    if (enc_pairs && !(lv->n_features == 2 && lv->n_levels == 16)) return -1;
     switch (lv->n_features) {
         case 1: hipLaunchKernelGGL(hash_bwd_f32_kernel<1>, dim3(grid), dim3(256), 0, s, xyzs, dout, *lv, n_max, n_dev, nm, dtable); break;
         case 2: {
             const int tiles = (n_max + 15) / 16;
             const int g2 = tiles < 4 ? 1 : (tiles / 4 < 8192 ? (tiles + 3) / 4 : 8192);
-            hipLaunchKernelGGL(hash_bwd_f32x2_kernel, dim3(g2), dim3(256), 0, s, xyzs, dout, *lv, n_max, n_dev, nm, dtable, found_inf);
+            hipLaunchKernelGGL(hash_bwd_f32x2_kernel, dim3(g2), dim3(256), 0, s, xyzs, dout, *lv, n_max, n_dev, nm, enc_pairs, dtable, found_inf);
             break;
         }
         case 4: hipLaunchKernelGGL(hash_bwd_f32_kernel<4>, dim3(grid), dim3(256), 0, s, xyzs, dout, *lv, n_max, n_dev, nm, dtable); break;
@@ -399,7 +409,7 @@ int ngp_hash_bwd_f32_ex(const float* xyzs, const float* dout, const ngp_hash_lev
 }
 
 int ngp_hash_bwd_f32(const float* xyzs, const float* dout, const ngp_hash_levels* lv, int n, float* dtable, void* stream) {
-    return ngp_hash_bwd_f32_ex(xyzs, dout, lv, n, nullptr, 0, 0.0f, 1.0f, dtable, nullptr, stream);
+    return ngp_hash_bwd_f32_ex(xyzs, dout, lv, n, nullptr, 0, 0.0f, 1.0f, 0, dtable, nullptr, stream);
 }
 
 int ngp_hash_fwd_f16(const float* xyzs, const uint16_t* table, const ngp_hash_levels* lv, int n, uint16_t* out, void* stream) {

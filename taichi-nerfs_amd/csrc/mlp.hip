@@ -52,16 +52,24 @@ constexpr int B_W1T = 38;  // [mt*2+s]    4
 
 __device__ __forceinline__ int chain_k(int s, int g, int j) { return 32 * s + 16 * (j >> 2) + 4 * g + (j & 3); }
 
+// Pair-major encoding layout (hash_grid.hip, hash_fwd_f32_xcd_kernel): plane p holds [level p f0,f1 | level 15-p f0,f1].
+// natural feature index (2*level + f) of slot `slot` in plane `p`:
+__device__ __forceinline__ int pair_nat(int p, int slot) { return slot < 2 ? 2 * p + slot : 2 * (15 - p) + (slot - 2); }
+// k-slot (g, j) of the layer-1 B fragment: natural layout reads features 8g..8g+7; pair layout reads planes 2g, 2g+1
+__device__ __forceinline__ int enc_feat(int pairs, int g, int j) { return pairs ? pair_nat(2 * g + (j >> 2), j & 3) : 8 * g + j; }
+// row i of M-tile mt of W1^T (= which enc feature a d_enc accumulator row is): pair layout makes rows 4g'..4g'+3 one plane
+__device__ __forceinline__ int enc_row(int pairs, int mt, int i) { return pairs ? pair_nat(4 * mt + (i >> 2), i & 3) : 16 * mt + i; }
+
 // One thread per (fragment, lane, slot): gathers the fp32 master weight, rounds to fp16 (what autocast's
 // weight.to(fp16) does) and stores it where the MFMA A operand of that lane wants it.
 __device__ __forceinline__ void pack_one(int tid, const float* W1, const float* W2, const float* W3, const float* W4,
-                                         const float* W5, half_t* wpack) {
+                                         const float* W5, int pairs, half_t* wpack) {
     const int j = tid & 7, lane = (tid >> 3) & 63, frag = tid >> 9;
     const int i = lane & 15, g = lane >> 4;
     float v = 0.0f;
     if (frag < F_W2) {                                  // W1 [64][32], plain k
         const int mt = frag - F_W1;
-        v = W1[(16 * mt + i) * 32 + 8 * g + j];
+        v = W1[(16 * mt + i) * 32 + enc_feat(pairs, g, j)];
     } else if (frag < F_W3) {                           // W2 [16][64], chained over a1
         const int s = frag - F_W2;
         v = W2[i * 64 + chain_k(s, g, j)];
@@ -90,16 +98,16 @@ __device__ __forceinline__ void pack_one(int tid, const float* W1, const float* 
         v = (j < 4) ? W2[(4 * g + j) * 64 + 16 * mt + i] : 0.0f;
     } else {                                            // W1^T: rows = enc features, k = dz1 chained
         const int mt = (frag - B_W1T) >> 1, s = (frag - B_W1T) & 1;
-        v = W1[chain_k(s, g, j) * 32 + 16 * mt + i];
+        v = W1[chain_k(s, g, j) * 32 + enc_row(pairs, mt, i)];
     }
     wpack[tid] = (half_t)v;
 }
 
 __global__ void __launch_bounds__(256) mlp_pack_kernel(const float* __restrict__ W1, const float* __restrict__ W2,
                                                        const float* __restrict__ W3, const float* __restrict__ W4,
-                                                       const float* __restrict__ W5, half_t* __restrict__ wpack) {
+                                                       const float* __restrict__ W5, int pairs, half_t* __restrict__ wpack) {
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (tid < N_ALL_FRAGS * 64 * 8) pack_one(tid, W1, W2, W3, W4, W5, wpack);
+    if (tid < N_ALL_FRAGS * 64 * 8) pack_one(tid, W1, W2, W3, W4, W5, pairs, wpack);
 }
 
 // Trainer fusion: Adam on the 9 408 flat MLP weights (same arithmetic as optim.hip's adam_kernel, state layout in
@@ -107,7 +115,7 @@ __global__ void __launch_bounds__(256) mlp_pack_kernel(const float* __restrict__
 __global__ void __launch_bounds__(1024) adam_mlp_pack_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                              float* __restrict__ v, const float* __restrict__ sf,
                                                              const int32_t* __restrict__ si, float beta1, float beta2, float eps,
-                                                             half_t* __restrict__ wpack) {
+                                                             int pairs, half_t* __restrict__ wpack) {
     const bool skip = si[4] != 0;
     const float inv_scale = sf[1], step_size = sf[2] / sf[3], bc2_sqrt = sf[4];
     for (int i = threadIdx.x; i < 9408; i += blockDim.x) {
@@ -123,7 +131,7 @@ __global__ void __launch_bounds__(1024) adam_mlp_pack_kernel(float* __restrict__
     }
     __syncthreads();
     for (int tid = threadIdx.x; tid < N_ALL_FRAGS * 64 * 8; tid += blockDim.x)
-        pack_one(tid, p, p + 2048, p + 3072, p + 5120, p + 9216, wpack);
+        pack_one(tid, p, p + 2048, p + 3072, p + 5120, p + 9216, pairs, wpack);
 }
 
 // ---- per-lane helpers -------------------------------------------------------------------------------------
@@ -173,6 +181,13 @@ __device__ __forceinline__ half4 sh_quad(int g, float x, float y, float z) {
     return r;
 }
 
+// the two 16-byte pieces of enc a lane (sample smp, group g) feeds into layer 1
+__device__ __forceinline__ void enc_ptrs(const float* __restrict__ enc, int pairs, size_t plane, int smp, int g, const float*& p0,
+                                         const float*& p1) {
+    if (pairs) { p0 = enc + ((size_t)(2 * g) * plane + smp) * 4; p1 = enc + ((size_t)(2 * g + 1) * plane + smp) * 4; }
+    else { p0 = enc + (size_t)smp * 32 + 8 * g; p1 = p0 + 4; }
+}
+
 struct TileFwd {            // everything the backward needs from the recomputed forward of one 16-sample tile
     half8 b_enc;            // layer-1 B operand (enc features 8g..8g+7)
     half4 a1[4];            // relu(L1), D layout (feature 16mt+4g+r)
@@ -187,12 +202,12 @@ __device__ __forceinline__ const half8& wfrag(const half8* __restrict__ wl, int 
 
 // forward of one tile; wl = packed weight image in LDS
 template <bool COLOR>
-__device__ __forceinline__ void tile_forward(const half8* __restrict__ wl, int lane, int g, const float* __restrict__ enc_row,
-                                             float dx, float dy, float dz, bool valid, TileFwd& t) {
+__device__ __forceinline__ void tile_forward(const half8* __restrict__ wl, int lane, int g, const float* __restrict__ ep0,
+                                             const float* __restrict__ ep1, float dx, float dy, float dz, bool valid, TileFwd& t) {
     const floatx4 zero = {0.f, 0.f, 0.f, 0.f};
     if (valid) {
-        const float4 e0 = *reinterpret_cast<const float4*>(enc_row + 8 * g);
-        const float4 e1 = *reinterpret_cast<const float4*>(enc_row + 8 * g + 4);
+        const float4 e0 = *reinterpret_cast<const float4*>(ep0);
+        const float4 e1 = *reinterpret_cast<const float4*>(ep1);
         t.b_enc[0] = (half_t)e0.x; t.b_enc[1] = (half_t)e0.y; t.b_enc[2] = (half_t)e0.z; t.b_enc[3] = (half_t)e0.w;
         t.b_enc[4] = (half_t)e1.x; t.b_enc[5] = (half_t)e1.y; t.b_enc[6] = (half_t)e1.z; t.b_enc[7] = (half_t)e1.w;
     } else {
@@ -239,9 +254,10 @@ __device__ __forceinline__ void load_wpack(const half_t* __restrict__ wpack, hal
 template <bool COLOR>
 __global__ void __launch_bounds__(256) mlp_fwd_kernel(const float* __restrict__ enc, const float* __restrict__ dirs,
                                                       const half_t* __restrict__ wpack, int S,
-                                                      const int32_t* __restrict__ n_dev, float* __restrict__ sigmas,
+                                                      const int32_t* __restrict__ n_dev, int pairs, float* __restrict__ sigmas,
                                                       half_t* __restrict__ rgbs) {
     __shared__ half8 wl[N_FWD_FRAGS * 64];
+    const size_t plane = (size_t)S;
     if (n_dev) S = min(S, *n_dev);
     load_wpack(wpack, wl, COLOR ? N_FWD_FRAGS : F_W3);
     const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
@@ -255,7 +271,9 @@ __global__ void __launch_bounds__(256) mlp_fwd_kernel(const float* __restrict__ 
             float dx = 0.f, dy = 0.f, dz = 1.f;
             if (COLOR && valid) { dx = dirs[3 * (size_t)smp]; dy = dirs[3 * (size_t)smp + 1]; dz = dirs[3 * (size_t)smp + 2]; }
             TileFwd t;
-            tile_forward<COLOR>(wl, lane, g, enc + (size_t)smp * 32, dx, dy, dz, valid, t);
+            const float *ep0, *ep1;
+            enc_ptrs(enc, pairs, plane, smp, g, ep0, ep1);
+            tile_forward<COLOR>(wl, lane, g, ep0, ep1, dx, dy, dz, valid, t);
             if (valid && g == 0) {
                 sigmas[smp] = t.sigma;
                 if (COLOR) { rgbs[3 * (size_t)smp] = t.rgb[0]; rgbs[3 * (size_t)smp + 1] = t.rgb[1]; rgbs[3 * (size_t)smp + 2] = t.rgb[2]; }
@@ -308,14 +326,15 @@ struct BwdIn {                             // prefetched per-round inputs of one
 
 __device__ __forceinline__ void bwd_prefetch(BwdIn& in, const float* __restrict__ enc, const float* __restrict__ dirs,
                                              const float* __restrict__ dsigmas, const half_t* __restrict__ drgbs, int smp, int S,
-                                             int g) {
+                                             int g, int pairs, size_t plane) {
     in.e0 = in.e1 = make_float4(0.f, 0.f, 0.f, 0.f);
     in.dx = 0.f; in.dy = 0.f; in.dz = 1.f; in.dsig = 0.f;
     in.drgb[0] = in.drgb[1] = in.drgb[2] = (half_t)0;
     if (smp < S) {
-        const float* row = enc + (size_t)smp * 32 + 8 * g;
-        in.e0 = *reinterpret_cast<const float4*>(row);
-        in.e1 = *reinterpret_cast<const float4*>(row + 4);
+        const float *ep0, *ep1;
+        enc_ptrs(enc, pairs, plane, smp, g, ep0, ep1);
+        in.e0 = *reinterpret_cast<const float4*>(ep0);
+        in.e1 = *reinterpret_cast<const float4*>(ep1);
         in.dx = dirs[3 * (size_t)smp]; in.dy = dirs[3 * (size_t)smp + 1]; in.dz = dirs[3 * (size_t)smp + 2];
         if (g == 0) {
             in.dsig = dsigmas[smp];
@@ -366,10 +385,11 @@ __device__ __forceinline__ void th_store_d(half_t* T16, int row0, int mt, int g,
 __global__ void __launch_bounds__(768) mlp_bwd_kernel(const float* __restrict__ enc, const float* __restrict__ dirs,
                                                        const half_t* __restrict__ wpack, const float* __restrict__ dsigmas,
                                                        const half_t* __restrict__ drgbs, int S,
-                                                       const int32_t* __restrict__ n_dev, float* __restrict__ d_enc,
+                                                       const int32_t* __restrict__ n_dev, int pairs, float* __restrict__ d_enc,
                                                        float* __restrict__ dW /*[N_W], pre-zeroed or accumulating*/,
                                                        int32_t* __restrict__ found_inf) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[N_ALL_FRAGS * 64 * 16 + BG * T_ROWS * T_STRIDE * 4];
+    const size_t plane = (size_t)S;
     if (n_dev) S = min(S, *n_dev);
     half8* wl = reinterpret_cast<half8*>(smem);
     load_wpack(wpack, wl, N_ALL_FRAGS);
@@ -395,7 +415,7 @@ __global__ void __launch_bounds__(768) mlp_bwd_kernel(const float* __restrict__ 
     for (int round = blockIdx.x; round < n_round; round += gridDim.x) {
         const int smp = (round * BG + grp) * 32 + col;
         BwdIn in;                     // 4 waves per SIMD hide this latency; a register prefetch would spill
-        bwd_prefetch(in, enc, dirs, dsigmas, drgbs, smp, S, g);
+        bwd_prefetch(in, enc, dirs, dsigmas, drgbs, smp, S, g, pairs, plane);
         TileFwd t;
         half4 dz5 = hzero, dz4[4], dz3[4], dz2, dz1[4];
         tile_forward_regs(wl, lane, g, in.e0, in.e1, in.dx, in.dy, in.dz, t);
@@ -437,7 +457,10 @@ __global__ void __launch_bounds__(768) mlp_bwd_kernel(const float* __restrict__ 
             for (int mt = 0; mt < 2; ++mt) {
                 floatx4 d = NGP_MFMA(wfrag(wl, B_W1T + 2 * mt, lane), b10, zero);
                 d = NGP_MFMA(wfrag(wl, B_W1T + 2 * mt + 1, lane), b11, d);
-                if (smp < S) *reinterpret_cast<float4*>(d_enc + (size_t)smp * 32 + 16 * mt + 4 * g) = make_float4(d[0], d[1], d[2], d[3]);
+                if (smp < S) {       // D rows 4g..4g+3 of tile mt = natural features 16mt+4g.. or, pair layout, plane 4mt+g
+                    float* dp = pairs ? d_enc + ((size_t)(4 * mt + g) * plane + smp) * 4 : d_enc + (size_t)smp * 32 + 16 * mt + 4 * g;
+                    *reinterpret_cast<float4*>(dp) = make_float4(d[0], d[1], d[2], d[3]);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -533,8 +556,9 @@ __global__ void __launch_bounds__(768) mlp_bwd_kernel(const float* __restrict__ 
             if (a1 != 0.0f) unsafeAtomicAdd(dW + OFF_W4 + o * 64 + 16 * (ntA + 1) + n, a1);
             if (b != 0.0f) unsafeAtomicAdd(dW + OFF_W3 + o * 32 + 16 * (wv & 1) + n, b);
         } else {
-            if (a0 != 0.0f) unsafeAtomicAdd(dW + OFF_W1 + o * 32 + n, a0);
-            if (a1 != 0.0f) unsafeAtomicAdd(dW + OFF_W1 + o * 32 + 16 + n, a1);
+            // column c of a dW1 tile is the c-th row of the transposed enc tile = k-slot (g' = c>>3, j' = c&7) of layer 1
+            if (a0 != 0.0f) unsafeAtomicAdd(dW + OFF_W1 + o * 32 + enc_feat(pairs, n >> 3, n & 7), a0);
+            if (a1 != 0.0f) unsafeAtomicAdd(dW + OFF_W1 + o * 32 + enc_feat(pairs, (16 + n) >> 3, n & 7), a1);
             if (b != 0.0f) unsafeAtomicAdd(dW + OFF_W2 + o2 * 64 + 16 * v4 + n, b);
             if (o2 < 3 && c != 0.0f) unsafeAtomicAdd(dW + OFF_W5 + o2 * 64 + 16 * v4 + n, c);
         }
@@ -551,18 +575,19 @@ extern "C" {
 
 int ngp_mlp_wpack_halfs(void) { return N_ALL_FRAGS * 64 * 8; }
 
-int ngp_mlp_pack(const float* W1, const float* W2, const float* W3, const float* W4, const float* W5, uint16_t* wpack, void* stream) {
+int ngp_mlp_pack(const float* W1, const float* W2, const float* W3, const float* W4, const float* W5, int enc_pairs, uint16_t* wpack,
+                 void* stream) {
     const int total = N_ALL_FRAGS * 64 * 8;
-    hipLaunchKernelGGL(mlp_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, W1, W2, W3, W4, W5,
+    hipLaunchKernelGGL(mlp_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, W1, W2, W3, W4, W5, enc_pairs,
                        (half_t*)wpack);
     NGP_LAUNCH_CHECK();
     return 0;
 }
 
 int ngp_adam_mlp_pack(float* p, float* g, float* m, float* v, const float* state_f, const int32_t* state_i, float beta1, float beta2,
-                      float eps, uint16_t* wpack, void* stream) {
+                      float eps, int enc_pairs, uint16_t* wpack, void* stream) {
     hipLaunchKernelGGL(adam_mlp_pack_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, p, g, m, v, state_f, state_i, beta1, beta2,
-                       eps, (half_t*)wpack);
+                       eps, enc_pairs, (half_t*)wpack);
     NGP_LAUNCH_CHECK();
     return 0;
 }
@@ -574,38 +599,38 @@ static inline int mlp_grid(int S) {
     return blocks < 1 ? 1 : blocks;
 }
 
-int ngp_mlp_fwd_ex(const float* enc, const float* dirs, const uint16_t* wpack, int n_max, const int32_t* n_dev, float* sigmas,
-                   uint16_t* rgbs, void* stream) {
+int ngp_mlp_fwd_ex(const float* enc, const float* dirs, const uint16_t* wpack, int n_max, const int32_t* n_dev, int enc_pairs,
+                   float* sigmas, uint16_t* rgbs, void* stream) {
     if (n_max <= 0) return 0;
     if (dirs && rgbs)
         hipLaunchKernelGGL(mlp_fwd_kernel<true>, dim3(mlp_grid(n_max)), dim3(256), 0, (hipStream_t)stream, enc, dirs,
-                           (const half_t*)wpack, n_max, n_dev, sigmas, (half_t*)rgbs);
+                           (const half_t*)wpack, n_max, n_dev, enc_pairs, sigmas, (half_t*)rgbs);
     else
         hipLaunchKernelGGL(mlp_fwd_kernel<false>, dim3(mlp_grid(n_max)), dim3(256), 0, (hipStream_t)stream, enc,
-                           (const float*)nullptr, (const half_t*)wpack, n_max, n_dev, sigmas, (half_t*)nullptr);
+                           (const float*)nullptr, (const half_t*)wpack, n_max, n_dev, enc_pairs, sigmas, (half_t*)nullptr);
     NGP_LAUNCH_CHECK();
     return 0;
 }
 
 int ngp_mlp_fwd(const float* enc, const float* dirs, const uint16_t* wpack, int n, float* sigmas, uint16_t* rgbs, void* stream) {
-    return ngp_mlp_fwd_ex(enc, dirs, wpack, n, nullptr, sigmas, rgbs, stream);
+    return ngp_mlp_fwd_ex(enc, dirs, wpack, n, nullptr, 0, sigmas, rgbs, stream);
 }
 
 int ngp_mlp_bwd_ex(const float* enc, const float* dirs, const uint16_t* wpack, const float* dsigmas, const uint16_t* drgbs,
-                   int n_max, const int32_t* n_dev, float* d_enc, float* dW, int32_t* found_inf, void* stream) {
+                   int n_max, const int32_t* n_dev, int enc_pairs, float* d_enc, float* dW, int32_t* found_inf, void* stream) {
     if (n_max <= 0) return 0;
     int blocks = ((n_max + 31) / 32 + BG - 1) / BG;
     if (blocks > 256) blocks = 256;                       // one 12-wave block per CU: 3 waves per SIMD
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(mlp_bwd_kernel, dim3(blocks), dim3(64 * BW), 0, (hipStream_t)stream, enc, dirs, (const half_t*)wpack, dsigmas,
-                       (const half_t*)drgbs, n_max, n_dev, d_enc, dW, found_inf);
+                       (const half_t*)drgbs, n_max, n_dev, enc_pairs, d_enc, dW, found_inf);
     NGP_LAUNCH_CHECK();
     return 0;
 }
 
 int ngp_mlp_bwd(const float* enc, const float* dirs, const uint16_t* wpack, const float* dsigmas, const uint16_t* drgbs, int n,
                 float* d_enc, float* dW, void* stream) {
-    return ngp_mlp_bwd_ex(enc, dirs, wpack, dsigmas, drgbs, n, nullptr, d_enc, dW, nullptr, stream);
+    return ngp_mlp_bwd_ex(enc, dirs, wpack, dsigmas, drgbs, n, nullptr, 0, d_enc, dW, nullptr, stream);
 }
 
 }  // extern "C"

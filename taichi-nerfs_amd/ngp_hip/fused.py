@@ -82,10 +82,11 @@ class FusedTrainRender(torch.autograd.Function):
         check(L.ngp_march_train_scan(_ptr(A.counts), n, _ptr(rays_a), _ptr(total), st), "ngp_march_train_scan")
         check(L.ngp_march_train_write(_ptr(rays_o), _ptr(rays_d), _ptr(rays_a), _ptr(A.stage), cfg.max_samples, n,
                                       _ptr(A.xyzs), _ptr(A.dirs), _ptr(A.deltas), _ptr(A.ts), st), "ngp_march_train_write")
-        check(L.ngp_hash_fwd_f32_ex(_ptr(A.xyzs), _ptr(table), ctypes.byref(cfg.levels), A.cap, _ptr(total), 1, cfg.lo, cfg.hi,
+        P = cfg.enc_pairs
+        check(L.ngp_hash_fwd_f32_ex(_ptr(A.xyzs), _ptr(table), ctypes.byref(cfg.levels), A.cap, _ptr(total), 1, cfg.lo, cfg.hi, P,
                                     _ptr(A.enc), st), "ngp_hash_fwd_f32_ex")
-        check(L.ngp_mlp_pack(_ptr(w1), _ptr(w2), _ptr(w3), _ptr(w4), _ptr(w5), _ptr(A.wpack), st), "ngp_mlp_pack")
-        check(L.ngp_mlp_fwd_ex(_ptr(A.enc), _ptr(A.dirs), _ptr(A.wpack), A.cap, _ptr(total), _ptr(A.sigmas), _ptr(A.rgbs), st),
+        check(L.ngp_mlp_pack(_ptr(w1), _ptr(w2), _ptr(w3), _ptr(w4), _ptr(w5), P, _ptr(A.wpack), st), "ngp_mlp_pack")
+        check(L.ngp_mlp_fwd_ex(_ptr(A.enc), _ptr(A.dirs), _ptr(A.wpack), A.cap, _ptr(total), P, _ptr(A.sigmas), _ptr(A.rgbs), st),
               "ngp_mlp_fwd_ex")
         vr_per_ray = torch.empty(n, **i32)
         opacity = torch.empty(n, **f32)
@@ -123,10 +124,11 @@ class FusedTrainRender(torch.autograd.Function):
                                         _ptr(A.ws), cfg.T_threshold, n, _ptr(A.d_sigmas), _ptr(A.d_rgbs), st),
               "ngp_composite_train_bwd")
         dW = torch.zeros(MLP_N_WEIGHTS, device=dev, dtype=torch.float32)
-        check(L.ngp_mlp_bwd_ex(_ptr(A.enc), _ptr(A.dirs), _ptr(A.wpack), _ptr(A.d_sigmas), _ptr(A.d_rgbs), A.cap, _ptr(total),
+        P = cfg.enc_pairs
+        check(L.ngp_mlp_bwd_ex(_ptr(A.enc), _ptr(A.dirs), _ptr(A.wpack), _ptr(A.d_sigmas), _ptr(A.d_rgbs), A.cap, _ptr(total), P,
                                _ptr(A.d_enc), _ptr(dW), _ptr(None), st), "ngp_mlp_bwd_ex")
         dtable = torch.zeros(ctx.table_numel, device=dev, dtype=torch.float32)
-        check(L.ngp_hash_bwd_f32_ex(_ptr(A.xyzs), _ptr(A.d_enc), ctypes.byref(cfg.levels), A.cap, _ptr(total), 1, cfg.lo, cfg.hi,
+        check(L.ngp_hash_bwd_f32_ex(_ptr(A.xyzs), _ptr(A.d_enc), ctypes.byref(cfg.levels), A.cap, _ptr(total), 1, cfg.lo, cfg.hi, P,
                                     _ptr(dtable), _ptr(None), st), "ngp_hash_bwd_f32_ex")
         grads = [g.view(shape) for g, shape in zip(dW.split(MLP_SPLITS), MLP_SHAPES)]
         return (None, None, None, dtable, *grads, None)
@@ -147,3 +149,5 @@ class RenderConfig:
         self.levels = model.pos_encoder.levels_struct
         self.lo = -float(model.scale)            # xyz_min / xyz_max of reference networks.py:57-58
         self.hi = float(model.scale)
+        # pair-major encoding planes (one level pair per XCD) whenever the table has the default 16 x 2 shape
+        self.enc_pairs = 1 if (self.levels.n_levels == 16 and self.levels.n_features == 2) else 0

@@ -84,8 +84,8 @@ SIGNATURES = {
     "ngp_march_test": [_P, _P, _P, _P, _P, _I, _I, _F, _F, _I, _I, _P, _P, _P, _P, _P, _P],
     "ngp_hash_fwd_f32": [_P, _P, _LV, _I, _P, _P],
     "ngp_hash_bwd_f32": [_P, _P, _LV, _I, _P, _P],
-    "ngp_hash_fwd_f32_ex": [_P, _P, _LV, _I, _P, _I, _F, _F, _P, _P],
-    "ngp_hash_bwd_f32_ex": [_P, _P, _LV, _I, _P, _I, _F, _F, _P, _P, _P],
+    "ngp_hash_fwd_f32_ex": [_P, _P, _LV, _I, _P, _I, _F, _F, _I, _P, _P],
+    "ngp_hash_bwd_f32_ex": [_P, _P, _LV, _I, _P, _I, _F, _F, _I, _P, _P, _P],
     "ngp_hash_fwd_f16": [_P, _P, _LV, _I, _P, _P],
     "ngp_hash_bwd_f16": [_P, _P, _LV, _I, _P, _P],
     "ngp_sh16_fwd": [_P, _I, _P, _P],
@@ -95,15 +95,15 @@ SIGNATURES = {
     "ngp_composite_train_fused": [_P, _P, _I, _P, _P, _P, _P, _F, _P, _F, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "ngp_composite_test": [_P, _P, _I, _P, _P, _P, _P, _F, _I, _P, _P, _P, _P],
     "ngp_mlp_wpack_halfs": [],
-    "ngp_mlp_pack": [_P, _P, _P, _P, _P, _P, _P],
+    "ngp_mlp_pack": [_P, _P, _P, _P, _P, _I, _P, _P],
     "ngp_mlp_fwd": [_P, _P, _P, _I, _P, _P, _P],
     "ngp_mlp_bwd": [_P, _P, _P, _P, _P, _I, _P, _P, _P],
-    "ngp_mlp_fwd_ex": [_P, _P, _P, _I, _P, _P, _P, _P],
-    "ngp_mlp_bwd_ex": [_P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P],
+    "ngp_mlp_fwd_ex": [_P, _P, _P, _I, _P, _I, _P, _P, _P],
+    "ngp_mlp_bwd_ex": [_P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P],
     "ngp_mse_loss_grad": [_P, _P, _P, _F, _I, _P, _P, _P, _P],
     "ngp_train_prologue": [_P, _P, _F, _F, _I, _F, _F, _F, _F, _I, _P],
     "ngp_adam_step": [_P, _P, _P, _P, ctypes.c_longlong, _P, _P, _F, _F, _F, _P],
-    "ngp_adam_mlp_pack": [_P, _P, _P, _P, _P, _P, _F, _F, _F, _P, _P],
+    "ngp_adam_mlp_pack": [_P, _P, _P, _P, _P, _P, _F, _F, _F, _I, _P, _P],
     "ngp_distortion_fwd": [_P, _P, _P, _P, _I, _P, _P, _P, _P],
     "ngp_distortion_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P],
     "ngp_occ_compact": [_P, _F, _I, _P, _P, _P],

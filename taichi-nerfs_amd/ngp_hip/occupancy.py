@@ -32,6 +32,8 @@ class OccupancyUpdater:
         self.tmp = torch.empty(model.cascades, G3, **f32)
         self.stats = torch.zeros(2, **f32)
         self.wpack = torch.empty(self.L.ngp_mlp_wpack_halfs(), device=dev, dtype=torch.float16)
+        lvs = model.pos_encoder.levels_struct
+        self.enc_pairs = 1 if (lvs.n_levels == 16 and lvs.n_features == 2) else 0
 
     @torch.no_grad()
     def update(self, density_threshold, warmup=False, decay=0.95):
@@ -42,7 +44,7 @@ class OccupancyUpdater:
             raise ValueError("density_grid must be contiguous")
         lv = m.pos_encoder.levels_struct
         ws = m._mlp_weights()
-        check(L.ngp_mlp_pack(*[_ptr(w) for w in ws], _ptr(self.wpack), st), "ngp_mlp_pack")
+        check(L.ngp_mlp_pack(*[_ptr(w) for w in ws], self.enc_pairs, _ptr(self.wpack), st), "ngp_mlp_pack")
         self.tmp.zero_()                                                       # density_grid_tmp = zeros_like, networks.py:261
         lo, hi = -float(m.scale), float(m.scale)
         for c in range(C):
@@ -76,9 +78,9 @@ class OccupancyUpdater:
                                        _ptr(self.indices), _ptr(self.xyzs), st), "ngp_occ_sample")
                 idx_ptr = _ptr(self.indices)
             check(L.ngp_hash_fwd_f32_ex(_ptr(self.xyzs), _ptr(m.pos_encoder.hash_table), ctypes.byref(lv), n, _ptr(None), 1, lo, hi,
-                                        _ptr(self.enc), st), "ngp_hash_fwd_f32_ex")
-            check(L.ngp_mlp_fwd_ex(_ptr(self.enc), _ptr(None), _ptr(self.wpack), n, _ptr(None), _ptr(self.sigmas), _ptr(None), st),
-                  "ngp_mlp_fwd_ex")
+                                        self.enc_pairs, _ptr(self.enc), st), "ngp_hash_fwd_f32_ex")
+            check(L.ngp_mlp_fwd_ex(_ptr(self.enc), _ptr(None), _ptr(self.wpack), n, _ptr(None), self.enc_pairs, _ptr(self.sigmas),
+                                   _ptr(None), st), "ngp_mlp_fwd_ex")
             check(L.ngp_occ_scatter(idx_ptr, _ptr(self.sigmas), n, _ptr(tmp_c), st), "ngp_occ_scatter")
         self.stats.zero_()
         check(L.ngp_occ_merge(_ptr(grid), _ptr(self.tmp), float(decay), C * G3, _ptr(self.stats), st), "ngp_occ_merge")

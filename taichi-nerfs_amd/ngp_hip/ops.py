@@ -236,7 +236,7 @@ def mlp_pack(weights):
             raise ValueError("fused MLP needs the default architecture; got weight shape %s, want %s" % (tuple(w.shape), shape))
         ws.append(_dev(w.detach().contiguous(), torch.float32, "mlp weight"))
     wpack = torch.empty(_lib().ngp_mlp_wpack_halfs(), device=ws[0].device, dtype=torch.float16)
-    check(_lib().ngp_mlp_pack(*[_ptr(w) for w in ws], _ptr(wpack), _stream()), "ngp_mlp_pack")
+    check(_lib().ngp_mlp_pack(*[_ptr(w) for w in ws], 0, _ptr(wpack), _stream()), "ngp_mlp_pack")
     return wpack
 
 

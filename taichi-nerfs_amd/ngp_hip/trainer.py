@@ -77,6 +77,8 @@ class FusedTrainer:
         self._cur = 0
         self._side = torch.cuda.Stream(device=dev)
         self._coarse_ver = None
+        lvs = model.pos_encoder.levels_struct
+        self.enc_pairs = 1 if (lvs.n_levels == 16 and lvs.n_features == 2) else 0
         self.wpack = torch.empty(self.L.ngp_mlp_wpack_halfs(), device=dev, dtype=torch.float16)
         self.repack()
 
@@ -84,7 +86,7 @@ class FusedTrainer:
         """Rebuild the fp16 MFMA weight image from the fp32 master weights (call after loading a checkpoint into the
         model; the training step keeps it current by itself)."""
         ws = self.model._mlp_weights()
-        check(self.L.ngp_mlp_pack(*[_ptr(w) for w in ws], _ptr(self.wpack), _stream()), "ngp_mlp_pack")
+        check(self.L.ngp_mlp_pack(*[_ptr(w) for w in ws], self.enc_pairs, _ptr(self.wpack), _stream()), "ngp_mlp_pack")
 
     # ------------------------------------------------------------------------------------------------ one step
     class _MarchSet:
@@ -170,18 +172,19 @@ class FusedTrainer:
         sf, si = self.state_f, self.state_i
         sq_err = torch.empty(n, **f32)
         found = ctypes.c_void_p(si.data_ptr() + 4 * _SI_FOUND_INF)
+        P = self.enc_pairs
         check(L.ngp_hash_fwd_f32_ex(_ptr(M.xyzs), _ptr(self.table), ctypes.byref(cfg.levels), A.cap, _ptr(total), 1, cfg.lo,
-                                    cfg.hi, _ptr(A.enc), st), "ngp_hash_fwd_f32_ex")
-        check(L.ngp_mlp_fwd_ex(_ptr(A.enc), _ptr(M.dirs), _ptr(self.wpack), A.cap, _ptr(total), _ptr(A.sigmas), _ptr(A.rgbs), st),
+                                    cfg.hi, P, _ptr(A.enc), st), "ngp_hash_fwd_f32_ex")
+        check(L.ngp_mlp_fwd_ex(_ptr(A.enc), _ptr(M.dirs), _ptr(self.wpack), A.cap, _ptr(total), P, _ptr(A.sigmas), _ptr(A.rgbs), st),
               "ngp_mlp_fwd_ex")
         # composite forward + MSE gradient + composite backward, one launch
         check(L.ngp_composite_train_fused(_ptr(A.sigmas), _ptr(A.rgbs), 1, _ptr(M.deltas), _ptr(M.ts), _ptr(rays_a), _ptr(target),
                                           self.bg, _ptr(sf), cfg.T_threshold, n, _ptr(vr_per_ray), _ptr(opacity), _ptr(depth),
                                           _ptr(rgb), _ptr(A.ws), _ptr(A.d_sigmas), _ptr(A.d_rgbs), _ptr(sq_err), st),
               "ngp_composite_train_fused")
-        check(L.ngp_mlp_bwd_ex(_ptr(A.enc), _ptr(M.dirs), _ptr(self.wpack), _ptr(A.d_sigmas), _ptr(A.d_rgbs), A.cap, _ptr(total),
+        check(L.ngp_mlp_bwd_ex(_ptr(A.enc), _ptr(M.dirs), _ptr(self.wpack), _ptr(A.d_sigmas), _ptr(A.d_rgbs), A.cap, _ptr(total), P,
                                _ptr(A.d_enc), _ptr(self.mlp_grad), found, st), "ngp_mlp_bwd_ex")
-        check(L.ngp_hash_bwd_f32_ex(_ptr(M.xyzs), _ptr(A.d_enc), ctypes.byref(cfg.levels), A.cap, _ptr(total), 1, cfg.lo, cfg.hi,
+        check(L.ngp_hash_bwd_f32_ex(_ptr(M.xyzs), _ptr(A.d_enc), ctypes.byref(cfg.levels), A.cap, _ptr(total), 1, cfg.lo, cfg.hi, P,
                                     _ptr(self.table_grad), found, st), "ngp_hash_bwd_f32_ex")
         if self.world > 1:
             self._all_reduce()
@@ -191,7 +194,7 @@ class FusedTrainer:
                               self.table.numel(), _ptr(sf), _ptr(si), self.beta1, self.beta2, self.eps, st), "ngp_adam_step")
         # Adam on the MLP weights + the fp16 fragment repack the next step needs, one launch
         check(L.ngp_adam_mlp_pack(_ptr(self.mlp_flat), _ptr(self.mlp_grad), _ptr(self.mlp_m), _ptr(self.mlp_v), _ptr(sf), _ptr(si),
-                                  self.beta1, self.beta2, self.eps, _ptr(self.wpack), st), "ngp_adam_mlp_pack")
+                                  self.beta1, self.beta2, self.eps, P, _ptr(self.wpack), st), "ngp_adam_mlp_pack")
         return {"rm_samples": total, "vr_per_ray": vr_per_ray, "rgb": rgb, "opacity": opacity, "depth": depth, "rays_a": rays_a,
                 "deltas": M.deltas, "ts": M.ts, "sq_err": sq_err}
 
