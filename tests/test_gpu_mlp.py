@@ -119,3 +119,57 @@ def test_ngp_forward_uses_fused_path_under_autocast(hip_lib):
     torch.testing.assert_close(s1, s2.float(), rtol=2e-2, atol=1e-3)
     torch.testing.assert_close(c1.float(), c2.float(), rtol=1e-2, atol=4e-3)
     torch.testing.assert_close(dens, s1, rtol=0, atol=0)
+
+
+def _to_pairs(enc_nat, n_max):
+    """[n,32] natural (level-major) -> pair-major planes [8, n_max, 4] (include/ngp_hip.h, enc_pairs)."""
+    n = enc_nat.shape[0]
+    out = torch.zeros(8, n_max, 4, device=enc_nat.device, dtype=enc_nat.dtype)
+    for p in range(8):
+        out[p, :n, 0:2] = enc_nat[:, 2 * p:2 * p + 2]
+        out[p, :n, 2:4] = enc_nat[:, 2 * (15 - p):2 * (15 - p) + 2]
+    return out
+
+
+def test_pair_major_layout_equals_natural_layout(hip_lib):
+    """The fused path's pair-major encoding planes are a pure re-indexing: hash fwd bit-exact, MLP fwd/bwd equal up to the
+    fp32 summation order inside one K=32 MFMA step, hash bwd equal up to atomic order."""
+    import ctypes
+    from ngp_hip import lib as L_, ops
+    from ngp_hip.ops import _ptr, _stream, check
+    L = L_.load()
+    m = _model()
+    n = 20000
+    lv = ops.make_levels(2**19, 16, 16, 1024, 2)
+    x = torch.rand(n, 3, device="cuda")
+    table = torch.rand(lv.total_entries * 2, device="cuda")
+    enc_nat = ops.hash_fwd_f32(x, table, lv)
+    enc_p = torch.zeros(8, n, 4, device="cuda")
+    check(L.ngp_hash_fwd_f32_ex(_ptr(x), _ptr(table), ctypes.byref(lv), n, _ptr(None), 0, 0.0, 1.0, 1, _ptr(enc_p), _stream()), "fwd")
+    assert torch.equal(enc_p, _to_pairs(enc_nat, n))
+    dirs = torch.randn(n, 3, device="cuda")
+    ws = [w.detach().contiguous() for w in m._mlp_weights()]
+    wp_nat = ops.mlp_pack(ws)
+    wp_pair = torch.empty_like(wp_nat)
+    check(L.ngp_mlp_pack(*[_ptr(w) for w in ws], 1, _ptr(wp_pair), _stream()), "pack")
+    s_nat, c_nat = ops.mlp_fwd(enc_nat, dirs, wp_nat)
+    s_p = torch.empty(n, device="cuda"); c_p = torch.empty(n, 3, device="cuda", dtype=torch.float16)
+    check(L.ngp_mlp_fwd_ex(_ptr(enc_p), _ptr(dirs), _ptr(wp_pair), n, _ptr(None), 1, _ptr(s_p), _ptr(c_p), _stream()), "mlp fwd")
+    torch.testing.assert_close(s_p, s_nat, rtol=2e-3, atol=1e-4)
+    torch.testing.assert_close(c_p.float(), c_nat.float(), rtol=0, atol=2e-3)
+    g_s = torch.randn(n, device="cuda") * 8
+    g_c = (torch.randn(n, 3, device="cuda") * 8).half()
+    de_nat, dw_nat = ops.mlp_bwd(enc_nat, dirs, wp_nat, g_s, g_c)
+    de_p = torch.zeros(8, n, 4, device="cuda"); dw_p = torch.zeros_like(dw_nat)
+    check(L.ngp_mlp_bwd_ex(_ptr(enc_p), _ptr(dirs), _ptr(wp_pair), _ptr(g_s), _ptr(g_c), n, _ptr(None), 1, _ptr(de_p), _ptr(dw_p),
+                           _ptr(None), _stream()), "mlp bwd")
+    rel = lambda a, b: ((a - b).norm() / b.norm()).item()
+    assert rel(de_p, _to_pairs(de_nat, n)) < 3e-3
+    assert rel(dw_p, dw_nat) < 3e-3
+    for k, (lo, hi) in enumerate(zip([0, 2048, 3072, 5120, 9216], [2048, 3072, 5120, 9216, 9408])):
+        assert rel(dw_p[lo:hi], dw_nat[lo:hi]) < 5e-3, k                 # W1's column permutation included
+    gt_nat = torch.zeros_like(table); gt_p = torch.zeros_like(table)
+    ops.hash_bwd_f32(x, de_nat, lv, gt_nat)
+    check(L.ngp_hash_bwd_f32_ex(_ptr(x), _ptr(_to_pairs(de_nat, n)), ctypes.byref(lv), n, _ptr(None), 0, 0.0, 1.0, 1, _ptr(gt_p),
+                                _ptr(None), _stream()), "hash bwd")
+    torch.testing.assert_close(gt_p, gt_nat, rtol=1e-4, atol=1e-5 * gt_nat.abs().max().item())
