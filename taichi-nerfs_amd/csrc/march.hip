@@ -12,6 +12,7 @@
 //   the expansion into xyzs/dirs/deltas/ts is a coalesced wave-per-ray kernel.  Samples are bit-identical to
 //   the reference's serial march (checked against the oracle).
 #include "ngp_device.h"
+#include <stdlib.h>
 
 namespace ngp {
 
@@ -20,6 +21,7 @@ struct MarchParams {
     uint32_t grid_size3;
     float grid_size_f, grid_size_inv, grid_max;   // G, 1/G, G-1
     float scale, esf, dt_min, dt_max;
+    float scale_inv, mb0, mb0_inv;                // 1/scale; mip_bound of cascade 0 = min(2^-1, scale) and its reciprocal
 };
 
 __host__ inline MarchParams make_march_params(int cascades, int grid_size, float scale, float esf) {
@@ -34,6 +36,9 @@ __host__ inline MarchParams make_march_params(int cascades, int grid_size, float
     p.esf = esf;
     p.dt_min = (float)(1.7320508075688772 / 1024);                       // utils.py:15
     p.dt_max = (float)(1.7320508075688772 * 2) * scale / (float)grid_size;  // utils.py:16,56-57
+    p.scale_inv = 1.0f / scale;
+    p.mb0 = 0.5f < scale ? 0.5f : scale;
+    p.mb0_inv = 1.0f / p.mb0;
     return p;
 }
 
@@ -44,23 +49,36 @@ struct CellProbe {
     uint32_t idx;
 };
 
-// ray_march.py:46-60 for one orbit point
+// ray_march.py:46-60 for one orbit point.  CASC1 (one cascade, e.g. Synthetic-NeRF): mip == 0 for every point, so
+// mip_bound = min(0.5, scale) and its reciprocal are wave-uniform constants.  Otherwise 1/mip_bound is 2^(1-mip) (exact,
+// what the IEEE division of 1 by a power of two returns) or the precomputed 1/scale -- bit-identical, no per-point divide.
+template <bool CASC1>
 __device__ __forceinline__ void probe_cell(const MarchParams& p, const float o[3], const float d[3], float t, float dt,
                                            CellProbe& c) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) c.xyz[k] = o[k] + t * d[k];
-    float mx = fmaxf(fmaxf(fabsf(c.xyz[0]), fabsf(c.xyz[1])), fabsf(c.xyz[2]));
-    int mip_pos = min(p.cascades - 1, max(0, frexp_bit(mx) + 1));                  // utils.py:78-84
-    int mip_dt = min(p.cascades - 1, max(0, frexp_bit(dt * p.grid_size_f)));       // utils.py:87-92
-    int mip = max(mip_pos, mip_dt);
-    c.mip_bound = fminf(ldexpf(1.0f, mip - 1), p.scale);
-    float mip_bound_inv = 1.0f / c.mip_bound;
+    float mip_bound_inv;
+    int mip = 0;
+    if (CASC1) {
+        c.mip_bound = p.mb0;
+        mip_bound_inv = p.mb0_inv;
+    } else {
+        float mx = fmaxf(fmaxf(fabsf(c.xyz[0]), fabsf(c.xyz[1])), fabsf(c.xyz[2]));
+        int mip_pos = min(p.cascades - 1, max(0, frexp_bit(mx) + 1));                  // utils.py:78-84
+        int mip_dt = min(p.cascades - 1, max(0, frexp_bit(dt * p.grid_size_f)));       // utils.py:87-92
+        mip = max(mip_pos, mip_dt);
+        const float pw = ldexpf(1.0f, mip - 1);
+        const bool use_pw = pw <= p.scale;                                             // min(2^(mip-1), scale)
+        c.mip_bound = use_pw ? pw : p.scale;
+        mip_bound_inv = use_pw ? ldexpf(1.0f, 1 - mip) : p.scale_inv;
+    }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         float v = 0.5f * (c.xyz[k] * mip_bound_inv + 1.0f) * p.grid_size_f;
         c.nxyz[k] = fminf(p.grid_max, fmaxf(0.0f, v));
     }
-    c.idx = (uint32_t)mip * p.grid_size3 + morton3d(f2u_sat(c.nxyz[0]), f2u_sat(c.nxyz[1]), f2u_sat(c.nxyz[2]));
+    // nxyz is clamped into [0, G-1] and never NaN (fminf/fmaxf drop NaNs): the hardware cvt is the truncating cast
+    c.idx = (uint32_t)mip * p.grid_size3 + morton3d((uint32_t)c.nxyz[0], (uint32_t)c.nxyz[1], (uint32_t)c.nxyz[2]);
 }
 
 // ray_march.py:68-71: t_target of the skip taken from an empty cell
@@ -106,18 +124,17 @@ __global__ void __launch_bounds__(256) ray_aabb_kernel(const float* __restrict__
 // the 128 single-lane-per-ray waves that left 7/8 of the SIMDs idle and each ray with a ~2000-instruction serial
 // chain per 8 steps.
 // ------------------------------------------------------------------------------------------------------
-constexpr int MARCH_GROUP = 16;
+constexpr int MARCH_GROUP = 32;
 constexpr int MARCH_MAX_COARSE_WORDS = 1024;            // 32 768 coarse blocks: up to 8 cascades of a 128^3 grid
 constexpr int ORBIT_BATCH = 8;      // used by the test-time kernel (one lane per ray)
 
-template <bool CONST_DT>
+template <bool CONST_DT, int G, bool CASC1>
 __global__ void __launch_bounds__(64) march_count_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
                                                          const float2* __restrict__ hits_t,
                                                          const uint8_t* __restrict__ bits, const float* __restrict__ noise,
                                                          MarchParams p, int max_samples, int n_rays,
                                                          const uint32_t* __restrict__ coarse /*nullable*/,
                                                          float2* __restrict__ stage, int32_t* __restrict__ counts) {
-    constexpr int G = MARCH_GROUP;
     constexpr int GROUPS = 64 / G;                          // one wave per block: the barriers below are wave-local
     __shared__ float4 pts[GROUPS][G];                       // (t, dt, skip target, occupied)
     // coarse occupancy: one bit per 8^3 block of cells == per 512 consecutive Morton codes (64 bitfield bytes).
@@ -161,33 +178,42 @@ __global__ void __launch_bounds__(64) march_count_kernel(const float* __restrict
     float2* row = stage + (size_t)rr * (size_t)max_samples;
     bool live = has_ray && (0.0f <= t) && (t < t2) && (n < max_samples);             // ray_march.py:46
     while (__any(live)) {
-        // lane `sub` walks `sub` steps along the orbit from the batch base (exact f32 adds, no closed form)
-        float tu = t;
+        // every lane walks the whole batch of G orbit steps from the batch base (exact f32 adds, no closed form) and keeps
+        // the point it owns (step `sub`), the batch's last point and the next batch's base -- no cross-lane traffic
+        float tu = t, t_last = t, tt = t;
         if (CONST_DT) {
 #pragma unroll
-            for (int k = 0; k < G - 1; ++k) tu = (k < sub) ? tu + dt_c : tu;
+            for (int k = 0; k < G; ++k) {
+                tu = (k == sub) ? tt : tu;
+                t_last = tt;
+                tt += dt_c;
+            }
         } else {
-            for (int k = 0; k < G - 1; ++k)
-                if (k < sub) tu += calc_dt(tu, p.esf, p.dt_min, p.dt_max);
+            for (int k = 0; k < G; ++k) {
+                if (k == sub) tu = tt;
+                t_last = tt;
+                tt += calc_dt(tt, p.esf, p.dt_min, p.dt_max);
+            }
         }
+        const float t_next_batch = tt;
         const float dtu = CONST_DT ? dt_c : calc_dt(tu, p.esf, p.dt_min, p.dt_max);
         const float t_after = tu + dtu;
         CellProbe c;
-        probe_cell(p, o, d, tu, dtu, c);
+        probe_cell<CASC1>(p, o, d, tu, dtu, c);
         bool occ = live;
         if (use_coarse && occ) { const uint32_t cb = c.idx >> 9; occ = (coarse_s[cb >> 5] >> (cb & 31u)) & 1u; }
         if (occ) occ = (bits[c.idx >> 3] >> (c.idx & 7u)) & 1u;                      // ray_march.py:60-61
         const float targ = skip_target(p, d, d_inv, tu, c);                          // ray_march.py:68-71
-        // Fast path: a batch with no occupied point and no skip that reaches past the next orbit point cannot emit,
-        // and leaves behind a skip target that is already behind the next batch -- no need to replay it.
+        // Fast path: a batch with no occupied point and no skip that reaches past the next orbit point cannot emit.  Every
+        // examined point of it leaves a skip target that is already behind the next point, so after the batch the target
+        // is either the incoming one (whole batch skipped) or irrelevant (-inf is equivalent).
         const unsigned long long interesting = __ballot(live && (occ || targ > t_after));
-        const float t_last = __shfl(tu, (grp + 1) * G - 1, 64), targ_last = __shfl(targ, (grp + 1) * G - 1, 64);
-        const float t_next_batch = __shfl(t_after, (grp + 1) * G - 1, 64);
-        const bool need = ((interesting >> (grp * G)) & ((1ull << G) - 1ull)) != 0ull;
+        const unsigned long long gmask = (G == 64) ? ~0ull : (((1ull << (G & 63)) - 1ull) << ((grp * G) & 63));
+        const bool need = (interesting & gmask) != 0ull;
         if (!need) {
             if (live) {
                 if (!(t_last < t2)) live = false;                                    // the orbit left the box inside this batch
-                t_target = fmaxf(t_target, targ_last);
+                if (!(t_target > t_last)) t_target = -INFINITY;
             }
         }
         if (interesting != 0ull) {
@@ -324,7 +350,7 @@ __global__ void __launch_bounds__(64) march_test_kernel(const float* __restrict_
         for (int u = 0; u < ORBIT_BATCH; ++u) {
             float dt = calc_dt(tt, p.esf, p.dt_min, p.dt_max);
             CellProbe c;
-            probe_cell(p, o, d, tt, dt, c);
+            probe_cell<false>(p, o, d, tt, dt, c);
             tb[u] = tt; dtb[u] = dt; ib[u] = c.idx;
             ob[u] = bits[c.idx >> 3];
             tt += dt;
@@ -344,7 +370,7 @@ __global__ void __launch_bounds__(64) march_test_kernel(const float* __restrict_
                 if (s >= max_samples) live = false;
             } else {
                 CellProbe c;
-                probe_cell(p, o, d, tu, dtb[u], c);
+                probe_cell<false>(p, o, d, tu, dtb[u], c);
                 t_target = skip_target(p, d, d_inv, tu, c);
             }
         }
@@ -391,13 +417,27 @@ int ngp_march_train_count_ex(const float* rays_o, const float* rays_d, const flo
                              float exp_step_factor, int max_samples, int n_rays, float* stage, int32_t* counts, void* stream) {
     if (n_rays <= 0) return 0;
     MarchParams p = make_march_params(cascades, grid_size, scale, exp_step_factor);
-    const dim3 grid((n_rays + 64 / MARCH_GROUP - 1) / (64 / MARCH_GROUP));
-    if (exp_step_factor == 0.0f)
-        hipLaunchKernelGGL(march_count_kernel<true>, grid, dim3(64), 0, (hipStream_t)stream, rays_o, rays_d,
-                           (const float2*)hits_t, density_bitfield, noise, p, max_samples, n_rays, coarse, (float2*)stage, counts);
-    else
-        hipLaunchKernelGGL(march_count_kernel<false>, grid, dim3(64), 0, (hipStream_t)stream, rays_o, rays_d,
-                           (const float2*)hits_t, density_bitfield, noise, p, max_samples, n_rays, coarse, (float2*)stage, counts);
+    // lanes per ray: more lanes = more resident waves for this latency-bound kernel, at the price of a longer replay when
+    // a batch contains occupied cells or real skips.  NGP_MARCH_GROUP overrides (16 / 32 / 64) for experiments.
+    static int group = -1;
+    if (group < 0) { const char* e = getenv("NGP_MARCH_GROUP"); group = e ? atoi(e) : MARCH_GROUP; }
+    hipStream_t s = (hipStream_t)stream;
+#define NGP_LAUNCH_MARCH(CD, GG, C1)                                                                                           \
+    hipLaunchKernelGGL((march_count_kernel<CD, GG, C1>), dim3((n_rays + 64 / GG - 1) / (64 / GG)), dim3(64), 0, s, rays_o,     \
+                       rays_d, (const float2*)hits_t, density_bitfield, noise, p, max_samples, n_rays, coarse, (float2*)stage, \
+                       counts)
+    const bool cd = exp_step_factor == 0.0f, c1 = cascades == 1;
+    if (group == 64) {
+        if (cd && c1) NGP_LAUNCH_MARCH(true, 64, true); else if (cd) NGP_LAUNCH_MARCH(true, 64, false);
+        else if (c1) NGP_LAUNCH_MARCH(false, 64, true); else NGP_LAUNCH_MARCH(false, 64, false);
+    } else if (group == 16) {
+        if (cd && c1) NGP_LAUNCH_MARCH(true, 16, true); else if (cd) NGP_LAUNCH_MARCH(true, 16, false);
+        else if (c1) NGP_LAUNCH_MARCH(false, 16, true); else NGP_LAUNCH_MARCH(false, 16, false);
+    } else {
+        if (cd && c1) NGP_LAUNCH_MARCH(true, 32, true); else if (cd) NGP_LAUNCH_MARCH(true, 32, false);
+        else if (c1) NGP_LAUNCH_MARCH(false, 32, true); else NGP_LAUNCH_MARCH(false, 32, false);
+    }
+#undef NGP_LAUNCH_MARCH
     NGP_LAUNCH_CHECK();
     return 0;
 }

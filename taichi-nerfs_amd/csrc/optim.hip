@@ -8,7 +8,8 @@
 // rate and bias corrections) is decided by a one-thread prologue kernel from device-resident state, so the whole
 // optimisation step is a fixed sequence of launches with no read-back (hipGraph-capturable).
 // Dense Adam matches torch.optim.Adam(eps=1e-15) arithmetic (train.py:151-156): every one of the 11.4 M table entries
-// is visited each step, exactly like the reference; traffic = read g,p,m,v + write p,m,v,g = 8 x 4 B per parameter.
+// is visited each step, exactly like the reference; traffic = read g,p,m,v + write p,m,v,g = 8 x 4 B per parameter
+// (3 x 4 B for entries that have never received a gradient: they are exact fixed points and are left alone).
 #include "ngp_device.h"
 
 namespace ngp {
@@ -53,7 +54,14 @@ __global__ void __launch_bounds__(256) adam_kernel(float4* __restrict__ p, float
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         if (skip) { g[i] = zero; continue; }
         const float4 gi = g[i];
-        float4 pi = p[i], mi = m[i], vi = v[i];
+        float4 mi = m[i], vi = v[i];
+        // an entry that never received a gradient (g = m = v = 0) is a fixed point of Adam: m' = v' = 0 and the update is
+        // lr * 0 / (0 + eps) = 0 exactly -- skip its parameter read and all four writes (hashed levels of a sparse scene
+        // leave a large part of the table untouched for the whole run)
+        if (gi.x == 0.f && gi.y == 0.f && gi.z == 0.f && gi.w == 0.f && mi.x == 0.f && mi.y == 0.f && mi.z == 0.f && mi.w == 0.f &&
+            vi.x == 0.f && vi.y == 0.f && vi.z == 0.f && vi.w == 0.f)
+            continue;
+        float4 pi = p[i];
 #define NGP_ADAM1(c)                                                          \
         {                                                                     \
             const float gr = gi.c * inv_scale;                                \
