@@ -55,6 +55,8 @@ def parse():
     ap.add_argument("--graph", action="store_true", help="replay the trainer step from a captured hipGraph (1 GPU)")
     ap.add_argument("--no-prefetch", dest="prefetch", action="store_false",
                     help="do not march the next batch on a side stream underneath the current step")
+    ap.add_argument("--comm", default="f32", choices=["f32", "bf16"],
+                    help="N>1: dtype the gradient bucket travels in (f32 = exact mean, the default; bf16 halves xGMI bytes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -187,7 +189,8 @@ def main():
     trainer = None
     if use_trainer:
         from ngp_hip.trainer import FusedTrainer
-        trainer = FusedTrainer(model, lr=1e-2, max_steps=20000, init_scale=2.0**19, world_size=world)
+        trainer = FusedTrainer(model, lr=1e-2, max_steps=20000, init_scale=2.0**19, world_size=world,
+                               grad_comm_dtype=torch.bfloat16 if args.comm == "bf16" else torch.float32)
     else:
         opt = torch.optim.Adam(model.parameters(), 1e-2, eps=1e-15, fused=True)
         sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, 20000, 1e-2 / 30)
@@ -358,7 +361,7 @@ def main():
                                    "(fwd+bwd+GradScaler+Adam, grid update every 16 steps)" % (
                                        "/C4" if world > 1 else "", args.rays, "f16" if args.half else "f32", args.regime),
                        "rays_per_gpu": args.rays, "global_batch": args.rays * world,
-                       "parallelism": "ray-sharded dp%d, RCCL all-reduce of %s" % (world, "grads") if world > 1 else "single GPU",
+                       "parallelism": "ray-sharded dp%d, RCCL all-reduce of %s" % (world, "one flat %s gradient bucket per step" % args.comm) if world > 1 else "single GPU",
                        "path": ("FusedTrainer" + ("+hipGraph" if args.graph else "")) if use_trainer else "modules+torch.optim"},
             "samples_per_sec": rm * world / elapsed, "rm_samples_per_ray": rm / total_rays * world, "vr_samples_per_ray": vr / total_rays * world,
             "kernels": ks, "roofline": roof, "rooflines": rooflines,

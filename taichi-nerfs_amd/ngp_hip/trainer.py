@@ -1,4 +1,4 @@
-"""FusedTrainer -- one Instant-NGP optimisation step as a fixed sequence of ~18 kernel launches, no host sync.
+"""FusedTrainer -- one Instant-NGP optimisation step as a fixed sequence of 11 kernel launches, no host sync.
 
 It performs exactly what the reference's training iteration does (train.py:168-201) for the default model:
     rays -> render (march, hash encode, MLPs, composite) -> MSE vs target -> backward -> GradScaler -> Adam(eps=1e-15)
@@ -8,8 +8,8 @@ but every piece is a libngp_hip kernel working on persistent buffers:
     allocation + memset, no autograd graph), and are unscaled + zeroed inside the Adam pass;
   * the inf/nan check, loss-scale growth/backoff, learning rate and bias corrections live in a tiny device-side state
     (ngp_train_prologue), so nothing is read back;
-  * with world_size > 1 each rank renders its own ray shard and the two gradient buffers (+ the inf flag) are
-    all-reduced over RCCL before the optimizer kernels -- the only exchange step.
+  * with world_size > 1 each rank renders its own ray shard and the gradient bucket (table | MLP | inf flag) is
+    all-reduced (one collective over one flat bucket) over RCCL before the optimizer kernels -- the only exchange step.
 The step can be captured into a hipGraph (`capture()`), after which `step()` is a graph replay.
 
 The reference's own loop (torch.optim.Adam + torch GradScaler + autograd through modules/) keeps working on the
@@ -33,7 +33,7 @@ class FusedTrainer:
 
     def __init__(self, model, lr=1e-2, betas=(0.9, 0.999), eps=1e-15, max_steps=20000, eta_min=None, init_scale=2.0**19,
                  growth_factor=2.0, backoff_factor=0.5, growth_interval=2000, exp_step_factor=0.0, T_threshold=1e-4,
-                 max_samples=1024, process_group=None, world_size=None):
+                 max_samples=1024, process_group=None, world_size=None, grad_comm_dtype=torch.float32):
         if not model.use_fused_mlp or model.half_opt:
             raise ValueError("FusedTrainer needs the default architecture with the fp32 hash table")
         self.model = model
@@ -63,8 +63,17 @@ class FusedTrainer:
         self.mlp_flat = flat
         self.table = model.pos_encoder.hash_table.data
         f32 = dict(device=dev, dtype=torch.float32)
-        self.table_grad = torch.zeros_like(self.table)
-        self.mlp_grad = torch.zeros(MLP_N_WEIGHTS, **f32)
+        # ONE flat gradient bucket [hash-table grad | MLP grad | inf flag]: a single all-reduce per step when world > 1
+        nt = self.table.numel()
+        assert nt % 4 == 0
+        self.grad_flat = torch.zeros(nt + MLP_N_WEIGHTS + 4, **f32)
+        self.table_grad = self.grad_flat[:nt].view_as(self.table)
+        self.mlp_grad = self.grad_flat[nt:nt + MLP_N_WEIGHTS]
+        self._flag_f = self.grad_flat[nt + MLP_N_WEIGHTS:nt + MLP_N_WEIGHTS + 1]
+        # optional 16-bit gradient transport: halves the bytes on xGMI; fp32 (exact mean) is the default
+        if grad_comm_dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("grad_comm_dtype must be torch.float32 or torch.bfloat16")
+        self._comm = None if grad_comm_dtype == torch.float32 or self.world == 1 else torch.empty_like(self.grad_flat, dtype=grad_comm_dtype)
         self.table_m, self.table_v = torch.zeros_like(self.table), torch.zeros_like(self.table)
         self.mlp_m, self.mlp_v = torch.zeros(MLP_N_WEIGHTS, **f32), torch.zeros(MLP_N_WEIGHTS, **f32)
         self.state_f = torch.zeros(8, **f32)
@@ -199,15 +208,24 @@ class FusedTrainer:
                 "deltas": M.deltas, "ts": M.ts, "sq_err": sq_err}
 
     def _all_reduce(self):
-        """Average the gradients of the ray shards (MSE is a mean over the local shard) and OR the inf flags."""
-        avg = dist.get_backend(self.group) == "nccl"
-        for g in (self.table_grad, self.mlp_grad):
-            if avg:
-                dist.all_reduce(g, op=dist.ReduceOp.AVG, group=self.group)
-            else:
-                dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
-                g.div_(self.world)
-        dist.all_reduce(self.state_i[_SI_FOUND_INF:_SI_FOUND_INF + 1], op=dist.ReduceOp.MAX, group=self.group)
+        """Average the gradients of the ray shards (MSE is a mean over the local shard) and OR the inf flags: ONE
+        collective over the flat bucket [table grad | MLP grad | flag] (the flag rides along as a float; any rank's
+        non-zero flag leaves a non-zero sum / mean)."""
+        flag_i = self.state_i[_SI_FOUND_INF:_SI_FOUND_INF + 1]
+        self._flag_f.copy_(flag_i)
+        buf = self.grad_flat
+        if self._comm is not None:
+            buf = self._comm
+            buf.copy_(self.grad_flat)                           # loss-scaled gradients: bf16 keeps the fp32 exponent range
+        if dist.get_backend(self.group) == "nccl":
+            dist.all_reduce(buf, op=dist.ReduceOp.AVG, group=self.group)
+        else:
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+            buf.div_(self.world)
+        if buf is not self.grad_flat:
+            self.grad_flat.copy_(buf)
+        flag_i.copy_(self._flag_f != 0)
+        self._flag_f.zero_()
 
     def step(self, rays_o, rays_d, target, prefetch=None):
         """rays_o, rays_d, target: [N,3] contiguous float32 device tensors (this rank's shard).  Returns the per-step

@@ -104,7 +104,7 @@ def test_trainer_graph_replay_equals_eager(hip_lib, lego_bitfield):
 
 
 def test_trainer_allreduce_path_on_rccl_world1(hip_lib, lego_bitfield):
-    """The N>1 exchange step (RCCL all-reduce of the two gradient buffers + the inf flag) exercised on the real `nccl`
+    """The N>1 exchange step (ONE RCCL all-reduce of the flat bucket [table grad | MLP grad | inf flag]) exercised on the real `nccl`
     backend with a 1-rank group: averaging over one rank must leave every buffer bit-identical.  (Multi-rank numerics are
     covered on CPU by tests/test_dist_gloo.py; the 8-GPU run is the driver's.)"""
     import os
@@ -124,6 +124,19 @@ def test_trainer_allreduce_path_on_rccl_world1(hip_lib, lego_bitfield):
         tr._all_reduce()
         torch.cuda.synchronize()
         assert torch.equal(tg, tr.table_grad) and torch.equal(mg, tr.mlp_grad)
+        # the inf flag rides in the same bucket: raised on this rank -> still raised after the collective, slot cleared
+        tr.state_i[3] = 1
+        tr._all_reduce()
+        assert int(tr.state_i[3]) == 1 and float(tr._flag_f) == 0.0
+        tr.state_i[3] = 0
+        tr._all_reduce()
+        assert int(tr.state_i[3]) == 0
+        # optional bf16 transport: gradients come back rounded to bf16 (rel. error <= 2^-8), nothing else changes
+        tr._comm = torch.empty_like(tr.grad_flat, dtype=torch.bfloat16)
+        tr._all_reduce()
+        torch.cuda.synchronize()
+        assert torch.equal(tr.table_grad, tg.bfloat16().float()) and torch.equal(tr.mlp_grad, mg.bfloat16().float())
+        tr._comm = None
         tr.table_grad.zero_(); tr.mlp_grad.zero_()
         for _ in range(3):
             tr.step(o, d, target)         # full steps with the collective inside
