@@ -37,6 +37,8 @@ TRAINER_KERNELS = {
     "ngp_mlp_bwd_ex": ("mlp_bwd", "mfma", 37632, "sample"),
     "ngp_hash_bwd_f32_ex": ("hash_bwd_f32", "hbm", 12 + 128 + 1024 + 1024, "sample"),
     "ngp_adam_step": ("adam", "hbm", 32, "param"),
+    "ngp_hash_fwd_bf16_ex": ("hash_fwd_bf16", "hbm", 12 + 512 + 128, "sample"),    # --table bf16: 4-byte gathers, f32 output
+    "ngp_adam_step_bf16": ("adam_bf16", "hbm", 34, "param"),                       # + the 2-byte storage copy
 }
 
 
@@ -49,6 +51,9 @@ def parse():
     ap.add_argument("--regime", default="lego", choices=["lego", "random50", "ones"],
                     help="occupancy bitfield: trained-Lego fixture (steady state), seeded 50%% (initialisation), all-ones")
     ap.add_argument("--half", action="store_true", help="half2 hash encoder (BASELINE C5)")
+    ap.add_argument("--table", default="f32", choices=["f32", "bf16"],
+                    help="hash-table storage the forward gathers from: f32 (the reference's default encoder; the headline line) "
+                         "or a bf16 copy of the fp32 master table (BASELINE config 2 wording)")
     ap.add_argument("--path", default="trainer", choices=["trainer", "modules"],
                     help="trainer: ngp_hip.trainer.FusedTrainer (device-resident step); modules: the reference's loop shape "
                          "(render() through modules/ + torch Adam + torch GradScaler)")
@@ -175,7 +180,10 @@ def main():
 
     torch.manual_seed(23)                       # identical replicas on every rank (train.py:39-42 uses 23)
     np.random.seed(23)
-    model = NGP(scale=0.5, max_res=1024, half_opt=args.half).to(dev)
+    if args.half and args.table != "f32":
+        raise SystemExit("--half already selects the fp16 table")
+    model = NGP(scale=0.5, max_res=1024, half_opt=args.half,
+                table_dtype=torch.bfloat16 if args.table == "bf16" else None).to(dev)
     golden = os.path.join(ROOT, "tests", "golden", "lego_density_bitfield.npz")
     if args.regime == "lego":
         bits_np = np.load(golden)["density_bitfield"]
@@ -319,7 +327,7 @@ def main():
                     else:
                         # _ex launches: device-side count (the live samples of the step) unless n_dev is NULL
                         # (occupancy-update encodes: exact n = arg 3)
-                        n_dev = a[4] if name in ("ngp_hash_fwd_f32_ex", "ngp_mlp_fwd_ex") else None
+                        n_dev = a[4] if name in ("ngp_hash_fwd_f32_ex", "ngp_hash_fwd_bf16_ex", "ngp_mlp_fwd_ex") else None
                         units = float(a[3]) if (n_dev is not None and getattr(n_dev, "value", 1) is None) else float(live)
                     work = per_unit * units + (8 * live if key == "march_count" else 0)
                     rec = agg.setdefault(key, [0, 0.0, 0.0, bound, per_unit, "sample" if unit == "n_arg" else unit, 0.0])
@@ -355,11 +363,11 @@ def main():
             "metric": "training rays/sec", "value": total_rays / elapsed, "unit": "rays/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f16-table+f16-mlp" if args.half else "f32-table+f16-mlp", "data": "synthetic",
+            "dtype": "f16-table+f16-mlp" if args.half else ("bf16-table(f32 master)+f16-mlp" if args.table == "bf16" else "f32-table+f16-mlp"), "data": "synthetic",
             "config": {"workload": "Synthetic-NeRF Lego shape (BASELINE C2%s): %d rays/GPU/step, scale 0.5, 1 cascade 128^3, "
                                    "hash grid L=16 F=2 T=2^19 max_res=1024 (%s table), occupancy=%s, full train step "
                                    "(fwd+bwd+GradScaler+Adam, grid update every 16 steps)" % (
-                                       "/C4" if world > 1 else "", args.rays, "f16" if args.half else "f32", args.regime),
+                                       "/C4" if world > 1 else "", args.rays, "f16" if args.half else args.table, args.regime),
                        "rays_per_gpu": args.rays, "global_batch": args.rays * world,
                        "parallelism": "ray-sharded dp%d, RCCL all-reduce of %s" % (world, "one flat %s gradient bucket per step" % args.comm) if world > 1 else "single GPU",
                        "path": ("FusedTrainer" + ("+hipGraph" if args.graph else "")) if use_trainer else "modules+torch.optim"},

@@ -107,6 +107,13 @@ int ngp_hash_bwd_f32(const float* xyzs, const float* dout /*[n, L*F]*/,
 int ngp_hash_fwd_f32_ex(const float* xyzs, const float* table, const ngp_hash_levels* lv, int n_max,
                         const int32_t* n_dev, int normalize, float lo, float hi, int enc_pairs, float* out,
                         void* stream);
+/* bf16-stored table (F = 2; entries packed as bf16 pairs): f32 interpolation and f32 output, i.e. bit-identical to
+ * ngp_hash_fwd_f32_ex on the bf16-rounded table at half the gather bytes (588 B/sample algorithmic).  The gradient of the
+ * encoding w.r.t. the table does not depend on the table values: the backward is ngp_hash_bwd_f32_ex into the fp32 master
+ * gradient. */
+int ngp_hash_fwd_bf16_ex(const float* xyzs, const uint16_t* table, const ngp_hash_levels* lv, int n_max,
+                         const int32_t* n_dev, int normalize, float lo, float hi, int enc_pairs, float* out,
+                         void* stream);
 /* found_inf (nullable): set to 1 when a non-finite incoming gradient is seen -- GradScaler's inf/nan check
  * (train.py:199) done where the data passes instead of in an extra pass over the 45.7 MB gradient. */
 int ngp_hash_bwd_f32_ex(const float* xyzs, const float* dout, const ngp_hash_levels* lv, int n_max,
@@ -190,6 +197,13 @@ int ngp_train_prologue(float* state_f, int32_t* state_i, float lr0, float eta_mi
 /* p, g, m, v: n floats each (n % 4 == 0, 16-byte aligned); g is unscaled on the fly and zero-filled. */
 int ngp_adam_step(float* p, float* g, float* m, float* v, long long n, const float* state_f,
                   const int32_t* state_i, float beta1, float beta2, float eps, void* stream);
+/* Same pass, additionally refreshing p_bf16 (n bf16, round-to-nearest-even) -- the table ngp_hash_fwd_bf16_ex gathers from.
+ * BASELINE config 2 names a bf16 hash grid; the reference itself has fp32 (hash_encoder.py) and fp16 (hash_encoder_half.py)
+ * tables only, so the semantics here are "fp32 master + 16-bit storage copy", as hash_encoder_half.py:367 does for fp16. */
+int ngp_adam_step_bf16(float* p, float* g, float* m, float* v, long long n, const float* state_f,
+                       const int32_t* state_i, float beta1, float beta2, float eps, uint16_t* p_bf16, void* stream);
+/* dst[i] = bf16(src[i]), round-to-nearest-even; n % 4 == 0 (the per-forward cast of hash_encoder_half.py:367, in bf16). */
+int ngp_cast_f32_bf16(const float* src, uint16_t* dst, long long n, void* stream);
 /* Adam on the 9 408 flat MLP weights (W1|W2|W3|W4|W5) + the fp16 fragment repack for the next step, one launch. */
 int ngp_adam_mlp_pack(float* p, float* g, float* m, float* v, const float* state_f, const int32_t* state_i,
                       float beta1, float beta2, float eps, int enc_pairs, uint16_t* wpack, void* stream);

@@ -91,7 +91,13 @@ struct XyzNorm {            // optional fused (x - lo) / (hi - lo) of reference 
 };
 __device__ __forceinline__ float norm01(const XyzNorm& nm, float v) { return nm.enabled ? (v - nm.lo) / (nm.hi - nm.lo) : v; }
 
-template <int F>
+// BF16 = true: the table is stored as bf16 pairs (uint32 per entry, F = 2 only); bf16 -> f32 is exact, the interpolation and
+// the output stay f32, so the result equals the f32 kernel run on the bf16-rounded table, bit for bit.
+__device__ __forceinline__ float2 bf16x2_to_f32(uint32_t u) {
+    return make_float2(__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u));
+}
+
+template <int F, bool BF16 = false>
 __global__ void __launch_bounds__(256) hash_fwd_f32_kernel(const float* __restrict__ xyzs, const float* __restrict__ table,
                                                            ngp_hash_levels lv, int n, const int32_t* __restrict__ n_dev,
                                                            XyzNorm nm, float* __restrict__ out) {
@@ -111,7 +117,8 @@ __global__ void __launch_bounds__(256) hash_fwd_f32_kernel(const float* __restri
 #pragma unroll
         for (int ci = 0; ci < 8; ++ci) {
             const float* p = table + (size_t)c.idx[ci] * F;
-            if constexpr (F == 2) { float2 t = *reinterpret_cast<const float2*>(p); v[ci][0] = t.x; v[ci][1] = t.y; }
+            if constexpr (BF16) { float2 t = bf16x2_to_f32(reinterpret_cast<const uint32_t*>(table)[c.idx[ci]]); v[ci][0] = t.x; v[ci][1] = t.y; }
+            else if constexpr (F == 2) { float2 t = *reinterpret_cast<const float2*>(p); v[ci][0] = t.x; v[ci][1] = t.y; }
             else if constexpr (F == 4) { float4 t = *reinterpret_cast<const float4*>(p); v[ci][0] = t.x; v[ci][1] = t.y; v[ci][2] = t.z; v[ci][3] = t.w; }
             else {
 #pragma unroll
@@ -144,6 +151,7 @@ __global__ void __launch_bounds__(256) hash_fwd_f32_kernel(const float* __restri
 // enc_pairs = 1 writes the PAIR-MAJOR layout out[(pair * n_max + i) * 4 + which * 2 + f] (pair = min(l, 15-l), which = l >= 8):
 // every block then stores 16 contiguous bytes per sample instead of two 8-byte pieces of a 128-byte row shared with the
 // other seven XCDs (another 1.5x, same microbenchmark); the fused MLP kernels and the scatter-add consume that layout.
+template <bool BF16>
 __global__ void __launch_bounds__(256) hash_fwd_f32_xcd_kernel(const float* __restrict__ xyzs, const float* __restrict__ table,
                                                                ngp_hash_levels lv, int n, const int32_t* __restrict__ n_dev,
                                                                XyzNorm nm, int enc_pairs, float* __restrict__ out) {
@@ -161,7 +169,10 @@ __global__ void __launch_bounds__(256) hash_fwd_f32_xcd_kernel(const float* __re
         corners<false>(L, level, lv.begin_fast_hash_level, x, y, z, c);
         float2 v[8];
 #pragma unroll
-        for (int ci = 0; ci < 8; ++ci) v[ci] = *reinterpret_cast<const float2*>(table + (size_t)c.idx[ci] * 2);
+        for (int ci = 0; ci < 8; ++ci) {
+            if constexpr (BF16) v[ci] = bf16x2_to_f32(reinterpret_cast<const uint32_t*>(table)[c.idx[ci]]);
+            else v[ci] = *reinterpret_cast<const float2*>(table + (size_t)c.idx[ci] * 2);
+        }
         float a0 = 0.0f, a1 = 0.0f;
 #pragma unroll
         for (int ci = 0; ci < 8; ++ci) { a0 += c.w[ci] * v[ci].x; a1 += c.w[ci] * v[ci].y; }   // same order as the generic kernel
@@ -365,7 +376,7 @@ int ngp_hash_fwd_f32_ex(const float* xyzs, const float* table, const ngp_hash_le
     if (lv->n_features == 2 && lv->n_levels == 16 && (n_max >= 4096 || enc_pairs)) {
         int tiles = (n_max + 127) / 128;
         if (tiles > 512) tiles = 512;                       // 4096 blocks, tile-stride beyond
-        hipLaunchKernelGGL(hash_fwd_f32_xcd_kernel, dim3(8 * tiles), dim3(256), 0, s, xyzs, table, *lv, n_max, n_dev, nm, enc_pairs, out);
+        hipLaunchKernelGGL(hash_fwd_f32_xcd_kernel<false>, dim3(8 * tiles), dim3(256), 0, s, xyzs, table, *lv, n_max, n_dev, nm, enc_pairs, out);
         NGP_LAUNCH_CHECK();
         return 0;
     }
@@ -375,6 +386,26 @@ int ngp_hash_fwd_f32_ex(const float* xyzs, const float* table, const ngp_hash_le
         case 4: hipLaunchKernelGGL(hash_fwd_f32_kernel<4>, dim3(grid), dim3(256), 0, s, xyzs, table, *lv, n_max, n_dev, nm, out); break;
         case 8: hipLaunchKernelGGL(hash_fwd_f32_kernel<8>, dim3(grid), dim3(256), 0, s, xyzs, table, *lv, n_max, n_dev, nm, out); break;
         default: return -1;
+    }
+    NGP_LAUNCH_CHECK();
+    return 0;
+}
+
+int ngp_hash_fwd_bf16_ex(const float* xyzs, const uint16_t* table, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev,
+                         int normalize, float lo, float hi, int enc_pairs, float* out, void* stream) {
+    if (n_max <= 0) return 0;
+    if (lv->n_levels < 1 || lv->n_levels > NGP_MAX_LEVELS || lv->n_features != 2) return -1;
+    hipStream_t s = (hipStream_t)stream;
+    const XyzNorm nm = {normalize, lo, hi};
+    const float* t = reinterpret_cast<const float*>(table);
+    if (enc_pairs && lv->n_levels != 16) return -1;
+    if (lv->n_levels == 16 && (n_max >= 4096 || enc_pairs)) {
+        int tiles = (n_max + 127) / 128;
+        if (tiles > 512) tiles = 512;
+        hipLaunchKernelGGL(hash_fwd_f32_xcd_kernel<true>, dim3(8 * tiles), dim3(256), 0, s, xyzs, t, *lv, n_max, n_dev, nm, enc_pairs, out);
+    } else {
+        const int grid = grid_for((long long)n_max * lv->n_levels, 256);
+        hipLaunchKernelGGL((hash_fwd_f32_kernel<2, true>), dim3(grid), dim3(256), 0, s, xyzs, t, *lv, n_max, n_dev, nm, out);
     }
     NGP_LAUNCH_CHECK();
     return 0;

@@ -45,9 +45,19 @@ __global__ void train_prologue_kernel(float* __restrict__ sf, int32_t* __restric
     si[SI_ITER] = iter + 1;
 }
 
+// round-to-nearest-even f32 -> bf16 (what torch's .bfloat16() does); NaN stays NaN
+__device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+
+// SHADOW: also refresh a bf16 copy of the parameters (the table the bf16 hash forward gathers from) in the same pass
+template <bool SHADOW>
 __global__ void __launch_bounds__(256) adam_kernel(float4* __restrict__ p, float4* __restrict__ g, float4* __restrict__ m,
                                                    float4* __restrict__ v, long n4, const float* __restrict__ sf,
-                                                   const int32_t* __restrict__ si, float beta1, float beta2, float eps) {
+                                                   const int32_t* __restrict__ si, float beta1, float beta2, float eps,
+                                                   uint2* __restrict__ shadow) {
     const bool skip = si[SI_SKIP] != 0;
     const float inv_scale = sf[SF_INV_SCALE], step_size = sf[SF_LR] / sf[SF_BC1], bc2_sqrt = sf[SF_BC2_SQRT];
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -73,6 +83,16 @@ __global__ void __launch_bounds__(256) adam_kernel(float4* __restrict__ p, float
         NGP_ADAM1(x) NGP_ADAM1(y) NGP_ADAM1(z) NGP_ADAM1(w)
 #undef NGP_ADAM1
         p[i] = pi; m[i] = mi; v[i] = vi; g[i] = zero;
+        if constexpr (SHADOW)
+            shadow[i] = make_uint2(f32_to_bf16_bits(pi.x) | (f32_to_bf16_bits(pi.y) << 16),
+                                   f32_to_bf16_bits(pi.z) | (f32_to_bf16_bits(pi.w) << 16));
+    }
+}
+
+__global__ void __launch_bounds__(256) cast_bf16_kernel(const float4* __restrict__ src, uint2* __restrict__ dst, long n4) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const float4 a = src[i];
+        dst[i] = make_uint2(f32_to_bf16_bits(a.x) | (f32_to_bf16_bits(a.y) << 16), f32_to_bf16_bits(a.z) | (f32_to_bf16_bits(a.w) << 16));
     }
 }
 
@@ -130,8 +150,32 @@ int ngp_adam_step(float* p, float* g, float* m, float* v, long long n, const flo
     const long n4 = (long)(n / 4);
     long blocks = (n4 + 255) / 256;
     if (blocks > 256L * 16) blocks = 256L * 16;
-    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (float4*)p, (float4*)g, (float4*)m,
-                       (float4*)v, n4, state_f, state_i, beta1, beta2, eps);
+    hipLaunchKernelGGL(adam_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (float4*)p, (float4*)g, (float4*)m,
+                       (float4*)v, n4, state_f, state_i, beta1, beta2, eps, (uint2*)nullptr);
+    NGP_LAUNCH_CHECK();
+    return 0;
+}
+
+int ngp_adam_step_bf16(float* p, float* g, float* m, float* v, long long n, const float* state_f, const int32_t* state_i,
+                       float beta1, float beta2, float eps, uint16_t* p_bf16, void* stream) {
+    if (n <= 0) return 0;
+    if (n % 4 != 0 || !p_bf16) return -1;
+    const long n4 = (long)(n / 4);
+    long blocks = (n4 + 255) / 256;
+    if (blocks > 256L * 16) blocks = 256L * 16;
+    hipLaunchKernelGGL(adam_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (float4*)p, (float4*)g, (float4*)m,
+                       (float4*)v, n4, state_f, state_i, beta1, beta2, eps, (uint2*)p_bf16);
+    NGP_LAUNCH_CHECK();
+    return 0;
+}
+
+int ngp_cast_f32_bf16(const float* src, uint16_t* dst, long long n, void* stream) {
+    if (n <= 0) return 0;
+    if (n % 4 != 0) return -1;
+    const long n4 = (long)(n / 4);
+    long blocks = (n4 + 255) / 256;
+    if (blocks > 256L * 16) blocks = 256L * 16;
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const float4*)src, (uint2*)dst, n4);
     NGP_LAUNCH_CHECK();
     return 0;
 }

@@ -26,12 +26,41 @@ class _HashEncodeF32(torch.autograd.Function):
         return None, dtable, None
 
 
+class _HashEncodeBF16(torch.autograd.Function):
+    """bf16-stored copy of the fp32 master table in the forward (half the gather bytes), the same fp32 scatter-add
+    backward: d(encoding)/d(table) does not depend on the table values."""
+
+    @staticmethod
+    def forward(ctx, positions, table, table_bf16, levels):
+        ctx.levels = levels
+        ctx.save_for_backward(positions)
+        ctx.table_numel = table.numel()
+        return _ops.hash_fwd_bf16(positions, table_bf16, levels)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (positions,) = ctx.saved_tensors
+        dtable = torch.zeros(ctx.table_numel, device=dout.device, dtype=torch.float32)
+        _ops.hash_bwd_f32(positions, dout.contiguous().float(), ctx.levels, dtable)
+        return None, dtable, None, None
+
+
 class HashEncoder(torch.nn.Module):
-    """positions [N,3] f32 in [0,1] -> embedding [N, levels*feature_per_level] f32 (level-major)."""
+    """positions [N,3] f32 in [0,1] -> embedding [N, levels*feature_per_level] f32 (level-major).
+
+    table_dtype=torch.bfloat16 (not in the reference; BASELINE config 2 names a bf16 hash grid): the forward gathers from
+    a bf16 copy of the fp32 master `hash_table` (refreshed whenever the parameter changes, the way hash_encoder_half.py:367
+    re-casts its fp16 copy every call); parameter, gradient, optimizer state and state_dict stay fp32."""
 
     def __init__(self, max_params: float = 2**19, levels: int = 16, base_res: float = 16.0, max_res: float = 2048.0,
-                 feature_per_level: int = 2):
+                 feature_per_level: int = 2, table_dtype=None):
         super().__init__()
+        if table_dtype not in (None, torch.float32, torch.bfloat16):
+            raise ValueError("table_dtype must be None / torch.float32 / torch.bfloat16")
+        if table_dtype == torch.bfloat16 and feature_per_level != 2:
+            raise ValueError("the bf16 table packs feature pairs: feature_per_level must be 2")
+        self.table_dtype = torch.bfloat16 if table_dtype == torch.bfloat16 else torch.float32
+        self._bf16, self._bf16_ver = None, None
         levels = int(levels)
         self.log_b = scale_in_level_np(base_res=base_res, max_res=max_res, levels=levels)
         self.base_res = base_res
@@ -59,5 +88,19 @@ class HashEncoder(torch.nn.Module):
     def levels_struct(self):
         return self._levels
 
+    def table_bf16(self):
+        """The bf16 copy the forward gathers from; re-cast only when the parameter was written through torch (optimizer
+        step, load_state_dict -- its version counter moves).  FusedTrainer updates parameter AND copy in its Adam kernel."""
+        t = self.hash_table
+        ver = (t.data_ptr(), t._version)
+        if self._bf16 is None or self._bf16.device != t.device:
+            self._bf16, self._bf16_ver = torch.empty(t.shape, device=t.device, dtype=torch.bfloat16), None
+        if self._bf16_ver != ver:
+            _ops.cast_bf16(t.detach(), self._bf16)
+            self._bf16_ver = ver
+        return self._bf16
+
     def forward(self, positions):
+        if self.table_dtype == torch.bfloat16:
+            return _HashEncodeBF16.apply(positions.contiguous(), self.hash_table, self.table_bf16(), self._levels)
         return _HashEncodeF32.apply(positions.contiguous(), self.hash_table.contiguous(), self._levels)

@@ -71,7 +71,7 @@ class NGP(nn.Module):
     def __init__(self, scale: float = 0.5, pos_encoder_type: str = 'hash', levels: int = 16, feature_per_level: int = 2,
                  log2_T: int = 19, base_res: int = 16, max_res: int = 2048, half_opt: bool = False,
                  xyz_net_width: int = 64, xyz_net_depth: int = 1, xyz_net_out_dim: int = 16, rgb_net_depth: int = 2,
-                 rgb_net_width: int = 64):
+                 rgb_net_width: int = 64, table_dtype=None):
         super().__init__()
         self.scale = scale
         self.half_opt = bool(half_opt)
@@ -95,8 +95,13 @@ class NGP(nn.Module):
             from .hash_encoder_half import HashEncoder
         else:
             from .hash_encoder import HashEncoder
+        enc_kw = {}
+        if table_dtype is not None:                  # bf16 storage copy of the fp32 table (fp32 encoder only)
+            if half_opt:
+                raise ValueError("table_dtype applies to the fp32 encoder; half_opt already selects the fp16 table")
+            enc_kw['table_dtype'] = table_dtype
         self.pos_encoder = HashEncoder(max_params=2**log2_T, base_res=base_res, max_res=max_res, levels=levels,
-                                       feature_per_level=feature_per_level)
+                                       feature_per_level=feature_per_level, **enc_kw)
 
         self.xyz_encoder = MLP(input_dim=self.pos_encoder.out_dim, output_dim=xyz_net_out_dim, net_depth=xyz_net_depth,
                                net_width=xyz_net_width, bias_enabled=False)

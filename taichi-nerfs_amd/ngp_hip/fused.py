@@ -83,8 +83,12 @@ class FusedTrainRender(torch.autograd.Function):
         check(L.ngp_march_train_write(_ptr(rays_o), _ptr(rays_d), _ptr(rays_a), _ptr(A.stage), cfg.max_samples, n,
                                       _ptr(A.xyzs), _ptr(A.dirs), _ptr(A.deltas), _ptr(A.ts), st), "ngp_march_train_write")
         P = cfg.enc_pairs
-        check(L.ngp_hash_fwd_f32_ex(_ptr(A.xyzs), _ptr(table), ctypes.byref(cfg.levels), A.cap, _ptr(total), 1, cfg.lo, cfg.hi, P,
-                                    _ptr(A.enc), st), "ngp_hash_fwd_f32_ex")
+        if cfg.table_bf16 is not None:
+            check(L.ngp_hash_fwd_bf16_ex(_ptr(A.xyzs), _ptr(cfg.table_bf16), ctypes.byref(cfg.levels), A.cap, _ptr(total), 1, cfg.lo,
+                                         cfg.hi, P, _ptr(A.enc), st), "ngp_hash_fwd_bf16_ex")
+        else:
+            check(L.ngp_hash_fwd_f32_ex(_ptr(A.xyzs), _ptr(table), ctypes.byref(cfg.levels), A.cap, _ptr(total), 1, cfg.lo, cfg.hi, P,
+                                        _ptr(A.enc), st), "ngp_hash_fwd_f32_ex")
         check(L.ngp_mlp_pack(_ptr(w1), _ptr(w2), _ptr(w3), _ptr(w4), _ptr(w5), P, _ptr(A.wpack), st), "ngp_mlp_pack")
         check(L.ngp_mlp_fwd_ex(_ptr(A.enc), _ptr(A.dirs), _ptr(A.wpack), A.cap, _ptr(total), P, _ptr(A.sigmas), _ptr(A.rgbs), st),
               "ngp_mlp_fwd_ex")
@@ -151,3 +155,5 @@ class RenderConfig:
         self.hi = float(model.scale)
         # pair-major encoding planes (one level pair per XCD) whenever the table has the default 16 x 2 shape
         self.enc_pairs = 1 if (self.levels.n_levels == 16 and self.levels.n_features == 2) else 0
+        enc = model.pos_encoder
+        self.table_bf16 = enc.table_bf16() if getattr(enc, "table_dtype", torch.float32) == torch.bfloat16 else None

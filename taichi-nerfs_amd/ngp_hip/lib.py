@@ -85,6 +85,7 @@ SIGNATURES = {
     "ngp_hash_fwd_f32": [_P, _P, _LV, _I, _P, _P],
     "ngp_hash_bwd_f32": [_P, _P, _LV, _I, _P, _P],
     "ngp_hash_fwd_f32_ex": [_P, _P, _LV, _I, _P, _I, _F, _F, _I, _P, _P],
+    "ngp_hash_fwd_bf16_ex": [_P, _P, _LV, _I, _P, _I, _F, _F, _I, _P, _P],
     "ngp_hash_bwd_f32_ex": [_P, _P, _LV, _I, _P, _I, _F, _F, _I, _P, _P, _P],
     "ngp_hash_fwd_f16": [_P, _P, _LV, _I, _P, _P],
     "ngp_hash_bwd_f16": [_P, _P, _LV, _I, _P, _P],
@@ -103,6 +104,8 @@ SIGNATURES = {
     "ngp_mse_loss_grad": [_P, _P, _P, _F, _I, _P, _P, _P, _P],
     "ngp_train_prologue": [_P, _P, _F, _F, _I, _F, _F, _F, _F, _I, _P],
     "ngp_adam_step": [_P, _P, _P, _P, ctypes.c_longlong, _P, _P, _F, _F, _F, _P],
+    "ngp_adam_step_bf16": [_P, _P, _P, _P, ctypes.c_longlong, _P, _P, _F, _F, _F, _P, _P],
+    "ngp_cast_f32_bf16": [_P, _P, ctypes.c_longlong, _P],
     "ngp_adam_mlp_pack": [_P, _P, _P, _P, _P, _P, _F, _F, _F, _I, _P, _P],
     "ngp_distortion_fwd": [_P, _P, _P, _P, _I, _P, _P, _P, _P],
     "ngp_distortion_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P],

@@ -77,8 +77,12 @@ class OccupancyUpdater:
                 check(L.ngp_occ_sample(_ptr(u_cell), _ptr(u_pick), _ptr(u_jit), _ptr(self.list), _ptr(self.count), self.M, G, s, hg,
                                        _ptr(self.indices), _ptr(self.xyzs), st), "ngp_occ_sample")
                 idx_ptr = _ptr(self.indices)
-            check(L.ngp_hash_fwd_f32_ex(_ptr(self.xyzs), _ptr(m.pos_encoder.hash_table), ctypes.byref(lv), n, _ptr(None), 1, lo, hi,
-                                        self.enc_pairs, _ptr(self.enc), st), "ngp_hash_fwd_f32_ex")
+            if getattr(m.pos_encoder, "table_dtype", torch.float32) == torch.bfloat16:
+                check(L.ngp_hash_fwd_bf16_ex(_ptr(self.xyzs), _ptr(m.pos_encoder.table_bf16()), ctypes.byref(lv), n, _ptr(None), 1, lo,
+                                             hi, self.enc_pairs, _ptr(self.enc), st), "ngp_hash_fwd_bf16_ex")
+            else:
+                check(L.ngp_hash_fwd_f32_ex(_ptr(self.xyzs), _ptr(m.pos_encoder.hash_table), ctypes.byref(lv), n, _ptr(None), 1, lo, hi,
+                                            self.enc_pairs, _ptr(self.enc), st), "ngp_hash_fwd_f32_ex")
             check(L.ngp_mlp_fwd_ex(_ptr(self.enc), _ptr(None), _ptr(self.wpack), n, _ptr(None), self.enc_pairs, _ptr(self.sigmas),
                                    _ptr(None), st), "ngp_mlp_fwd_ex")
             check(L.ngp_occ_scatter(idx_ptr, _ptr(self.sigmas), n, _ptr(tmp_c), st), "ngp_occ_scatter")

@@ -134,6 +134,26 @@ def hash_fwd_f32(xyzs, table, lv):
     return out
 
 
+def cast_bf16(src, dst=None):
+    """dst = bf16(src), round-to-nearest-even (ngp_cast_f32_bf16); numel % 4 == 0."""
+    _dev(src, torch.float32, "src")
+    if dst is None:
+        dst = torch.empty(src.shape, device=src.device, dtype=torch.bfloat16)
+    _dev(dst, torch.bfloat16, "dst")
+    check(_lib().ngp_cast_f32_bf16(_ptr(src), _ptr(dst), src.numel(), _stream()), "ngp_cast_f32_bf16")
+    return dst
+
+
+def hash_fwd_bf16(xyzs, table_bf16, lv):
+    """bf16-stored table (F = 2), f32 interpolation and output [n, L*2]."""
+    _dev(xyzs, torch.float32, "xyzs"); _dev(table_bf16, torch.bfloat16, "hash_table(bf16)")
+    n = xyzs.shape[0]
+    out = torch.empty(n, lv.n_levels * lv.n_features, device=xyzs.device, dtype=torch.float32)
+    check(_lib().ngp_hash_fwd_bf16_ex(_ptr(xyzs), _ptr(table_bf16), ctypes.byref(lv), n, _ptr(None), 0, 0.0, 1.0, 0, _ptr(out),
+                                      _stream()), "ngp_hash_fwd_bf16_ex")
+    return out
+
+
 def hash_bwd_f32(xyzs, dout, lv, dtable):
     _dev(xyzs, torch.float32, "xyzs"); _dev(dout, torch.float32, "dout"); _dev(dtable, torch.float32, "dtable")
     check(_lib().ngp_hash_bwd_f32(_ptr(xyzs), _ptr(dout), ctypes.byref(lv), xyzs.shape[0], _ptr(dtable), _stream()),

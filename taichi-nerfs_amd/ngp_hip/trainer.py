@@ -89,12 +89,18 @@ class FusedTrainer:
         lvs = model.pos_encoder.levels_struct
         self.enc_pairs = 1 if (lvs.n_levels == 16 and lvs.n_features == 2) else 0
         self.wpack = torch.empty(self.L.ngp_mlp_wpack_halfs(), device=dev, dtype=torch.float16)
+        # bf16 storage copy of the table (HashEncoder(table_dtype=torch.bfloat16)): gathered by the forward, refreshed by Adam
+        self.table_bf16 = (model.pos_encoder.table_bf16()
+                           if getattr(model.pos_encoder, "table_dtype", torch.float32) == torch.bfloat16 else None)
         self.repack()
 
     def repack(self):
         """Rebuild the fp16 MFMA weight image from the fp32 master weights (call after loading a checkpoint into the
         model; the training step keeps it current by itself)."""
         ws = self.model._mlp_weights()
+        if self.table_bf16 is not None:
+            self.model.pos_encoder._bf16_ver = None                             # force a re-cast of the bf16 table copy
+            assert self.model.pos_encoder.table_bf16() is self.table_bf16
         check(self.L.ngp_mlp_pack(*[_ptr(w) for w in ws], self.enc_pairs, _ptr(self.wpack), _stream()), "ngp_mlp_pack")
 
     # ------------------------------------------------------------------------------------------------ one step
@@ -182,8 +188,12 @@ class FusedTrainer:
         sq_err = torch.empty(n, **f32)
         found = ctypes.c_void_p(si.data_ptr() + 4 * _SI_FOUND_INF)
         P = self.enc_pairs
-        check(L.ngp_hash_fwd_f32_ex(_ptr(M.xyzs), _ptr(self.table), ctypes.byref(cfg.levels), A.cap, _ptr(total), 1, cfg.lo,
-                                    cfg.hi, P, _ptr(A.enc), st), "ngp_hash_fwd_f32_ex")
+        if self.table_bf16 is not None:
+            check(L.ngp_hash_fwd_bf16_ex(_ptr(M.xyzs), _ptr(self.table_bf16), ctypes.byref(cfg.levels), A.cap, _ptr(total), 1, cfg.lo,
+                                         cfg.hi, P, _ptr(A.enc), st), "ngp_hash_fwd_bf16_ex")
+        else:
+            check(L.ngp_hash_fwd_f32_ex(_ptr(M.xyzs), _ptr(self.table), ctypes.byref(cfg.levels), A.cap, _ptr(total), 1, cfg.lo,
+                                        cfg.hi, P, _ptr(A.enc), st), "ngp_hash_fwd_f32_ex")
         check(L.ngp_mlp_fwd_ex(_ptr(A.enc), _ptr(M.dirs), _ptr(self.wpack), A.cap, _ptr(total), P, _ptr(A.sigmas), _ptr(A.rgbs), st),
               "ngp_mlp_fwd_ex")
         # composite forward + MSE gradient + composite backward, one launch
@@ -199,8 +209,13 @@ class FusedTrainer:
             self._all_reduce()
         check(L.ngp_train_prologue(_ptr(sf), _ptr(si), self.lr0, self.eta_min, self.t_max, self.beta1,
                                    self.beta2, self.growth, self.backoff, self.growth_interval, st), "ngp_train_prologue")
-        check(L.ngp_adam_step(_ptr(self.table), _ptr(self.table_grad), _ptr(self.table_m), _ptr(self.table_v),
-                              self.table.numel(), _ptr(sf), _ptr(si), self.beta1, self.beta2, self.eps, st), "ngp_adam_step")
+        if self.table_bf16 is not None:
+            check(L.ngp_adam_step_bf16(_ptr(self.table), _ptr(self.table_grad), _ptr(self.table_m), _ptr(self.table_v),
+                                       self.table.numel(), _ptr(sf), _ptr(si), self.beta1, self.beta2, self.eps, _ptr(self.table_bf16),
+                                       st), "ngp_adam_step_bf16")
+        else:
+            check(L.ngp_adam_step(_ptr(self.table), _ptr(self.table_grad), _ptr(self.table_m), _ptr(self.table_v),
+                                  self.table.numel(), _ptr(sf), _ptr(si), self.beta1, self.beta2, self.eps, st), "ngp_adam_step")
         # Adam on the MLP weights + the fp16 fragment repack the next step needs, one launch
         check(L.ngp_adam_mlp_pack(_ptr(self.mlp_flat), _ptr(self.mlp_grad), _ptr(self.mlp_m), _ptr(self.mlp_v), _ptr(sf), _ptr(si),
                                   self.beta1, self.beta2, self.eps, P, _ptr(self.wpack), st), "ngp_adam_mlp_pack")

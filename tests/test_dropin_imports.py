@@ -59,4 +59,8 @@ def test_public_signatures_match_reference():
         for node in tree.body:
             if isinstance(node, ast.ClassDef) and node.name == cls.__name__:
                 init = [f for f in node.body if isinstance(f, ast.FunctionDef) and f.name == "__init__"][0]
-                assert list(inspect.signature(cls.__init__).parameters) == [a.arg for a in init.args.args], (fname, cls)
+                ours = inspect.signature(cls.__init__).parameters
+                ref_args = [a.arg for a in init.args.args]
+                # every reference parameter, same order; extensions only as trailing keyword arguments with defaults
+                assert list(ours)[:len(ref_args)] == ref_args, (fname, cls)
+                assert all(ours[k].default is not inspect.Parameter.empty for k in list(ours)[len(ref_args):]), (fname, cls)
