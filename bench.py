@@ -47,7 +47,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--rays", type=int, default=8192, help="rays per GPU per step (BASELINE C2: 8192)")
+    ap.add_argument("--rays", type=int, default=None, help="rays per GPU per step (default: 8192 for lego = BASELINE C2, 65536 for garden = C3)")
+    ap.add_argument("--scene", default="lego", choices=["lego", "garden"],
+                    help="lego = BASELINE C2 (scale 0.5, 1 cascade, max_res 1024, the headline); garden = BASELINE C3 shape "
+                         "(scale 16, 6 cascades, max_res 4096, exponential stepping, black background, distortion loss 1e-3)")
     ap.add_argument("--regime", default="lego", choices=["lego", "random50", "ones"],
                     help="occupancy bitfield: trained-Lego fixture (steady state), seeded 50%% (initialisation), all-ones")
     ap.add_argument("--half", action="store_true", help="half2 hash encoder (BASELINE C5)")
@@ -182,10 +185,17 @@ def main():
     np.random.seed(23)
     if args.half and args.table != "f32":
         raise SystemExit("--half already selects the fp16 table")
-    model = NGP(scale=0.5, max_res=1024, half_opt=args.half,
+    garden = args.scene == "garden"
+    if args.rays is None:
+        args.rays = 65536 if garden else 8192
+    esf = 1.0 / 256 if garden else 0.0                                       # train.py:54
+    w_dist = 1e-3 if garden else 0.0                                         # opt.py:77-83 "1e-3 for real scene"
+    model = NGP(scale=16.0 if garden else 0.5, max_res=4096 if garden else 1024, half_opt=args.half,
                 table_dtype=torch.bfloat16 if args.table == "bf16" else None).to(dev)
     golden = os.path.join(ROOT, "tests", "golden", "lego_density_bitfield.npz")
-    if args.regime == "lego":
+    if garden:
+        bits_np = synthetic.ball_slab_bitfield(model.cascades, 16.0, seed=23)
+    elif args.regime == "lego":
         bits_np = np.load(golden)["density_bitfield"]
     elif args.regime == "random50":
         bits_np = synthetic.random_bitfield(1, fraction=0.5, seed=23)
@@ -198,6 +208,7 @@ def main():
     if use_trainer:
         from ngp_hip.trainer import FusedTrainer
         trainer = FusedTrainer(model, lr=1e-2, max_steps=20000, init_scale=2.0**19, world_size=world,
+                               exp_step_factor=esf, distortion_loss_w=w_dist,
                                grad_comm_dtype=torch.bfloat16 if args.comm == "bf16" else torch.float32)
     else:
         opt = torch.optim.Adam(model.parameters(), 1e-2, eps=1e-15, fused=True)
@@ -209,7 +220,7 @@ def main():
     n_pool = 8
     pool = []
     for b in range(n_pool):
-        o, d = synthetic.lego_rays(args.rays, seed=1000 + 97 * b + rank)
+        o, d = (synthetic.garden_rays if garden else synthetic.lego_rays)(args.rays, seed=1000 + 97 * b + rank)
         g = torch.Generator(device="cpu").manual_seed(b * 131 + rank)
         pool.append((torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev), torch.rand(args.rays, 3, generator=g).to(dev)))
 
@@ -266,8 +277,11 @@ def main():
                 # the freshly packed bitfield is overwritten again -- the update's full cost is still paid.
                 model.update_density_grid(0.01 * MAX_SAMPLES / 3**0.5, warmup=False)
                 model.density_bitfield.copy_(bits)
-            res = render(model, rays_o, rays_d, exp_step_factor=0.0)
+            res = render(model, rays_o, rays_d, exp_step_factor=esf)
             loss = F.mse_loss(res["rgb"], target)
+            if w_dist > 0:
+                from modules.distortion import distortion_loss
+                loss = loss + w_dist * distortion_loss(res).mean()
         opt.zero_grad()
         scaler.scale(loss).backward()
         if reducer is not None:
@@ -364,7 +378,11 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16-table+f16-mlp" if args.half else ("bf16-table(f32 master)+f16-mlp" if args.table == "bf16" else "f32-table+f16-mlp"), "data": "synthetic",
-            "config": {"workload": "Synthetic-NeRF Lego shape (BASELINE C2%s): %d rays/GPU/step, scale 0.5, 1 cascade 128^3, "
+            "config": {"workload": ("360_v2 Garden shape (BASELINE C3): %d rays/GPU/step, scale 16, 6 cascades 128^3, hash grid L=16 F=2 "
+                                    "T=2^19 max_res=4096 (%s table), exp_step_factor 1/256, synthetic ball+slab+far-cells occupancy, "
+                                    "MSE + 1e-3 distortion loss, full train step (fwd+bwd+GradScaler+Adam, grid update every 16 steps)"
+                                    % (args.rays, "f16" if args.half else args.table)) if garden else
+                                   "Synthetic-NeRF Lego shape (BASELINE C2%s): %d rays/GPU/step, scale 0.5, 1 cascade 128^3, "
                                    "hash grid L=16 F=2 T=2^19 max_res=1024 (%s table), occupancy=%s, full train step "
                                    "(fwd+bwd+GradScaler+Adam, grid update every 16 steps)" % (
                                        "/C4" if world > 1 else "", args.rays, "f16" if args.half else args.table, args.regime),
@@ -374,7 +392,7 @@ def main():
             "samples_per_sec": rm * world / elapsed, "rm_samples_per_ray": rm / total_rays * world, "vr_samples_per_ray": vr / total_rays * world,
             "kernels": ks, "roofline": roof, "rooflines": rooflines,
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and not garden:     # the CPU leg restates the C2 workload only
             out["cpu_baseline"] = cpu_baseline(bits_np if args.regime == "lego" else np.load(golden)["density_bitfield"],
                                                args.cpu_seconds)
         print(json.dumps(out))

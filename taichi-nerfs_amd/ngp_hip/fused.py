@@ -41,6 +41,14 @@ class TrainArena:
         self.d_enc = torch.empty(cap, 32, **f32)
         self.wpack = torch.empty(_lib_mod.load().ngp_mlp_wpack_halfs(), device=device, dtype=torch.float16)
         self._coarse = {}
+        self._scratch = {}
+
+    def scratch(self, name):
+        """Lazily allocated per-sample f32 [cap] work buffers (distortion-loss scans and gradient)."""
+        buf = self._scratch.get(name)
+        if buf is None:
+            buf = self._scratch[name] = torch.empty(self.cap, device=self.stage.device, dtype=torch.float32)
+        return buf
 
     def coarse_for(self, cfg):
         words = cfg.cascades * cfg.grid_size**3 // 512 // 32

@@ -33,7 +33,8 @@ class FusedTrainer:
 
     def __init__(self, model, lr=1e-2, betas=(0.9, 0.999), eps=1e-15, max_steps=20000, eta_min=None, init_scale=2.0**19,
                  growth_factor=2.0, backoff_factor=0.5, growth_interval=2000, exp_step_factor=0.0, T_threshold=1e-4,
-                 max_samples=1024, process_group=None, world_size=None, grad_comm_dtype=torch.float32):
+                 max_samples=1024, process_group=None, world_size=None, grad_comm_dtype=torch.float32,
+                 distortion_loss_w=0.0):
         if not model.use_fused_mlp or model.half_opt:
             raise ValueError("FusedTrainer needs the default architecture with the fp32 hash table")
         self.model = model
@@ -48,6 +49,7 @@ class FusedTrainer:
         self.growth, self.backoff, self.growth_interval = float(growth_factor), float(backoff_factor), int(growth_interval)
         self.exp_step_factor, self.T_threshold, self.max_samples = float(exp_step_factor), float(T_threshold), int(max_samples)
         self.bg = 1.0 if exp_step_factor == 0 else 0.0                    # rendering.py:219-226
+        self.distortion_loss_w = float(distortion_loss_w)                # train.py:194-195 (0 = off, the reference default)
         self.group = process_group
         self.world = world_size if world_size is not None else (dist.get_world_size(process_group) if dist.is_initialized() else 1)
 
@@ -80,6 +82,7 @@ class FusedTrainer:
         self.state_i = torch.zeros(8, device=dev, dtype=torch.int32)
         self.state_f[_SF_LOSS_SCALE] = float(init_scale)
         self._graph = None
+        self._grads_only = False
         self._static = None
         self.stats = {}
         self._sets = {}
@@ -196,17 +199,23 @@ class FusedTrainer:
                                         cfg.hi, P, _ptr(A.enc), st), "ngp_hash_fwd_f32_ex")
         check(L.ngp_mlp_fwd_ex(_ptr(A.enc), _ptr(M.dirs), _ptr(self.wpack), A.cap, _ptr(total), P, _ptr(A.sigmas), _ptr(A.rgbs), st),
               "ngp_mlp_fwd_ex")
-        # composite forward + MSE gradient + composite backward, one launch
-        check(L.ngp_composite_train_fused(_ptr(A.sigmas), _ptr(A.rgbs), 1, _ptr(M.deltas), _ptr(M.ts), _ptr(rays_a), _ptr(target),
-                                          self.bg, _ptr(sf), cfg.T_threshold, n, _ptr(vr_per_ray), _ptr(opacity), _ptr(depth),
-                                          _ptr(rgb), _ptr(A.ws), _ptr(A.d_sigmas), _ptr(A.d_rgbs), _ptr(sq_err), st),
-              "ngp_composite_train_fused")
+        if self.distortion_loss_w > 0:
+            sq_err = self._composite_with_distortion(A, M, target, cfg, n, vr_per_ray, opacity, depth, rgb)
+        else:
+          # composite forward + MSE gradient + composite backward, one launch
+          check(L.ngp_composite_train_fused(_ptr(A.sigmas), _ptr(A.rgbs), 1, _ptr(M.deltas), _ptr(M.ts), _ptr(rays_a), _ptr(target),
+                                            self.bg, _ptr(sf), cfg.T_threshold, n, _ptr(vr_per_ray), _ptr(opacity), _ptr(depth),
+                                            _ptr(rgb), _ptr(A.ws), _ptr(A.d_sigmas), _ptr(A.d_rgbs), _ptr(sq_err), st),
+                "ngp_composite_train_fused")
         check(L.ngp_mlp_bwd_ex(_ptr(A.enc), _ptr(M.dirs), _ptr(self.wpack), _ptr(A.d_sigmas), _ptr(A.d_rgbs), A.cap, _ptr(total), P,
                                _ptr(A.d_enc), _ptr(self.mlp_grad), found, st), "ngp_mlp_bwd_ex")
         check(L.ngp_hash_bwd_f32_ex(_ptr(M.xyzs), _ptr(A.d_enc), ctypes.byref(cfg.levels), A.cap, _ptr(total), 1, cfg.lo, cfg.hi, P,
                                     _ptr(self.table_grad), found, st), "ngp_hash_bwd_f32_ex")
         if self.world > 1:
             self._all_reduce()
+        if self._grads_only:
+            return {"rm_samples": total, "vr_per_ray": vr_per_ray, "rgb": rgb, "opacity": opacity, "depth": depth, "rays_a": rays_a,
+                    "deltas": M.deltas, "ts": M.ts, "sq_err": sq_err}
         check(L.ngp_train_prologue(_ptr(sf), _ptr(si), self.lr0, self.eta_min, self.t_max, self.beta1,
                                    self.beta2, self.growth, self.backoff, self.growth_interval, st), "ngp_train_prologue")
         if self.table_bf16 is not None:
@@ -221,6 +230,34 @@ class FusedTrainer:
                                   self.beta1, self.beta2, self.eps, P, _ptr(self.wpack), st), "ngp_adam_mlp_pack")
         return {"rm_samples": total, "vr_per_ray": vr_per_ray, "rgb": rgb, "opacity": opacity, "depth": depth, "rays_a": rays_a,
                 "deltas": M.deltas, "ts": M.ts, "sq_err": sq_err}
+
+    def _composite_with_distortion(self, A, M, target, cfg, n, vr_per_ray, opacity, depth, rgb):
+        """loss = MSE + w * mean(distortion) (train.py:193-195): the distortion gradient w.r.t. the sample weights has to
+        exist before the composite backward runs, so the single fused launch becomes composite fwd -> distortion fwd/bwd ->
+        MSE gradient -> composite bwd (all the same kernels the operator path uses).  Returns the per-ray squared error
+        stand-in used for logging (MSE part only)."""
+        L, st, sf = self.L, _stream(), self.state_f
+        f32 = dict(device=self.dev, dtype=torch.float32)
+        rays_a = M.rays_a
+        check(L.ngp_composite_train_fwd(_ptr(A.sigmas), _ptr(A.rgbs), 1, _ptr(M.deltas), _ptr(M.ts), _ptr(rays_a), cfg.T_threshold,
+                                        n, _ptr(vr_per_ray), _ptr(opacity), _ptr(depth), _ptr(rgb), _ptr(A.ws), st),
+              "ngp_composite_train_fwd")
+        dist_loss = torch.zeros(n, **f32)
+        ws_inc, wts_inc, g_ws = A.scratch("ws_inc"), A.scratch("wts_inc"), A.scratch("g_ws")
+        check(L.ngp_distortion_fwd(_ptr(A.ws), _ptr(M.deltas), _ptr(M.ts), _ptr(rays_a), n, _ptr(dist_loss), _ptr(ws_inc),
+                                   _ptr(wts_inc), st), "ngp_distortion_fwd")
+        # d(w * mean(dist)) / d dist[r] = w / n, loss-scaled on the device like every other gradient
+        g_dist = (sf[_SF_LOSS_SCALE] * (self.distortion_loss_w / n)).expand(n).contiguous()
+        check(L.ngp_distortion_bwd(_ptr(g_dist), _ptr(A.ws), _ptr(M.deltas), _ptr(M.ts), _ptr(ws_inc), _ptr(wts_inc), _ptr(rays_a), n,
+                                   _ptr(g_ws), st), "ngp_distortion_bwd")
+        g_rgb, g_op = torch.empty(n, 3, **f32), torch.empty(n, **f32)
+        check(L.ngp_mse_loss_grad(_ptr(rgb), _ptr(opacity), _ptr(target), self.bg, n, _ptr(sf), _ptr(g_rgb), _ptr(g_op), st),
+              "ngp_mse_loss_grad")
+        check(L.ngp_composite_train_bwd(_ptr(g_op), _ptr(None), _ptr(g_rgb), _ptr(g_ws), _ptr(A.sigmas), _ptr(A.rgbs), 1, _ptr(M.deltas),
+                                        _ptr(M.ts), _ptr(rays_a), _ptr(opacity), _ptr(depth), _ptr(rgb), _ptr(A.ws), cfg.T_threshold, n,
+                                        _ptr(A.d_sigmas), _ptr(A.d_rgbs), st), "ngp_composite_train_bwd")
+        self._dist_loss = dist_loss
+        return None
 
     def _all_reduce(self):
         """Average the gradients of the ray shards (MSE is a mean over the local shard) and OR the inf flags: ONE
@@ -258,6 +295,23 @@ class FusedTrainer:
         self.stats = self._launch(rays_o.contiguous().float(), rays_d.contiguous().float(), target.contiguous().float(), prefetch)
         return self.stats
 
+    def compute_gradients(self, rays_o, rays_d, target):
+        """Forward + backward of one batch WITHOUT the optimizer (diagnostics / gradient tests): returns the outputs plus
+        clones of the table and MLP gradients divided by the current loss scale; accumulators and the inf flag are cleared."""
+        if self._graph is not None:
+            raise RuntimeError("not available after capture()")
+        self._grads_only = True
+        try:
+            out = self._launch(rays_o.contiguous().float(), rays_d.contiguous().float(), target.contiguous().float())
+        finally:
+            self._grads_only = False
+        inv = 1.0 / self.state_f[_SF_LOSS_SCALE]
+        out["table_grad"], out["mlp_grad"] = self.table_grad * inv, self.mlp_grad * inv
+        out["found_inf"] = self.state_i[_SI_FOUND_INF].clone()
+        self.grad_flat.zero_()
+        self.state_i[_SI_FOUND_INF] = 0
+        return out
+
     def capture(self, n_rays):
         """Capture one step into a hipGraph (single-GPU; the RCCL path stays eager).  Subsequent step() calls copy the
         batch into static buffers and replay."""
@@ -287,6 +341,8 @@ class FusedTrainer:
     def last_loss(self):
         """MSE of the last step (host sync: logging only)."""
         se = self.stats.get("sq_err")
+        if se is None and self.distortion_loss_w > 0 and self.stats:
+            return float(self.state_f[_SF_LOSS].item())                   # written by ngp_mse_loss_grad
         return float("nan") if se is None else float(se.sum().item()) / (3.0 * se.numel())
 
     def loss_scale(self):
