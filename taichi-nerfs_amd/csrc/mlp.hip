@@ -135,29 +135,30 @@ __global__ void __launch_bounds__(1024) adam_mlp_pack_kernel(float* __restrict__
 }
 
 // ---- per-lane helpers -------------------------------------------------------------------------------------
-__device__ __forceinline__ half4 relu_h4(const floatx4& d) {
-    half4 r;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { half_t h = (half_t)d[k]; r[k] = h > (half_t)0 ? h : (half_t)0; }
-    return r;
-}
-__device__ __forceinline__ half4 to_h4(const floatx4& d) {
-    half4 r;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) r[k] = (half_t)d[k];
-    return r;
+// The data path is VALU-issue bound (ISA count: ~20 VALU per MFMA before this formulation), so everything between two MFMAs
+// is written with the packed f16 instructions of gfx950: v_cvt_pk_f16_f32 (round-to-nearest-even, two values per issue),
+// v_pk_max_f16 / v_pk_min_f16, v_pk_min_u16 / v_pk_mul_lo_u16 -- no per-element compare + select, no lane masks in SGPRs.
+typedef unsigned short ushort4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ half4 to_h4(const floatx4& d) { return __builtin_convertvector(d, half4); }
+__device__ __forceinline__ half4 relu_h4(const floatx4& d) {             // relu(f16(d)); max(-0, +0) = +0 on AMD
+    const half4 z = {(half_t)0, (half_t)0, (half_t)0, (half_t)0};
+    return __builtin_elementwise_max(to_h4(d), z);
 }
 __device__ __forceinline__ half8 cat_h4(const half4& a, const half4& b) {
-    half8 r;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { r[k] = a[k]; r[4 + k] = b[k]; }
-    return r;
+    return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
 }
-__device__ __forceinline__ half4 mask_h4(const floatx4& d, const half4& act) {   // dz = (act > 0) ? f16(d) : 0
-    half4 r;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) r[k] = act[k] > (half_t)0 ? (half_t)d[k] : (half_t)0;
-    return r;
+// dz = (act > 0) ? f16(d) : 0   (threshold_backward).  act >= +0, so its bit pattern is non-zero exactly when act > 0:
+// B = min(bits, 1) * 0x7C00 is +inf where the unit was active and +0 where it was not, and clamp(x, -B, +B) passes or
+// zeroes x -- including x = +-inf (stays non-finite for the GradScaler check; x * mask would turn a masked inf into NaN).
+__device__ __forceinline__ half4 mask_h4(const floatx4& d, const half4& act) {
+    typedef unsigned int uint2v __attribute__((ext_vector_type(2)));
+    const uint2v a = __builtin_bit_cast(uint2v, act);
+    uint2v b;
+    // (the compiler turns the C form of this into per-element compare + select; keep the two packed instructions)
+    asm("v_pk_min_u16 %0, %2, %4\n\tv_pk_mul_lo_u16 %0, %0, %5\n\tv_pk_min_u16 %1, %3, %4\n\tv_pk_mul_lo_u16 %1, %1, %5"
+        : "=&v"(b.x), "=&v"(b.y) : "v"(a.x), "v"(a.y), "s"(0x00010001u), "s"(0x7C007C00u));
+    const half4 B = __builtin_bit_cast(half4, b);
+    return __builtin_elementwise_max(__builtin_elementwise_min(to_h4(d), B), -B);
 }
 
 // SH coefficients 4g..4g+3 of the encoded direction (x,y,z) = (d/|d| + 1)/2, spherical_harmonics.py:27-42
@@ -283,28 +284,30 @@ __global__ void __launch_bounds__(256) mlp_fwd_kernel(const float* __restrict__ 
 }
 
 // ---- backward kernel ------------------------------------------------------------------------------------------
-constexpr int T_STRIDE = 20;              // uint32 per transposed row: 16 sample pairs + 4 pad (80 B rows: conflict-free b128 reads)
-constexpr int T_ROWS = 128;               // dZ rows [0,64) + X rows [64,128)
+// Weight gradients contract over SAMPLES, while the data path keeps one sample per lane: the operands have to be transposed
+// through LDS.  Every wave stores its activations / pre-activation gradients UNtransposed, [sample row][feature column], with
+// 8- and 16-byte stores straight from the MFMA register layout, and the dW waves read them back with gfx950's transposing LDS
+// read (ds_read_b64_tr_b16): within a 16-lane group, lane i supplies the address of 4 contiguous halfs (sample row i/4,
+// features 4(i%4)..) and lane c receives feature c of the group's 4 sample rows -- the A/B fragment of a K = samples MFMA.
+// (Measured on the previous scheme, which transposed on the write side with 120 ds_write_b16 per lane and round: those
+// stores were 31 % of the kernel, profiles/microbench/r01_mlp_bwd_breakdown.txt.)
+constexpr int IMG_P = 144;                // halfs per sample row: 64 dZ + 64 X columns + 16 pad = 288 B (72 dwords = 8 mod 32:
+                                          // the 64-lane b64 stores spread evenly over the banks; tr reads of 4 rows hit 4 x 8 banks)
+constexpr int IMG_X = 64;                 // first X column
+constexpr int IMG_HALFS = 32 * IMG_P;     // one 32-sample group
 constexpr int N_W = 2048 + 1024 + 2048 + 4096 + 192;    // 9408 weights
 constexpr int OFF_W1 = 0, OFF_W2 = 2048, OFF_W3 = 3072, OFF_W4 = 5120, OFF_W5 = 9216;
 
-__device__ __forceinline__ uint32_t pack2(half_t a, half_t b) {
-    return (uint32_t)__builtin_bit_cast(unsigned short, a) | ((uint32_t)__builtin_bit_cast(unsigned short, b) << 16);
-}
-
-// write a D-layout quantity (feature 16mt+4g+r, r=0..3) of both tiles into transposed rows [row0 + feature]
-__device__ __forceinline__ void t_store_d(uint32_t* T, int row0, int mt, int g, int n, const half4& v0, const half4& v1) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) T[(row0 + 16 * mt + 4 * g + r) * T_STRIDE + n] = pack2(v0[r], v1[r]);
-}
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ half8 t_load(const uint32_t* T, int row, int g) {
-    const u32x4 v = *reinterpret_cast<const u32x4*>(T + row * T_STRIDE + 4 * g);   // samples 8g..8g+7 of `row`
-    return __builtin_bit_cast(half8, v);
-}
-__device__ __forceinline__ void wave_lds_fence() {      // same-wave LDS ops retire in order; this only pins the compiler
-    __builtin_amdgcn_wave_barrier();
-    asm volatile("" ::: "memory");
+typedef short short4v __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) short4v* lds_s4_ptr;
+__device__ __forceinline__ void img_store(half_t* row, int col, const half4& v) { *reinterpret_cast<half4*>(row + col) = v; }
+// fragment of the 16-feature tile at column cb over the group's 32 samples: k-slot (q, j) = sample row 4q + j (j < 4) or
+// 16 + 4q + (j - 4); both operands of an MFMA use the same mapping, which is all a contraction needs
+__device__ __forceinline__ half8 img_load_tr(const half_t* img, int cb, int q, int i) {
+    const half_t* p = img + (4 * q + (i >> 2)) * IMG_P + cb + 4 * (i & 3);
+    const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)p);
+    const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(p + 16 * IMG_P));
+    return cat_h4(__builtin_bit_cast(half4, lo), __builtin_bit_cast(half4, hi));
 }
 
 // Block = 12 waves (3 per SIMD, <= 168 registers each).  Every wave runs the data path (forward recompute + dX chain)
@@ -316,7 +319,6 @@ __device__ __forceinline__ void wave_lds_fence() {      // same-wave LDS ops ret
 // reduced across waves at the end.
 constexpr int BW = 12;                     // waves per block
 constexpr int BG = BW / 2;                 // 32-sample groups per round
-constexpr int T_STRIDE_H = 2 * T_STRIDE;   // the same 80-byte rows, addressed in halfs
 
 struct BwdIn {                             // prefetched per-round inputs of one lane
     float4 e0, e1;                         // enc features 8g..8g+7
@@ -376,27 +378,21 @@ __device__ __forceinline__ void tile_forward_regs(const half8* __restrict__ wl, 
     }
 }
 
-// transposed stores, one half per (feature row, sample): T16[row][2n + parity]
-__device__ __forceinline__ void th_store_d(half_t* T16, int row0, int mt, int g, int col, const half4& v) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) T16[(row0 + 16 * mt + 4 * g + r) * T_STRIDE_H + col] = v[r];
-}
-
 __global__ void __launch_bounds__(768) mlp_bwd_kernel(const float* __restrict__ enc, const float* __restrict__ dirs,
                                                        const half_t* __restrict__ wpack, const float* __restrict__ dsigmas,
                                                        const half_t* __restrict__ drgbs, int S,
                                                        const int32_t* __restrict__ n_dev, int pairs, float* __restrict__ d_enc,
                                                        float* __restrict__ dW /*[N_W], pre-zeroed or accumulating*/,
                                                        int32_t* __restrict__ found_inf) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[N_ALL_FRAGS * 64 * 16 + BG * T_ROWS * T_STRIDE * 4];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[N_ALL_FRAGS * 64 * 16 + BG * IMG_HALFS * 2];
     const size_t plane = (size_t)S;
     if (n_dev) S = min(S, *n_dev);
     half8* wl = reinterpret_cast<half8*>(smem);
     load_wpack(wpack, wl, N_ALL_FRAGS);
     const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
     const int grp = wv >> 1, par = wv & 1;
-    uint32_t* Tall = reinterpret_cast<uint32_t*>(smem + N_ALL_FRAGS * 64 * 16);
-    half_t* T16 = reinterpret_cast<half_t*>(Tall + grp * (T_ROWS * T_STRIDE));     // this wave pair's transposed tile
+    half_t* Iall = reinterpret_cast<half_t*>(smem + N_ALL_FRAGS * 64 * 16);
+    half_t* irow = Iall + grp * IMG_HALFS + (16 * par + n) * IMG_P;                // this lane's sample row in its group image
     const int col = 2 * n + par;
     const int n_iter = (S + 31) >> 5;
     const int n_round = (n_iter + BG - 1) / BG;
@@ -465,80 +461,74 @@ __global__ void __launch_bounds__(768) mlp_bwd_kernel(const float* __restrict__ 
             }
         }
 
-        // ---- weight gradients, one layer at a time: every wave publishes its dZ / X columns, then accumulates ITS dW
-        //      tiles over the tiles of all BG groups ----
+        // ---- weight gradients, one layer at a time: every wave publishes its dZ / X rows, then accumulates ITS dW
+        //      tiles over the images of all BG groups ----
         // layer 5: dZ5 [16] x a4 [64]      (owners: waves 8..11)
+        img_store(irow, 4 * g, dz5);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) T16[(4 * g + r) * T_STRIDE_H + col] = dz5[r];
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) th_store_d(T16, 64, mt, g, col, t.a4[mt]);
+        for (int mt = 0; mt < 4; ++mt) img_store(irow, IMG_X + 16 * mt + 4 * g, t.a4[mt]);
         __syncthreads();
         if (!lo8) {
 #pragma unroll 2
             for (int k = 0; k < BG; ++k) {
-                const uint32_t* Tk = Tall + k * (T_ROWS * T_STRIDE);
-                accC = NGP_MFMA(t_load(Tk, n, g), t_load(Tk, 64 + 16 * v4 + n, g), accC);
+                const half_t* Ik = Iall + k * IMG_HALFS;
+                accC = NGP_MFMA(img_load_tr(Ik, 0, g, n), img_load_tr(Ik, IMG_X + 16 * v4, g, n), accC);
             }
         }
         __syncthreads();
         // layer 4: dZ4 [64] x a3 [64]      (owners: waves 0..7, two tiles each)
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) { th_store_d(T16, 0, mt, g, col, dz4[mt]); th_store_d(T16, 64, mt, g, col, t.a3[mt]); }
+        for (int mt = 0; mt < 4; ++mt) { img_store(irow, 16 * mt + 4 * g, dz4[mt]); img_store(irow, IMG_X + 16 * mt + 4 * g, t.a3[mt]); }
         __syncthreads();
         if (lo8) {
 #pragma unroll 2
             for (int k = 0; k < BG; ++k) {
-                const uint32_t* Tk = Tall + k * (T_ROWS * T_STRIDE);
-                const half8 a = t_load(Tk, 16 * mtA + n, g);
-                accA0 = NGP_MFMA(a, t_load(Tk, 64 + 16 * ntA + n, g), accA0);
-                accA1 = NGP_MFMA(a, t_load(Tk, 64 + 16 * (ntA + 1) + n, g), accA1);
+                const half_t* Ik = Iall + k * IMG_HALFS;
+                const half8 a = img_load_tr(Ik, 16 * mtA, g, n);
+                accA0 = NGP_MFMA(a, img_load_tr(Ik, IMG_X + 16 * ntA, g, n), accA0);
+                accA1 = NGP_MFMA(a, img_load_tr(Ik, IMG_X + 16 * (ntA + 1), g, n), accA1);
             }
         }
         __syncthreads();
-        // layer 3: dZ3 [64] x in3 [32]     (owners: waves 0..7)
+        // layer 3: dZ3 [64] x in3 [32]     (owners: waves 0..7); in3 = [SH 0..15 | h 0..15], this lane holds 4g..4g+3 of each
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) th_store_d(T16, 0, mt, g, col, dz3[mt]);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int row = (j < 4) ? (4 * g + j) : (16 + 4 * g + (j - 4));
-            T16[(64 + row) * T_STRIDE_H + col] = t.b_in3[j];
-        }
+        for (int mt = 0; mt < 4; ++mt) img_store(irow, 16 * mt + 4 * g, dz3[mt]);
+        img_store(irow, IMG_X + 4 * g, __builtin_shufflevector(t.b_in3, t.b_in3, 0, 1, 2, 3));
+        img_store(irow, IMG_X + 16 + 4 * g, __builtin_shufflevector(t.b_in3, t.b_in3, 4, 5, 6, 7));
         __syncthreads();
         if (lo8) {
 #pragma unroll 2
             for (int k = 0; k < BG; ++k) {
-                const uint32_t* Tk = Tall + k * (T_ROWS * T_STRIDE);
-                accB = NGP_MFMA(t_load(Tk, 16 * (wv >> 1) + n, g), t_load(Tk, 64 + 16 * (wv & 1) + n, g), accB);
+                const half_t* Ik = Iall + k * IMG_HALFS;
+                accB = NGP_MFMA(img_load_tr(Ik, 16 * (wv >> 1), g, n), img_load_tr(Ik, IMG_X + 16 * (wv & 1), g, n), accB);
             }
         }
         __syncthreads();
         // layer 2: dZ2 [16] x a1 [64]      (owners: waves 8..11)
+        img_store(irow, 4 * g, dz2);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) T16[(4 * g + r) * T_STRIDE_H + col] = dz2[r];
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) th_store_d(T16, 64, mt, g, col, t.a1[mt]);
+        for (int mt = 0; mt < 4; ++mt) img_store(irow, IMG_X + 16 * mt + 4 * g, t.a1[mt]);
         __syncthreads();
         if (!lo8) {
 #pragma unroll 2
             for (int k = 0; k < BG; ++k) {
-                const uint32_t* Tk = Tall + k * (T_ROWS * T_STRIDE);
-                accB = NGP_MFMA(t_load(Tk, n, g), t_load(Tk, 64 + 16 * v4 + n, g), accB);
+                const half_t* Ik = Iall + k * IMG_HALFS;
+                accB = NGP_MFMA(img_load_tr(Ik, 0, g, n), img_load_tr(Ik, IMG_X + 16 * v4, g, n), accB);
             }
         }
         __syncthreads();
-        // layer 1: dZ1 [64] x enc [32]     (owners: waves 8..11, two tiles each)
+        // layer 1: dZ1 [64] x enc [32]     (owners: waves 8..11, two tiles each); X column c = k-slot (g' = c>>3, j' = c&7)
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) th_store_d(T16, 0, mt, g, col, dz1[mt]);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) T16[(64 + 8 * g + j) * T_STRIDE_H + col] = t.b_enc[j];
+        for (int mt = 0; mt < 4; ++mt) img_store(irow, 16 * mt + 4 * g, dz1[mt]);
+        *reinterpret_cast<half8*>(irow + IMG_X + 8 * g) = t.b_enc;
         __syncthreads();
         if (!lo8) {
 #pragma unroll 2
             for (int k = 0; k < BG; ++k) {
-                const uint32_t* Tk = Tall + k * (T_ROWS * T_STRIDE);
-                const half8 a = t_load(Tk, 16 * mtA + n, g);
-                accA0 = NGP_MFMA(a, t_load(Tk, 64 + n, g), accA0);
-                accA1 = NGP_MFMA(a, t_load(Tk, 64 + 16 + n, g), accA1);
+                const half_t* Ik = Iall + k * IMG_HALFS;
+                const half8 a = img_load_tr(Ik, 16 * mtA, g, n);
+                accA0 = NGP_MFMA(a, img_load_tr(Ik, IMG_X, g, n), accA0);
+                accA1 = NGP_MFMA(a, img_load_tr(Ik, IMG_X + 16, g, n), accA1);
             }
         }
         __syncthreads();
