@@ -147,19 +147,29 @@ __device__ __forceinline__ half4 relu_h4(const floatx4& d) {             // relu
 __device__ __forceinline__ half8 cat_h4(const half4& a, const half4& b) {
     return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
 }
-// dz = (act > 0) ? f16(d) : 0   (threshold_backward).  act >= +0, so its bit pattern is non-zero exactly when act > 0:
-// B = min(bits, 1) * 0x7C00 is +inf where the unit was active and +0 where it was not, and clamp(x, -B, +B) passes or
-// zeroes x -- including x = +-inf (stays non-finite for the GradScaler check; x * mask would turn a masked inf into NaN).
+// dz = (act > 0) ? f16(d) : 0   (threshold_backward).  act >= +0, so (0 - bits(act)) as int16 is negative exactly when
+// act > 0: an arithmetic shift by 15 turns that into the 0xFFFF / 0 select mask, and one AND applies it -- an active unit keeps
+// every bit of f16(d) (inf / NaN included, for the GradScaler check), a masked one gives +0.
 __device__ __forceinline__ half4 mask_h4(const floatx4& d, const half4& act) {
     typedef unsigned int uint2v __attribute__((ext_vector_type(2)));
-    const uint2v a = __builtin_bit_cast(uint2v, act);
-    uint2v b;
-    // (the compiler turns the C form of this into per-element compare + select; keep the two packed instructions)
-    asm("v_pk_min_u16 %0, %2, %4\n\tv_pk_mul_lo_u16 %0, %0, %5\n\tv_pk_min_u16 %1, %3, %4\n\tv_pk_mul_lo_u16 %1, %1, %5"
-        : "=&v"(b.x), "=&v"(b.y) : "v"(a.x), "v"(a.y), "s"(0x00010001u), "s"(0x7C007C00u));
-    const half4 B = __builtin_bit_cast(half4, b);
-    return __builtin_elementwise_max(__builtin_elementwise_min(to_h4(d), B), -B);
+    const uint2v a = __builtin_bit_cast(uint2v, act), h = __builtin_bit_cast(uint2v, to_h4(d));
+    uint2v r;
+    // written out: the C form becomes per-element compare + select
+    asm("v_pk_sub_i16 %0, 0, %2\n\t"
+        "v_pk_sub_i16 %1, 0, %3\n\t"
+        "v_pk_ashrrev_i16 %0, 15, %0 op_sel_hi:[0,1]\n\t"
+        "v_pk_ashrrev_i16 %1, 15, %1 op_sel_hi:[0,1]\n\t"
+        "v_and_b32 %0, %0, %4\n\t"
+        "v_and_b32 %1, %1, %5"
+        : "=&v"(r.x), "=&v"(r.y) : "v"(a.x), "v"(a.y), "v"(h.x), "v"(h.y));
+    return __builtin_bit_cast(half4, r);
 }
+
+// 1-ulp hardware approximations (v_exp_f32 / v_rcp_f32 / v_rsq_f32) where the result is rounded to fp16 anyway: the
+// IEEE-exact expf / division / sqrt sequences were ~100 of the ~550 VALU instructions of a backward round
+__device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
 
 // SH coefficients 4g..4g+3 of the encoded direction (x,y,z) = (d/|d| + 1)/2, spherical_harmonics.py:27-42
 __device__ __forceinline__ half4 sh_quad(int g, float x, float y, float z) {
@@ -222,7 +232,7 @@ __device__ __forceinline__ void tile_forward(const half8* __restrict__ wl, int l
     t.h = to_h4(d2);
     t.sigma = expf((float)t.h[0]);                                         // TruncExp forward, fp32
     if (COLOR) {
-        const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);       // d / ||d||, networks.py:162
+        const float inv = fast_rsq(dx * dx + dy * dy + dz * dz);           // d / ||d||, networks.py:162
         const float x = (dx * inv + 1.0f) / 2.0f, y = (dy * inv + 1.0f) / 2.0f, z = (dz * inv + 1.0f) / 2.0f;   // :163
         t.b_in3 = cat_h4(sh_quad(g, x, y, z), t.h);
 #pragma unroll
@@ -239,7 +249,7 @@ __device__ __forceinline__ void tile_forward(const half8* __restrict__ wl, int l
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float c = (float)(half_t)d5[r];                          // Linear output is fp16
-            t.rgb[r] = (half_t)(1.0f / (1.0f + expf(-c)));                 // nn.Sigmoid on an fp16 tensor
+            t.rgb[r] = (half_t)fast_rcp(1.0f + fast_exp(-c));              // nn.Sigmoid on an fp16 tensor
         }
     }
 }
@@ -291,32 +301,46 @@ __global__ void __launch_bounds__(256) mlp_fwd_kernel(const float* __restrict__ 
 // features 4(i%4)..) and lane c receives feature c of the group's 4 sample rows -- the A/B fragment of a K = samples MFMA.
 // (Measured on the previous scheme, which transposed on the write side with 120 ds_write_b16 per lane and round: those
 // stores were 31 % of the kernel, profiles/microbench/r01_mlp_bwd_breakdown.txt.)
-constexpr int IMG_P = 144;                // halfs per sample row: 64 dZ + 64 X columns + 16 pad = 288 B (72 dwords = 8 mod 32:
-                                          // the 64-lane b64 stores spread evenly over the banks; tr reads of 4 rows hit 4 x 8 banks)
-constexpr int IMG_X = 64;                 // first X column
-constexpr int IMG_HALFS = 32 * IMG_P;     // one 32-sample group
+// Image of one 32-sample group: [feature tile T][row block rb = sample row / 4][4 rows][16 features] halfs, i.e. every
+// [4 samples][16 features] block a 16-lane tr-read group consumes is 128 contiguous bytes and the two blocks of a 32-lane LDS
+// service group are adjacent (256 B = all 64 banks once): the layout ds_read_b64_tr_b16 reads without bank conflicts
+// (row-strided images cost ~5 extra LDS cycles per read, SQ_LDS_BANK_CONFLICT; padding and XOR swizzles do not help there).
+// Stores: a 16-lane ds_write_b64 group holds 16 sample rows of ONE granule (4 halfs) column, which would land 4-way on the
+// same banks; granule gi of a block is therefore kept at slot gi ^ (rb & 3) -- the group then covers all 32 banks once.
+constexpr int IMG_TILE = 8 * 64;          // halfs per feature tile (8 row blocks x 128 B)
+constexpr int IMG_TILES = 13;             // up to 208 feature columns are live at a time
+constexpr int IMG_HALFS = IMG_TILES * IMG_TILE;     // 13 KB per group
+// tile map of the three dW phases
+constexpr int A_DZ5 = 0, A_DZ4 = 1, A_A4 = 5, A_A3 = 9;            // phase A: layers 5 and 4
+constexpr int B_DZ3 = 0, B_DZ2 = 4, B_IN3 = 5, B_A1 = 7;           // phase B: layers 3 and 2
+constexpr int C_DZ1 = 0, C_ENC = 4;                                // phase C: layer 1
 constexpr int N_W = 2048 + 1024 + 2048 + 4096 + 192;    // 9408 weights
 constexpr int OFF_W1 = 0, OFF_W2 = 2048, OFF_W3 = 3072, OFF_W4 = 5120, OFF_W5 = 9216;
 
 typedef short short4v __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) short4v* lds_s4_ptr;
-__device__ __forceinline__ void img_store(half_t* row, int col, const half4& v) { *reinterpret_cast<half4*>(row + col) = v; }
-// fragment of the 16-feature tile at column cb over the group's 32 samples: k-slot (q, j) = sample row 4q + j (j < 4) or
-// 16 + 4q + (j - 4); both operands of an MFMA use the same mapping, which is all a contraction needs
-__device__ __forceinline__ half8 img_load_tr(const half_t* img, int cb, int q, int i) {
-    const half_t* p = img + (4 * q + (i >> 2)) * IMG_P + cb + 4 * (i & 3);
+// lofs = this lane's (row block, row, swizzled granule) offset inside a tile
+__device__ __forceinline__ void img_store(half_t* img, int tile, int lofs, const half4& v) {
+    *reinterpret_cast<half4*>(img + tile * IMG_TILE + lofs) = v;
+}
+// fragment of feature tile `tile` over the group's 32 samples: k-slot (q, j) = sample row 4q + j (j < 4) or 16 + 4q + (j - 4)
+// (row blocks q and q + 4, same swizzle key); both operands of an MFMA use the same mapping, which is all a contraction needs
+__device__ __forceinline__ half8 img_load_tr(const half_t* img, int tile, int q, int i) {
+    const half_t* p = img + tile * IMG_TILE + q * 64 + (i >> 2) * 16 + 4 * ((i & 3) ^ q);
     const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)p);
-    const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(p + 16 * IMG_P));
+    const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(p + 4 * 64));
     return cat_h4(__builtin_bit_cast(half4, lo), __builtin_bit_cast(half4, hi));
 }
 
-// Block = 12 waves (3 per SIMD, <= 168 registers each).  Every wave runs the data path (forward recompute + dX chain)
-// of ONE 16-sample tile; waves 2k and 2k+1 interleave their samples into one 32-sample group k (sample = 32 it + 2n +
-// (wave & 1)) so that a group's transposed tile has K = 32.  The 40 dW output tiles (16x16 each) are DISTRIBUTED over
-// the 12 waves (3-4 tiles = 12-16 accumulator registers per wave instead of 160 in a wave-private scheme), and each wave
-// accumulates its tiles over the transposed dZ / X tiles of all 6 groups (K = 192 samples per round).  One layer at a
-// time: 6 x 10 KB of LDS tiles, two block barriers per layer.  A block's waves own disjoint dW tiles, so nothing is
-// reduced across waves at the end.
+// Block = 12 waves (3 per SIMD).  Every wave runs the data path (forward recompute + dX chain) of ONE 16-sample tile; waves
+// 2k and 2k+1 form the 32-sample group k (image rows 16 * (wave & 1) + n).  The 40 dW output tiles (16x16 each) are
+// DISTRIBUTED over the 12 waves (4 accumulators per wave instead of 160 in a wave-private scheme); each wave accumulates its
+// tiles over the images of all 6 groups (K = 192 samples per round).  Three store -> barrier -> accumulate -> barrier phases
+// per round, two layers at a time so that both wave classes have work in a phase:
+//     phase A: layer 4 (waves 0..7, two tiles each)  + layer 5 (waves 8..11)
+//     phase B: layer 3 (waves 0..7)                  + layer 2 (waves 8..11)
+//     phase C: layer 1 (waves 0..7)
+// A block's waves own disjoint dW tiles, so nothing is reduced across waves at the end.
 constexpr int BW = 12;                     // waves per block
 constexpr int BG = BW / 2;                 // 32-sample groups per round
 
@@ -357,7 +381,7 @@ __device__ __forceinline__ void tile_forward_regs(const half8* __restrict__ wl, 
     d2 = NGP_MFMA(wfrag(wl, F_W2 + 1, lane), cat_h4(t.a1[2], t.a1[3]), d2);
     t.h = to_h4(d2);
     t.sigma = expf((float)t.h[0]);
-    const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+    const float inv = fast_rsq(dx * dx + dy * dy + dz * dz);
     const float x = (dx * inv + 1.0f) / 2.0f, y = (dy * inv + 1.0f) / 2.0f, z = (dz * inv + 1.0f) / 2.0f;
     t.b_in3 = cat_h4(sh_quad(g, x, y, z), t.h);
 #pragma unroll
@@ -374,7 +398,7 @@ __device__ __forceinline__ void tile_forward_regs(const half8* __restrict__ wl, 
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const float c = (float)(half_t)d5[r];
-        t.rgb[r] = (half_t)(1.0f / (1.0f + expf(-c)));
+        t.rgb[r] = (half_t)fast_rcp(1.0f + fast_exp(-c));
     }
 }
 
@@ -392,21 +416,24 @@ __global__ void __launch_bounds__(768) mlp_bwd_kernel(const float* __restrict__ 
     const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
     const int grp = wv >> 1, par = wv & 1;
     half_t* Iall = reinterpret_cast<half_t*>(smem + N_ALL_FRAGS * 64 * 16);
-    half_t* irow = Iall + grp * IMG_HALFS + (16 * par + n) * IMG_P;                // this lane's sample row in its group image
-    const int col = 2 * n + par;
+    half_t* img = Iall + grp * IMG_HALFS;                                           // this wave pair's group image
+    const int col = 16 * par + n;                                                   // sample slot inside the 32-sample group
     const int n_iter = (S + 31) >> 5;
     const int n_round = (n_iter + BG - 1) / BG;
     const floatx4 zero = {0.f, 0.f, 0.f, 0.f};
     const half4 hzero = {(half_t)0, (half_t)0, (half_t)0, (half_t)0};
 
     // dW tile ownership (40 tiles of 16x16 over 12 waves):
-    //   waves 0..7  (w)    : L4 tiles (mt = w>>1, nt = 2(w&1), 2(w&1)+1) -> accA0/accA1 ;  L3 tile (mt = w>>1, nt = w&1) -> accB
-    //   waves 8..11 (v=w-8): L1 tiles (mt = v, nt = 0, 1)                -> accA0/accA1 ;  L2 tile (nt = v) -> accB ;
-    //                        L5 tile (nt = v) -> accC
+    //   waves 0..7  (w)    : L4 tiles (mt = w>>1, nt = 2(w&1), 2(w&1)+1) -> accA0/accA1 ;  L3 tile (mt = w>>1, nt = w&1) -> accB ;
+    //                        L1 tile (mt = w>>1, nt = w&1) -> accC
+    //   waves 8..11 (v=w-8): L2 tile (nt = v) -> accB ;  L5 tile (nt = v) -> accC
     floatx4 accA0 = zero, accA1 = zero, accB = zero, accC = zero;
     const bool lo8 = wv < 8;
     const int v4 = wv - 8;
-    const int mtA = lo8 ? (wv >> 1) : v4, ntA = lo8 ? 2 * (wv & 1) : 0;
+    const int mtL = wv >> 1, ntL = wv & 1;         // lo8: tile row / column of the L3 and L1 tiles, tile row of the L4 pair
+    // image row 16 par + n -> row block 4 par + (n >> 2), row n & 3, swizzle key n >> 2; this lane's D-layout granule is g
+    const int lrow = (4 * par + (n >> 2)) * 64 + (n & 3) * 16;
+    const int lofs = lrow + 4 * (g ^ (n >> 2));
 
     for (int round = blockIdx.x; round < n_round; round += gridDim.x) {
         const int smp = (round * BG + grp) * 32 + col;
@@ -440,7 +467,7 @@ __global__ void __launch_bounds__(768) mlp_bwd_kernel(const float* __restrict__ 
             dz2 = to_h4(dh);
             if (g == 0) {                                                     // TruncExp backward, networks.py:28-30
                 const float h0 = (float)t.h[0];
-                const half_t gs = (half_t)(in.dsig * expf(fminf(fmaxf(h0, -15.0f), 15.0f)));
+                const half_t gs = (half_t)(in.dsig * fast_exp(fminf(fmaxf(h0, -15.0f), 15.0f)));
                 dz2[0] = (half_t)((float)dz2[0] + (float)gs);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -461,74 +488,71 @@ __global__ void __launch_bounds__(768) mlp_bwd_kernel(const float* __restrict__ 
             }
         }
 
-        // ---- weight gradients, one layer at a time: every wave publishes its dZ / X rows, then accumulates ITS dW
-        //      tiles over the images of all BG groups ----
-        // layer 5: dZ5 [16] x a4 [64]      (owners: waves 8..11)
-        img_store(irow, 4 * g, dz5);
+        // ---- weight gradients: every wave publishes its dZ / X rows, then accumulates ITS dW tiles over all BG group images ----
+        // phase A: layer 5 (dZ5 [16] x a4 [64]) and layer 4 (dZ4 [64] x a3 [64])
+        img_store(img, A_DZ5, lofs, dz5);
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) img_store(irow, IMG_X + 16 * mt + 4 * g, t.a4[mt]);
-        __syncthreads();
-        if (!lo8) {
-#pragma unroll 2
-            for (int k = 0; k < BG; ++k) {
-                const half_t* Ik = Iall + k * IMG_HALFS;
-                accC = NGP_MFMA(img_load_tr(Ik, 0, g, n), img_load_tr(Ik, IMG_X + 16 * v4, g, n), accC);
-            }
+        for (int mt = 0; mt < 4; ++mt) {
+            img_store(img, A_DZ4 + mt, lofs, dz4[mt]);
+            img_store(img, A_A4 + mt, lofs, t.a4[mt]);
+            img_store(img, A_A3 + mt, lofs, t.a3[mt]);
         }
-        __syncthreads();
-        // layer 4: dZ4 [64] x a3 [64]      (owners: waves 0..7, two tiles each)
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) { img_store(irow, 16 * mt + 4 * g, dz4[mt]); img_store(irow, IMG_X + 16 * mt + 4 * g, t.a3[mt]); }
         __syncthreads();
         if (lo8) {
 #pragma unroll 2
             for (int k = 0; k < BG; ++k) {
                 const half_t* Ik = Iall + k * IMG_HALFS;
-                const half8 a = img_load_tr(Ik, 16 * mtA, g, n);
-                accA0 = NGP_MFMA(a, img_load_tr(Ik, IMG_X + 16 * ntA, g, n), accA0);
-                accA1 = NGP_MFMA(a, img_load_tr(Ik, IMG_X + 16 * (ntA + 1), g, n), accA1);
+                const half8 a = img_load_tr(Ik, A_DZ4 + mtL, g, n);
+                accA0 = NGP_MFMA(a, img_load_tr(Ik, A_A3 + 2 * ntL, g, n), accA0);
+                accA1 = NGP_MFMA(a, img_load_tr(Ik, A_A3 + 2 * ntL + 1, g, n), accA1);
+            }
+        } else {
+#pragma unroll 2
+            for (int k = 0; k < BG; ++k) {
+                const half_t* Ik = Iall + k * IMG_HALFS;
+                accC = NGP_MFMA(img_load_tr(Ik, A_DZ5, g, n), img_load_tr(Ik, A_A4 + v4, g, n), accC);
             }
         }
         __syncthreads();
-        // layer 3: dZ3 [64] x in3 [32]     (owners: waves 0..7); in3 = [SH 0..15 | h 0..15], this lane holds 4g..4g+3 of each
+        // phase B: layer 3 (dZ3 [64] x in3 [32], in3 = [SH 0..15 | h 0..15]) and layer 2 (dZ2 [16] x a1 [64])
+        img_store(img, B_DZ2, lofs, dz2);
+        img_store(img, B_IN3, lofs, __builtin_shufflevector(t.b_in3, t.b_in3, 0, 1, 2, 3));
+        img_store(img, B_IN3 + 1, lofs, __builtin_shufflevector(t.b_in3, t.b_in3, 4, 5, 6, 7));
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) img_store(irow, 16 * mt + 4 * g, dz3[mt]);
-        img_store(irow, IMG_X + 4 * g, __builtin_shufflevector(t.b_in3, t.b_in3, 0, 1, 2, 3));
-        img_store(irow, IMG_X + 16 + 4 * g, __builtin_shufflevector(t.b_in3, t.b_in3, 4, 5, 6, 7));
+        for (int mt = 0; mt < 4; ++mt) {
+            img_store(img, B_DZ3 + mt, lofs, dz3[mt]);
+            img_store(img, B_A1 + mt, lofs, t.a1[mt]);
+        }
         __syncthreads();
         if (lo8) {
 #pragma unroll 2
             for (int k = 0; k < BG; ++k) {
                 const half_t* Ik = Iall + k * IMG_HALFS;
-                accB = NGP_MFMA(img_load_tr(Ik, 16 * (wv >> 1), g, n), img_load_tr(Ik, IMG_X + 16 * (wv & 1), g, n), accB);
+                accB = NGP_MFMA(img_load_tr(Ik, B_DZ3 + mtL, g, n), img_load_tr(Ik, B_IN3 + ntL, g, n), accB);
             }
-        }
-        __syncthreads();
-        // layer 2: dZ2 [16] x a1 [64]      (owners: waves 8..11)
-        img_store(irow, 4 * g, dz2);
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) img_store(irow, IMG_X + 16 * mt + 4 * g, t.a1[mt]);
-        __syncthreads();
-        if (!lo8) {
+        } else {
 #pragma unroll 2
             for (int k = 0; k < BG; ++k) {
                 const half_t* Ik = Iall + k * IMG_HALFS;
-                accB = NGP_MFMA(img_load_tr(Ik, 0, g, n), img_load_tr(Ik, IMG_X + 16 * v4, g, n), accB);
+                accB = NGP_MFMA(img_load_tr(Ik, B_DZ2, g, n), img_load_tr(Ik, B_A1 + v4, g, n), accB);
             }
         }
         __syncthreads();
-        // layer 1: dZ1 [64] x enc [32]     (owners: waves 8..11, two tiles each); X column c = k-slot (g' = c>>3, j' = c&7)
+        // phase C: layer 1 (dZ1 [64] x enc [32]); X column c = k-slot (g' = c>>3, j' = c&7) of layer 1: this lane's 8g..8g+7
+        // are granules 2(g&1), 2(g&1)+1 of tile g>>1
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) img_store(irow, 16 * mt + 4 * g, dz1[mt]);
-        *reinterpret_cast<half8*>(irow + IMG_X + 8 * g) = t.b_enc;
+        for (int mt = 0; mt < 4; ++mt) img_store(img, C_DZ1 + mt, lofs, dz1[mt]);
+        {
+            const int te = C_ENC + (g >> 1), sw = n >> 2, gi = 2 * (g & 1);
+            img_store(img, te, lrow + 4 * (gi ^ sw), __builtin_shufflevector(t.b_enc, t.b_enc, 0, 1, 2, 3));
+            img_store(img, te, lrow + 4 * ((gi + 1) ^ sw), __builtin_shufflevector(t.b_enc, t.b_enc, 4, 5, 6, 7));
+        }
         __syncthreads();
-        if (!lo8) {
+        if (lo8) {
 #pragma unroll 2
             for (int k = 0; k < BG; ++k) {
                 const half_t* Ik = Iall + k * IMG_HALFS;
-                const half8 a = img_load_tr(Ik, 16 * mtA, g, n);
-                accA0 = NGP_MFMA(a, img_load_tr(Ik, IMG_X, g, n), accA0);
-                accA1 = NGP_MFMA(a, img_load_tr(Ik, IMG_X + 16, g, n), accA1);
+                accC = NGP_MFMA(img_load_tr(Ik, C_DZ1 + mtL, g, n), img_load_tr(Ik, C_ENC + ntL, g, n), accC);
             }
         }
         __syncthreads();
@@ -539,16 +563,15 @@ __global__ void __launch_bounds__(768) mlp_bwd_kernel(const float* __restrict__ 
     bool bad = false;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int o = 16 * mtA + 4 * g + r, o2 = 4 * g + r;
+        const int o = 16 * mtL + 4 * g + r, o2 = 4 * g + r;
         const float a0 = accA0[r], a1 = accA1[r], b = accB[r], c = accC[r];
         if (lo8) {
-            if (a0 != 0.0f) unsafeAtomicAdd(dW + OFF_W4 + o * 64 + 16 * ntA + n, a0);
-            if (a1 != 0.0f) unsafeAtomicAdd(dW + OFF_W4 + o * 64 + 16 * (ntA + 1) + n, a1);
-            if (b != 0.0f) unsafeAtomicAdd(dW + OFF_W3 + o * 32 + 16 * (wv & 1) + n, b);
+            if (a0 != 0.0f) unsafeAtomicAdd(dW + OFF_W4 + o * 64 + 32 * ntL + n, a0);
+            if (a1 != 0.0f) unsafeAtomicAdd(dW + OFF_W4 + o * 64 + 32 * ntL + 16 + n, a1);
+            if (b != 0.0f) unsafeAtomicAdd(dW + OFF_W3 + o * 32 + 16 * ntL + n, b);
+            // column c of a dW1 tile is the c-th enc column = k-slot (g' = c>>3, j' = c&7) of layer 1
+            if (c != 0.0f) unsafeAtomicAdd(dW + OFF_W1 + o * 32 + enc_feat(pairs, (16 * ntL + n) >> 3, n & 7), c);
         } else {
-            // column c of a dW1 tile is the c-th row of the transposed enc tile = k-slot (g' = c>>3, j' = c&7) of layer 1
-            if (a0 != 0.0f) unsafeAtomicAdd(dW + OFF_W1 + o * 32 + enc_feat(pairs, n >> 3, n & 7), a0);
-            if (a1 != 0.0f) unsafeAtomicAdd(dW + OFF_W1 + o * 32 + enc_feat(pairs, (16 + n) >> 3, n & 7), a1);
             if (b != 0.0f) unsafeAtomicAdd(dW + OFF_W2 + o2 * 64 + 16 * v4 + n, b);
             if (o2 < 3 && c != 0.0f) unsafeAtomicAdd(dW + OFF_W5 + o2 * 64 + 16 * v4 + n, c);
         }
