@@ -211,46 +211,38 @@ struct TileFwd {            // everything the backward needs from the recomputed
 
 __device__ __forceinline__ const half8& wfrag(const half8* __restrict__ wl, int id, int lane) { return wl[id * 64 + lane]; }
 
-// forward of one tile; wl = packed weight image in LDS
+// forward of one 16-sample tile from registers; wl = packed weight image in LDS
 template <bool COLOR>
-__device__ __forceinline__ void tile_forward(const half8* __restrict__ wl, int lane, int g, const float* __restrict__ ep0,
-                                             const float* __restrict__ ep1, float dx, float dy, float dz, bool valid, TileFwd& t) {
+__device__ __forceinline__ void tile_forward_regs(const half8* __restrict__ wl, int lane, int g, const float4& e0, const float4& e1,
+                                                  float dx, float dy, float dz, TileFwd& t) {
     const floatx4 zero = {0.f, 0.f, 0.f, 0.f};
-    if (valid) {
-        const float4 e0 = *reinterpret_cast<const float4*>(ep0);
-        const float4 e1 = *reinterpret_cast<const float4*>(ep1);
-        t.b_enc[0] = (half_t)e0.x; t.b_enc[1] = (half_t)e0.y; t.b_enc[2] = (half_t)e0.z; t.b_enc[3] = (half_t)e0.w;
-        t.b_enc[4] = (half_t)e1.x; t.b_enc[5] = (half_t)e1.y; t.b_enc[6] = (half_t)e1.z; t.b_enc[7] = (half_t)e1.w;
-    } else {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) t.b_enc[k] = (half_t)0;
-    }
+    t.b_enc[0] = (half_t)e0.x; t.b_enc[1] = (half_t)e0.y; t.b_enc[2] = (half_t)e0.z; t.b_enc[3] = (half_t)e0.w;
+    t.b_enc[4] = (half_t)e1.x; t.b_enc[5] = (half_t)e1.y; t.b_enc[6] = (half_t)e1.z; t.b_enc[7] = (half_t)e1.w;
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) t.a1[mt] = relu_h4(NGP_MFMA(wfrag(wl, F_W1 + mt, lane), t.b_enc, zero));
     floatx4 d2 = NGP_MFMA(wfrag(wl, F_W2 + 0, lane), cat_h4(t.a1[0], t.a1[1]), zero);
     d2 = NGP_MFMA(wfrag(wl, F_W2 + 1, lane), cat_h4(t.a1[2], t.a1[3]), d2);
     t.h = to_h4(d2);
-    t.sigma = expf((float)t.h[0]);                                         // TruncExp forward, fp32
-    if (COLOR) {
-        const float inv = fast_rsq(dx * dx + dy * dy + dz * dz);           // d / ||d||, networks.py:162
-        const float x = (dx * inv + 1.0f) / 2.0f, y = (dy * inv + 1.0f) / 2.0f, z = (dz * inv + 1.0f) / 2.0f;   // :163
-        t.b_in3 = cat_h4(sh_quad(g, x, y, z), t.h);
+    t.sigma = expf((float)t.h[0]);
+    if (!COLOR) return;
+    const float inv = fast_rsq(dx * dx + dy * dy + dz * dz);
+    const float x = (dx * inv + 1.0f) / 2.0f, y = (dy * inv + 1.0f) / 2.0f, z = (dz * inv + 1.0f) / 2.0f;
+    t.b_in3 = cat_h4(sh_quad(g, x, y, z), t.h);
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) t.a3[mt] = relu_h4(NGP_MFMA(wfrag(wl, F_W3 + mt, lane), t.b_in3, zero));
-        const half8 b30 = cat_h4(t.a3[0], t.a3[1]), b31 = cat_h4(t.a3[2], t.a3[3]);
+    for (int mt = 0; mt < 4; ++mt) t.a3[mt] = relu_h4(NGP_MFMA(wfrag(wl, F_W3 + mt, lane), t.b_in3, zero));
+    const half8 b30 = cat_h4(t.a3[0], t.a3[1]), b31 = cat_h4(t.a3[2], t.a3[3]);
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            floatx4 d4 = NGP_MFMA(wfrag(wl, F_W4 + 2 * mt, lane), b30, zero);
-            d4 = NGP_MFMA(wfrag(wl, F_W4 + 2 * mt + 1, lane), b31, d4);
-            t.a4[mt] = relu_h4(d4);
-        }
-        floatx4 d5 = NGP_MFMA(wfrag(wl, F_W5 + 0, lane), cat_h4(t.a4[0], t.a4[1]), zero);
-        d5 = NGP_MFMA(wfrag(wl, F_W5 + 1, lane), cat_h4(t.a4[2], t.a4[3]), d5);
+    for (int mt = 0; mt < 4; ++mt) {
+        floatx4 d4 = NGP_MFMA(wfrag(wl, F_W4 + 2 * mt, lane), b30, zero);
+        d4 = NGP_MFMA(wfrag(wl, F_W4 + 2 * mt + 1, lane), b31, d4);
+        t.a4[mt] = relu_h4(d4);
+    }
+    floatx4 d5 = NGP_MFMA(wfrag(wl, F_W5 + 0, lane), cat_h4(t.a4[0], t.a4[1]), zero);
+    d5 = NGP_MFMA(wfrag(wl, F_W5 + 1, lane), cat_h4(t.a4[2], t.a4[3]), d5);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float c = (float)(half_t)d5[r];                          // Linear output is fp16
-            t.rgb[r] = (half_t)fast_rcp(1.0f + fast_exp(-c));              // nn.Sigmoid on an fp16 tensor
-        }
+    for (int r = 0; r < 4; ++r) {
+        const float c = (float)(half_t)d5[r];
+        t.rgb[r] = (half_t)fast_rcp(1.0f + fast_exp(-c));
     }
 }
 
@@ -261,7 +253,23 @@ __device__ __forceinline__ void load_wpack(const half_t* __restrict__ wpack, hal
     __syncthreads();
 }
 
-// ---- forward kernel: persistent waves, 32 samples (two interleaved 16-sample tiles) per trip ------------------
+// ---- forward kernel: persistent waves, 32 samples (two 16-sample tiles) per trip; the next trip's inputs are requested
+//      before this trip's math (the loads are the only long-latency operations of a trip) ----------------------------------
+struct FwdIn { float4 e0, e1; float dx, dy, dz; };
+template <bool COLOR>
+__device__ __forceinline__ void fwd_load(FwdIn& in, const float* __restrict__ enc, const float* __restrict__ dirs, int smp, int S,
+                                         int g, int pairs, size_t plane) {
+    in.e0 = in.e1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    in.dx = 0.f; in.dy = 0.f; in.dz = 1.f;
+    if (smp < S) {
+        const float *ep0, *ep1;
+        enc_ptrs(enc, pairs, plane, smp, g, ep0, ep1);
+        in.e0 = *reinterpret_cast<const float4*>(ep0);
+        in.e1 = *reinterpret_cast<const float4*>(ep1);
+        if (COLOR) { in.dx = dirs[3 * (size_t)smp]; in.dy = dirs[3 * (size_t)smp + 1]; in.dz = dirs[3 * (size_t)smp + 2]; }
+    }
+}
+
 template <bool COLOR>
 __global__ void __launch_bounds__(256) mlp_fwd_kernel(const float* __restrict__ enc, const float* __restrict__ dirs,
                                                       const half_t* __restrict__ wpack, int S,
@@ -274,18 +282,21 @@ __global__ void __launch_bounds__(256) mlp_fwd_kernel(const float* __restrict__ 
     const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
     const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), n_waves = gridDim.x * (blockDim.x >> 6);
     const int n_iter = (S + 31) >> 5;
+    FwdIn nxt[2];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) fwd_load<COLOR>(nxt[tt], enc, dirs, wave * 32 + 16 * tt + n, S, g, pairs, plane);
     for (int it = wave; it < n_iter; it += n_waves) {
+        const FwdIn cur[2] = {nxt[0], nxt[1]};
+        if (it + n_waves < n_iter) {
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) fwd_load<COLOR>(nxt[tt], enc, dirs, (it + n_waves) * 32 + 16 * tt + n, S, g, pairs, plane);
+        }
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
-            const int smp = it * 32 + 2 * n + tt;
-            const bool valid = smp < S;
-            float dx = 0.f, dy = 0.f, dz = 1.f;
-            if (COLOR && valid) { dx = dirs[3 * (size_t)smp]; dy = dirs[3 * (size_t)smp + 1]; dz = dirs[3 * (size_t)smp + 2]; }
+            const int smp = it * 32 + 16 * tt + n;
             TileFwd t;
-            const float *ep0, *ep1;
-            enc_ptrs(enc, pairs, plane, smp, g, ep0, ep1);
-            tile_forward<COLOR>(wl, lane, g, ep0, ep1, dx, dy, dz, valid, t);
-            if (valid && g == 0) {
+            tile_forward_regs<COLOR>(wl, lane, g, cur[tt].e0, cur[tt].e1, cur[tt].dx, cur[tt].dy, cur[tt].dz, t);
+            if (smp < S && g == 0) {
                 sigmas[smp] = t.sigma;
                 if (COLOR) { rgbs[3 * (size_t)smp] = t.rgb[0]; rgbs[3 * (size_t)smp + 1] = t.rgb[1]; rgbs[3 * (size_t)smp + 2] = t.rgb[2]; }
             }
@@ -369,39 +380,6 @@ __device__ __forceinline__ void bwd_prefetch(BwdIn& in, const float* __restrict_
     }
 }
 
-// forward of one tile from prefetched registers
-__device__ __forceinline__ void tile_forward_regs(const half8* __restrict__ wl, int lane, int g, const float4& e0, const float4& e1,
-                                                  float dx, float dy, float dz, TileFwd& t) {
-    const floatx4 zero = {0.f, 0.f, 0.f, 0.f};
-    t.b_enc[0] = (half_t)e0.x; t.b_enc[1] = (half_t)e0.y; t.b_enc[2] = (half_t)e0.z; t.b_enc[3] = (half_t)e0.w;
-    t.b_enc[4] = (half_t)e1.x; t.b_enc[5] = (half_t)e1.y; t.b_enc[6] = (half_t)e1.z; t.b_enc[7] = (half_t)e1.w;
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) t.a1[mt] = relu_h4(NGP_MFMA(wfrag(wl, F_W1 + mt, lane), t.b_enc, zero));
-    floatx4 d2 = NGP_MFMA(wfrag(wl, F_W2 + 0, lane), cat_h4(t.a1[0], t.a1[1]), zero);
-    d2 = NGP_MFMA(wfrag(wl, F_W2 + 1, lane), cat_h4(t.a1[2], t.a1[3]), d2);
-    t.h = to_h4(d2);
-    t.sigma = expf((float)t.h[0]);
-    const float inv = fast_rsq(dx * dx + dy * dy + dz * dz);
-    const float x = (dx * inv + 1.0f) / 2.0f, y = (dy * inv + 1.0f) / 2.0f, z = (dz * inv + 1.0f) / 2.0f;
-    t.b_in3 = cat_h4(sh_quad(g, x, y, z), t.h);
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) t.a3[mt] = relu_h4(NGP_MFMA(wfrag(wl, F_W3 + mt, lane), t.b_in3, zero));
-    const half8 b30 = cat_h4(t.a3[0], t.a3[1]), b31 = cat_h4(t.a3[2], t.a3[3]);
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        floatx4 d4 = NGP_MFMA(wfrag(wl, F_W4 + 2 * mt, lane), b30, zero);
-        d4 = NGP_MFMA(wfrag(wl, F_W4 + 2 * mt + 1, lane), b31, d4);
-        t.a4[mt] = relu_h4(d4);
-    }
-    floatx4 d5 = NGP_MFMA(wfrag(wl, F_W5 + 0, lane), cat_h4(t.a4[0], t.a4[1]), zero);
-    d5 = NGP_MFMA(wfrag(wl, F_W5 + 1, lane), cat_h4(t.a4[2], t.a4[3]), d5);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const float c = (float)(half_t)d5[r];
-        t.rgb[r] = (half_t)fast_rcp(1.0f + fast_exp(-c));
-    }
-}
-
 __global__ void __launch_bounds__(768) mlp_bwd_kernel(const float* __restrict__ enc, const float* __restrict__ dirs,
                                                        const half_t* __restrict__ wpack, const float* __restrict__ dsigmas,
                                                        const half_t* __restrict__ drgbs, int S,
@@ -441,7 +419,7 @@ __global__ void __launch_bounds__(768) mlp_bwd_kernel(const float* __restrict__ 
         bwd_prefetch(in, enc, dirs, dsigmas, drgbs, smp, S, g, pairs, plane);
         TileFwd t;
         half4 dz5 = hzero, dz4[4], dz3[4], dz2, dz1[4];
-        tile_forward_regs(wl, lane, g, in.e0, in.e1, in.dx, in.dy, in.dz, t);
+        tile_forward_regs<true>(wl, lane, g, in.e0, in.e1, in.dx, in.dy, in.dz, t);
         if (g == 0) {
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
