@@ -37,6 +37,7 @@ TRAINER_KERNELS = {
     "ngp_mlp_bwd_ex": ("mlp_bwd", "mfma", 37632, "sample"),
     "ngp_hash_bwd_f32_ex": ("hash_bwd_f32", "hbm", 12 + 128 + 1024 + 1024, "sample"),
     "ngp_adam_step": ("adam", "hbm", 32, "param"),
+    "ngp_adam_all": ("adam", "hbm", 32, "param"),                                  # table pass (+ the MLP block riding along)
     "ngp_hash_fwd_bf16_ex": ("hash_fwd_bf16", "hbm", 12 + 512 + 128, "sample"),    # --table bf16: 4-byte gathers, f32 output
     "ngp_adam_step_bf16": ("adam_bf16", "hbm", 34, "param"),                       # + the 2-byte storage copy
 }
@@ -225,8 +226,11 @@ def main():
         pool.append((torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev), torch.rand(args.rays, 3, generator=g).to(dev)))
 
     state = {"rm": 0, "vr": 0, "k": 0}
-    stat_log = torch.zeros(args.steps + args.warmup + 4, 1, device=dev, dtype=torch.int32)
-    vr_log = torch.zeros((args.steps + args.warmup + 4) // 8 + 1, args.rays, device=dev, dtype=torch.int32)
+    # sample counts are informational: they are copied out on every STAT_EVERY-th step only (a 4-byte device-to-device copy
+    # is a ~4.5 us kernel on the step's stream); 7 is coprime with the 8-batch pool, so every batch is sampled
+    STAT_EVERY = 7
+    stat_log = torch.zeros((args.steps + args.warmup + 4) // STAT_EVERY + 1, 1, device=dev, dtype=torch.int32)
+    vr_log = torch.zeros((args.steps + args.warmup + 4) // STAT_EVERY + 1, args.rays, device=dev, dtype=torch.int32)
 
     # the trainer launches go straight through the C ABI: HIP events around the big kernels, on the launch stream
     c_events = {}
@@ -258,13 +262,11 @@ def main():
         nxt = pool[(i + 1) % n_pool]
         pre = (nxt[0], nxt[1]) if (args.prefetch and (i + 1) % 16 != 0) else None      # never across a grid update
         out = trainer.step(rays_o, rays_d, target, prefetch=pre)
-        # sample counts: copy the two device counters into a preallocated log (2 tiny D2D copies, no reductions in the loop)
         k = state["k"]
-        if k < stat_log.shape[0]:
-            stat_log[k, 0].copy_(out["rm_samples"][0])
-            if k % 8 == 0:                               # the composited-sample count is informational: sample it
-                vr_log[k // 8].copy_(out["vr_per_ray"])
-            state["k"] = k + 1
+        if k % STAT_EVERY == 0 and k // STAT_EVERY < stat_log.shape[0]:
+            stat_log[k // STAT_EVERY, 0].copy_(out["rm_samples"][0])
+            vr_log[k // STAT_EVERY].copy_(out["vr_per_ray"])
+        state["k"] = k + 1
 
     def step(i):
         if use_trainer:
@@ -316,9 +318,9 @@ def main():
         elapsed = float(tt.item())
 
     if use_trainer:
-        state["rm"] = stat_log[:state["k"]].sum(dtype=torch.int64)
-        n_vr = (state["k"] + 7) // 8
-        state["vr"] = vr_log[:n_vr].sum(dtype=torch.int64) * state["k"] // max(n_vr, 1)
+        n_st = (state["k"] + STAT_EVERY - 1) // STAT_EVERY
+        state["rm"] = stat_log[:n_st].sum(dtype=torch.int64) * state["k"] // max(n_st, 1)
+        state["vr"] = vr_log[:n_st].sum(dtype=torch.int64) * state["k"] // max(n_st, 1)
     rm = int(state["rm"]); vr = int(state["vr"])
     total_rays = args.rays * world * args.steps
     if rank == 0:

@@ -204,6 +204,11 @@ int ngp_adam_step_bf16(float* p, float* g, float* m, float* v, long long n, cons
                        const int32_t* state_i, float beta1, float beta2, float eps, uint16_t* p_bf16, void* stream);
 /* dst[i] = bf16(src[i]), round-to-nearest-even; n % 4 == 0 (the per-forward cast of hash_encoder_half.py:367, in bf16). */
 int ngp_cast_f32_bf16(const float* src, uint16_t* dst, long long n, void* stream);
+/* The whole optimizer pass in one launch: ngp_adam_step (or ngp_adam_step_bf16 when table_bf16 != NULL) on the table and
+ * ngp_adam_mlp_pack on the MLP weights, the latter in the first workgroup while the others stream the table. */
+int ngp_adam_all(float* table, float* table_g, float* table_m, float* table_v, long long n, uint16_t* table_bf16,
+                 float* mlp, float* mlp_g, float* mlp_m, float* mlp_v, const float* state_f, const int32_t* state_i,
+                 float beta1, float beta2, float eps, int enc_pairs, uint16_t* wpack, void* stream);
 /* Adam on the 9 408 flat MLP weights (W1|W2|W3|W4|W5) + the fp16 fragment repack for the next step, one launch. */
 int ngp_adam_mlp_pack(float* p, float* g, float* m, float* v, const float* state_f, const int32_t* state_i,
                       float beta1, float beta2, float eps, int enc_pairs, uint16_t* wpack, void* stream);

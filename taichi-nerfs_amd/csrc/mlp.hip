@@ -112,12 +112,14 @@ __global__ void __launch_bounds__(256) mlp_pack_kernel(const float* __restrict__
 
 // Trainer fusion: Adam on the 9 408 flat MLP weights (same arithmetic as optim.hip's adam_kernel, state layout in
 // include/ngp_hip.h) followed by the fp16 fragment repack for the next step, in ONE block -- replaces two launches.
-__global__ void __launch_bounds__(1024) adam_mlp_pack_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
-                                                             float* __restrict__ v, const float* __restrict__ sf,
-                                                             const int32_t* __restrict__ si, float beta1, float beta2, float eps,
-                                                             int pairs, half_t* __restrict__ wpack) {
-    const bool skip = si[4] != 0;
-    const float inv_scale = sf[1], step_size = sf[2] / sf[3], bc2_sqrt = sf[4];
+// Adam on the 9408 MLP weights, then the fp16 fragment repack for the next step (one block: the repack reads what the block's
+// own threads just wrote)
+__device__ __forceinline__ void adam_mlp_pack_block(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, const float* __restrict__ sf,
+                                                    const int32_t* __restrict__ si, float beta1, float beta2, float eps,
+                                                    int pairs, half_t* __restrict__ wpack) {
+    const bool skip = si[SI_SKIP] != 0;
+    const float inv_scale = sf[SF_INV_SCALE], step_size = sf[SF_LR] / sf[SF_BC1], bc2_sqrt = sf[SF_BC2_SQRT];
     for (int i = threadIdx.x; i < 9408; i += blockDim.x) {
         if (!skip) {
             const float gr = g[i] * inv_scale;
@@ -130,8 +132,31 @@ __global__ void __launch_bounds__(1024) adam_mlp_pack_kernel(float* __restrict__
         g[i] = 0.0f;
     }
     __syncthreads();
-    for (int tid = threadIdx.x; tid < N_ALL_FRAGS * 64 * 8; tid += blockDim.x)
-        pack_one(tid, p, p + 2048, p + 3072, p + 5120, p + 9216, pairs, wpack);
+    // one 16-byte fragment slot (8 halfs) per work item: eight independent weight loads in flight per thread
+    for (int item = threadIdx.x; item < N_ALL_FRAGS * 64; item += blockDim.x) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pack_one(8 * item + j, p, p + 2048, p + 3072, p + 5120, p + 9216, pairs, wpack);
+    }
+}
+
+__global__ void __launch_bounds__(1024) adam_mlp_pack_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                             float* __restrict__ v, const float* __restrict__ sf,
+                                                             const int32_t* __restrict__ si, float beta1, float beta2, float eps,
+                                                             int pairs, half_t* __restrict__ wpack) {
+    adam_mlp_pack_block(p, g, m, v, sf, si, beta1, beta2, eps, pairs, wpack);
+}
+
+// The whole optimizer pass in ONE launch: block 0 (dispatched first) does the MLP weights + repack while blocks 1.. stream the
+// hash table -- the 16 us small-kernel tail of the step disappears under the 46 us table pass.
+template <bool SHADOW>
+__global__ void __launch_bounds__(1024) adam_all_kernel(float4* __restrict__ tp, float4* __restrict__ tg, float4* __restrict__ tm,
+                                                        float4* __restrict__ tv, long n4, uint2* __restrict__ shadow,
+                                                        float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                        float* __restrict__ v, const float* __restrict__ sf,
+                                                        const int32_t* __restrict__ si, float beta1, float beta2, float eps,
+                                                        int pairs, half_t* __restrict__ wpack) {
+    if (blockIdx.x == 0) adam_mlp_pack_block(p, g, m, v, sf, si, beta1, beta2, eps, pairs, wpack);
+    else adam_table_pass<SHADOW>(tp, tg, tm, tv, n4, sf, si, beta1, beta2, eps, shadow, (long)blockIdx.x - 1, (long)gridDim.x - 1);
 }
 
 // ---- per-lane helpers -------------------------------------------------------------------------------------
@@ -579,6 +604,26 @@ int ngp_adam_mlp_pack(float* p, float* g, float* m, float* v, const float* state
                       float eps, int enc_pairs, uint16_t* wpack, void* stream) {
     hipLaunchKernelGGL(adam_mlp_pack_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, p, g, m, v, state_f, state_i, beta1, beta2,
                        eps, enc_pairs, (half_t*)wpack);
+    NGP_LAUNCH_CHECK();
+    return 0;
+}
+
+int ngp_adam_all(float* table, float* table_g, float* table_m, float* table_v, long long n, uint16_t* table_bf16, float* mlp,
+                 float* mlp_g, float* mlp_m, float* mlp_v, const float* state_f, const int32_t* state_i, float beta1, float beta2,
+                 float eps, int enc_pairs, uint16_t* wpack, void* stream) {
+    if (n <= 0 || n % 4 != 0) return -1;
+    const long n4 = (long)(n / 4);
+    long blocks = (n4 + 1023) / 1024;
+    if (blocks > 256L * 4) blocks = 256L * 4;                 // 4 x 1024-thread blocks per CU, grid-stride beyond
+    const dim3 grid((unsigned)blocks + 1), block(1024);
+    if (table_bf16)
+        hipLaunchKernelGGL(adam_all_kernel<true>, grid, block, 0, (hipStream_t)stream, (float4*)table, (float4*)table_g, (float4*)table_m,
+                           (float4*)table_v, n4, (uint2*)table_bf16, mlp, mlp_g, mlp_m, mlp_v, state_f, state_i, beta1, beta2, eps,
+                           enc_pairs, (half_t*)wpack);
+    else
+        hipLaunchKernelGGL(adam_all_kernel<false>, grid, block, 0, (hipStream_t)stream, (float4*)table, (float4*)table_g, (float4*)table_m,
+                           (float4*)table_v, n4, (uint2*)nullptr, mlp, mlp_g, mlp_m, mlp_v, state_f, state_i, beta1, beta2, eps,
+                           enc_pairs, (half_t*)wpack);
     NGP_LAUNCH_CHECK();
     return 0;
 }

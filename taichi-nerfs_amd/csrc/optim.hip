@@ -14,8 +14,6 @@
 
 namespace ngp {
 
-enum { SF_LOSS_SCALE = 0, SF_INV_SCALE = 1, SF_LR = 2, SF_BC1 = 3, SF_BC2_SQRT = 4, SF_LOSS = 5, SF_LOSS_ACC = 6 };
-enum { SI_ITER = 0, SI_OPT_STEP = 1, SI_GROWTH = 2, SI_FOUND_INF = 3, SI_SKIP = 4, SI_SKIPPED_TOTAL = 5 };
 
 __global__ void train_prologue_kernel(float* __restrict__ sf, int32_t* __restrict__ si, float lr0, float eta_min, int t_max,
                                       float beta1, float beta2, float growth, float backoff, int growth_interval) {
@@ -45,48 +43,14 @@ __global__ void train_prologue_kernel(float* __restrict__ sf, int32_t* __restric
     si[SI_ITER] = iter + 1;
 }
 
-// round-to-nearest-even f32 -> bf16 (what torch's .bfloat16() does); NaN stays NaN
-__device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
-    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
-}
-
-// SHADOW: also refresh a bf16 copy of the parameters (the table the bf16 hash forward gathers from) in the same pass
+// the dense Adam pass itself (adam_table_pass) lives in ngp_device.h: the fused "table + MLP + repack" kernel of mlp.hip runs the
+// same code.  SHADOW: also refresh a bf16 copy of the parameters (the table the bf16 hash forward gathers from).
 template <bool SHADOW>
 __global__ void __launch_bounds__(256) adam_kernel(float4* __restrict__ p, float4* __restrict__ g, float4* __restrict__ m,
                                                    float4* __restrict__ v, long n4, const float* __restrict__ sf,
                                                    const int32_t* __restrict__ si, float beta1, float beta2, float eps,
                                                    uint2* __restrict__ shadow) {
-    const bool skip = si[SI_SKIP] != 0;
-    const float inv_scale = sf[SF_INV_SCALE], step_size = sf[SF_LR] / sf[SF_BC1], bc2_sqrt = sf[SF_BC2_SQRT];
-    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
-        if (skip) { g[i] = zero; continue; }
-        const float4 gi = g[i];
-        float4 mi = m[i], vi = v[i];
-        // an entry that never received a gradient (g = m = v = 0) is a fixed point of Adam: m' = v' = 0 and the update is
-        // lr * 0 / (0 + eps) = 0 exactly -- skip its parameter read and all four writes (hashed levels of a sparse scene
-        // leave a large part of the table untouched for the whole run)
-        if (gi.x == 0.f && gi.y == 0.f && gi.z == 0.f && gi.w == 0.f && mi.x == 0.f && mi.y == 0.f && mi.z == 0.f && mi.w == 0.f &&
-            vi.x == 0.f && vi.y == 0.f && vi.z == 0.f && vi.w == 0.f)
-            continue;
-        float4 pi = p[i];
-#define NGP_ADAM1(c)                                                          \
-        {                                                                     \
-            const float gr = gi.c * inv_scale;                                \
-            mi.c = mi.c + (gr - mi.c) * (1.0f - beta1);                       \
-            vi.c = vi.c * beta2 + gr * gr * (1.0f - beta2);                   \
-            const float denom = sqrtf(vi.c) / bc2_sqrt + eps;                 \
-            pi.c = pi.c - step_size * (mi.c / denom);                         \
-        }
-        NGP_ADAM1(x) NGP_ADAM1(y) NGP_ADAM1(z) NGP_ADAM1(w)
-#undef NGP_ADAM1
-        p[i] = pi; m[i] = mi; v[i] = vi; g[i] = zero;
-        if constexpr (SHADOW)
-            shadow[i] = make_uint2(f32_to_bf16_bits(pi.x) | (f32_to_bf16_bits(pi.y) << 16),
-                                   f32_to_bf16_bits(pi.z) | (f32_to_bf16_bits(pi.w) << 16));
-    }
+    adam_table_pass<SHADOW>(p, g, m, v, n4, sf, si, beta1, beta2, eps, shadow, (long)blockIdx.x, (long)gridDim.x);
 }
 
 __global__ void __launch_bounds__(256) cast_bf16_kernel(const float4* __restrict__ src, uint2* __restrict__ dst, long n4) {

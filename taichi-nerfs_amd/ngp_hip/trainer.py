@@ -218,16 +218,10 @@ class FusedTrainer:
                     "deltas": M.deltas, "ts": M.ts, "sq_err": sq_err}
         check(L.ngp_train_prologue(_ptr(sf), _ptr(si), self.lr0, self.eta_min, self.t_max, self.beta1,
                                    self.beta2, self.growth, self.backoff, self.growth_interval, st), "ngp_train_prologue")
-        if self.table_bf16 is not None:
-            check(L.ngp_adam_step_bf16(_ptr(self.table), _ptr(self.table_grad), _ptr(self.table_m), _ptr(self.table_v),
-                                       self.table.numel(), _ptr(sf), _ptr(si), self.beta1, self.beta2, self.eps, _ptr(self.table_bf16),
-                                       st), "ngp_adam_step_bf16")
-        else:
-            check(L.ngp_adam_step(_ptr(self.table), _ptr(self.table_grad), _ptr(self.table_m), _ptr(self.table_v),
-                                  self.table.numel(), _ptr(sf), _ptr(si), self.beta1, self.beta2, self.eps, st), "ngp_adam_step")
-        # Adam on the MLP weights + the fp16 fragment repack the next step needs, one launch
-        check(L.ngp_adam_mlp_pack(_ptr(self.mlp_flat), _ptr(self.mlp_grad), _ptr(self.mlp_m), _ptr(self.mlp_v), _ptr(sf), _ptr(si),
-                                  self.beta1, self.beta2, self.eps, P, _ptr(self.wpack), st), "ngp_adam_mlp_pack")
+        # Adam on the table (+ its bf16 copy) and on the MLP weights + the fp16 fragment repack the next step needs: one launch
+        check(L.ngp_adam_all(_ptr(self.table), _ptr(self.table_grad), _ptr(self.table_m), _ptr(self.table_v), self.table.numel(),
+                             _ptr(self.table_bf16), _ptr(self.mlp_flat), _ptr(self.mlp_grad), _ptr(self.mlp_m), _ptr(self.mlp_v),
+                             _ptr(sf), _ptr(si), self.beta1, self.beta2, self.eps, P, _ptr(self.wpack), st), "ngp_adam_all")
         return {"rm_samples": total, "vr_per_ray": vr_per_ray, "rgb": rgb, "opacity": opacity, "depth": depth, "rays_a": rays_a,
                 "deltas": M.deltas, "ts": M.ts, "sq_err": sq_err}
 

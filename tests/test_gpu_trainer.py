@@ -144,3 +144,45 @@ def test_trainer_allreduce_path_on_rccl_world1(hip_lib, lego_bitfield):
         assert tr.counters()["iter"] == 3 and np.isfinite(tr.last_loss())
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+def test_adam_all_equals_separate_launches(hip_lib, bf16):
+    """ngp_adam_all (table pass + MLP Adam + fragment repack in one launch) == ngp_adam_step[_bf16] + ngp_adam_mlp_pack,
+    bit for bit, including the skipped-step branch."""
+    from ngp_hip import lib as L
+    from ngp_hip.ops import _ptr, _stream
+    lib = L.load()
+    n = 1 << 20
+    for skip in (0, 1):
+        torch.manual_seed(3 + skip)
+        mk = lambda k: torch.randn(k, device="cuda")
+        tp, tg, tm, tv = mk(n), mk(n) * 512, mk(n).abs() * 0.1, mk(n).abs() * 0.01
+        tg[: n // 4] = 0; tm[: n // 4] = 0; tv[: n // 4] = 0                  # never-touched entries
+        wp, wg, wm, wv = mk(9408) * 0.2, mk(9408) * 512, mk(9408) * 0.1, mk(9408).abs() * 0.01
+        sf = torch.zeros(8, device="cuda"); si = torch.zeros(8, device="cuda", dtype=torch.int32)
+        sf[0] = 512.0; si[3] = skip
+        L.check(lib.ngp_train_prologue(_ptr(sf), _ptr(si), 1e-2, 1e-2 / 30, 100, 0.9, 0.999, 2.0, 0.5, 2000, _stream()), "prologue")
+        A = [t.clone() for t in (tp, tg, tm, tv, wp, wg, wm, wv)]
+        B = [t.clone() for t in (tp, tg, tm, tv, wp, wg, wm, wv)]
+        sh_a = A[0].bfloat16() if bf16 else None
+        sh_b = B[0].bfloat16() if bf16 else None
+        nh = lib.ngp_mlp_wpack_halfs()
+        wk_a, wk_b = torch.zeros(nh, device="cuda", dtype=torch.float16), torch.zeros(nh, device="cuda", dtype=torch.float16)
+        L.check(lib.ngp_adam_all(_ptr(A[0]), _ptr(A[1]), _ptr(A[2]), _ptr(A[3]), n, _ptr(sh_a), _ptr(A[4]), _ptr(A[5]), _ptr(A[6]),
+                                 _ptr(A[7]), _ptr(sf), _ptr(si), 0.9, 0.999, 1e-15, 1, _ptr(wk_a), _stream()), "adam_all")
+        if bf16:
+            L.check(lib.ngp_adam_step_bf16(_ptr(B[0]), _ptr(B[1]), _ptr(B[2]), _ptr(B[3]), n, _ptr(sf), _ptr(si), 0.9, 0.999, 1e-15,
+                                           _ptr(sh_b), _stream()), "adam_bf16")
+        else:
+            L.check(lib.ngp_adam_step(_ptr(B[0]), _ptr(B[1]), _ptr(B[2]), _ptr(B[3]), n, _ptr(sf), _ptr(si), 0.9, 0.999, 1e-15,
+                                      _stream()), "adam")
+        L.check(lib.ngp_adam_mlp_pack(_ptr(B[4]), _ptr(B[5]), _ptr(B[6]), _ptr(B[7]), _ptr(sf), _ptr(si), 0.9, 0.999, 1e-15, 1,
+                                      _ptr(wk_b), _stream()), "adam_mlp_pack")
+        torch.cuda.synchronize()
+        for a, b in zip(A, B):
+            assert torch.equal(a, b)
+        assert torch.equal(wk_a.view(torch.int16), wk_b.view(torch.int16)) and wk_a.any()
+        if bf16:
+            assert torch.equal(sh_a.view(torch.int16), sh_b.view(torch.int16))
+        assert (skip == 1) == torch.equal(A[0], tp)                            # a skipped step leaves the parameters alone
