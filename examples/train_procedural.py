@@ -119,21 +119,22 @@ def main():
         sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, args.steps, 1e-2 / 30)
         scaler = torch.amp.GradScaler("cuda", init_scale=2.0**19)
 
+    # device-resident training split: batch sampling + get_rays in one kernel (ngp_hip/rays.py)
+    from ngp_hip.rays import RayBatcher, get_rays
+    batcher = RayBatcher(train_imgs, train_poses, dirs, batch_size=args.batch)
     thr = 0.01 * MAX_SAMPLES / 3**0.5
     torch.cuda.synchronize()
     t0 = time.time()
     log = []
+    nxt = batcher.sample()
     for step in range(args.steps):
-        img_idx = torch.randint(0, args.n_train, (args.batch,), device=dev)
-        pix_idx = torch.randint(0, args.wh * args.wh, (args.batch,), device=dev)
-        pose = train_poses[img_idx]
-        rays_d = (dirs[pix_idx][:, None, :] @ pose[:, :, :3].transpose(1, 2))[:, 0]
-        rays_o = pose[:, :, 3]
-        target = train_imgs[img_idx, pix_idx]
+        cur, nxt = nxt, batcher.sample()                       # one batch of lookahead: its march runs under this step
+        rays_o, rays_d, target = cur["rays_o"], cur["rays_d"], cur["rgb"]
         if args.path == "trainer":
             if step % 16 == 0:
                 trainer.update_density_grid(thr, warmup=step < 256)
-            st = trainer.step(rays_o.contiguous(), rays_d.contiguous(), target.contiguous())
+            pre = (nxt["rays_o"], nxt["rays_d"]) if (step + 1) % 16 != 0 else None     # never across a grid update
+            st = trainer.step(rays_o, rays_d, target, prefetch=pre)
             if step % 500 == 0:
                 log.append((step, trainer.last_loss(), int(st["rm_samples"][0]) / args.batch))
         else:
@@ -157,7 +158,7 @@ def main():
     with torch.no_grad():
         model.eval()
         for p, gt in zip(test_poses, test_imgs):
-            rays_o, rays_d = p[:, 3].expand_as(dirs).contiguous(), (dirs @ p[:, :3].T).contiguous()   # fp32 (get_rays)
+            rays_o, rays_d = get_rays(dirs, p)                                                      # fp32, like ray_utils.get_rays
             with torch.autocast("cuda", dtype=torch.float16):
                 res = render(model, rays_o, rays_d, test_time=True, exp_step_factor=0.0)
             psnrs.append(-10.0 * math.log10(F.mse_loss(res["rgb"], gt).item()))

@@ -227,6 +227,17 @@ int ngp_distortion_bwd(const float* dL_dloss, const float* ws, const float* delt
                        const float* ws_inc, const float* wts_inc, const int32_t* rays_a, int n_rays,
                        float* dL_dws, void* stream);
 
+/* ---- f-4  camera rays and training-batch sampling (datasets/ray_utils.py:51-80, datasets/base.py:34-61, train.py:171-184)
+ * get_rays:    rays_d[k,i] = sum_j directions[k,j] * c2w[i,j], rays_o[k] = c2w[:,3]; poses = [n,3,4] (per_ray_pose = 1, the
+ *              training batch) or one [3,4] pose for all rays (per_ray_pose = 0, an evaluation image).
+ * sample_rays: for sample k: image i = img_idx[k] (img0 when img_idx is NULL = 'same_image' sampling), pixel p = pix_idx[k];
+ *              pose = poses[i], direction = directions[p], rgb[k] = rays[i, p, 0:3] (rays = [n_img, hw, ray_c] f32, rgb nullable). */
+int ngp_get_rays(const float* directions /*[n,3]*/, const float* poses, int per_ray_pose, int n, float* rays_o,
+                 float* rays_d, void* stream);
+int ngp_sample_rays(const float* poses /*[n_img,3,4]*/, const float* directions /*[hw,3]*/, const float* rays, int ray_c,
+                    long long hw, const int64_t* img_idx, long long img0, const int64_t* pix_idx, int n, float* rays_o,
+                    float* rays_d, float* rgb, void* stream);
+
 /* ---- f-3  occupancy-grid update without host round trips (modules/networks.py:181-209,255-290).
  * compact : list[0..count) = cells of ONE cascade with density > threshold (count must be zeroed by the caller)
  * sample  : m uniform cells (u_cell [m] in [0,1) -> Morton code) + m picks from the list (u_pick [m]) -> Morton indices [2m] and jittered

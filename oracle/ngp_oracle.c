@@ -596,6 +596,30 @@ ORA_API void ora_composite_test(const float* sigmas, const float* rgbs, const fl
     }
 }
 
+/* f-4 get_rays -- datasets/ray_utils.py:51-80: rays_d = directions @ c2w[:, :3].T (per-ray or single pose), rays_o = c2w[..., 3]
+ * expanded.  The reference's matmul leaves the summation order to the BLAS; restated left to right, no contraction. */
+static void ray_from_pose(const float* c2w, const float* dir, float* o, float* d) {
+    for (int i = 0; i < 3; ++i) {
+        d[i] = (dir[0] * c2w[4 * i] + dir[1] * c2w[4 * i + 1]) + dir[2] * c2w[4 * i + 2];
+        o[i] = c2w[4 * i + 3];
+    }
+}
+ORA_API void ora_get_rays(const float* directions, const float* poses, int per_ray_pose, int n, float* rays_o, float* rays_d) {
+    for (int k = 0; k < n; ++k)
+        ray_from_pose(poses + (per_ray_pose ? 12 * (size_t)k : 0), directions + 3 * (size_t)k, rays_o + 3 * (size_t)k, rays_d + 3 * (size_t)k);
+}
+/* training-batch sampling -- datasets/base.py:34-61 (rays[img_idxs, pix_idxs][:, :3], poses[img_idxs], directions[pix_idxs])
+ * followed by get_rays (train.py:184) */
+ORA_API void ora_sample_rays(const float* poses, const float* directions, const float* rays, int ray_c, long long hw,
+                             const int64_t* img_idx, long long img0, const int64_t* pix_idx, int n, float* rays_o, float* rays_d,
+                             float* rgb) {
+    for (int k = 0; k < n; ++k) {
+        const long long img = img_idx ? img_idx[k] : img0, pix = pix_idx[k];
+        ray_from_pose(poses + 12 * img, directions + 3 * pix, rays_o + 3 * (size_t)k, rays_d + 3 * (size_t)k);
+        if (rgb) for (int c = 0; c < 3; ++c) rgb[3 * (size_t)k + c] = rays[((size_t)img * hw + pix) * ray_c + c];
+    }
+}
+
 /* a-10 grid utilities -- modules/utils.py:120-169 */
 ORA_API void ora_morton3d(const int32_t* coords, int m, int32_t* indices) {
     for (int i = 0; i < m; ++i) indices[i] = (int32_t)morton3d((uint32_t)coords[3 * i], (uint32_t)coords[3 * i + 1], (uint32_t)coords[3 * i + 2]);

@@ -211,6 +211,28 @@ def composite_test(sigmas, rgbs, deltas, ts, pack_info, alive, T_threshold, opac
                              _p(depth), _p(rgb))
 
 
+def get_rays(directions, c2w):
+    """datasets/ray_utils.py:51-80; c2w [3,4] or [n,3,4]."""
+    d, c = _f32(directions), _f32(c2w)
+    n = d.shape[0]
+    o, r = np.empty((n, 3), np.float32), np.empty((n, 3), np.float32)
+    lib().ora_get_rays(_p(d), _p(c), int(c.ndim == 3), n, _p(o), _p(r))
+    return o, r
+
+
+def sample_rays(poses, directions, rays, img_idx, pix_idx):
+    """img_idx: int (same_image) or int64 [n]; returns rays_o, rays_d, rgb."""
+    ps, d, ry = _f32(poses), _f32(directions), _f32(rays)
+    pix = np.ascontiguousarray(pix_idx, dtype=np.int64)
+    n = pix.shape[0]
+    per = not np.isscalar(img_idx)
+    img = np.ascontiguousarray(img_idx, dtype=np.int64) if per else None
+    o, r, c = np.empty((n, 3), np.float32), np.empty((n, 3), np.float32), np.empty((n, 3), np.float32)
+    lib().ora_sample_rays(_p(ps), _p(d), _p(ry), ry.shape[-1], ctypes.c_longlong(ry.shape[1]), _p(img),
+                          ctypes.c_longlong(0 if per else int(img_idx)), _p(pix), n, _p(o), _p(r), _p(c))
+    return o, r, c
+
+
 def morton3d(coords):
     c = np.ascontiguousarray(coords, dtype=np.int32)
     out = np.empty(c.shape[0], np.int32)

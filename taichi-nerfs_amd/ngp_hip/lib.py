@@ -15,7 +15,7 @@ PKG_ROOT = os.path.dirname(_HERE)
 CSRC = os.path.join(PKG_ROOT, "csrc")
 INCLUDE = os.path.join(os.path.dirname(PKG_ROOT), "include")
 LIB_PATH = os.path.join(CSRC, "libngp_hip.so")
-SOURCES = ["march.hip", "hash_grid.hip", "composite.hip", "sh_grid.hip", "mlp.hip", "optim.hip", "distortion.hip", "occupancy.hip"]
+SOURCES = ["march.hip", "hash_grid.hip", "composite.hip", "sh_grid.hip", "mlp.hip", "optim.hip", "distortion.hip", "occupancy.hip", "rays.hip"]
 HEADERS = ["ngp_device.h"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
 
@@ -110,6 +110,8 @@ SIGNATURES = {
     "ngp_adam_mlp_pack": [_P, _P, _P, _P, _P, _P, _F, _F, _F, _I, _P, _P],
     "ngp_distortion_fwd": [_P, _P, _P, _P, _I, _P, _P, _P, _P],
     "ngp_distortion_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P],
+    "ngp_get_rays": [_P, _P, _I, _I, _P, _P, _P],
+    "ngp_sample_rays": [_P, _P, _P, _I, ctypes.c_longlong, _P, ctypes.c_longlong, _P, _I, _P, _P, _P, _P],
     "ngp_occ_compact": [_P, _F, _I, _P, _P, _P],
     "ngp_occ_sample": [_P, _P, _P, _P, _P, _I, _I, _F, _F, _P, _P, _P],
     "ngp_occ_all_cells": [_P, _I, _I, _F, _F, _P, _P],
