@@ -70,10 +70,10 @@ def test_render_matches_oracle_pipeline(oracle, hip_lib, lego_bitfield, fused):
     # radiance: within 1e-3 (mean), and no outlier beyond a few fp16 ulps of the accumulated colour
     got = res["rgb"].float().detach().cpu().numpy()
     err = np.abs(got - rgb)
-    assert err.mean() < 1e-3, err.mean()
-    assert err.max() < 1e-2, err.max()
+    assert err.mean() < 1e-5, err.mean()         # measured 6e-8: the fp16 rounding points coincide, only fp32 summation order differs
+    assert err.max() < 1e-4, err.max()           # measured 1e-6
     psnr = -10 * np.log10(np.mean((got - rgb) ** 2))
     print("e2e fused=%s: samples %d, mean|d rgb| %.2e, max %.2e, PSNR(HIP vs oracle) %.1f dB" % (fused, total, err.mean(), err.max(), psnr))
-    assert psnr > 55.0, psnr
-    np.testing.assert_allclose(res["opacity"].float().detach().cpu().numpy(), op, atol=5e-3)
-    np.testing.assert_allclose(res["depth"].float().detach().cpu().numpy(), dep, atol=5e-3)
+    assert psnr > 100.0, psnr
+    np.testing.assert_allclose(res["opacity"].float().detach().cpu().numpy(), op, atol=1e-4)
+    np.testing.assert_allclose(res["depth"].float().detach().cpu().numpy(), dep, atol=1e-4)
