@@ -234,6 +234,8 @@ int ngp_distortion_bwd(const float* dL_dloss, const float* ws, const float* delt
  *              pose = poses[i], direction = directions[p], rgb[k] = rays[i, p, 0:3] (rays = [n_img, hw, ray_c] f32, rgb nullable). */
 int ngp_get_rays(const float* directions /*[n,3]*/, const float* poses, int per_ray_pose, int n, float* rays_o,
                  float* rays_d, void* stream);
+/* up to three n-float copies in one launch (src NULL = slot unused): stages a batch into the static buffers of a captured step */
+int ngp_stage_batch(const float* a, float* da, const float* b, float* db, const float* c, float* dc, int n, void* stream);
 int ngp_sample_rays(const float* poses /*[n_img,3,4]*/, const float* directions /*[hw,3]*/, const float* rays, int ray_c,
                     long long hw, const int64_t* img_idx, long long img0, const int64_t* pix_idx, int n, float* rays_o,
                     float* rays_d, float* rgb, void* stream);

@@ -44,6 +44,17 @@ __global__ void __launch_bounds__(256) sample_rays_kernel(const float* __restric
     }
 }
 
+// up to three equal-length float copies in one launch (batch -> the static buffers a captured training step reads)
+__global__ void __launch_bounds__(256) stage_batch_kernel(const float* __restrict__ a, float* __restrict__ da,
+                                                          const float* __restrict__ b, float* __restrict__ db,
+                                                          const float* __restrict__ c, float* __restrict__ dc, int n) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        if (a) da[i] = a[i];
+        if (b) db[i] = b[i];
+        if (c) dc[i] = c[i];
+    }
+}
+
 }  // namespace ngp
 
 using namespace ngp;
@@ -68,6 +79,16 @@ int ngp_sample_rays(const float* poses, const float* directions, const float* ra
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(sample_rays_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, poses, directions, rays, ray_c, hw, img_idx,
                        img0, pix_idx, n, rays_o, rays_d, rgb);
+    NGP_LAUNCH_CHECK();
+    return 0;
+}
+
+int ngp_stage_batch(const float* a, float* da, const float* b, float* db, const float* c, float* dc, int n, void* stream) {
+    if (n <= 0) return 0;
+    if ((a && !da) || (b && !db) || (c && !dc)) return -1;
+    int blocks = (n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(stage_batch_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, da, b, db, c, dc, n);
     NGP_LAUNCH_CHECK();
     return 0;
 }

@@ -111,6 +111,7 @@ SIGNATURES = {
     "ngp_distortion_fwd": [_P, _P, _P, _P, _I, _P, _P, _P, _P],
     "ngp_distortion_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P],
     "ngp_get_rays": [_P, _P, _I, _I, _P, _P, _P],
+    "ngp_stage_batch": [_P, _P, _P, _P, _P, _P, _I, _P],
     "ngp_sample_rays": [_P, _P, _P, _I, ctypes.c_longlong, _P, ctypes.c_longlong, _P, _I, _P, _P, _P, _P],
     "ngp_occ_compact": [_P, _F, _I, _P, _P, _P],
     "ngp_occ_sample": [_P, _P, _P, _P, _P, _I, _I, _F, _F, _P, _P, _P],

@@ -125,6 +125,7 @@ class FusedTrainer:
             self.ready = None               # event recorded on the side stream when a prefetched march has finished
             self.key = None                 # (data_ptr of rays_o, rays_d) the set was marched for
 
+
     def _march_sets(self, n):
         key = n
         sets = self._sets.get(key)
@@ -143,11 +144,12 @@ class FusedTrainer:
             self._coarse_ver = ver
         return coarse
 
-    def _march(self, M, rays_o, rays_d, cfg, A):
+    def _march(self, M, rays_o, rays_d, cfg, A, coarse=None):
         """ray-AABB + count/scan/write into march set M on the CURRENT stream."""
         L, st, n = self.L, _stream(), rays_o.shape[0]
         noise = torch.rand(n, device=self.dev, dtype=torch.float32)                         # ray_march.py:138
-        coarse = self._coarse_bits(cfg, A)
+        if coarse is None:
+            coarse = self._coarse_bits(cfg, A)
         check(L.ngp_march_train_count_ex(_ptr(rays_o), _ptr(rays_d), _ptr(None), _ptr(cfg.bitfield), _ptr(coarse), _ptr(noise),
                                          cfg.cascades, cfg.grid_size, cfg.scale, cfg.exp_step_factor, cfg.max_samples, n,
                                          _ptr(M.stage), _ptr(M.counts), st), "ngp_march_train_count_ex")   # slab test inline
@@ -157,11 +159,9 @@ class FusedTrainer:
         M.key = (rays_o.data_ptr(), rays_d.data_ptr())
 
     def _launch(self, rays_o, rays_d, target, prefetch=None):
-        L, m, st = self.L, self.model, _stream()
         n = rays_o.shape[0]
-        dev = self.dev
-        cfg = RenderConfig(m, self.exp_step_factor, self.T_threshold, self.max_samples)
-        A = TrainArena.get(dev, n, self.max_samples)
+        cfg = RenderConfig(self.model, self.exp_step_factor, self.T_threshold, self.max_samples)
+        A = TrainArena.get(self.dev, n, self.max_samples)
         sets = self._march_sets(n)
         M = sets[self._cur]
         if M.ready is not None and M.key == (rays_o.data_ptr(), rays_d.data_ptr()):
@@ -169,7 +169,7 @@ class FusedTrainer:
         else:
             self._march(M, rays_o, rays_d, cfg, A)
         M.ready = None
-        if prefetch is not None and self._graph is None:
+        if prefetch is not None:
             # software pipelining across steps: the march only depends on the rays and the occupancy bitfield, never on
             # the weights, and it is latency-bound (few resident waves) -- run the NEXT batch's march on a side stream
             # underneath this step's bandwidth-bound kernels.
@@ -181,7 +181,26 @@ class FusedTrainer:
                 self._march(nxt, prefetch[0], prefetch[1], cfg, A)
                 nxt.ready = torch.cuda.Event()
                 nxt.ready.record(self._side)
-        self._cur = 1 - self._cur
+        cur, self._cur = self._cur, 1 - self._cur
+        if self._graph is None:
+            return self._shade(M, n, target, cfg, A)
+        # hipGraph mode: the shading / backward / optimizer chain of march set `cur` is one graph launch
+        if n != self._graph_n:
+            raise ValueError("graph mode was captured for %d rays per step" % self._graph_n)
+        check(self.L.ngp_stage_batch(_ptr(target), _ptr(self._static_target), _ptr(None), _ptr(None), _ptr(None), _ptr(None), 3 * n,
+                                     _stream()), "ngp_stage_batch")
+        if cur not in self._graph:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                stats = self._shade(M, n, self._static_target, cfg, A)
+            self._graph[cur] = (g, stats)
+        g, stats = self._graph[cur]
+        g.replay()
+        return stats
+
+    def _shade(self, M, n, target, cfg, A):
+        """Everything after the march: encode, MLPs, composite + loss, backward, [all-reduce], optimizer -- on the current stream."""
+        L, st, dev = self.L, _stream(), self.dev
         i32 = dict(device=dev, dtype=torch.int32)
         f32 = dict(device=dev, dtype=torch.float32)
         rays_a, total = M.rays_a, M.total
@@ -279,11 +298,6 @@ class FusedTrainer:
         prefetch=(next_rays_o, next_rays_d): the NEXT step's rays, if already known and if the occupancy grid will not be
         updated in between -- their march then overlaps this step on a side stream (the tensors must stay alive and
         unmodified until that next step() call, which must receive the very same tensors)."""
-        if self._graph is not None:
-            so, sd, stg = self._static
-            so.copy_(rays_o); sd.copy_(rays_d); stg.copy_(target)
-            self._graph.replay()
-            return self.stats
         if prefetch is not None:
             prefetch = (prefetch[0].contiguous().float(), prefetch[1].contiguous().float())
         self.stats = self._launch(rays_o.contiguous().float(), rays_d.contiguous().float(), target.contiguous().float(), prefetch)
@@ -307,25 +321,19 @@ class FusedTrainer:
         return out
 
     def capture(self, n_rays):
-        """Capture one step into a hipGraph (single-GPU; the RCCL path stays eager).  Subsequent step() calls copy the
-        batch into static buffers and replay."""
+        """Switch to hipGraph replay (single-GPU; the RCCL path stays eager).  The encode -> MLPs -> composite + loss -> backward
+        -> optimizer chain becomes ONE graph launch per step (one graph per march-set parity, captured on first use) preceded by
+        a one-launch staging copy of the target colours; the march stays eager -- the current batch's if it was not prefetched,
+        the next batch's on the side stream -- because hipGraph executes parallel branches of one graph back to back
+        (measured: a march branch inside the graph added its full 0.1 ms to the step), which would undo the overlap."""
         if self.world > 1:
             raise RuntimeError("graph capture is only wired for the single-GPU step")
-        f32 = dict(device=self.dev, dtype=torch.float32)
-        so, sd, stg = torch.zeros(n_rays, 3, **f32), torch.ones(n_rays, 3, **f32), torch.zeros(n_rays, 3, **f32)
-        TrainArena.get(self.dev, n_rays, self.max_samples)                 # allocate the arena outside the graph pool
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):                                       # warm-up on a side stream (torch graph rule)
-            for _ in range(2):
-                self._launch(so, sd, stg)
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            self.stats = self._launch(so, sd, stg)
-        self._graph, self._static = g, (so, sd, stg)
-        return g
+        TrainArena.get(self.dev, n_rays, self.max_samples)                 # allocate the arena outside the graph pools
+        self._march_sets(n_rays)
+        self._static_target = torch.zeros(n_rays, 3, device=self.dev, dtype=torch.float32)
+        self._graph = {}                                                    # march-set parity -> (CUDAGraph, outputs)
+        self._graph_n = n_rays
+        return self._graph
 
     # ------------------------------------------------------------------------------------------------ bookkeeping
     def update_density_grid(self, density_threshold, warmup=False, **kw):
