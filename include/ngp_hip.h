@@ -241,14 +241,15 @@ int ngp_sample_rays(const float* poses /*[n_img,3,4]*/, const float* directions 
                     float* rays_d, float* rgb, void* stream);
 
 /* ---- f-3  occupancy-grid update without host round trips (modules/networks.py:181-209,255-290).
- * compact : list[0..count) = cells of ONE cascade with density > threshold (count must be zeroed by the caller)
+ * compact : list[0..count) = cells of ONE cascade with density > threshold, in cell order (deterministic); count is written
  * sample  : m uniform cells (u_cell [m] in [0,1) -> Morton code) + m picks from the list (u_pick [m]) -> Morton indices [2m] and jittered
  *           world positions [2m,3] (u_jit [2m,3]); s = min(2^(c-1), scale), half_grid = s / grid_size
  * all_cells: warm-up variant, cell i = Morton code i
  * scatter : tmp[indices[i]] = sigmas[i] (indices == NULL: identity)
  * merge   : grid = grid < 0 ? grid : max(grid*decay, tmp); stats[0] += sum, stats[1] += count of positive cells (zero stats first)
  * pack    : bitfield bit = grid > min(stats[0]/stats[1], density_threshold) */
-int ngp_occ_compact(const float* density_grid, float threshold, int n_cells, int32_t* list, int32_t* count, void* stream);
+int ngp_occ_compact(const float* density_grid, float threshold, int n_cells, int32_t* list, int32_t* count,
+                    int32_t* scratch /*[1024]*/, void* stream);
 int ngp_occ_sample(const float* u_cell, const float* u_pick, const float* u_jit, const int32_t* list, const int32_t* count,
                    int m, int grid_size, float s, float half_grid, int32_t* indices, float* xyzs, void* stream);
 int ngp_occ_all_cells(const float* u_jit, int n_cells, int grid_size, float s, float half_grid, float* xyzs, void* stream);

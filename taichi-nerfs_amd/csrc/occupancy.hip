@@ -11,20 +11,45 @@
 namespace ngp {
 
 // cells of one cascade with density > threshold -> list[0 .. count) (order unspecified; they are sampled uniformly)
-__global__ void __launch_bounds__(256) occ_compact_kernel(const float* __restrict__ grid, float thr, int n_cells,
-                                                          int32_t* __restrict__ list, int32_t* __restrict__ count) {
-    // every wave owns a contiguous chunk: count it, reserve its slice with ONE returning atomic (same-address atomics
-    // serialise at ~12 ns each: one per 64 cells cost 390 us for 128^3 cells), then write it
-    const int n_waves = gridDim.x * (blockDim.x >> 6);
-    const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int chunk = ((n_cells + n_waves - 1) / n_waves + 63) & ~63;
-    const int lo = wave * chunk, hi = min(lo + chunk, n_cells);
+// Deterministic three-launch compaction (count per wave chunk -> one-block exclusive scan -> write): the list comes out in
+// cell order on every run and every rank (an atomic slice reservation would order the chunks by arrival), and nothing
+// serialises on a same-address atomic (~12 ns each: one per 64 cells once cost 390 us for 128^3 cells).
+constexpr int OCC_WAVES = 1024;            // 256 blocks x 4 waves; also the scan block's width
+__device__ __forceinline__ void occ_chunk(int n_cells, int& lo, int& hi) {
+    const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int chunk = ((n_cells + OCC_WAVES - 1) / OCC_WAVES + 63) & ~63;
+    lo = min(wave * chunk, n_cells); hi = min(lo + chunk, n_cells);
+}
+__global__ void __launch_bounds__(256) occ_count_kernel(const float* __restrict__ grid, float thr, int n_cells,
+                                                        int32_t* __restrict__ wave_counts) {
+    int lo, hi;
+    occ_chunk(n_cells, lo, hi);
+    const int lane = threadIdx.x & 63;
     int mine = 0;
     for (int i = lo + lane; i < hi; i += 64) mine += grid[i] > thr ? 1 : 0;                  // networks.py:198-199
     const int total = wave_sum_i(mine);
+    if (lane == 0) wave_counts[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = total;
+}
+__global__ void __launch_bounds__(OCC_WAVES) occ_scan_kernel(int32_t* __restrict__ wave_counts, int32_t* __restrict__ count) {
+    __shared__ int part[OCC_WAVES / 64];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int c = wave_counts[t];
+    int incl = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(incl, d, 64); if (lane >= d) incl += up; }
+    if (lane == 63) part[w] = incl;
+    __syncthreads();
     int base = 0;
-    if (lane == 0 && total) base = atomicAdd(count, total);
-    base = __shfl(base, 0, 64);
+    for (int k = 0; k < w; ++k) base += part[k];
+    wave_counts[t] = base + incl - c;                                                        // exclusive prefix = the chunk's slice start
+    if (t == OCC_WAVES - 1) count[0] = base + incl;
+}
+__global__ void __launch_bounds__(256) occ_write_kernel(const float* __restrict__ grid, float thr, int n_cells,
+                                                        const int32_t* __restrict__ wave_base, int32_t* __restrict__ list) {
+    int lo, hi;
+    occ_chunk(n_cells, lo, hi);
+    const int lane = threadIdx.x & 63;
+    int base = wave_base[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)];
     for (int i0 = lo; i0 < hi; i0 += 64) {
         const int i = i0 + lane;
         const bool occ = i < hi && grid[i] > thr;
@@ -128,11 +153,14 @@ using namespace ngp;
 
 extern "C" {
 
-int ngp_occ_compact(const float* density_grid, float threshold, int n_cells, int32_t* list, int32_t* count, void* stream) {
+int ngp_occ_compact(const float* density_grid, float threshold, int n_cells, int32_t* list, int32_t* count, int32_t* scratch,
+                    void* stream) {
     if (n_cells <= 0) return 0;
-    int blocks = (n_cells + 255) / 256;
-    if (blocks > 128) blocks = 128;                          // 512 waves -> 512 reserving atomics
-    hipLaunchKernelGGL(occ_compact_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, density_grid, threshold, n_cells, list, count);
+    if (!scratch) return -1;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(occ_count_kernel, dim3(OCC_WAVES / 4), dim3(256), 0, s, density_grid, threshold, n_cells, scratch);
+    hipLaunchKernelGGL(occ_scan_kernel, dim3(1), dim3(OCC_WAVES), 0, s, scratch, count);
+    hipLaunchKernelGGL(occ_write_kernel, dim3(OCC_WAVES / 4), dim3(256), 0, s, density_grid, threshold, n_cells, scratch, list);
     NGP_LAUNCH_CHECK();
     return 0;
 }
@@ -164,7 +192,7 @@ int ngp_occ_scatter(const int32_t* indices, const float* sigmas, int n, float* t
 int ngp_occ_merge(float* density_grid, const float* tmp, float decay, int n, float* stats, void* stream) {
     if (n <= 0) return 0;
     int blocks = (n + 255) / 256;
-    if (blocks > 1024) blocks = 1024;
+    if (blocks > 128) blocks = 128;            // two same-address atomics per block at ~12 ns each: keep the block count low
     hipLaunchKernelGGL(occ_merge_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, density_grid, tmp, decay, n, stats);
     NGP_LAUNCH_CHECK();
     return 0;

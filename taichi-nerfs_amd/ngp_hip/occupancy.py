@@ -25,6 +25,7 @@ class OccupancyUpdater:
         f32 = dict(device=dev, dtype=torch.float32)
         self.list = torch.empty(G3, device=dev, dtype=torch.int32)
         self.count = torch.zeros(1, device=dev, dtype=torch.int32)
+        self.scratch = torch.empty(1024, device=dev, dtype=torch.int32)
         self.indices = torch.empty(2 * self.M, device=dev, dtype=torch.int32)
         self.xyzs = torch.empty(n_max, 3, **f32)
         self.enc = torch.empty(n_max, 32, **f32)
@@ -71,8 +72,7 @@ class OccupancyUpdater:
                 u_sorted = (cs[:, :self.M] / cs[:, self.M:self.M + 1]).contiguous()
                 u_cell, u_pick = u_sorted[0], u_sorted[1]
                 u_jit = torch.rand(n * 3, device=self.dev)
-                self.count.zero_()
-                check(L.ngp_occ_compact(_ptr(grid_c), float(density_threshold), G3, _ptr(self.list), _ptr(self.count), st),
+                check(L.ngp_occ_compact(_ptr(grid_c), float(density_threshold), G3, _ptr(self.list), _ptr(self.count), _ptr(self.scratch), st),
                       "ngp_occ_compact")
                 check(L.ngp_occ_sample(_ptr(u_cell), _ptr(u_pick), _ptr(u_jit), _ptr(self.list), _ptr(self.count), self.M, G, s, hg,
                                        _ptr(self.indices), _ptr(self.xyzs), st), "ngp_occ_sample")

@@ -188,3 +188,22 @@ def test_fused_occupancy_update_matches_torch_formulation(hip_lib, monkeypatch):
     assert (g[before < 0] == before[before < 0]).all()
     assert (g[before >= 0] >= before[before >= 0] * 0.95 - 1e-6).all()      # decay/max merge
     assert ((g - before * 0.95).abs() > 1e-6).float().mean().item() > 0.2   # a good part of the cells was re-sampled
+
+
+def test_occupancy_compaction_is_deterministic_and_ordered(hip_lib):
+    """ngp_occ_compact: list == the occupied cells in cell order (what torch.nonzero gives in networks.py:198-199), count exact,
+    identical on every call (replicas on different ranks pick the same cells from it)."""
+    from ngp_hip import lib as L
+    from ngp_hip.ops import _ptr, _stream
+    lib = L.load()
+    torch.manual_seed(4)
+    for n_cells, frac in ((128**3, 0.04), (128**3, 0.9), (100003, 0.5), (64, 1.0)):
+        grid = torch.rand(n_cells, device="cuda")
+        thr = 1.0 - frac
+        lst = torch.full((n_cells,), -1, device="cuda", dtype=torch.int32)
+        cnt = torch.full((1,), -7, device="cuda", dtype=torch.int32)
+        scratch = torch.empty(1024, device="cuda", dtype=torch.int32)
+        L.check(lib.ngp_occ_compact(_ptr(grid), thr, n_cells, _ptr(lst), _ptr(cnt), _ptr(scratch), _stream()), "ngp_occ_compact")
+        want = torch.nonzero(grid > thr)[:, 0].to(torch.int32)
+        assert int(cnt) == want.numel()
+        assert torch.equal(lst[:want.numel()], want) and (lst[want.numel():] == -1).all()
