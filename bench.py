@@ -375,6 +375,12 @@ def main():
         eligible = [k for k in rooflines if not (k == "march_count" and use_trainer and args.prefetch and not args.graph)]
         dom = max(eligible, key=lambda k: ks[k]["total_ms"], default=None)
         roof = rooflines.get(dom)
+        if roof is not None and dom == "hash_bwd_f32":
+            # transparency: achieved prices EVERY live sample at the SURVEY 8(d) figure (like the reference's autodiff kernel);
+            # samples behind early termination carry exact-zero gradients and are skipped after their 140-byte read
+            roof = dict(roof, note="scatter-add skips zero-gradient samples (behind early termination): %.0f%% of the marched samples "
+                                   "were composited in this run; see profiles/microbench/r01_hash_bwd_breakdown.txt"
+                                   % (100.0 * vr / max(rm, 1)))
         out = {
             "metric": "training rays/sec", "value": total_rays / elapsed, "unit": "rays/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,

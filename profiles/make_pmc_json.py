@@ -10,7 +10,7 @@ import statistics
 import sys
 
 KEYS = {"hash_fwd_f32_xcd_kernel": "hash_fwd_f32", "hash_fwd_f32_kernel<2>": "hash_fwd_f32_generic", "hash_bwd_f32x2_kernel": "hash_bwd_f32", "mlp_fwd_kernelILb1": "mlp_fwd",
-        "mlp_bwd_kernel": "mlp_bwd", "adam_kernel": "adam", "march_count_kernel": "march_count",
+        "mlp_bwd_kernel": "mlp_bwd", "adam_kernel": "adam", "adam_all_kernel": "adam", "march_count_kernel": "march_count",
         "composite_fwd_kernel": "composite_fwd", "composite_bwd_kernel": "composite_bwd"}
 
 

@@ -118,7 +118,19 @@ __global__ void __launch_bounds__(256) occ_scatter_kernel(const int32_t* __restr
 __global__ void __launch_bounds__(256) occ_merge_kernel(float* __restrict__ grid, const float* __restrict__ tmp, float decay, int n,
                                                         float* __restrict__ stats /*[0] sum, [1] count*/) {
     float sum = 0.f, cnt = 0.f;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int n4 = n >> 2;
+    float4* g4 = reinterpret_cast<float4*>(grid);
+    const float4* t4 = reinterpret_cast<const float4*>(tmp);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) {
+        float4 g = g4[i];
+        const float4 t = t4[i];
+#define NGP_MERGE1(c) { if (!(g.c < 0.f)) g.c = fmaxf(g.c * decay, t.c); if (g.c > 0.f) { sum += g.c; cnt += 1.f; } }
+        NGP_MERGE1(x) NGP_MERGE1(y) NGP_MERGE1(z) NGP_MERGE1(w)
+#undef NGP_MERGE1
+        g4[i] = g;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {                   // tail (n is a multiple of 4 for 128^3 grids)
+        const int i = (n4 << 2) + threadIdx.x;
         float g = grid[i];
         if (!(g < 0.f)) g = fmaxf(g * decay, tmp[i]);
         grid[i] = g;
@@ -192,7 +204,8 @@ int ngp_occ_scatter(const int32_t* indices, const float* sigmas, int n, float* t
 int ngp_occ_merge(float* density_grid, const float* tmp, float decay, int n, float* stats, void* stream) {
     if (n <= 0) return 0;
     int blocks = (n + 255) / 256;
-    if (blocks > 128) blocks = 128;            // two same-address atomics per block at ~12 ns each: keep the block count low
+    blocks = (blocks + 3) / 4;                 // float4 per thread
+    if (blocks > 512) blocks = 512;            // two same-address atomics per block at ~12 ns each: keep the block count moderate
     hipLaunchKernelGGL(occ_merge_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, density_grid, tmp, decay, n, stats);
     NGP_LAUNCH_CHECK();
     return 0;
