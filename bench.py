@@ -38,6 +38,9 @@ TRAINER_KERNELS = {
     "ngp_hash_bwd_f32_ex": ("hash_bwd_f32", "hbm", 12 + 128 + 1024 + 1024, "sample"),
     "ngp_adam_step": ("adam", "hbm", 32, "param"),
     "ngp_adam_all": ("adam", "hbm", 32, "param"),                                  # table pass (+ the MLP block riding along)
+    "ngp_hash_fwd_f16_ex": ("hash_fwd_f16", "hbm", 12 + 512 + 128, "sample"),      # --half: 4-byte gathers, f32 output to the arena
+    "ngp_hash_bwd_f16_ex": ("hash_bwd_f16", "hbm", 12 + 128 + 512 + 512, "sample"),
+    "ngp_adam_all_ex": ("adam", "hbm", 32, "param"),
     "ngp_hash_fwd_bf16_ex": ("hash_fwd_bf16", "hbm", 12 + 512 + 128, "sample"),    # --table bf16: 4-byte gathers, f32 output
     "ngp_adam_step_bf16": ("adam_bf16", "hbm", 34, "param"),                       # + the 2-byte storage copy
 }
@@ -180,7 +183,7 @@ def main():
     timer = KernelTimer()
     timer.wrap(ops, "hash_fwd_f32", lambda xyzs, table, lv: xyzs.shape[0])
     timer.wrap(ops, "hash_bwd_f32", lambda xyzs, dout, lv, dtable: xyzs.shape[0])
-    use_trainer = args.path == "trainer" and not args.half
+    use_trainer = args.path == "trainer"
 
     torch.manual_seed(23)                       # identical replicas on every rank (train.py:39-42 uses 23)
     np.random.seed(23)
@@ -208,7 +211,7 @@ def main():
     trainer = None
     if use_trainer:
         from ngp_hip.trainer import FusedTrainer
-        trainer = FusedTrainer(model, lr=1e-2, max_steps=20000, init_scale=2.0**19, world_size=world,
+        trainer = FusedTrainer(model, lr=1e-2, max_steps=20000, init_scale=2.0**16 if args.half else 2.0**19, world_size=world,
                                exp_step_factor=esf, distortion_loss_w=w_dist,
                                grad_comm_dtype=torch.bfloat16 if args.comm == "bf16" else torch.float32)
     else:
@@ -335,7 +338,7 @@ def main():
                     if name == "ngp_adam_step" and a[4] < 1000000:
                         continue                               # the 9 408-weight pass: keep the table pass only
                     if unit == "param":
-                        units = float(a[4])
+                        units = float(a[5] if name == "ngp_adam_all_ex" else a[4])
                     elif unit == "ray":
                         units = float(args.rays)
                     elif unit == "n_arg":
@@ -343,7 +346,7 @@ def main():
                     else:
                         # _ex launches: device-side count (the live samples of the step) unless n_dev is NULL
                         # (occupancy-update encodes: exact n = arg 3)
-                        n_dev = a[4] if name in ("ngp_hash_fwd_f32_ex", "ngp_hash_fwd_bf16_ex", "ngp_mlp_fwd_ex") else None
+                        n_dev = a[4] if name in ("ngp_hash_fwd_f32_ex", "ngp_hash_fwd_bf16_ex", "ngp_hash_fwd_f16_ex", "ngp_mlp_fwd_ex") else None
                         units = float(a[3]) if (n_dev is not None and getattr(n_dev, "value", 1) is None) else float(live)
                     work = per_unit * units + (8 * live if key == "march_count" else 0)
                     rec = agg.setdefault(key, [0, 0.0, 0.0, bound, per_unit, "sample" if unit == "n_arg" else unit, 0.0])

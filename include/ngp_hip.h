@@ -127,6 +127,19 @@ int ngp_hash_fwd_f16(const float* xyzs, const uint16_t* table, const ngp_hash_le
 int ngp_hash_bwd_f16(const float* xyzs, const uint16_t* dout, const ngp_hash_levels* lv, int n,
                      uint16_t* dtable /*[entries,2] f16*/, void* stream);
 
+/* Fused-path forms of the half2 encoder (same arithmetic, the buffers of the fp32 fused path): the forward widens its f16
+ * result to f32 (exact) into the natural [n,32] or the pair-major layout; the backward takes the fp32 d_enc of the fused MLP
+ * backward, rounds it to f16 like the reference's fp16 output gradient, merges equal-cell runs of consecutive samples before
+ * the packed f16 atomic (so the f16 accumulation order differs from a serial run: tolerance-checked), and flags non-finite
+ * incoming gradients.  ngp_check_finite_f16 scans the ACCUMULATED f16 gradient (n % 8 == 0) for inf / nan. */
+int ngp_hash_fwd_f16_ex(const float* xyzs, const uint16_t* table, const ngp_hash_levels* lv, int n_max,
+                        const int32_t* n_dev, int normalize, float lo, float hi, int enc_pairs, float* out,
+                        void* stream);
+int ngp_hash_bwd_f16_ex(const float* xyzs, const float* dout, const ngp_hash_levels* lv, int n_max,
+                        const int32_t* n_dev, int normalize, float lo, float hi, int enc_pairs, uint16_t* dtable,
+                        int32_t* found_inf, void* stream);
+int ngp_check_finite_f16(const uint16_t* g, long long n, int32_t* found_inf, void* stream);
+
 /* ---- a-6  dir_encoder (modules/spherical_harmonics.py:7-42) + analytic backward -------------- */
 int ngp_sh16_fwd(const float* dirs /*[n,3]*/, int n, float* out /*[n,16]*/, void* stream);
 int ngp_sh16_bwd(const float* dirs, const float* dout /*[n,16]*/, int n, float* ddirs /*[n,3]*/,
@@ -209,6 +222,12 @@ int ngp_cast_f32_bf16(const float* src, uint16_t* dst, long long n, void* stream
 int ngp_adam_all(float* table, float* table_g, float* table_m, float* table_v, long long n, uint16_t* table_bf16,
                  float* mlp, float* mlp_g, float* mlp_m, float* mlp_v, const float* state_f, const int32_t* state_i,
                  float beta1, float beta2, float eps, int enc_pairs, uint16_t* wpack, void* stream);
+/* General form: table_g is fp32 or (grad_is_f16) the half2 encoder's f16 gradient buffer, widened to fp32 on the fly;
+ * copy_kind 0 = no storage copy, 1 = bf16, 2 = f16 (the table the f16 forward gathers from, hash_encoder_half.py:367). */
+int ngp_adam_all_ex(float* table, void* table_g, int grad_is_f16, float* table_m, float* table_v, long long n,
+                    uint16_t* table_16, int copy_kind, float* mlp, float* mlp_g, float* mlp_m, float* mlp_v,
+                    const float* state_f, const int32_t* state_i, float beta1, float beta2, float eps, int enc_pairs,
+                    uint16_t* wpack, void* stream);
 /* Adam on the 9 408 flat MLP weights (W1|W2|W3|W4|W5) + the fp16 fragment repack for the next step, one launch. */
 int ngp_adam_mlp_pack(float* p, float* g, float* m, float* v, const float* state_f, const int32_t* state_i,
                       float beta1, float beta2, float eps, int enc_pairs, uint16_t* wpack, void* stream);

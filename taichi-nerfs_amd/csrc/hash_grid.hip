@@ -151,7 +151,10 @@ __global__ void __launch_bounds__(256) hash_fwd_f32_kernel(const float* __restri
 // enc_pairs = 1 writes the PAIR-MAJOR layout out[(pair * n_max + i) * 4 + which * 2 + f] (pair = min(l, 15-l), which = l >= 8):
 // every block then stores 16 contiguous bytes per sample instead of two 8-byte pieces of a 128-byte row shared with the
 // other seven XCDs (another 1.5x, same microbenchmark); the fused MLP kernels and the scatter-add consume that layout.
-template <bool BF16>
+// MODE 0: f32 table.  MODE 1: bf16 storage copy, f32 arithmetic.  MODE 2: the half2 encoder's arithmetic (hash_encoder_half.py:
+// 112-161: f16 table, cell cast to f16 before the subtract, every w * table term rounded to f16, f16 accumulation) with the
+// result widened to f32 (exact) so the consumers of the fused path stay the same.
+template <int MODE>
 __global__ void __launch_bounds__(256) hash_fwd_f32_xcd_kernel(const float* __restrict__ xyzs, const float* __restrict__ table,
                                                                ngp_hash_levels lv, int n, const int32_t* __restrict__ n_dev,
                                                                XyzNorm nm, int enc_pairs, float* __restrict__ out) {
@@ -166,16 +169,25 @@ __global__ void __launch_bounds__(256) hash_fwd_f32_xcd_kernel(const float* __re
         const float x = norm01(nm, xyzs[3 * (size_t)i]), y = norm01(nm, xyzs[3 * (size_t)i + 1]),
                     z = norm01(nm, xyzs[3 * (size_t)i + 2]);
         Corners c;
-        corners<false>(L, level, lv.begin_fast_hash_level, x, y, z, c);
+        corners<MODE == 2>(L, level, lv.begin_fast_hash_level, x, y, z, c);
         float2 v[8];
 #pragma unroll
         for (int ci = 0; ci < 8; ++ci) {
-            if constexpr (BF16) v[ci] = bf16x2_to_f32(reinterpret_cast<const uint32_t*>(table)[c.idx[ci]]);
+            if constexpr (MODE == 1) v[ci] = bf16x2_to_f32(reinterpret_cast<const uint32_t*>(table)[c.idx[ci]]);
+            else if constexpr (MODE == 2) v[ci] = __half22float2(reinterpret_cast<const __half2*>(table)[c.idx[ci]]);
             else v[ci] = *reinterpret_cast<const float2*>(table + (size_t)c.idx[ci] * 2);
         }
         float a0 = 0.0f, a1 = 0.0f;
+        if constexpr (MODE == 2) {
+            __half2 acc = __floats2half2_rn(0.0f, 0.0f);
 #pragma unroll
-        for (int ci = 0; ci < 8; ++ci) { a0 += c.w[ci] * v[ci].x; a1 += c.w[ci] * v[ci].y; }   // same order as the generic kernel
+            for (int ci = 0; ci < 8; ++ci) acc = __hadd2(acc, __floats2half2_rn(c.w[ci] * v[ci].x, c.w[ci] * v[ci].y));   // :159
+            const float2 r = __half22float2(acc);
+            a0 = r.x; a1 = r.y;
+        } else {
+#pragma unroll
+            for (int ci = 0; ci < 8; ++ci) { a0 += c.w[ci] * v[ci].x; a1 += c.w[ci] * v[ci].y; }   // same order as the generic kernel
+        }
         float* o = enc_pairs ? out + ((size_t)pair * plane + i) * 4 + which * 2 : out + (size_t)i * 32 + level * 2;
         *reinterpret_cast<float2*>(o) = make_float2(a0, a1);
     }
@@ -351,6 +363,108 @@ __global__ void __launch_bounds__(256) hash_bwd_f16_kernel(const float* __restri
     }
 }
 
+// half2 backward, fused-path form: same arithmetic per contribution as hash_bwd_f16_kernel (g = f16(dout), val = f16(w * g),
+// zero skip, packed f16x2 atomic), shaped like hash_bwd_f32x2_kernel: a lane pair = (sample, x-corner bit) -- the two entries are
+// adjacent 4-byte words, one 64-byte line 7 times out of 8 -- a wave = 32 consecutive samples x one level, and equal-cell
+// runs of consecutive samples are summed (in f32, rounded once) with a segmented wave scan before the single atomic.
+// dout is the fp32 d_enc of the fused MLP backward (natural or pair-major layout).
+__global__ void __launch_bounds__(256) hash_bwd_f16x2_kernel(const float* __restrict__ xyzs, const float* __restrict__ dout,
+                                                             ngp_hash_levels lv, int n, const int32_t* __restrict__ n_dev,
+                                                             XyzNorm nm, int enc_pairs, __half2* __restrict__ dtable,
+                                                             int32_t* __restrict__ found_inf) {
+    __shared__ LevelLDS L;
+    load_levels(lv, L);
+    const size_t plane = (size_t)n;
+    if (n_dev) n = min(n, *n_dev);
+    const int nl = lv.n_levels, bfhl = lv.begin_fast_hash_level;
+    const int lane = threadIdx.x & 63;
+    const int s_in = lane >> 1, xb = lane & 1;
+    const int n_tiles = (n + 31) >> 5;
+    const int waves_per_block = blockDim.x >> 6;
+    typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+    for (int tile = blockIdx.x * waves_per_block + (threadIdx.x >> 6); tile < n_tiles; tile += gridDim.x * waves_per_block) {
+        const int i = tile * 32 + s_in;
+        const bool valid = i < n;
+        float x = 0.f, y = 0.f, z = 0.f;
+        if (valid) { x = norm01(nm, xyzs[3 * (size_t)i]); y = norm01(nm, xyzs[3 * (size_t)i + 1]); z = norm01(nm, xyzs[3 * (size_t)i + 2]); }
+        for (int level = 0; level < nl; ++level) {
+            float2 g = make_float2(0.f, 0.f);
+            if (valid) {
+                const float* gp = enc_pairs ? dout + ((size_t)(level < 8 ? level : 15 - level) * plane + i) * 4 + (level < 8 ? 0 : 2)
+                                            : dout + (size_t)i * (nl * 2) + level * 2;
+                g = *reinterpret_cast<const float2*>(gp);
+            }
+            g = __half22float2(__floats2half2_rn(g.x, g.y));              // the encoder's output gradient is an fp16 tensor
+            if (found_inf && !(isfinite(g.x) && isfinite(g.y))) *found_inf = 1;
+            const float scale = L.scale[level];
+            const uint32_t res = L.res[level], size = L.size[level], mode = L.mode[level];
+            const float px = x * scale + 0.5f, py = y * scale + 0.5f, pz = z * scale + 0.5f;
+            const uint32_t cx = f2u_sat(floorf(px)), cy = f2u_sat(floorf(py)), cz = f2u_sat(floorf(pz));
+            // hash_encoder_half.py:133: the cell is cast to f16 before the subtract
+            const float fx = px - __half2float(__float2half_rn((float)cx)), fy = py - __half2float(__float2half_rn((float)cy)),
+                        fz = pz - __half2float(__float2half_rn((float)cz));
+            const uint32_t pcx = __shfl_up(cx, 2, 64), pcy = __shfl_up(cy, 2, 64), pcz = __shfl_up(cz, 2, 64);
+            const int pvalid = __shfl_up((int)valid, 2, 64);
+            const bool head = (s_in == 0) || !valid || !pvalid || cx != pcx || cy != pcy || cz != pcz;
+            const int nhead = __shfl_down((int)head, 2, 64);
+            const bool tail = valid && ((s_in == 31) || nhead);
+            const float wx = xb ? fx : 1.0f - fx;
+            const uint32_t gx = cx + (uint32_t)xb;
+            float v0[4], v1[4];
+            uint32_t e[4];
+            const bool dense = level < bfhl;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {              // k = (z bit, y bit)
+                const int yb = k & 1, zb = k >> 1;
+                const float w = (1.0f * wx) * (yb ? fy : 1.0f - fy) * (zb ? fz : 1.0f - fz);
+                const uint32_t gy = cy + (uint32_t)yb, gz = cz + (uint32_t)zb;
+                uint32_t h = dense ? (gx + gy * res + gz * res * res) : (gx ^ (gy * 2654435761u) ^ (gz * 805459861u));
+                if (mode == 1u) h &= (size - 1u);
+                else if (mode == 0u) { if (h >= size) { h -= size; if (h >= size) h %= size; } }
+                else h = h % size;
+                e[k] = L.offset[level] + h;
+                const float2 r = __half22float2(__floats2half2_rn(w * g.x, w * g.y));          // cast(w * g, f16) :205-208
+                v0[k] = r.x; v1[k] = r.y;
+            }
+            bool hf = head;
+#pragma unroll
+            for (int d = 2; d < 64; d <<= 1) {
+                const int hup = __shfl_up((int)hf, d, 64);
+                float u0[4], u1[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { u0[k] = __shfl_up(v0[k], d, 64); u1[k] = __shfl_up(v1[k], d, 64); }
+                if (lane >= d && !hf) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { v0[k] += u0[k]; v1[k] += u1[k]; }
+                    hf = hup != 0;
+                }
+            }
+            if (tail) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    half2v val;
+                    val.x = (_Float16)v0[k]; val.y = (_Float16)v1[k];
+                    if (val.x == (_Float16)0 && val.y == (_Float16)0) continue;                 // :212
+                    __builtin_amdgcn_global_atomic_fadd_v2f16((__attribute__((address_space(1))) half2v*)(dtable + e[k]), val);
+                }
+            }
+        }
+    }
+}
+
+// any non-finite value in an f16 gradient buffer -> *found_inf = 1 (f16 sums overflow easily: GradScaler's check has to see
+// the ACCUMULATED gradient, train.py:199)
+__global__ void __launch_bounds__(256) check_finite_f16_kernel(const uint4* __restrict__ g, long n8, int32_t* __restrict__ found_inf) {
+    bool bad = false;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+        const uint4 v = g[i];
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) bad |= ((w[k] & 0x7c00u) == 0x7c00u) || ((w[k] & 0x7c000000u) == 0x7c000000u);   // exponent all ones
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) *found_inf = 1;
+}
+
 inline int grid_for(long long work, int block) {
     long long b = (work + block - 1) / block;
     const long long cap = 256LL * 16;      // 256 CUs x 16 blocks, grid-stride beyond that
@@ -376,7 +490,7 @@ int ngp_hash_fwd_f32_ex(const float* xyzs, const float* table, const ngp_hash_le
     if (lv->n_features == 2 && lv->n_levels == 16 && (n_max >= 4096 || enc_pairs)) {
         int tiles = (n_max + 127) / 128;
         if (tiles > 512) tiles = 512;                       // 4096 blocks, tile-stride beyond
-        hipLaunchKernelGGL(hash_fwd_f32_xcd_kernel<false>, dim3(8 * tiles), dim3(256), 0, s, xyzs, table, *lv, n_max, n_dev, nm, enc_pairs, out);
+        hipLaunchKernelGGL(hash_fwd_f32_xcd_kernel<0>, dim3(8 * tiles), dim3(256), 0, s, xyzs, table, *lv, n_max, n_dev, nm, enc_pairs, out);
         NGP_LAUNCH_CHECK();
         return 0;
     }
@@ -402,7 +516,7 @@ int ngp_hash_fwd_bf16_ex(const float* xyzs, const uint16_t* table, const ngp_has
     if (lv->n_levels == 16 && (n_max >= 4096 || enc_pairs)) {
         int tiles = (n_max + 127) / 128;
         if (tiles > 512) tiles = 512;
-        hipLaunchKernelGGL(hash_fwd_f32_xcd_kernel<true>, dim3(8 * tiles), dim3(256), 0, s, xyzs, t, *lv, n_max, n_dev, nm, enc_pairs, out);
+        hipLaunchKernelGGL(hash_fwd_f32_xcd_kernel<1>, dim3(8 * tiles), dim3(256), 0, s, xyzs, t, *lv, n_max, n_dev, nm, enc_pairs, out);
     } else {
         const int grid = grid_for((long long)n_max * lv->n_levels, 256);
         hipLaunchKernelGGL((hash_fwd_f32_kernel<2, true>), dim3(grid), dim3(256), 0, s, xyzs, t, *lv, n_max, n_dev, nm, out);
@@ -459,6 +573,44 @@ int ngp_hash_bwd_f16(const float* xyzs, const uint16_t* dout, const ngp_hash_lev
     const int grid = grid_for((long long)n * lv->n_levels, 256);
     hipLaunchKernelGGL(hash_bwd_f16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, xyzs, (const __half2*)dout, *lv, n,
                        (__half2*)dtable);
+    NGP_LAUNCH_CHECK();
+    return 0;
+}
+
+int ngp_hash_fwd_f16_ex(const float* xyzs, const uint16_t* table, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev,
+                        int normalize, float lo, float hi, int enc_pairs, float* out, void* stream) {
+    if (n_max <= 0) return 0;
+    if (lv->n_levels != 16 || lv->n_features != 2) return -1;
+    int tiles = (n_max + 127) / 128;
+    if (tiles > 512) tiles = 512;
+    const XyzNorm nm = {normalize, lo, hi};
+    hipLaunchKernelGGL(hash_fwd_f32_xcd_kernel<2>, dim3(8 * tiles), dim3(256), 0, (hipStream_t)stream, xyzs,
+                       reinterpret_cast<const float*>(table), *lv, n_max, n_dev, nm, enc_pairs, out);
+    NGP_LAUNCH_CHECK();
+    return 0;
+}
+
+int ngp_hash_bwd_f16_ex(const float* xyzs, const float* dout, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev, int normalize,
+                        float lo, float hi, int enc_pairs, uint16_t* dtable, int32_t* found_inf, void* stream) {
+    if (n_max <= 0) return 0;
+    if (lv->n_features != 2 || lv->n_levels < 1 || lv->n_levels > NGP_MAX_LEVELS) return -1;
+    if (enc_pairs && lv->n_levels != 16) return -1;
+    const XyzNorm nm = {normalize, lo, hi};
+    const int tiles = (n_max + 31) / 32;
+    const int g2 = tiles < 4 ? 1 : (tiles / 4 < 8192 ? (tiles + 3) / 4 : 8192);
+    hipLaunchKernelGGL(hash_bwd_f16x2_kernel, dim3(g2), dim3(256), 0, (hipStream_t)stream, xyzs, dout, *lv, n_max, n_dev, nm, enc_pairs,
+                       (__half2*)dtable, found_inf);
+    NGP_LAUNCH_CHECK();
+    return 0;
+}
+
+int ngp_check_finite_f16(const uint16_t* g, long long n, int32_t* found_inf, void* stream) {
+    if (n <= 0) return 0;
+    if (n % 8 != 0) return -1;
+    long blocks = (n / 8 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(check_finite_f16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)g, (long)(n / 8),
+                       found_inf);
     NGP_LAUNCH_CHECK();
     return 0;
 }

@@ -148,15 +148,15 @@ __global__ void __launch_bounds__(1024) adam_mlp_pack_kernel(float* __restrict__
 
 // The whole optimizer pass in ONE launch: block 0 (dispatched first) does the MLP weights + repack while blocks 1.. stream the
 // hash table -- the 16 us small-kernel tail of the step disappears under the 46 us table pass.
-template <bool SHADOW>
-__global__ void __launch_bounds__(1024) adam_all_kernel(float4* __restrict__ tp, float4* __restrict__ tg, float4* __restrict__ tm,
+template <int SHADOW, bool GRAD16>
+__global__ void __launch_bounds__(1024) adam_all_kernel(float4* __restrict__ tp, void* __restrict__ tg, float4* __restrict__ tm,
                                                         float4* __restrict__ tv, long n4, uint2* __restrict__ shadow,
                                                         float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                         float* __restrict__ v, const float* __restrict__ sf,
                                                         const int32_t* __restrict__ si, float beta1, float beta2, float eps,
                                                         int pairs, half_t* __restrict__ wpack) {
     if (blockIdx.x == 0) adam_mlp_pack_block(p, g, m, v, sf, si, beta1, beta2, eps, pairs, wpack);
-    else adam_table_pass<SHADOW>(tp, tg, tm, tv, n4, sf, si, beta1, beta2, eps, shadow, (long)blockIdx.x - 1, (long)gridDim.x - 1);
+    else adam_table_pass<SHADOW, GRAD16>(tp, tg, tm, tv, n4, sf, si, beta1, beta2, eps, shadow, (long)blockIdx.x - 1, (long)gridDim.x - 1);
 }
 
 // ---- per-lane helpers -------------------------------------------------------------------------------------
@@ -608,24 +608,35 @@ int ngp_adam_mlp_pack(float* p, float* g, float* m, float* v, const float* state
     return 0;
 }
 
-int ngp_adam_all(float* table, float* table_g, float* table_m, float* table_v, long long n, uint16_t* table_bf16, float* mlp,
-                 float* mlp_g, float* mlp_m, float* mlp_v, const float* state_f, const int32_t* state_i, float beta1, float beta2,
-                 float eps, int enc_pairs, uint16_t* wpack, void* stream) {
+#define NGP_ADAM_ALL(SH, G16)                                                                                                     \
+    hipLaunchKernelGGL((adam_all_kernel<SH, G16>), grid, block, 0, (hipStream_t)stream, (float4*)table, table_g, (float4*)table_m,    \
+                       (float4*)table_v, n4, (uint2*)table_16, mlp, mlp_g, mlp_m, mlp_v, state_f, state_i, beta1, beta2, eps,         \
+                       enc_pairs, (half_t*)wpack)
+
+int ngp_adam_all_ex(float* table, void* table_g, int grad_is_f16, float* table_m, float* table_v, long long n, uint16_t* table_16,
+                    int copy_kind, float* mlp, float* mlp_g, float* mlp_m, float* mlp_v, const float* state_f, const int32_t* state_i,
+                    float beta1, float beta2, float eps, int enc_pairs, uint16_t* wpack, void* stream) {
     if (n <= 0 || n % 4 != 0) return -1;
+    if ((copy_kind != 0) != (table_16 != nullptr) || copy_kind < 0 || copy_kind > 2) return -1;
     const long n4 = (long)(n / 4);
     long blocks = (n4 + 1023) / 1024;
     if (blocks > 256L * 4) blocks = 256L * 4;                 // 4 x 1024-thread blocks per CU, grid-stride beyond
     const dim3 grid((unsigned)blocks + 1), block(1024);
-    if (table_bf16)
-        hipLaunchKernelGGL(adam_all_kernel<true>, grid, block, 0, (hipStream_t)stream, (float4*)table, (float4*)table_g, (float4*)table_m,
-                           (float4*)table_v, n4, (uint2*)table_bf16, mlp, mlp_g, mlp_m, mlp_v, state_f, state_i, beta1, beta2, eps,
-                           enc_pairs, (half_t*)wpack);
-    else
-        hipLaunchKernelGGL(adam_all_kernel<false>, grid, block, 0, (hipStream_t)stream, (float4*)table, (float4*)table_g, (float4*)table_m,
-                           (float4*)table_v, n4, (uint2*)nullptr, mlp, mlp_g, mlp_m, mlp_v, state_f, state_i, beta1, beta2, eps,
-                           enc_pairs, (half_t*)wpack);
+    if (grad_is_f16) {
+        if (copy_kind == 2) NGP_ADAM_ALL(2, true); else if (copy_kind == 1) NGP_ADAM_ALL(1, true); else NGP_ADAM_ALL(0, true);
+    } else {
+        if (copy_kind == 2) NGP_ADAM_ALL(2, false); else if (copy_kind == 1) NGP_ADAM_ALL(1, false); else NGP_ADAM_ALL(0, false);
+    }
     NGP_LAUNCH_CHECK();
     return 0;
+}
+#undef NGP_ADAM_ALL
+
+int ngp_adam_all(float* table, float* table_g, float* table_m, float* table_v, long long n, uint16_t* table_bf16, float* mlp,
+                 float* mlp_g, float* mlp_m, float* mlp_v, const float* state_f, const int32_t* state_i, float beta1, float beta2,
+                 float eps, int enc_pairs, uint16_t* wpack, void* stream) {
+    return ngp_adam_all_ex(table, table_g, 0, table_m, table_v, n, table_bf16, table_bf16 ? 1 : 0, mlp, mlp_g, mlp_m, mlp_v, state_f,
+                           state_i, beta1, beta2, eps, enc_pairs, wpack, stream);
 }
 
 static inline int mlp_grid(int S) {

@@ -6,6 +6,7 @@
 // tolerance-checked instead of bit-checked.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
 #include <stdint.h>
 #include "../../include/ngp_hip.h"
 
@@ -119,19 +120,36 @@ __device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {
     return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
 }
 
+// round-to-nearest-even f32 -> f16 bits (the per-forward cast of hash_encoder_half.py:367)
+__device__ __forceinline__ uint32_t f32_to_f16_bits(float f) { return (uint32_t)__half_as_ushort(__float2half_rn(f)); }
+
 // torch.optim.Adam(eps) arithmetic on float4s, grid-stride over `n_blocks` blocks of which this is `block`; unscales the
-// gradient on the fly and zero-fills it.  SHADOW: also refresh a bf16 copy of the parameters.
-template <bool SHADOW>
-__device__ __forceinline__ void adam_table_pass(float4* __restrict__ p, float4* __restrict__ g, float4* __restrict__ m,
+// gradient on the fly and zero-fills it.
+// SHADOW: also refresh a 16-bit storage copy of the parameters (1 = bf16, 2 = f16).  GRAD16: the gradient buffer is f16 (the
+// half2 encoder's, hash_encoder_half.py:350-358) and is widened to f32 here, like autograd does for the fp32 master parameter.
+template <int SHADOW, bool GRAD16 = false>
+__device__ __forceinline__ void adam_table_pass(float4* __restrict__ p, void* __restrict__ gv, float4* __restrict__ m,
                                                 float4* __restrict__ v, long n4, const float* __restrict__ sf,
                                                 const int32_t* __restrict__ si, float beta1, float beta2, float eps,
                                                 uint2* __restrict__ shadow, long block, long n_blocks) {
     const bool skip = si[SI_SKIP] != 0;
     const float inv_scale = sf[SF_INV_SCALE], step_size = sf[SF_LR] / sf[SF_BC1], bc2_sqrt = sf[SF_BC2_SQRT];
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4* g32 = reinterpret_cast<float4*>(gv);
+    uint2* g16 = reinterpret_cast<uint2*>(gv);
     for (long i = block * blockDim.x + threadIdx.x; i < n4; i += n_blocks * blockDim.x) {
-        if (skip) { g[i] = zero; continue; }
-        const float4 gi = g[i];
+        float4 gi;
+        if constexpr (GRAD16) {
+            const uint2 r = g16[i];
+            const float2 a = __half22float2(*reinterpret_cast<const __half2*>(&r.x)), b = __half22float2(*reinterpret_cast<const __half2*>(&r.y));
+            gi = make_float4(a.x, a.y, b.x, b.y);
+        } else {
+            gi = g32[i];
+        }
+        if (skip) {
+            if constexpr (GRAD16) g16[i] = make_uint2(0u, 0u); else g32[i] = zero;
+            continue;
+        }
         float4 mi = m[i], vi = v[i];
         // an entry that never received a gradient (g = m = v = 0) is a fixed point of Adam: m' = v' = 0 and the update is
         // lr * 0 / (0 + eps) = 0 exactly -- skip its parameter read and all four writes (hashed levels of a sparse scene
@@ -150,10 +168,14 @@ __device__ __forceinline__ void adam_table_pass(float4* __restrict__ p, float4* 
         }
         NGP_ADAM1(x) NGP_ADAM1(y) NGP_ADAM1(z) NGP_ADAM1(w)
 #undef NGP_ADAM1
-        p[i] = pi; m[i] = mi; v[i] = vi; g[i] = zero;
-        if constexpr (SHADOW)
+        p[i] = pi; m[i] = mi; v[i] = vi;
+        if constexpr (GRAD16) g16[i] = make_uint2(0u, 0u); else g32[i] = zero;
+        if constexpr (SHADOW == 1)
             shadow[i] = make_uint2(f32_to_bf16_bits(pi.x) | (f32_to_bf16_bits(pi.y) << 16),
                                    f32_to_bf16_bits(pi.z) | (f32_to_bf16_bits(pi.w) << 16));
+        if constexpr (SHADOW == 2)
+            shadow[i] = make_uint2(f32_to_f16_bits(pi.x) | (f32_to_f16_bits(pi.y) << 16),
+                                   f32_to_f16_bits(pi.z) | (f32_to_f16_bits(pi.w) << 16));
     }
 }
 

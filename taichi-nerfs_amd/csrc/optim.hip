@@ -45,7 +45,7 @@ __global__ void train_prologue_kernel(float* __restrict__ sf, int32_t* __restric
 
 // the dense Adam pass itself (adam_table_pass) lives in ngp_device.h: the fused "table + MLP + repack" kernel of mlp.hip runs the
 // same code.  SHADOW: also refresh a bf16 copy of the parameters (the table the bf16 hash forward gathers from).
-template <bool SHADOW>
+template <int SHADOW>
 __global__ void __launch_bounds__(256) adam_kernel(float4* __restrict__ p, float4* __restrict__ g, float4* __restrict__ m,
                                                    float4* __restrict__ v, long n4, const float* __restrict__ sf,
                                                    const int32_t* __restrict__ si, float beta1, float beta2, float eps,
@@ -114,7 +114,7 @@ int ngp_adam_step(float* p, float* g, float* m, float* v, long long n, const flo
     const long n4 = (long)(n / 4);
     long blocks = (n4 + 255) / 256;
     if (blocks > 256L * 16) blocks = 256L * 16;
-    hipLaunchKernelGGL(adam_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (float4*)p, (float4*)g, (float4*)m,
+    hipLaunchKernelGGL(adam_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (float4*)p, (float4*)g, (float4*)m,
                        (float4*)v, n4, state_f, state_i, beta1, beta2, eps, (uint2*)nullptr);
     NGP_LAUNCH_CHECK();
     return 0;
@@ -127,7 +127,7 @@ int ngp_adam_step_bf16(float* p, float* g, float* m, float* v, long long n, cons
     const long n4 = (long)(n / 4);
     long blocks = (n4 + 255) / 256;
     if (blocks > 256L * 16) blocks = 256L * 16;
-    hipLaunchKernelGGL(adam_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (float4*)p, (float4*)g, (float4*)m,
+    hipLaunchKernelGGL(adam_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (float4*)p, (float4*)g, (float4*)m,
                        (float4*)v, n4, state_f, state_i, beta1, beta2, eps, (uint2*)p_bf16);
     NGP_LAUNCH_CHECK();
     return 0;

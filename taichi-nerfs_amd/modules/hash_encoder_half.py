@@ -61,6 +61,22 @@ class HashEncoder(torch.nn.Module):
         self.register_buffer('hash_grad', torch.zeros_like(self.hash_table, dtype=torch.float32))
         self._grad_h = None
 
+    @property
+    def levels_struct(self):
+        return self._levels
+
+    def table_f16(self):
+        """fp16 copy of the fp32 master table for the fused kernels; re-cast (the reference casts on every forward, :367) only
+        when the parameter was written through torch.  FusedTrainer updates parameter AND copy in its Adam kernel."""
+        t = self.hash_table
+        ver = (t.data_ptr(), t._version)
+        if getattr(self, "_f16", None) is None or self._f16.device != t.device:
+            self._f16, self._f16_ver = torch.empty(t.shape, device=t.device, dtype=torch.float16), None
+        if self._f16_ver != ver:
+            self._f16.copy_(t.detach())
+            self._f16_ver = ver
+        return self._f16
+
     def _grad_f16(self, device):
         if self._grad_h is None or self._grad_h.device != device:
             self._grad_h = torch.zeros(self.hash_table.shape, device=device, dtype=torch.float16)

@@ -208,7 +208,7 @@ class NGP(nn.Module):
 
     @torch.no_grad()
     def update_density_grid(self, density_threshold, warmup=False, decay=0.95, erode=False):
-        if (not erode and self.density_grid.is_cuda and self._fused_ok(self.density_grid) and not self.half_opt
+        if (not erode and self.density_grid.is_cuda and self._fused_ok(self.density_grid)
                 and os.environ.get("NGP_FUSED_OCCUPANCY", "1") != "0"):
             # same algorithm, device-resident (no torch.nonzero / .item() host round trips): ngp_hip/occupancy.py
             upd = getattr(self, '_occ_updater', None)

@@ -89,6 +89,9 @@ SIGNATURES = {
     "ngp_hash_bwd_f32_ex": [_P, _P, _LV, _I, _P, _I, _F, _F, _I, _P, _P, _P],
     "ngp_hash_fwd_f16": [_P, _P, _LV, _I, _P, _P],
     "ngp_hash_bwd_f16": [_P, _P, _LV, _I, _P, _P],
+    "ngp_hash_fwd_f16_ex": [_P, _P, _LV, _I, _P, _I, _F, _F, _I, _P, _P],
+    "ngp_hash_bwd_f16_ex": [_P, _P, _LV, _I, _P, _I, _F, _F, _I, _P, _P, _P],
+    "ngp_check_finite_f16": [_P, ctypes.c_longlong, _P, _P],
     "ngp_sh16_fwd": [_P, _I, _P, _P],
     "ngp_sh16_bwd": [_P, _P, _I, _P, _P],
     "ngp_composite_train_fwd": [_P, _P, _I, _P, _P, _P, _F, _I, _P, _P, _P, _P, _P, _P],
@@ -107,6 +110,7 @@ SIGNATURES = {
     "ngp_adam_step_bf16": [_P, _P, _P, _P, ctypes.c_longlong, _P, _P, _F, _F, _F, _P, _P],
     "ngp_cast_f32_bf16": [_P, _P, ctypes.c_longlong, _P],
     "ngp_adam_all": [_P, _P, _P, _P, ctypes.c_longlong, _P, _P, _P, _P, _P, _P, _P, _F, _F, _F, _I, _P, _P],
+    "ngp_adam_all_ex": [_P, _P, _I, _P, _P, ctypes.c_longlong, _P, _I, _P, _P, _P, _P, _P, _P, _F, _F, _F, _I, _P, _P],
     "ngp_adam_mlp_pack": [_P, _P, _P, _P, _P, _P, _F, _F, _F, _I, _P, _P],
     "ngp_distortion_fwd": [_P, _P, _P, _P, _I, _P, _P, _P, _P],
     "ngp_distortion_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P],

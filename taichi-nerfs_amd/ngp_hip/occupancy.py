@@ -77,7 +77,10 @@ class OccupancyUpdater:
                 check(L.ngp_occ_sample(_ptr(u_cell), _ptr(u_pick), _ptr(u_jit), _ptr(self.list), _ptr(self.count), self.M, G, s, hg,
                                        _ptr(self.indices), _ptr(self.xyzs), st), "ngp_occ_sample")
                 idx_ptr = _ptr(self.indices)
-            if getattr(m.pos_encoder, "table_dtype", torch.float32) == torch.bfloat16:
+            if getattr(m, "half_opt", False):                                  # half2 encoder: its own arithmetic on the f16 copy
+                check(L.ngp_hash_fwd_f16_ex(_ptr(self.xyzs), _ptr(m.pos_encoder.table_f16()), ctypes.byref(lv), n, _ptr(None), 1, lo, hi,
+                                            self.enc_pairs, _ptr(self.enc), st), "ngp_hash_fwd_f16_ex")
+            elif getattr(m.pos_encoder, "table_dtype", torch.float32) == torch.bfloat16:
                 check(L.ngp_hash_fwd_bf16_ex(_ptr(self.xyzs), _ptr(m.pos_encoder.table_bf16()), ctypes.byref(lv), n, _ptr(None), 1, lo,
                                              hi, self.enc_pairs, _ptr(self.enc), st), "ngp_hash_fwd_bf16_ex")
             else:

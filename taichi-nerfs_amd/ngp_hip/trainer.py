@@ -35,8 +35,9 @@ class FusedTrainer:
                  growth_factor=2.0, backoff_factor=0.5, growth_interval=2000, exp_step_factor=0.0, T_threshold=1e-4,
                  max_samples=1024, process_group=None, world_size=None, grad_comm_dtype=torch.float32,
                  distortion_loss_w=0.0):
-        if not model.use_fused_mlp or model.half_opt:
-            raise ValueError("FusedTrainer needs the default architecture with the fp32 hash table")
+        if not model.use_fused_mlp:
+            raise ValueError("FusedTrainer needs the default architecture (L=16, F=2 hash grid, 64-wide MLPs)")
+        self.half = bool(model.half_opt)              # half2 encoder (hash_encoder_half.py): f16 table copy, f16 gradient buffer
         self.model = model
         self.L = _lib_mod.load()
         dev = model.pos_encoder.hash_table.device
@@ -63,20 +64,27 @@ class FusedTrainer:
             w.data = flat[off:off + n].view_as(w)
             off += n
         self.mlp_flat = flat
-        self.table = model.pos_encoder.hash_table.data
+        self.table = model.pos_encoder.hash_table.data.view(-1)          # [entries * 2] (the half encoder's parameter is 2-D)
         f32 = dict(device=dev, dtype=torch.float32)
         # ONE flat gradient bucket [hash-table grad | MLP grad | inf flag]: a single all-reduce per step when world > 1
         nt = self.table.numel()
-        assert nt % 4 == 0
-        self.grad_flat = torch.zeros(nt + MLP_N_WEIGHTS + 4, **f32)
-        self.table_grad = self.grad_flat[:nt].view_as(self.table)
-        self.mlp_grad = self.grad_flat[nt:nt + MLP_N_WEIGHTS]
-        self._flag_f = self.grad_flat[nt + MLP_N_WEIGHTS:nt + MLP_N_WEIGHTS + 1]
+        assert nt % 8 == 0
+        if self.half:
+            # the half2 encoder accumulates its table gradient in f16 (one packed atomic per corner): separate f16 buffer
+            self.table_grad = torch.zeros(nt, device=dev, dtype=torch.float16)
+            self.grad_flat = torch.zeros(MLP_N_WEIGHTS + 4, **f32)
+            self.mlp_grad = self.grad_flat[:MLP_N_WEIGHTS]
+            self._flag_f = self.grad_flat[MLP_N_WEIGHTS:MLP_N_WEIGHTS + 1]
+        else:
+            self.grad_flat = torch.zeros(nt + MLP_N_WEIGHTS + 4, **f32)
+            self.table_grad = self.grad_flat[:nt].view_as(self.table)
+            self.mlp_grad = self.grad_flat[nt:nt + MLP_N_WEIGHTS]
+            self._flag_f = self.grad_flat[nt + MLP_N_WEIGHTS:nt + MLP_N_WEIGHTS + 1]
         # optional 16-bit gradient transport: halves the bytes on xGMI; fp32 (exact mean) is the default
         if grad_comm_dtype not in (torch.float32, torch.bfloat16):
             raise ValueError("grad_comm_dtype must be torch.float32 or torch.bfloat16")
         self._comm = None if grad_comm_dtype == torch.float32 or self.world == 1 else torch.empty_like(self.grad_flat, dtype=grad_comm_dtype)
-        self.table_m, self.table_v = torch.zeros_like(self.table), torch.zeros_like(self.table)
+        self.table_m, self.table_v = torch.zeros(nt, **f32), torch.zeros(nt, **f32)
         self.mlp_m, self.mlp_v = torch.zeros(MLP_N_WEIGHTS, **f32), torch.zeros(MLP_N_WEIGHTS, **f32)
         self.state_f = torch.zeros(8, **f32)
         self.state_i = torch.zeros(8, device=dev, dtype=torch.int32)
@@ -95,6 +103,7 @@ class FusedTrainer:
         # bf16 storage copy of the table (HashEncoder(table_dtype=torch.bfloat16)): gathered by the forward, refreshed by Adam
         self.table_bf16 = (model.pos_encoder.table_bf16()
                            if getattr(model.pos_encoder, "table_dtype", torch.float32) == torch.bfloat16 else None)
+        self.table_f16 = model.pos_encoder.table_f16().view(-1) if self.half else None
         self.repack()
 
     def repack(self):
@@ -104,6 +113,9 @@ class FusedTrainer:
         if self.table_bf16 is not None:
             self.model.pos_encoder._bf16_ver = None                             # force a re-cast of the bf16 table copy
             assert self.model.pos_encoder.table_bf16() is self.table_bf16
+        if self.half:
+            self.model.pos_encoder._f16_ver = None
+            assert self.model.pos_encoder.table_f16().data_ptr() == self.table_f16.data_ptr()
         check(self.L.ngp_mlp_pack(*[_ptr(w) for w in ws], self.enc_pairs, _ptr(self.wpack), _stream()), "ngp_mlp_pack")
 
     # ------------------------------------------------------------------------------------------------ one step
@@ -210,7 +222,10 @@ class FusedTrainer:
         sq_err = torch.empty(n, **f32)
         found = ctypes.c_void_p(si.data_ptr() + 4 * _SI_FOUND_INF)
         P = self.enc_pairs
-        if self.table_bf16 is not None:
+        if self.half:
+            check(L.ngp_hash_fwd_f16_ex(_ptr(M.xyzs), _ptr(self.table_f16), ctypes.byref(cfg.levels), A.cap, _ptr(total), 1, cfg.lo,
+                                        cfg.hi, P, _ptr(A.enc), st), "ngp_hash_fwd_f16_ex")
+        elif self.table_bf16 is not None:
             check(L.ngp_hash_fwd_bf16_ex(_ptr(M.xyzs), _ptr(self.table_bf16), ctypes.byref(cfg.levels), A.cap, _ptr(total), 1, cfg.lo,
                                          cfg.hi, P, _ptr(A.enc), st), "ngp_hash_fwd_bf16_ex")
         else:
@@ -228,19 +243,27 @@ class FusedTrainer:
                 "ngp_composite_train_fused")
         check(L.ngp_mlp_bwd_ex(_ptr(A.enc), _ptr(M.dirs), _ptr(self.wpack), _ptr(A.d_sigmas), _ptr(A.d_rgbs), A.cap, _ptr(total), P,
                                _ptr(A.d_enc), _ptr(self.mlp_grad), found, st), "ngp_mlp_bwd_ex")
-        check(L.ngp_hash_bwd_f32_ex(_ptr(M.xyzs), _ptr(A.d_enc), ctypes.byref(cfg.levels), A.cap, _ptr(total), 1, cfg.lo, cfg.hi, P,
-                                    _ptr(self.table_grad), found, st), "ngp_hash_bwd_f32_ex")
+        if self.half:
+            check(L.ngp_hash_bwd_f16_ex(_ptr(M.xyzs), _ptr(A.d_enc), ctypes.byref(cfg.levels), A.cap, _ptr(total), 1, cfg.lo, cfg.hi, P,
+                                        _ptr(self.table_grad), found, st), "ngp_hash_bwd_f16_ex")
+        else:
+            check(L.ngp_hash_bwd_f32_ex(_ptr(M.xyzs), _ptr(A.d_enc), ctypes.byref(cfg.levels), A.cap, _ptr(total), 1, cfg.lo, cfg.hi, P,
+                                        _ptr(self.table_grad), found, st), "ngp_hash_bwd_f32_ex")
         if self.world > 1:
             self._all_reduce()
+        if self.half:       # f16 sums overflow easily: GradScaler's check must see the ACCUMULATED (and reduced) gradient
+            check(L.ngp_check_finite_f16(_ptr(self.table_grad), self.table_grad.numel(), found, st), "ngp_check_finite_f16")
         if self._grads_only:
             return {"rm_samples": total, "vr_per_ray": vr_per_ray, "rgb": rgb, "opacity": opacity, "depth": depth, "rays_a": rays_a,
                     "deltas": M.deltas, "ts": M.ts, "sq_err": sq_err}
         check(L.ngp_train_prologue(_ptr(sf), _ptr(si), self.lr0, self.eta_min, self.t_max, self.beta1,
                                    self.beta2, self.growth, self.backoff, self.growth_interval, st), "ngp_train_prologue")
         # Adam on the table (+ its bf16 copy) and on the MLP weights + the fp16 fragment repack the next step needs: one launch
-        check(L.ngp_adam_all(_ptr(self.table), _ptr(self.table_grad), _ptr(self.table_m), _ptr(self.table_v), self.table.numel(),
-                             _ptr(self.table_bf16), _ptr(self.mlp_flat), _ptr(self.mlp_grad), _ptr(self.mlp_m), _ptr(self.mlp_v),
-                             _ptr(sf), _ptr(si), self.beta1, self.beta2, self.eps, P, _ptr(self.wpack), st), "ngp_adam_all")
+        copy16, kind = (self.table_f16, 2) if self.half else ((self.table_bf16, 1) if self.table_bf16 is not None else (None, 0))
+        check(L.ngp_adam_all_ex(_ptr(self.table), _ptr(self.table_grad), int(self.half), _ptr(self.table_m), _ptr(self.table_v),
+                                self.table.numel(), _ptr(copy16), kind, _ptr(self.mlp_flat), _ptr(self.mlp_grad), _ptr(self.mlp_m),
+                                _ptr(self.mlp_v), _ptr(sf), _ptr(si), self.beta1, self.beta2, self.eps, P, _ptr(self.wpack), st),
+              "ngp_adam_all_ex")
         return {"rm_samples": total, "vr_per_ray": vr_per_ray, "rgb": rgb, "opacity": opacity, "depth": depth, "rays_a": rays_a,
                 "deltas": M.deltas, "ts": M.ts, "sq_err": sq_err}
 
@@ -278,6 +301,12 @@ class FusedTrainer:
         non-zero flag leaves a non-zero sum / mean)."""
         flag_i = self.state_i[_SI_FOUND_INF:_SI_FOUND_INF + 1]
         self._flag_f.copy_(flag_i)
+        if self.half:                                              # the f16 table gradient travels as it is (22.8 MB)
+            if dist.get_backend(self.group) == "nccl":
+                dist.all_reduce(self.table_grad, op=dist.ReduceOp.AVG, group=self.group)
+            else:
+                dist.all_reduce(self.table_grad, op=dist.ReduceOp.SUM, group=self.group)
+                self.table_grad.div_(self.world)
         buf = self.grad_flat
         if self._comm is not None:
             buf = self._comm
@@ -314,9 +343,11 @@ class FusedTrainer:
         finally:
             self._grads_only = False
         inv = 1.0 / self.state_f[_SF_LOSS_SCALE]
-        out["table_grad"], out["mlp_grad"] = self.table_grad * inv, self.mlp_grad * inv
+        out["table_grad"], out["mlp_grad"] = self.table_grad.float() * inv, self.mlp_grad * inv
         out["found_inf"] = self.state_i[_SI_FOUND_INF].clone()
         self.grad_flat.zero_()
+        if self.half:
+            self.table_grad.zero_()
         self.state_i[_SI_FOUND_INF] = 0
         return out
 
