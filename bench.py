@@ -167,13 +167,25 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    # NGP_BENCH_BACKEND=gloo + NGP_BENCH_ONE_DEVICE=1: run the N > 1 code path with every rank on GPU 0 (RCCL refuses two ranks
+    # on one device) -- a functional check of the sharding / barrier / max-over-ranks logic on a 1-GPU box, not a measurement
+    backend = os.environ.get("NGP_BENCH_BACKEND", "nccl")
+    if os.environ.get("NGP_BENCH_ONE_DEVICE", "0") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from ngp_hip import lib, ops, synthetic
     from ngp_hip.dist import GradReducer
+    if world > 1:                   # one rank (re)builds the extension if it has to; the others wait instead of racing hipcc
+        if rank == 0:
+            lib.build()
+        dist.barrier()
     lib.build()
     lib.load()
     import modules.hash_encoder as _he
