@@ -100,7 +100,8 @@ class FusedTrainer:
         # 2 = after the MLP forward (default: measured 4-5 % faster than 0 -- the march then overlaps the composite, the MLP
         # backward and the scatter-add instead of the gather-bound encode), 3 = before the scatter-add
         import os as _os
-        self._prefetch_at = int(_os.environ.get("NGP_PREFETCH_AT", "2"))
+        # (with world > 1 the default is 3: the march then runs underneath the gradient all-reduce)
+        self._prefetch_at = int(_os.environ.get("NGP_PREFETCH_AT", "2" if self.world == 1 else "3"))
         self._coarse_ver = None
         lvs = model.pos_encoder.levels_struct
         self.enc_pairs = 1 if (lvs.n_levels == 16 and lvs.n_features == 2) else 0
