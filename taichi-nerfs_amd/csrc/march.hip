@@ -262,31 +262,31 @@ __global__ void __launch_bounds__(256) bitfield_coarsen_kernel(const uint4* __re
     if (lane == 32 && w < n_coarse) coarse[w >> 5] = (uint32_t)(m >> 32);
 }
 
-// exclusive prefix sum over per-ray counts -> rays_a (ray order) + total.  One 1024-thread block, chunked.
+// exclusive prefix sum over per-ray counts -> rays_a (ray order) + total.  One 1024-thread block; every thread owns a
+// contiguous slice of ceil(n / 1024) rays (one pass to sum it, one block-wide scan of the 1024 sums, one pass to write):
+// two barriers in total -- the chunked version's 3 barriers + a dependent load per 1024 rays made this little kernel the
+// second-longest link of the side-stream march chain.
 __global__ void __launch_bounds__(1024) march_scan_kernel(const int32_t* __restrict__ counts, int n_rays,
                                                           int32_t* __restrict__ rays_a, int32_t* __restrict__ total) {
     __shared__ int wave_tot[16];
-    __shared__ int carry_s;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (tid == 0) carry_s = 0;
+    const int per = (n_rays + 1023) >> 10;
+    const int lo = min(tid * per, n_rays), hi = min(lo + per, n_rays);
+    int sum = 0;
+    for (int i = lo; i < hi; ++i) sum += counts[i];
+    const int inc = wave_scan_add_i(sum, lane);
+    if (lane == 63) wave_tot[wv] = inc;
     __syncthreads();
-    for (int base = 0; base < n_rays; base += 1024) {
-        int i = base + tid;
-        int c = (i < n_rays) ? counts[i] : 0;
-        int inc = wave_scan_add_i(c, lane);
-        if (lane == 63) wave_tot[wv] = inc;
-        __syncthreads();
-        int carry = carry_s;
-        int woff = 0;
+    int woff = 0;
 #pragma unroll
-        for (int w = 0; w < 16; ++w) woff += (w < wv) ? wave_tot[w] : 0;
-        int start = carry + woff + inc - c;
-        if (i < n_rays) { rays_a[3 * i] = i; rays_a[3 * i + 1] = start; rays_a[3 * i + 2] = c; }
-        __syncthreads();
-        if (tid == 1023) carry_s = start + c;
-        __syncthreads();
+    for (int w = 0; w < 16; ++w) woff += (w < wv) ? wave_tot[w] : 0;
+    int run = woff + inc - sum;
+    for (int i = lo; i < hi; ++i) {
+        const int c = counts[i];
+        rays_a[3 * i] = i; rays_a[3 * i + 1] = run; rays_a[3 * i + 2] = c;
+        run += c;
     }
-    if (tid == 0) total[0] = carry_s;
+    if (tid == 1023) total[0] = woff + inc;
 }
 
 // expansion: one wave per ray, lanes stride over the ray's staged samples (coalesced stores)
