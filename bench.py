@@ -206,8 +206,10 @@ def main():
         args.rays = 65536 if garden else 8192
     esf = 1.0 / 256 if garden else 0.0                                       # train.py:54
     w_dist = 1e-3 if garden else 0.0                                         # opt.py:77-83 "1e-3 for real scene"
-    model = NGP(scale=16.0 if garden else 0.5, max_res=4096 if garden else 1024, half_opt=args.half,
-                table_dtype=torch.bfloat16 if args.table == "bf16" else None).to(dev)
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):         # the encoder announces itself like the reference's does: keep stdout = the JSON line
+        model = NGP(scale=16.0 if garden else 0.5, max_res=4096 if garden else 1024, half_opt=args.half,
+                    table_dtype=torch.bfloat16 if args.table == "bf16" else None).to(dev)
     golden = os.path.join(ROOT, "tests", "golden", "lego_density_bitfield.npz")
     if garden:
         bits_np = synthetic.ball_slab_bitfield(model.cascades, 16.0, seed=23)
