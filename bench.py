@@ -36,6 +36,9 @@ TRAINER_KERNELS = {
     "ngp_mlp_fwd_ex": ("mlp_fwd", "mfma", 18816, "sample"),
     "ngp_mlp_bwd_ex": ("mlp_bwd", "mfma", 37632, "sample"),
     "ngp_hash_bwd_f32_ex": ("hash_bwd_f32", "hbm", 12 + 128 + 1024 + 1024, "sample"),
+    "ngp_mlp_bwd_live": ("mlp_bwd", "mfma", 37632, "live"),                        # backward kernels run on the live-sample list
+    "ngp_hash_bwd_f32_live": ("hash_bwd_f32", "hbm", 12 + 128 + 1024 + 1024, "live"),
+    "ngp_hash_bwd_f16_live": ("hash_bwd_f16", "hbm", 12 + 128 + 512 + 512, "live"),
     "ngp_adam_step": ("adam", "hbm", 32, "param"),
     "ngp_adam_all": ("adam", "hbm", 32, "param"),                                  # table pass (+ the MLP block riding along)
     "ngp_hash_fwd_f16_ex": ("hash_fwd_f16", "hbm", 12 + 512 + 128, "sample"),      # --half: 4-byte gathers, f32 output to the arena
@@ -248,6 +251,7 @@ def main():
     STAT_EVERY = 7
     stat_log = torch.zeros((args.steps + args.warmup + 4) // STAT_EVERY + 1, 1, device=dev, dtype=torch.int32)
     vr_log = torch.zeros((args.steps + args.warmup + 4) // STAT_EVERY + 1, args.rays, device=dev, dtype=torch.int32)
+    live_log = torch.zeros((args.steps + args.warmup + 4) // STAT_EVERY + 1, 1, device=dev, dtype=torch.int32)
 
     # the trainer launches go straight through the C ABI: HIP events around the big kernels, on the launch stream
     c_events = {}
@@ -283,6 +287,7 @@ def main():
         if k % STAT_EVERY == 0 and k // STAT_EVERY < stat_log.shape[0]:
             stat_log[k // STAT_EVERY, 0].copy_(out["rm_samples"][0])
             vr_log[k // STAT_EVERY].copy_(out["vr_per_ray"])
+            live_log[k // STAT_EVERY, 0].copy_(trainer._live_total[0])
         state["k"] = k + 1
 
     def step(i):
@@ -344,7 +349,8 @@ def main():
         ks = timer.summary()
         rooflines = {}
         if use_trainer:
-            live = rm / max(args.steps, 1)                     # live samples per step (launches are sized for the arena)
+            live = rm / max(args.steps, 1)                     # marched samples per step (launches are sized for the arena)
+            live_avg = (float(live_log[:n_st].sum(dtype=torch.int64)) / max(n_st, 1)) if trainer.live_backward else live
             agg = {}                                           # key -> [launches, total_ms, total_work, bound, per_unit, unit, units]
             for name, evs in c_events.items():
                 key, bound, per_unit, unit = TRAINER_KERNELS[name]
@@ -357,13 +363,15 @@ def main():
                         units = float(args.rays)
                     elif unit == "n_arg":
                         units = float(a[3])
+                    elif unit == "live":
+                        units = float(live_avg)
                     else:
                         # _ex launches: device-side count (the live samples of the step) unless n_dev is NULL
                         # (occupancy-update encodes: exact n = arg 3)
                         n_dev = a[4] if name in ("ngp_hash_fwd_f32_ex", "ngp_hash_fwd_bf16_ex", "ngp_hash_fwd_f16_ex", "ngp_mlp_fwd_ex") else None
                         units = float(a[3]) if (n_dev is not None and getattr(n_dev, "value", 1) is None) else float(live)
                     work = per_unit * units + (8 * live if key == "march_count" else 0)
-                    rec = agg.setdefault(key, [0, 0.0, 0.0, bound, per_unit, "sample" if unit == "n_arg" else unit, 0.0])
+                    rec = agg.setdefault(key, [0, 0.0, 0.0, bound, per_unit, "sample" if unit in ("n_arg", "live") else unit, 0.0])
                     rec[0] += 1; rec[1] += e0.elapsed_time(e1); rec[2] += work; rec[6] += units
             for key, (n_l, tot_ms, tot_work, bound, per_unit, unit, tot_units) in agg.items():
                 ks[key] = {"launches": n_l, "avg_ms": tot_ms / n_l, "total_ms": tot_ms, "avg_units": tot_units / n_l}
@@ -395,9 +403,17 @@ def main():
         if roof is not None and dom == "hash_bwd_f32":
             # transparency: achieved prices EVERY live sample at the SURVEY 8(d) figure (like the reference's autodiff kernel);
             # samples behind early termination carry exact-zero gradients and are skipped after their 140-byte read
-            roof = dict(roof, note="scatter-add skips zero-gradient samples (behind early termination): %.0f%% of the marched samples "
-                                   "were composited in this run; see profiles/microbench/r01_hash_bwd_breakdown.txt"
-                                   % (100.0 * vr / max(rm, 1)))
+            # the scatter-add is bound by the chip's float-atomic LINE-REQUEST rate, not by HBM bytes: <= 4 distinct 64-byte lines per
+            # (live sample, level) -- the reference's hash keeps only the x-neighbour on a line -- against ~21 G line requests/s
+            # measured for random lines (profiles/r01_microbench_atomics2.txt).  Upper bound (run merging removes some requests).
+            lines = 4.0 * 16.0 * roof["avg_units_per_launch"]
+            roof = dict(roof, note="the backward runs on the live samples only (those in front of each ray's early-termination point: "
+                                   "%.0f%% of the marched samples in this run); achieved = algorithmic bytes x LIVE samples per launch; "
+                                   "the kernel's real bound is the atomic line-request rate, see atomic_line_rate" % (100.0 * vr / max(rm, 1)),
+                        atomic_line_rate={"line_requests_per_launch_upper_bound": lines,
+                                          "achieved_G_per_s": lines / (roof["avg_launch_ms"] * 1e-3) / 1e9,
+                                          "measured_peak_G_per_s": 21.0,
+                                          "frac": lines / (roof["avg_launch_ms"] * 1e-3) / 21.0e9})
         out = {
             "metric": "training rays/sec", "value": total_rays / elapsed, "unit": "rays/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,

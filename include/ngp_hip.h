@@ -170,6 +170,22 @@ int ngp_composite_train_fused(const float* sigmas, const void* rgbs, int rgbs_is
                               float* opacity, float* depth, float* rgb, float* ws, float* d_sigmas, void* d_rgbs,
                               float* sq_err, void* stream);
 
+/* Live-sample list for the backward pass: the first vr_per_ray[r] samples of ray r (those in front of the early-termination
+ * point, volume_train.py:31-47) are the only ones with a non-zero gradient.  live_idx[j] = sample index of the j-th live
+ * sample (ray order), live_total[0] = their number, live_off = [n_rays] scratch.  ngp_mlp_bwd_live / ngp_hash_bwd_*_live run
+ * on that list: position j reads sample live_idx[j] (enc, dirs, gradients, xyzs) and d_enc is written / read at position j. */
+int ngp_live_compact(const int32_t* rays_a, const int32_t* vr_per_ray /*[n], by ray index*/, int n_rays, int32_t* live_off,
+                     int32_t* live_idx, int32_t* live_total, void* stream);
+int ngp_mlp_bwd_live(const float* enc, const float* dirs, const uint16_t* wpack, const float* dsigmas, const uint16_t* drgbs,
+                     int n_max, const int32_t* n_dev, const int32_t* live_idx, int enc_pairs, float* d_enc, float* dW,
+                     int32_t* found_inf, void* stream);
+int ngp_hash_bwd_f32_live(const float* xyzs, const float* dout, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev,
+                          const int32_t* live_idx, int normalize, float lo, float hi, int enc_pairs, float* dtable,
+                          int32_t* found_inf, void* stream);
+int ngp_hash_bwd_f16_live(const float* xyzs, const float* dout, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev,
+                          const int32_t* live_idx, int normalize, float lo, float hi, int enc_pairs, uint16_t* dtable,
+                          int32_t* found_inf, void* stream);
+
 /* ---- a-8  composite_test (modules/volume_render_test.py:4-54) -------------------------------- */
 int ngp_composite_test(const float* sigmas, const void* rgbs, int rgbs_is_half, const float* deltas,
                        const float* ts, const int64_t* pack_info /*[n,2]*/,

@@ -236,8 +236,8 @@ __global__ void __launch_bounds__(256) hash_bwd_f32_kernel(const float* __restri
 // order-nondeterministic in the reference too).
 __global__ void __launch_bounds__(256) hash_bwd_f32x2_kernel(const float* __restrict__ xyzs, const float* __restrict__ dout,
                                                              ngp_hash_levels lv, int n, const int32_t* __restrict__ n_dev,
-                                                             XyzNorm nm, int enc_pairs, float* __restrict__ dtable,
-                                                             int32_t* __restrict__ found_inf) {
+                                                             const int32_t* __restrict__ idx, XyzNorm nm, int enc_pairs,
+                                                             float* __restrict__ dtable, int32_t* __restrict__ found_inf) {
     __shared__ LevelLDS L;
     load_levels(lv, L);
     const size_t plane = (size_t)n;
@@ -248,10 +248,13 @@ __global__ void __launch_bounds__(256) hash_bwd_f32x2_kernel(const float* __rest
     const int n_tiles = (n + 15) >> 4;
     const int waves_per_block = blockDim.x >> 6;
     for (int tile = blockIdx.x * waves_per_block + (threadIdx.x >> 6); tile < n_tiles; tile += gridDim.x * waves_per_block) {
-        const int i = tile * 16 + s_in;
+        const int i = tile * 16 + s_in;                  // position in dout (and in the live list, when there is one)
         const bool valid = i < n;
         float x = 0.f, y = 0.f, z = 0.f;
-        if (valid) { x = norm01(nm, xyzs[3 * (size_t)i]); y = norm01(nm, xyzs[3 * (size_t)i + 1]); z = norm01(nm, xyzs[3 * (size_t)i + 2]); }
+        if (valid) {
+            const size_t src = idx ? (size_t)idx[i] : (size_t)i;
+            x = norm01(nm, xyzs[3 * src]); y = norm01(nm, xyzs[3 * src + 1]); z = norm01(nm, xyzs[3 * src + 2]);
+        }
         for (int level = 0; level < nl; ++level) {
             const size_t gi = enc_pairs ? ((size_t)(level < 8 ? level : 15 - level) * plane + i) * 4 + (level < 8 ? 0 : 2) + f
                                         : (size_t)i * (nl * 2) + level * 2 + f;
@@ -370,8 +373,8 @@ __global__ void __launch_bounds__(256) hash_bwd_f16_kernel(const float* __restri
 // dout is the fp32 d_enc of the fused MLP backward (natural or pair-major layout).
 __global__ void __launch_bounds__(256) hash_bwd_f16x2_kernel(const float* __restrict__ xyzs, const float* __restrict__ dout,
                                                              ngp_hash_levels lv, int n, const int32_t* __restrict__ n_dev,
-                                                             XyzNorm nm, int enc_pairs, __half2* __restrict__ dtable,
-                                                             int32_t* __restrict__ found_inf) {
+                                                             const int32_t* __restrict__ idx, XyzNorm nm, int enc_pairs,
+                                                             __half2* __restrict__ dtable, int32_t* __restrict__ found_inf) {
     __shared__ LevelLDS L;
     load_levels(lv, L);
     const size_t plane = (size_t)n;
@@ -386,7 +389,10 @@ __global__ void __launch_bounds__(256) hash_bwd_f16x2_kernel(const float* __rest
         const int i = tile * 32 + s_in;
         const bool valid = i < n;
         float x = 0.f, y = 0.f, z = 0.f;
-        if (valid) { x = norm01(nm, xyzs[3 * (size_t)i]); y = norm01(nm, xyzs[3 * (size_t)i + 1]); z = norm01(nm, xyzs[3 * (size_t)i + 2]); }
+        if (valid) {
+            const size_t src = idx ? (size_t)idx[i] : (size_t)i;
+            x = norm01(nm, xyzs[3 * src]); y = norm01(nm, xyzs[3 * src + 1]); z = norm01(nm, xyzs[3 * src + 2]);
+        }
         for (int level = 0; level < nl; ++level) {
             float2 g = make_float2(0.f, 0.f);
             if (valid) {
@@ -529,20 +535,22 @@ int ngp_hash_fwd_f32(const float* xyzs, const float* table, const ngp_hash_level
     return ngp_hash_fwd_f32_ex(xyzs, table, lv, n, nullptr, 0, 0.0f, 1.0f, 0, out, stream);
 }
 
-int ngp_hash_bwd_f32_ex(const float* xyzs, const float* dout, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev,
-                        int normalize, float lo, float hi, int enc_pairs, float* dtable, int32_t* found_inf, void* stream) {
+int ngp_hash_bwd_f32_live(const float* xyzs, const float* dout, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev,
+                          const int32_t* live_idx, int normalize, float lo, float hi, int enc_pairs, float* dtable, int32_t* found_inf,
+                          void* stream) {
     if (n_max <= 0) return 0;
     if (lv->n_levels < 1 || lv->n_levels > NGP_MAX_LEVELS) return -1;
     const int grid = grid_for((long long)n_max * lv->n_levels, 256);
     hipStream_t s = (hipStream_t)stream;
     const XyzNorm nm = {normalize, lo, hi};
     if (enc_pairs && !(lv->n_features == 2 && lv->n_levels == 16)) return -1;
+    if (live_idx && lv->n_features != 2) return -1;
     switch (lv->n_features) {
         case 1: hipLaunchKernelGGL(hash_bwd_f32_kernel<1>, dim3(grid), dim3(256), 0, s, xyzs, dout, *lv, n_max, n_dev, nm, dtable); break;
         case 2: {
             const int tiles = (n_max + 15) / 16;
             const int g2 = tiles < 4 ? 1 : (tiles / 4 < 8192 ? (tiles + 3) / 4 : 8192);
-            hipLaunchKernelGGL(hash_bwd_f32x2_kernel, dim3(g2), dim3(256), 0, s, xyzs, dout, *lv, n_max, n_dev, nm, enc_pairs, dtable, found_inf);
+            hipLaunchKernelGGL(hash_bwd_f32x2_kernel, dim3(g2), dim3(256), 0, s, xyzs, dout, *lv, n_max, n_dev, live_idx, nm, enc_pairs, dtable, found_inf);
             break;
         }
         case 4: hipLaunchKernelGGL(hash_bwd_f32_kernel<4>, dim3(grid), dim3(256), 0, s, xyzs, dout, *lv, n_max, n_dev, nm, dtable); break;
@@ -551,6 +559,11 @@ int ngp_hash_bwd_f32_ex(const float* xyzs, const float* dout, const ngp_hash_lev
     }
     NGP_LAUNCH_CHECK();
     return 0;
+}
+
+int ngp_hash_bwd_f32_ex(const float* xyzs, const float* dout, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev,
+                        int normalize, float lo, float hi, int enc_pairs, float* dtable, int32_t* found_inf, void* stream) {
+    return ngp_hash_bwd_f32_live(xyzs, dout, lv, n_max, n_dev, nullptr, normalize, lo, hi, enc_pairs, dtable, found_inf, stream);
 }
 
 int ngp_hash_bwd_f32(const float* xyzs, const float* dout, const ngp_hash_levels* lv, int n, float* dtable, void* stream) {
@@ -590,18 +603,24 @@ int ngp_hash_fwd_f16_ex(const float* xyzs, const uint16_t* table, const ngp_hash
     return 0;
 }
 
-int ngp_hash_bwd_f16_ex(const float* xyzs, const float* dout, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev, int normalize,
-                        float lo, float hi, int enc_pairs, uint16_t* dtable, int32_t* found_inf, void* stream) {
+int ngp_hash_bwd_f16_live(const float* xyzs, const float* dout, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev,
+                          const int32_t* live_idx, int normalize, float lo, float hi, int enc_pairs, uint16_t* dtable, int32_t* found_inf,
+                          void* stream) {
     if (n_max <= 0) return 0;
     if (lv->n_features != 2 || lv->n_levels < 1 || lv->n_levels > NGP_MAX_LEVELS) return -1;
     if (enc_pairs && lv->n_levels != 16) return -1;
     const XyzNorm nm = {normalize, lo, hi};
     const int tiles = (n_max + 31) / 32;
     const int g2 = tiles < 4 ? 1 : (tiles / 4 < 8192 ? (tiles + 3) / 4 : 8192);
-    hipLaunchKernelGGL(hash_bwd_f16x2_kernel, dim3(g2), dim3(256), 0, (hipStream_t)stream, xyzs, dout, *lv, n_max, n_dev, nm, enc_pairs,
-                       (__half2*)dtable, found_inf);
+    hipLaunchKernelGGL(hash_bwd_f16x2_kernel, dim3(g2), dim3(256), 0, (hipStream_t)stream, xyzs, dout, *lv, n_max, n_dev, live_idx, nm,
+                       enc_pairs, (__half2*)dtable, found_inf);
     NGP_LAUNCH_CHECK();
     return 0;
+}
+
+int ngp_hash_bwd_f16_ex(const float* xyzs, const float* dout, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev, int normalize,
+                        float lo, float hi, int enc_pairs, uint16_t* dtable, int32_t* found_inf, void* stream) {
+    return ngp_hash_bwd_f16_live(xyzs, dout, lv, n_max, n_dev, nullptr, normalize, lo, hi, enc_pairs, dtable, found_inf, stream);
 }
 
 int ngp_check_finite_f16(const uint16_t* g, long long n, int32_t* found_inf, void* stream) {

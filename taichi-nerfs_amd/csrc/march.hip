@@ -289,6 +289,39 @@ __global__ void __launch_bounds__(1024) march_scan_kernel(const int32_t* __restr
     if (tid == 1023) total[0] = woff + inc;
 }
 
+// ---- live-sample list for the backward pass ------------------------------------------------------------------------------
+// Only the samples the compositor actually used -- the first vr[r] of ray r, i.e. those in front of the early-termination point
+// (volume_train.py:31-47) -- receive a non-zero gradient; everything behind is exact zero.  In a trained scene that is one
+// sample in five to ten, so the MLP backward and the hash scatter-add run on a compacted list: live_idx[j] = index of the
+// j-th live sample (ray order, sample order), live_total = their number.  Same results; the float atomics only see fewer zeros.
+__global__ void __launch_bounds__(1024) live_scan_kernel(const int32_t* __restrict__ vr_per_ray, int n_rays,
+                                                         int32_t* __restrict__ live_off, int32_t* __restrict__ live_total) {
+    __shared__ int wave_tot[16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int per = (n_rays + 1023) >> 10;
+    const int lo = min(tid * per, n_rays), hi = min(lo + per, n_rays);
+    int sum = 0;
+    for (int i = lo; i < hi; ++i) sum += vr_per_ray[i];
+    const int inc = wave_scan_add_i(sum, lane);
+    if (lane == 63) wave_tot[wv] = inc;
+    __syncthreads();
+    int woff = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) woff += (w < wv) ? wave_tot[w] : 0;
+    int run = woff + inc - sum;
+    for (int i = lo; i < hi; ++i) { live_off[i] = run; run += vr_per_ray[i]; }
+    if (tid == 1023) live_total[0] = woff + inc;
+}
+__global__ void __launch_bounds__(256) live_fill_kernel(const int32_t* __restrict__ rays_a, const int32_t* __restrict__ vr_per_ray,
+                                                        const int32_t* __restrict__ live_off, int n_rays,
+                                                        int32_t* __restrict__ live_idx) {
+    const int n = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (n >= n_rays) return;
+    const int ray = rays_a[3 * n], start = rays_a[3 * n + 1];
+    const int cnt = vr_per_ray[ray], base = live_off[ray];
+    for (int k = lane_id(); k < cnt; k += NGP_WAVE) live_idx[base + k] = start + k;
+}
+
 // expansion: one wave per ray, lanes stride over the ray's staged samples (coalesced stores)
 __global__ void __launch_bounds__(256) march_write_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
                                                           const int32_t* __restrict__ rays_a, const float2* __restrict__ stage,
@@ -444,6 +477,16 @@ int ngp_march_train_count_ex(const float* rays_o, const float* rays_d, const flo
 
 int ngp_march_train_scan(const int32_t* counts, int n_rays, int32_t* rays_a, int32_t* total, void* stream) {
     hipLaunchKernelGGL(march_scan_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, counts, n_rays, rays_a, total);
+    NGP_LAUNCH_CHECK();
+    return 0;
+}
+
+int ngp_live_compact(const int32_t* rays_a, const int32_t* vr_per_ray, int n_rays, int32_t* live_off, int32_t* live_idx,
+                     int32_t* live_total, void* stream) {
+    if (n_rays <= 0) return 0;
+    hipLaunchKernelGGL(live_scan_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, vr_per_ray, n_rays, live_off, live_total);
+    hipLaunchKernelGGL(live_fill_kernel, dim3((n_rays + 3) / 4), dim3(256), 0, (hipStream_t)stream, rays_a, vr_per_ray, live_off, n_rays,
+                       live_idx);
     NGP_LAUNCH_CHECK();
     return 0;
 }

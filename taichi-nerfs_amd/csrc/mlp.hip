@@ -388,19 +388,20 @@ struct BwdIn {                             // prefetched per-round inputs of one
 
 __device__ __forceinline__ void bwd_prefetch(BwdIn& in, const float* __restrict__ enc, const float* __restrict__ dirs,
                                              const float* __restrict__ dsigmas, const half_t* __restrict__ drgbs, int smp, int S,
-                                             int g, int pairs, size_t plane) {
+                                             int g, int pairs, size_t plane, const int32_t* __restrict__ idx) {
     in.e0 = in.e1 = make_float4(0.f, 0.f, 0.f, 0.f);
     in.dx = 0.f; in.dy = 0.f; in.dz = 1.f; in.dsig = 0.f;
     in.drgb[0] = in.drgb[1] = in.drgb[2] = (half_t)0;
     if (smp < S) {
+        const int src = idx ? idx[smp] : smp;            // compacted backward: position smp of the live list = sample idx[smp]
         const float *ep0, *ep1;
-        enc_ptrs(enc, pairs, plane, smp, g, ep0, ep1);
+        enc_ptrs(enc, pairs, plane, src, g, ep0, ep1);
         in.e0 = *reinterpret_cast<const float4*>(ep0);
         in.e1 = *reinterpret_cast<const float4*>(ep1);
-        in.dx = dirs[3 * (size_t)smp]; in.dy = dirs[3 * (size_t)smp + 1]; in.dz = dirs[3 * (size_t)smp + 2];
+        in.dx = dirs[3 * (size_t)src]; in.dy = dirs[3 * (size_t)src + 1]; in.dz = dirs[3 * (size_t)src + 2];
         if (g == 0) {
-            in.dsig = dsigmas[smp];
-            in.drgb[0] = drgbs[3 * (size_t)smp]; in.drgb[1] = drgbs[3 * (size_t)smp + 1]; in.drgb[2] = drgbs[3 * (size_t)smp + 2];
+            in.dsig = dsigmas[src];
+            in.drgb[0] = drgbs[3 * (size_t)src]; in.drgb[1] = drgbs[3 * (size_t)src + 1]; in.drgb[2] = drgbs[3 * (size_t)src + 2];
         }
     }
 }
@@ -408,7 +409,8 @@ __device__ __forceinline__ void bwd_prefetch(BwdIn& in, const float* __restrict_
 __global__ void __launch_bounds__(768) mlp_bwd_kernel(const float* __restrict__ enc, const float* __restrict__ dirs,
                                                        const half_t* __restrict__ wpack, const float* __restrict__ dsigmas,
                                                        const half_t* __restrict__ drgbs, int S,
-                                                       const int32_t* __restrict__ n_dev, int pairs, float* __restrict__ d_enc,
+                                                       const int32_t* __restrict__ n_dev, const int32_t* __restrict__ idx, int pairs,
+                                                       float* __restrict__ d_enc,
                                                        float* __restrict__ dW /*[N_W], pre-zeroed or accumulating*/,
                                                        int32_t* __restrict__ found_inf) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[N_ALL_FRAGS * 64 * 16 + BG * IMG_HALFS * 2];
@@ -441,7 +443,7 @@ __global__ void __launch_bounds__(768) mlp_bwd_kernel(const float* __restrict__ 
     for (int round = blockIdx.x; round < n_round; round += gridDim.x) {
         const int smp = (round * BG + grp) * 32 + col;
         BwdIn in;                     // 4 waves per SIMD hide this latency; a register prefetch would spill
-        bwd_prefetch(in, enc, dirs, dsigmas, drgbs, smp, S, g, pairs, plane);
+        bwd_prefetch(in, enc, dirs, dsigmas, drgbs, smp, S, g, pairs, plane, idx);
         TileFwd t;
         half4 dz5 = hzero, dz4[4], dz3[4], dz2, dz1[4];
         tile_forward_regs<true>(wl, lane, g, in.e0, in.e1, in.dx, in.dy, in.dz, t);
@@ -663,16 +665,22 @@ int ngp_mlp_fwd(const float* enc, const float* dirs, const uint16_t* wpack, int 
     return ngp_mlp_fwd_ex(enc, dirs, wpack, n, nullptr, 0, sigmas, rgbs, stream);
 }
 
-int ngp_mlp_bwd_ex(const float* enc, const float* dirs, const uint16_t* wpack, const float* dsigmas, const uint16_t* drgbs,
-                   int n_max, const int32_t* n_dev, int enc_pairs, float* d_enc, float* dW, int32_t* found_inf, void* stream) {
+int ngp_mlp_bwd_live(const float* enc, const float* dirs, const uint16_t* wpack, const float* dsigmas, const uint16_t* drgbs,
+                     int n_max, const int32_t* n_dev, const int32_t* live_idx, int enc_pairs, float* d_enc, float* dW,
+                     int32_t* found_inf, void* stream) {
     if (n_max <= 0) return 0;
     int blocks = ((n_max + 31) / 32 + BG - 1) / BG;
     if (blocks > 256) blocks = 256;                       // one 12-wave block per CU: 3 waves per SIMD
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(mlp_bwd_kernel, dim3(blocks), dim3(64 * BW), 0, (hipStream_t)stream, enc, dirs, (const half_t*)wpack, dsigmas,
-                       (const half_t*)drgbs, n_max, n_dev, enc_pairs, d_enc, dW, found_inf);
+                       (const half_t*)drgbs, n_max, n_dev, live_idx, enc_pairs, d_enc, dW, found_inf);
     NGP_LAUNCH_CHECK();
     return 0;
+}
+
+int ngp_mlp_bwd_ex(const float* enc, const float* dirs, const uint16_t* wpack, const float* dsigmas, const uint16_t* drgbs,
+                   int n_max, const int32_t* n_dev, int enc_pairs, float* d_enc, float* dW, int32_t* found_inf, void* stream) {
+    return ngp_mlp_bwd_live(enc, dirs, wpack, dsigmas, drgbs, n_max, n_dev, nullptr, enc_pairs, d_enc, dW, found_inf, stream);
 }
 
 int ngp_mlp_bwd(const float* enc, const float* dirs, const uint16_t* wpack, const float* dsigmas, const uint16_t* drgbs, int n,

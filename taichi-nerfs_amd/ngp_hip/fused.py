@@ -42,6 +42,11 @@ class TrainArena:
         self.wpack = torch.empty(_lib_mod.load().ngp_mlp_wpack_halfs(), device=device, dtype=torch.float16)
         self._coarse = {}
         self._scratch = {}
+        self.live_idx = torch.empty(cap, device=device, dtype=torch.int32)     # compacted backward: indices of the live samples
+        self._live_off = torch.empty(n_rays, device=device, dtype=torch.int32)
+
+    def live_off(self, n):
+        return self._live_off
 
     def scratch(self, name):
         """Lazily allocated per-sample f32 [cap] work buffers (distortion-loss scans and gradient)."""

@@ -92,6 +92,10 @@ SIGNATURES = {
     "ngp_hash_fwd_f16_ex": [_P, _P, _LV, _I, _P, _I, _F, _F, _I, _P, _P],
     "ngp_hash_bwd_f16_ex": [_P, _P, _LV, _I, _P, _I, _F, _F, _I, _P, _P, _P],
     "ngp_check_finite_f16": [_P, ctypes.c_longlong, _P, _P],
+    "ngp_live_compact": [_P, _P, _I, _P, _P, _P, _P],
+    "ngp_mlp_bwd_live": [_P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P],
+    "ngp_hash_bwd_f32_live": [_P, _P, _LV, _I, _P, _P, _I, _F, _F, _I, _P, _P, _P],
+    "ngp_hash_bwd_f16_live": [_P, _P, _LV, _I, _P, _P, _I, _F, _F, _I, _P, _P, _P],
     "ngp_sh16_fwd": [_P, _I, _P, _P],
     "ngp_sh16_bwd": [_P, _P, _I, _P, _P],
     "ngp_composite_train_fwd": [_P, _P, _I, _P, _P, _P, _F, _I, _P, _P, _P, _P, _P, _P],

@@ -51,6 +51,8 @@ class FusedTrainer:
         self.exp_step_factor, self.T_threshold, self.max_samples = float(exp_step_factor), float(T_threshold), int(max_samples)
         self.bg = 1.0 if exp_step_factor == 0 else 0.0                    # rendering.py:219-226
         self.distortion_loss_w = float(distortion_loss_w)                # train.py:194-195 (0 = off, the reference default)
+        import os as _os0
+        self.live_backward = _os0.environ.get("NGP_LIVE_BACKWARD", "1") != "0"
         self.group = process_group
         self.world = world_size if world_size is not None else (dist.get_world_size(process_group) if dist.is_initialized() else 1)
 
@@ -89,6 +91,7 @@ class FusedTrainer:
         self.state_f = torch.zeros(8, **f32)
         self.state_i = torch.zeros(8, device=dev, dtype=torch.int32)
         self.state_f[_SF_LOSS_SCALE] = float(init_scale)
+        self._live_total = torch.zeros(1, device=dev, dtype=torch.int32)
         self._graph = None
         self._grads_only = False
         self._static = None
@@ -96,12 +99,13 @@ class FusedTrainer:
         self._sets = {}
         self._cur = 0
         self._side = torch.cuda.Stream(device=dev)
-        # where in the step the next batch's march is put on the side stream: 0 = at the start, 1 = after the hash gather,
-        # 2 = after the MLP forward (default: measured 4-5 % faster than 0 -- the march then overlaps the composite, the MLP
-        # backward and the scatter-add instead of the gather-bound encode), 3 = before the scatter-add
+        # where in the step the next batch's march is put on the side stream: 0 = at the start, 1 = after the hash gather
+        # (default: with the backward running on the live samples only, the ~115 us march chain has to start this early to be
+        # done before the step is; A/B on one box: 0.327 ms at 1, 0.331 at 0, 0.342 at 2), 2 = after the MLP forward, 3 = before
+        # the scatter-add
         import os as _os
         # (with world > 1 the default is 3: the march then runs underneath the gradient all-reduce)
-        self._prefetch_at = int(_os.environ.get("NGP_PREFETCH_AT", "2" if self.world == 1 else "3"))
+        self._prefetch_at = int(_os.environ.get("NGP_PREFETCH_AT", "1" if self.world == 1 else "3"))
         self._coarse_ver = None
         lvs = model.pos_encoder.levels_struct
         self.enc_pairs = 1 if (lvs.n_levels == 16 and lvs.n_features == 2) else 0
@@ -256,16 +260,25 @@ class FusedTrainer:
                                             self.bg, _ptr(sf), cfg.T_threshold, n, _ptr(vr_per_ray), _ptr(opacity), _ptr(depth),
                                             _ptr(rgb), _ptr(A.ws), _ptr(A.d_sigmas), _ptr(A.d_rgbs), _ptr(sq_err), st),
                 "ngp_composite_train_fused")
-        check(L.ngp_mlp_bwd_ex(_ptr(A.enc), _ptr(M.dirs), _ptr(self.wpack), _ptr(A.d_sigmas), _ptr(A.d_rgbs), A.cap, _ptr(total), P,
-                               _ptr(A.d_enc), _ptr(self.mlp_grad), found, st), "ngp_mlp_bwd_ex")
+        # backward on the LIVE samples only (those in front of each ray's early-termination point; the rest have exact-zero
+        # gradients): a compacted index list, then the MLP backward and the scatter-add run over it
+        live_idx, live_total = A.live_idx, self._live_total
+        if self.live_backward:
+            check(L.ngp_live_compact(_ptr(rays_a), _ptr(vr_per_ray), n, _ptr(A.live_off(n)), _ptr(live_idx), _ptr(live_total), st),
+                  "ngp_live_compact")
+            cnt = live_total
+        else:
+            live_idx, cnt = None, total
+        check(L.ngp_mlp_bwd_live(_ptr(A.enc), _ptr(M.dirs), _ptr(self.wpack), _ptr(A.d_sigmas), _ptr(A.d_rgbs), A.cap, _ptr(cnt),
+                                 _ptr(live_idx), P, _ptr(A.d_enc), _ptr(self.mlp_grad), found, st), "ngp_mlp_bwd_live")
         if hook is not None:
             hook(); hook = None                                             # position 3: under the scatter-add and the optimizer
         if self.half:
-            check(L.ngp_hash_bwd_f16_ex(_ptr(M.xyzs), _ptr(A.d_enc), ctypes.byref(cfg.levels), A.cap, _ptr(total), 1, cfg.lo, cfg.hi, P,
-                                        _ptr(self.table_grad), found, st), "ngp_hash_bwd_f16_ex")
+            check(L.ngp_hash_bwd_f16_live(_ptr(M.xyzs), _ptr(A.d_enc), ctypes.byref(cfg.levels), A.cap, _ptr(cnt), _ptr(live_idx), 1,
+                                          cfg.lo, cfg.hi, P, _ptr(self.table_grad), found, st), "ngp_hash_bwd_f16_live")
         else:
-            check(L.ngp_hash_bwd_f32_ex(_ptr(M.xyzs), _ptr(A.d_enc), ctypes.byref(cfg.levels), A.cap, _ptr(total), 1, cfg.lo, cfg.hi, P,
-                                        _ptr(self.table_grad), found, st), "ngp_hash_bwd_f32_ex")
+            check(L.ngp_hash_bwd_f32_live(_ptr(M.xyzs), _ptr(A.d_enc), ctypes.byref(cfg.levels), A.cap, _ptr(cnt), _ptr(live_idx), 1,
+                                          cfg.lo, cfg.hi, P, _ptr(self.table_grad), found, st), "ngp_hash_bwd_f32_live")
         if self.world > 1:
             self._all_reduce()
         if self.half:       # f16 sums overflow easily: GradScaler's check must see the ACCUMULATED (and reduced) gradient
