@@ -433,6 +433,7 @@ __global__ void __launch_bounds__(768) mlp_bwd_kernel(const float* __restrict__ 
     //                        L1 tile (mt = w>>1, nt = w&1) -> accC
     //   waves 8..11 (v=w-8): L2 tile (nt = v) -> accB ;  L5 tile (nt = v) -> accC
     floatx4 accA0 = zero, accA1 = zero, accB = zero, accC = zero;
+    bool bad_denc = false;             // a non-finite d_enc value: the same condition the scatter-add flags on its input
     const bool lo8 = wv < 8;
     const int v4 = wv - 8;
     const int mtL = wv >> 1, ntL = wv & 1;         // lo8: tile row / column of the L3 and L1 tiles, tile row of the L4 pair
@@ -485,6 +486,7 @@ __global__ void __launch_bounds__(768) mlp_bwd_kernel(const float* __restrict__ 
             for (int mt = 0; mt < 2; ++mt) {
                 floatx4 d = NGP_MFMA(wfrag(wl, B_W1T + 2 * mt, lane), b10, zero);
                 d = NGP_MFMA(wfrag(wl, B_W1T + 2 * mt + 1, lane), b11, d);
+                bad_denc |= !(isfinite(d[0]) && isfinite(d[1]) && isfinite(d[2]) && isfinite(d[3]));
                 if (smp < S) {       // D rows 4g..4g+3 of tile mt = natural features 16mt+4g.. or, pair layout, plane 4mt+g
                     float* dp = pairs ? d_enc + ((size_t)(4 * mt + g) * plane + smp) * 4 : d_enc + (size_t)smp * 32 + 16 * mt + 4 * g;
                     *reinterpret_cast<float4*>(dp) = make_float4(d[0], d[1], d[2], d[3]);
@@ -582,7 +584,7 @@ __global__ void __launch_bounds__(768) mlp_bwd_kernel(const float* __restrict__ 
         }
         bad |= !isfinite(a0) || !isfinite(a1) || !isfinite(b) || !isfinite(c);
     }
-    if (found_inf && bad) *found_inf = 1;
+    if (found_inf && (bad || bad_denc)) *found_inf = 1;
 }
 
 }  // namespace ngp
