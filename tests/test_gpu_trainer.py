@@ -200,3 +200,38 @@ def test_adam_all_equals_separate_launches(hip_lib, bf16):
         if bf16:
             assert torch.equal(sh_a.view(torch.int16), sh_b.view(torch.int16))
         assert (skip == 1) == torch.equal(A[0], tp)                            # a skipped step leaves the parameters alone
+
+
+def test_live_backward_equals_full_backward(hip_lib, lego_bitfield):
+    """Backward over the compacted live-sample list (ngp_live_compact + *_live kernels) == backward over every marched sample:
+    the skipped samples sit behind their ray's early-termination point and carry exact-zero gradients."""
+    from ngp_hip.trainer import FusedTrainer
+    m, o, d, target = _make(lego_bitfield, n=4096)
+    tr = FusedTrainer(m, init_scale=2.0**10)
+    # raise the density until a good part of the rays terminates early (exp(h0) has to reach ~1e4 at this step size)
+    for _ in range(10):
+        st = tr.compute_gradients(o, d, target)
+        if int(st["vr_per_ray"].sum()) < 0.6 * int(st["rm_samples"][0]):
+            break
+        with torch.no_grad():
+            m.xyz_encoder.output_layer.weight.mul_(3.0)
+        tr.repack()
+    outs = []
+    for live in (True, False):
+        tr.live_backward = live
+        torch.manual_seed(77)
+        outs.append(tr.compute_gradients(o, d, target))
+    a, b = outs
+    n_live, n_all = int(tr._live_total), int(a["rm_samples"][0])
+    assert 0 < n_live < 0.8 * n_all and n_live == int(a["vr_per_ray"].sum())
+    assert torch.equal(a["rays_a"], b["rays_a"]) and torch.equal(a["rgb"], b["rgb"])
+    for k in ("table_grad", "mlp_grad"):
+        ga, gb = a[k], b[k]
+        assert torch.equal(ga != 0, gb != 0) or ((ga != 0) == (gb != 0)).float().mean().item() > 0.9999
+        assert ((ga - gb).norm() / gb.norm()).item() < 1e-5      # float-atomic / MFMA accumulation order only
+    # the live list is the per-ray prefixes, in ray order
+    from ngp_hip.fused import TrainArena
+    A = TrainArena.get(o.device, o.shape[0], 1024)
+    ra, vr = a["rays_a"].cpu().numpy(), a["vr_per_ray"].cpu().numpy()
+    want = np.concatenate([np.arange(s, s + vr[r]) for r, s, c in ra]) if n_live else np.zeros(0)
+    assert np.array_equal(A.live_idx[:n_live].cpu().numpy(), want)
