@@ -1,21 +1,26 @@
-"""FusedTrainer -- one Instant-NGP optimisation step as a fixed sequence of 11 kernel launches, no host sync.
+"""FusedTrainer -- one Instant-NGP optimisation step as a fixed sequence of 12 kernel launches, no host sync.
 
-It performs exactly what the reference's training iteration does (train.py:168-201) for the default model:
-    rays -> render (march, hash encode, MLPs, composite) -> MSE vs target -> backward -> GradScaler -> Adam(eps=1e-15)
-    -> CosineAnnealingLR
+It performs exactly what the reference's training iteration does (train.py:168-201) for the default model (fp32, bf16-copy or
+half2 hash encoder):
+    rays -> render (march, hash encode, MLPs, composite) -> MSE [+ distortion] vs target -> backward -> GradScaler
+    -> Adam(eps=1e-15) -> CosineAnnealingLR
 but every piece is a libngp_hip kernel working on persistent buffers:
-  * gradients are accumulated by the backward kernels straight into persistent buffers (no per-step 45.7 MB
-    allocation + memset, no autograd graph), and are unscaled + zeroed inside the Adam pass;
+  * gradients are accumulated by the backward kernels straight into persistent buffers (no per-step 45.7 MB allocation +
+    memset, no autograd graph), and are unscaled + zeroed inside the Adam pass;
+  * the backward runs over the LIVE samples only -- those in front of each ray's early-termination point, the others have
+    exact-zero gradients -- through a compacted index list (ngp_live_compact);
   * the inf/nan check, loss-scale growth/backoff, learning rate and bias corrections live in a tiny device-side state
-    (ngp_train_prologue), so nothing is read back;
-  * with world_size > 1 each rank renders its own ray shard and the gradient bucket (table | MLP | inf flag) is
-    all-reduced (one collective over one flat bucket) over RCCL before the optimizer kernels -- the only exchange step.
-The step can be captured into a hipGraph (`capture()`), after which `step()` is a graph replay.
+    (ngp_train_prologue), so nothing is read back; table Adam, MLP Adam and the fp16 fragment repack are one launch;
+  * the NEXT batch's march runs on a side stream underneath the current step (it only depends on rays and the bitfield);
+  * with world_size > 1 each rank renders its own ray shard and the gradient bucket (table | MLP | inf flag) is all-reduced
+    (one collective over one flat bucket) over RCCL before the optimizer kernels -- the only exchange step.
+`capture()` switches the shading -> optimizer chain to hipGraph replay (measured slower than eager on ROCm 7: not the default).
 
-The reference's own loop (torch.optim.Adam + torch GradScaler + autograd through modules/) keeps working on the
-drop-in operators; this class is the MI355X-native fast path that bench.py measures."""
+The reference's own loop (torch.optim.Adam + torch GradScaler + autograd through modules/) keeps working on the drop-in
+operators; this class is the MI355X-native fast path that bench.py measures."""
 import ctypes
 import math
+import os
 
 import torch
 import torch.distributed as dist
@@ -51,8 +56,8 @@ class FusedTrainer:
         self.exp_step_factor, self.T_threshold, self.max_samples = float(exp_step_factor), float(T_threshold), int(max_samples)
         self.bg = 1.0 if exp_step_factor == 0 else 0.0                    # rendering.py:219-226
         self.distortion_loss_w = float(distortion_loss_w)                # train.py:194-195 (0 = off, the reference default)
-        import os as _os0
-        self.live_backward = _os0.environ.get("NGP_LIVE_BACKWARD", "1") != "0"
+        # backward over the samples in front of each ray's early-termination point only (NGP_LIVE_BACKWARD=0: over all of them)
+        self.live_backward = os.environ.get("NGP_LIVE_BACKWARD", "1") != "0"
         self.group = process_group
         self.world = world_size if world_size is not None else (dist.get_world_size(process_group) if dist.is_initialized() else 1)
 
@@ -94,7 +99,6 @@ class FusedTrainer:
         self._live_total = torch.zeros(1, device=dev, dtype=torch.int32)
         self._graph = None
         self._grads_only = False
-        self._static = None
         self.stats = {}
         self._sets = {}
         self._cur = 0
@@ -255,11 +259,11 @@ class FusedTrainer:
         if self.distortion_loss_w > 0:
             sq_err = self._composite_with_distortion(A, M, target, cfg, n, vr_per_ray, opacity, depth, rgb)
         else:
-          # composite forward + MSE gradient + composite backward, one launch
-          check(L.ngp_composite_train_fused(_ptr(A.sigmas), _ptr(A.rgbs), 1, _ptr(M.deltas), _ptr(M.ts), _ptr(rays_a), _ptr(target),
-                                            self.bg, _ptr(sf), cfg.T_threshold, n, _ptr(vr_per_ray), _ptr(opacity), _ptr(depth),
-                                            _ptr(rgb), _ptr(A.ws), _ptr(A.d_sigmas), _ptr(A.d_rgbs), _ptr(sq_err), st),
-                "ngp_composite_train_fused")
+            # composite forward + MSE gradient + composite backward, one launch
+            check(L.ngp_composite_train_fused(_ptr(A.sigmas), _ptr(A.rgbs), 1, _ptr(M.deltas), _ptr(M.ts), _ptr(rays_a), _ptr(target),
+                                              self.bg, _ptr(sf), cfg.T_threshold, n, _ptr(vr_per_ray), _ptr(opacity), _ptr(depth),
+                                              _ptr(rgb), _ptr(A.ws), _ptr(A.d_sigmas), _ptr(A.d_rgbs), _ptr(sq_err), st),
+                  "ngp_composite_train_fused")
         # backward on the LIVE samples only (those in front of each ray's early-termination point; the rest have exact-zero
         # gradients): a compacted index list, then the MLP backward and the scatter-add run over it
         live_idx, live_total = A.live_idx, self._live_total
