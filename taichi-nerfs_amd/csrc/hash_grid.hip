@@ -4,10 +4,16 @@
 // modules/hash_encoder_half.py:112-213 of the reference.
 //
 // Layout: table is the reference's flat [entries, F] array (level l occupies entries
-// [offset_l, offset_l + size_l)); out/dout are [n, L*F], level-major, feature-minor.
-// Mapping: one lane per (sample, level) with the level index fastest, so a wave covers 64/L consecutive
-// samples and writes 64*F*4 contiguous bytes; the 8 corner loads of a lane are issued back to back
-// (8 independent 8-byte gathers in flight per lane).  The level table sits in LDS.
+// [offset_l, offset_l + size_l)); out/dout are [n, L*F], level-major, feature-minor -- or, on the fused path (L = 16,
+// F = 2), eight pair-major planes [8][n_max][4] (plane p = levels p and 15 - p).
+// Kernels, generic to specialised:
+//   hash_fwd_f32_kernel<F>        one lane per (sample, level), level fastest; 8 independent gathers in flight per lane
+//   hash_fwd_f32_xcd_kernel<MODE> block b encodes level pair (b % 8, 15 - b % 8): every XCD's L2 keeps its slice of the table;
+//                                 MODE selects the fp32 table, a bf16 storage copy, or the half2 encoder's f16 arithmetic
+//   hash_bwd_f32_kernel<F>        generic scatter-add, one lane per (sample, level)
+//   hash_bwd_f32x2_kernel         F = 2: lane quads on one 64-byte line + run merging (the atomic line-request rate is the bound)
+//   hash_fwd/bwd_f16_kernel       the half2 encoder as the reference writes it; hash_bwd_f16x2_kernel its fused-path form
+// The backward kernels optionally run over a compacted list of live samples (live_idx).  The level table sits in LDS.
 #include "ngp_device.h"
 #include <hip/hip_fp16.h>
 

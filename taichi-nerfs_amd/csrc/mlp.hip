@@ -18,10 +18,15 @@
 //
 // Backward recomputes the forward per tile (cheaper than storing 0.68 KB/sample of activations), propagates
 // dX = W^T dZ through the same register-chaining trick, and forms the weight gradients dW = dZ X^T with the sample
-// index as K: that needs [feature][sample] fragments, so dZ and X of one layer at a time are transposed through a
-// 10 KB LDS tile per 32-sample group.  The 40 dW output tiles are distributed over the 16 waves of a block (each wave
-// sums ITS tiles over all the block's samples), accumulate in fp32 registers across the whole persistent loop and leave the block
-// as line-coalesced global atomics -- no cross-wave reduction.
+// index as K: that needs [feature][sample] fragments, so every wave stores its dZ / X rows untransposed into a blocked
+// LDS image (13 KB per 32-sample group) and the dW waves read them back with gfx950's transposing LDS read
+// (ds_read_b64_tr_b16).  The 40 dW output tiles are distributed over the 12 waves of a block (each wave sums ITS tiles
+// over all the block's samples), accumulate in fp32 registers across the whole persistent loop and leave the block as
+// line-coalesced global atomics -- no cross-wave reduction.  It runs over the live-sample list of the trainer
+// (ngp_mlp_bwd_live) or over all samples.
+// Both kernels are VALU-issue bound, not MFMA bound (16-sample tiles: 4 output values per lane and MFMA to convert,
+// activate and re-pack): everything between two MFMAs uses the packed f16 instructions (profiles/microbench/
+// r01_mlp_bwd_breakdown.txt).
 //
 // Numerics are tolerance-checked against an fp32 torch restatement and against torch's own autocast path
 // (tests/test_gpu_mlp.py); bf16/fp16 MFMA is used because this is the one genuine dense contraction on the path.
@@ -443,7 +448,7 @@ __global__ void __launch_bounds__(768) mlp_bwd_kernel(const float* __restrict__ 
 
     for (int round = blockIdx.x; round < n_round; round += gridDim.x) {
         const int smp = (round * BG + grp) * 32 + col;
-        BwdIn in;                     // 4 waves per SIMD hide this latency; a register prefetch would spill
+        BwdIn in;                     // (a register prefetch of the next round's inputs was measured: no gain, +14 VGPR)
         bwd_prefetch(in, enc, dirs, dsigmas, drgbs, smp, S, g, pairs, plane, idx);
         TileFwd t;
         half4 dz5 = hzero, dz4[4], dz3[4], dz2, dz1[4];
