@@ -45,3 +45,14 @@ def test_get_ray_directions_mirror_matches_reference():
     assert np.array_equal(d.numpy(), G["directions_hw"]) and np.array_equal(uv.numpy(), G["uv"])
     r = get_ray_directions(H, W, K, random=True)
     assert r.shape == (H * W, 3) and float((r - torch.from_numpy(G["directions"])).abs().max()) <= 0.5 / 13.5 + 1e-6
+
+
+def test_ray_helpers_have_no_cpu_path():
+    """The product path fails loudly on host tensors instead of falling back."""
+    import pytest
+    from ngp_hip.rays import RayBatcher, get_rays
+    d = torch.from_numpy(G["directions"])
+    with pytest.raises(Exception):
+        get_rays(d, torch.from_numpy(G["poses"][0]))
+    with pytest.raises(Exception):
+        RayBatcher(torch.rand(5, d.shape[0], 3), torch.from_numpy(G["poses"]), d)
