@@ -1,7 +1,10 @@
 """Mirror of reference modules/rendering.py: `render()` (:12-57) with its train (:161-228) and progressive
 test-time (:62-158) paths, on the HIP operators."""
+import os
+
 import torch
 
+from ngp_hip import ops as _ops
 from .intersection import ray_aabb_intersection
 from .ray_march import raymarching_test, raymarching_train
 from .volume_render_test import composite_test
@@ -20,6 +23,8 @@ def render(model, rays_o, rays_d, test_time=False, exp_step_factor=0, T_threshol
     rays_o, rays_d = rays_o.contiguous().float(), rays_d.contiguous().float()      # geometry is fp32 (ray_utils.py:50)
     hits_t = ray_aabb_intersection(rays_o, rays_d, model.scale)
     if test_time:
+        if rays_o.is_cuda and os.environ.get("NGP_FUSED_EVAL", "1") != "0":
+            return _render_rays_test_oneshot(model, rays_o, rays_d, hits_t, exp_step_factor, T_threshold, max_samples)
         return _render_rays_test(model, rays_o, rays_d, hits_t, exp_step_factor, T_threshold, max_samples)
     return _render_rays_train(model, rays_o, rays_d, hits_t, exp_step_factor, T_threshold)
 
@@ -54,6 +59,43 @@ def _render_rays_test(model, rays_o, rays_d, hits_t, exp_step_factor, T_threshol
         composite_test(sigmas, rgbs, deltas, ts, pack_info, alive, T_threshold, opacity, depth, rgb)
         alive = alive[alive >= 0]
         total_samples += pack_info[:, 1].sum()
+    rgb += _background(exp_step_factor, device) * (1 - opacity)[:, None]
+    return {'opacity': opacity, 'depth': depth, 'rgb': rgb, 'total_samples': total_samples}
+
+
+EVAL_CHUNK = 65536
+
+
+@torch.no_grad()
+def _render_rays_test_oneshot(model, rays_o, rays_d, hits_t, exp_step_factor, T_threshold, max_samples, chunk=None):
+    """Evaluation render without the progressive rounds: the test-time march (no jitter) visits exactly the samples the
+    training march visits with zero noise, and compositing a ray front to back until T <= T_threshold gives what the
+    round-by-round `composite_test` accumulates (tests/test_gpu_configs.py::test_garden_eval_path_..., test_gpu_eval.py).
+    So an image is rendered in chunks of 65536 rays as march -> shade -> composite, one host read of the sample count per
+    chunk instead of two per round -- the reference's loop (kept below as `_render_rays_test`, NGP_FUSED_EVAL=0) needs
+    hundreds of rounds for rays that never saturate.  `total_samples` counts the samples in front of the termination point,
+    like the reference's sum of per-round counts up to the round granularity."""
+    n_rays = len(rays_o)
+    device = rays_o.device
+    chunk = chunk or EVAL_CHUNK
+    opacity = torch.empty(n_rays, device=device)
+    depth = torch.empty(n_rays, device=device)
+    rgb = torch.empty(n_rays, 3, device=device)
+    total_samples = torch.zeros((), device=device, dtype=torch.int64)
+    for a in range(0, n_rays, chunk):
+        b = min(a + chunk, n_rays)
+        o, d, h = rays_o[a:b], rays_d[a:b], hits_t[a:b].contiguous()
+        noise = torch.zeros(b - a, device=device)
+        rays_a, xyzs, dirs, deltas, ts, total = _ops.march_train(o, d, h, model.density_bitfield, noise, model.cascades, model.scale,
+                                                                 exp_step_factor, model.grid_size, max_samples)
+        if xyzs.shape[0] == 0:
+            opacity[a:b] = 0; depth[a:b] = 0; rgb[a:b] = 0
+            continue
+        sigmas, rgbs = model(xyzs, dirs)
+        vr, op_c, dep_c, rgb_c, _ws = _ops.composite_train_fwd(sigmas.contiguous().float(), rgbs.contiguous(), deltas, ts, rays_a,
+                                                               T_threshold)
+        opacity[a:b] = op_c; depth[a:b] = dep_c; rgb[a:b] = rgb_c
+        total_samples += vr.sum()
     rgb += _background(exp_step_factor, device) * (1 - opacity)[:, None]
     return {'opacity': opacity, 'depth': depth, 'rgb': rgb, 'total_samples': total_samples}
 
