@@ -235,3 +235,46 @@ def test_live_backward_equals_full_backward(hip_lib, lego_bitfield):
     ra, vr = a["rays_a"].cpu().numpy(), a["vr_per_ray"].cpu().numpy()
     want = np.concatenate([np.arange(s, s + vr[r]) for r, s, c in ra]) if n_live else np.zeros(0)
     assert np.array_equal(A.live_idx[:n_live].cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("kind", ["f32", "bf16", "half"])
+def test_checkpoint_roundtrip_through_trainer(hip_lib, lego_bitfield, kind):
+    """state_dict out of a trained FusedTrainer model -> fresh model + trainer (load_state_dict + repack) renders the same image;
+    the 16-bit table copies and the packed MLP fragments follow the loaded parameters."""
+    from modules.networks import NGP
+    from modules.rendering import render
+    from ngp_hip import synthetic
+    from ngp_hip.trainer import FusedTrainer
+    kw = dict(table_dtype=torch.bfloat16) if kind == "bf16" else (dict(half_opt=True) if kind == "half" else {})
+    torch.manual_seed(0)
+    m = NGP(scale=0.5, max_res=1024, **kw).cuda()
+    m.density_bitfield.copy_(torch.from_numpy(lego_bitfield).cuda())
+    with torch.no_grad():
+        m.pos_encoder.hash_table.uniform_(0.0, 0.2)
+    o, d = synthetic.lego_rays(2048, seed=9)
+    o, d = torch.from_numpy(o).cuda(), torch.from_numpy(d).cuda()
+    target = torch.rand(2048, 3, device="cuda")
+    tr = FusedTrainer(m, init_scale=2.0**7)
+    for _ in range(5):
+        tr.step(o, d, target)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    m2 = NGP(scale=0.5, max_res=1024, **kw).cuda()
+    tr2 = FusedTrainer(m2, init_scale=2.0**7)
+    m2.load_state_dict(sd)
+    tr2.repack()
+    for mm in (m, m2):
+        mm.eval()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        a = render(m, o, d, test_time=True, exp_step_factor=0.0)["rgb"]
+        b = render(m2, o, d, test_time=True, exp_step_factor=0.0)["rgb"]
+    assert torch.equal(a, b)
+    if kind == "bf16":
+        assert torch.equal(tr2.table_bf16.view(torch.int16), m2.pos_encoder.hash_table.detach().bfloat16().view(torch.int16))
+    if kind == "half":
+        assert torch.equal(tr2.table_f16.view(torch.int16), m2.pos_encoder.hash_table.detach().reshape(-1).half().view(torch.int16))
+    # and training continues from the loaded state (the flat MLP buffer still aliases the module parameters)
+    l0 = None
+    for _ in range(4):
+        tr2.step(o, d, target)
+        l0 = tr2.last_loss() if l0 is None else l0
+    assert np.isfinite(tr2.last_loss()) and tr2.last_loss() <= l0 * 1.05
