@@ -91,6 +91,8 @@ def main():
     ap.add_argument("--n_test", type=int, default=8)
     ap.add_argument("--batch", type=int, default=8192)
     ap.add_argument("--path", default="trainer", choices=["trainer", "modules"])
+    ap.add_argument("--encoder", default="f32", choices=["f32", "bf16", "half"],
+                    help="hash table: fp32 (reference default), bf16 storage copy, or the half2 encoder (hash_encoder_half)")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
     dev = torch.device("cuda")
@@ -109,7 +111,8 @@ def main():
     train_poses, test_poses = poses[:args.n_train], poses[args.n_train:]
     train_imgs, test_imgs = imgs[:args.n_train], imgs[args.n_train:]
 
-    model = NGP(scale=0.5, max_res=1024).to(dev)
+    model = NGP(scale=0.5, max_res=1024, half_opt=args.encoder == "half",
+                table_dtype=torch.bfloat16 if args.encoder == "bf16" else None).to(dev)
     K = torch.tensor([[focal, 0, args.wh / 2], [0, focal, args.wh / 2], [0, 0, 1]], device=dev)
     model.mark_invisible_cells(K, train_poses, (args.wh, args.wh))
     if args.path == "trainer":
@@ -163,7 +166,7 @@ def main():
                 res = render(model, rays_o, rays_d, test_time=True, exp_step_factor=0.0)
             psnrs.append(-10.0 * math.log10(F.mse_loss(res["rgb"], gt).item()))
     torch.cuda.synchronize()
-    out = {"scene": "procedural Lego-shape (NOT Synthetic-NeRF Lego)", "path": args.path, "steps": args.steps, "batch": args.batch,
+    out = {"scene": "procedural Lego-shape (NOT Synthetic-NeRF Lego)", "path": args.path, "encoder": args.encoder, "steps": args.steps, "batch": args.batch,
            "train_views": args.n_train, "test_views": args.n_test, "image_wh": args.wh, "test_psnr_mean": sum(psnrs) / len(psnrs),
            "test_psnr_min": min(psnrs), "train_seconds": t_train, "train_rays_per_sec": args.steps * args.batch / t_train,
            "eval_seconds": time.time() - t0, "gt_render_seconds": t_data, "log(step,loss,rm_samples_per_ray)": log,
