@@ -196,6 +196,8 @@ class FusedTrainer:
             self._march(M, rays_o, rays_d, cfg, A)
         M.ready = None
         hook = None
+        if prefetch is not None and (prefetch[0].shape != rays_o.shape or prefetch[1].shape != rays_d.shape):
+            raise ValueError("prefetch rays must have the shape of the current batch (the two march buffers are sized per batch size)")
         if prefetch is not None:
             # software pipelining across steps: the march only depends on the rays and the occupancy bitfield, never on
             # the weights, and it is latency-bound (few resident waves) -- run the NEXT batch's march on a side stream
