@@ -5,6 +5,12 @@ ray-AABB -> occupancy march -> hash-grid encode -> MLPs (+SH) -> composite -> MS
 hash scatter-add) -> (N>1: RCCL all-reduce of all gradients) -> GradScaler unscale + Adam; plus the reference's
 occupancy-grid update every 16 steps (train.py:178-182), whose cost stays inside the timed region.
 
+The measured state is a TRAINING state, not an initialisation artefact (default --regime scene): target colours are the
+dense-integration render of an analytic Lego-shape scene (ngp_hip/synthetic.py), and before the warm-up the model is
+conditioned, untimed, by --condition seeded optimisation steps on that scene with the reference's schedule (occupancy
+warm-up for the first 256 steps, update every 16).  From there on the occupancy grid is the model's own, samples per ray
+and the live fraction are stable, and `--steps 20 --warmup 5` measures the same step as `--steps 200 --warmup 20`.
+
 Usage: python bench.py --gpus N --steps K --warmup W   (N>1 via torch.distributed.run, one rank per GPU)
 Prints ONE JSON line on rank 0.
 """
@@ -58,8 +64,15 @@ def parse():
     ap.add_argument("--scene", default="lego", choices=["lego", "garden"],
                     help="lego = BASELINE C2 (scale 0.5, 1 cascade, max_res 1024, the headline); garden = BASELINE C3 shape "
                          "(scale 16, 6 cascades, max_res 4096, exponential stepping, black background, distortion loss 1e-3)")
-    ap.add_argument("--regime", default="lego", choices=["lego", "random50", "ones"],
-                    help="occupancy bitfield: trained-Lego fixture (steady state), seeded 50%% (initialisation), all-ones")
+    ap.add_argument("--regime", default="scene", choices=["scene", "lego", "random50", "ones"],
+                    help="scene (default): analytic-scene targets + a conditioned model marching its OWN occupancy grid.  The others "
+                         "are round-1's synthetic-state diagnostics (random target colours, the bitfield overwritten every update): "
+                         "lego = trained-Lego fixture bitfield, random50 = seeded 50%% (initialisation regime), ones = all occupied")
+    ap.add_argument("--condition", type=int, default=1024,
+                    help="--regime scene: untimed, seeded optimisation steps on the scene before the warm-up (multiple of 16)")
+    ap.add_argument("--pool", type=int, default=32, help="--regime scene: resident batches the steps cycle through")
+    ap.add_argument("--no-kernel-events", dest="kernel_events", action="store_false",
+                    help="no per-kernel HIP events inside the timed region (A/B for the event overhead)")
     ap.add_argument("--half", action="store_true", help="half2 hash encoder (BASELINE C5)")
     ap.add_argument("--table", default="f32", choices=["f32", "bf16"],
                     help="hash-table storage the forward gathers from: f32 (the reference's default encoder; the headline line) "
@@ -111,9 +124,11 @@ class KernelTimer:
         return out
 
 
-def cpu_baseline(bits, seconds):
+def cpu_baseline(bits, seconds, table=None, weights=None, targets=None):
     """The oracle (C restatement of the reference's kernels, OpenMP over all host cores) + the same MLPs in fp32
-    torch-CPU, timed on 1024-ray batches (BASELINE config 0) of the same workload for ~`seconds`."""
+    torch-CPU, timed on 1024-ray batches (BASELINE config 0) of the same workload for ~`seconds`: same ray generator,
+    and -- when given -- the bench's own conditioned model state (occupancy bitfield, hash table, MLP weights) and the
+    same analytic-scene targets, so the CPU leg sees the sample counts and early termination the GPU leg sees."""
     from oracle import ngp_oracle as ora
     from ngp_hip import synthetic
     ora.build()
@@ -122,17 +137,23 @@ def cpu_baseline(bits, seconds):
     n = 1024
     lv = ora.make_levels(2**19, 16, 16, 1024, 2)
     rng = np.random.default_rng(0)
-    table = rng.random(lv.total_entries * 2, dtype=np.float32)
-    w = [torch.randn(64, 32) * 0.2, torch.randn(16, 64) * 0.2, torch.randn(64, 32) * 0.2, torch.randn(64, 64) * 0.2,
-         torch.randn(3, 64) * 0.2]
-    for t in w:
-        t.requires_grad_(True)
-    target = torch.rand(n, 3)
+    if table is None:
+        table = rng.random(lv.total_entries * 2, dtype=np.float32)
+    if weights is None:
+        weights = [torch.randn(64, 32) * 0.2, torch.randn(16, 64) * 0.2, torch.randn(64, 32) * 0.2, torch.randn(64, 64) * 0.2,
+                   torch.randn(3, 64) * 0.2]
+    w = [t.detach().clone().float().requires_grad_(True) for t in weights]
     dtable = np.zeros(lv.total_entries * 2, np.float32)
-    done, t0, samples = 0, time.perf_counter(), 0
+    done, samples, live = 0, 0, 0
     it = 0
+    batches = []
+    for b in range(4):                           # rays + targets are made before the clock starts (inputs resident, like the GPU leg)
+        o, d = synthetic.lego_rays(n, seed=100 + b)
+        tgt = (synthetic.procedural_render_gt(torch.from_numpy(o), torch.from_numpy(d)) if targets == "scene" else torch.rand(n, 3))
+        batches.append((o, d, tgt))
+    t0 = time.perf_counter()
     while True:
-        o, d = synthetic.lego_rays(n, seed=100 + it)
+        o, d, target = batches[it % len(batches)]
         noise = rng.random(n, dtype=np.float32)
         hits = ora.ray_aabb(o, d, 0.5)
         rays_a, xyzs, dirs, deltas, ts, S = ora.march_train(o, d, hits, bits, noise, 1, 0.5, 0.0, 128, 1024)
@@ -145,7 +166,7 @@ def cpu_baseline(bits, seconds):
         rgbs = torch.sigmoid(torch.relu(torch.relu(torch.cat([sh, h], 1) @ w[2].T) @ w[3].T) @ w[4].T)
         tot, op, dep, rgb, ws = ora.composite_train_fwd(sigma.detach().numpy(), rgbs.detach().numpy(), deltas, ts, rays_a, 1e-4)
         rgb_t = torch.from_numpy(rgb) + (1 - torch.from_numpy(op))[:, None]
-        g_rgb = (2.0 / (3 * n) * (rgb_t - target)).numpy()
+        g_rgb = (2.0 / (3 * n) * (rgb_t - target)).numpy().astype(np.float32)
         g_op = -g_rgb.sum(1)
         ds, dc = ora.composite_train_bwd(g_op, None, g_rgb, None, sigma.detach().numpy(), rgbs.detach().numpy(), deltas, ts,
                                          rays_a, 1e-4)
@@ -154,13 +175,15 @@ def cpu_baseline(bits, seconds):
         ora.hash_bwd_f32_atomic(x01, enc.grad.numpy(), lv, dtable)
         for t in w:
             t.grad = None
-        done += n; samples += S; it += 1
+        done += n; samples += S; live += int(np.sum(tot)); it += 1
         el = time.perf_counter() - t0
         if el >= seconds:
             break
     return {"value": done / el, "unit": "rays/s", "cores": cores, "kind": "port",
-            "sample": "%d batches x 1024 Lego-shape rays (%.1f samples/ray), oracle/ngp_oracle.c (OpenMP) + fp32 torch-CPU MLP, "
-                      "fwd+bwd without optimizer, %.1f s" % (it, samples / max(done, 1), el)}
+            "sample": "%d batches x 1024 Lego-shape rays (%.1f marched / %.1f composited samples per ray, %s model state), "
+                      "oracle/ngp_oracle.c (OpenMP) + fp32 torch-CPU MLP, fwd+bwd without optimizer, %.1f s"
+                      % (it, samples / max(done, 1), live / max(done, 1),
+                         "the bench's conditioned" if targets == "scene" else "random-init", el)}
 
 
 def main():
@@ -191,7 +214,6 @@ def main():
         dist.barrier()
     lib.build()
     lib.load()
-    import modules.hash_encoder as _he
     from modules.networks import NGP
     from modules.rendering import MAX_SAMPLES, render
 
@@ -205,6 +227,11 @@ def main():
     if args.half and args.table != "f32":
         raise SystemExit("--half already selects the fp16 table")
     garden = args.scene == "garden"
+    if garden and args.regime == "scene":
+        args.regime = "lego"                     # there is no analytic Garden scene: C3 keeps the synthetic-occupancy diagnostic state
+    scene = args.regime == "scene"
+    if scene and args.condition % 16 != 0:
+        raise SystemExit("--condition must be a multiple of 16 (the occupancy-update cadence)")
     if args.rays is None:
         args.rays = 65536 if garden else 8192
     esf = 1.0 / 256 if garden else 0.0                                       # train.py:54
@@ -214,16 +241,18 @@ def main():
         model = NGP(scale=16.0 if garden else 0.5, max_res=4096 if garden else 1024, half_opt=args.half,
                     table_dtype=torch.bfloat16 if args.table == "bf16" else None).to(dev)
     golden = os.path.join(ROOT, "tests", "golden", "lego_density_bitfield.npz")
+    bits = bits_np = None
     if garden:
         bits_np = synthetic.ball_slab_bitfield(model.cascades, 16.0, seed=23)
     elif args.regime == "lego":
         bits_np = np.load(golden)["density_bitfield"]
     elif args.regime == "random50":
         bits_np = synthetic.random_bitfield(1, fraction=0.5, seed=23)
-    else:
+    elif args.regime == "ones":
         bits_np = np.full(128**3 // 8, 255, np.uint8)
-    bits = torch.from_numpy(bits_np).to(dev)
-    model.density_bitfield.copy_(bits)
+    if bits_np is not None:
+        bits = torch.from_numpy(bits_np).to(dev)
+        model.density_bitfield.copy_(bits)
 
     trainer = None
     if use_trainer:
@@ -237,26 +266,35 @@ def main():
         scaler = torch.amp.GradScaler("cuda", init_scale=2.0**16 if args.half else 2.0**19)
         reducer = GradReducer(model, world) if world > 1 else None
 
-    # a pool of synthetic batches resident in HBM before the timed region (rank-dependent shards of one stream)
-    n_pool = 8
+    # a pool of synthetic batches resident in HBM before the timed region (rank-dependent shards of one stream of seeds);
+    # scene regime: every ray's target colour is the analytic scene's radiance along it, rendered here once
+    n_pool = args.pool if scene else 8
     pool = []
     for b in range(n_pool):
         o, d = (synthetic.garden_rays if garden else synthetic.lego_rays)(args.rays, seed=1000 + 97 * b + rank)
-        g = torch.Generator(device="cpu").manual_seed(b * 131 + rank)
-        pool.append((torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev), torch.rand(args.rays, 3, generator=g).to(dev)))
+        o, d = torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev)
+        if scene:
+            tgt = synthetic.procedural_render_gt(o, d).contiguous()
+        else:
+            g = torch.Generator(device="cpu").manual_seed(b * 131 + rank)
+            tgt = torch.rand(args.rays, 3, generator=g).to(dev)
+        pool.append((o, d, tgt))
 
+    n_extra = args.steps + 8                                  # the no-prefetch leg after the timed region logs too
     state = {"rm": 0, "vr": 0, "k": 0}
     # sample counts are informational: they are copied out on every STAT_EVERY-th step only (a 4-byte device-to-device copy
-    # is a ~4.5 us kernel on the step's stream); 7 is coprime with the 8-batch pool, so every batch is sampled
+    # is a ~4.5 us kernel on the step's stream); 7 is coprime with the pool size, so every batch is sampled
     STAT_EVERY = 7
-    stat_log = torch.zeros((args.steps + args.warmup + 4) // STAT_EVERY + 1, 1, device=dev, dtype=torch.int32)
-    vr_log = torch.zeros((args.steps + args.warmup + 4) // STAT_EVERY + 1, args.rays, device=dev, dtype=torch.int32)
-    live_log = torch.zeros((args.steps + args.warmup + 4) // STAT_EVERY + 1, 1, device=dev, dtype=torch.int32)
+    n_log = (args.steps + args.warmup + n_extra + 4) // STAT_EVERY + 1
+    stat_log = torch.zeros(n_log, 1, device=dev, dtype=torch.int32)
+    vr_log = torch.zeros(n_log, 1, device=dev, dtype=torch.int32)
+    live_log = torch.zeros(n_log, 1, device=dev, dtype=torch.int32)
 
     # the trainer launches go straight through the C ABI: HIP events around the big kernels, on the launch stream
     c_events = {}
     # events are created up front (hipEventCreate inside the timed loop costs more than the kernels it would time)
-    event_pool = [torch.cuda.Event(enable_timing=True) for _ in range(2 * 8 * (args.steps + 2))] if use_trainer and not args.graph else []
+    event_pool = ([torch.cuda.Event(enable_timing=True) for _ in range(2 * 10 * (args.steps + 2))]
+                  if use_trainer and not args.graph and args.kernel_events else [])
     if use_trainer and not args.graph:
         L = lib.load()
 
@@ -273,34 +311,42 @@ def main():
                 return rc
             setattr(L, name, timed)
         for name in TRAINER_KERNELS:
-            wrap_entry(name)
+            if hasattr(L, name):
+                wrap_entry(name)
 
-    def trainer_step(i):
+    thr = 0.01 * MAX_SAMPLES / 3**0.5                        # train.py:180
+
+    def grid_update(i):
+        """train.py:178-182: every 16 steps, all cells during the first 256 steps.  Scene regime: the model's own grid is what
+        the next steps march.  Diagnostic regimes: the update's full cost is paid, then the fixed bitfield is put back."""
+        if use_trainer:
+            trainer.update_density_grid(thr, warmup=scene and i < 256)
+        else:
+            model.update_density_grid(thr, warmup=scene and i < 256)
+        if not scene:
+            model.density_bitfield.copy_(bits)
+
+    def trainer_step(i, prefetch=True, log=True):
         rays_o, rays_d, target = pool[i % n_pool]
         if i % 16 == 0:
-            trainer.update_density_grid(0.01 * MAX_SAMPLES / 3**0.5, warmup=False)
-            model.density_bitfield.copy_(bits)          # see the comment in step() below
+            grid_update(i)
         nxt = pool[(i + 1) % n_pool]
-        pre = (nxt[0], nxt[1]) if (args.prefetch and (i + 1) % 16 != 0) else None      # never across a grid update
+        pre = (nxt[0], nxt[1]) if (prefetch and (i + 1) % 16 != 0) else None      # never across a grid update
         out = trainer.step(rays_o, rays_d, target, prefetch=pre)
         k = state["k"]
-        if k % STAT_EVERY == 0 and k // STAT_EVERY < stat_log.shape[0]:
+        if log and k % STAT_EVERY == 0 and k // STAT_EVERY < stat_log.shape[0]:
             stat_log[k // STAT_EVERY, 0].copy_(out["rm_samples"][0])
-            vr_log[k // STAT_EVERY].copy_(out["vr_per_ray"])
+            vr_log[k // STAT_EVERY, 0] = out["vr_per_ray"].sum()
             live_log[k // STAT_EVERY, 0].copy_(trainer._live_total[0])
         state["k"] = k + 1
 
-    def step(i):
+    def step(i, prefetch=True, log=True):
         if use_trainer:
-            return trainer_step(i)
+            return trainer_step(i, prefetch, log)
         rays_o, rays_d, target = pool[i % n_pool]
         with torch.autocast(device_type="cuda", dtype=torch.float16):
             if i % 16 == 0:
-                # occupancy-grid maintenance at the reference's cadence; the bench keeps marching the fixed
-                # synthetic-scene bitfield (a random-init model cannot reproduce a trained scene's occupancy), so
-                # the freshly packed bitfield is overwritten again -- the update's full cost is still paid.
-                model.update_density_grid(0.01 * MAX_SAMPLES / 3**0.5, warmup=False)
-                model.density_bitfield.copy_(bits)
+                grid_update(i)
             res = render(model, rays_o, rays_d, exp_step_factor=esf)
             loss = F.mse_loss(res["rgb"], target)
             if w_dist > 0:
@@ -321,16 +367,27 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(i)
+    # ---- untimed conditioning: the model becomes a (partly) trained model of the scene its targets come from --------------
+    base = 0
+    t_cond = 0.0
+    if scene:
+        fence()
+        t0 = time.perf_counter()
+        for i in range(args.condition):
+            step(i, prefetch=args.prefetch, log=False)
+        fence()
+        t_cond = time.perf_counter() - t0
+        base = args.condition
+    for i in range(base, base + args.warmup):
+        step(i, prefetch=args.prefetch, log=False)
     if use_trainer and args.graph and world == 1:
         trainer.capture(args.rays)
     state["rm"] = 0; state["vr"] = 0; state["k"] = 0
     timer.enabled = True
     fence()
     t0 = time.perf_counter()
-    for i in range(args.warmup, args.warmup + args.steps):
-        step(i)
+    for i in range(base + args.warmup, base + args.warmup + args.steps):
+        step(i, prefetch=args.prefetch)
     fence()
     elapsed = time.perf_counter() - t0
     timer.enabled = False
@@ -338,19 +395,41 @@ def main():
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    k_timed = state["k"]
+
+    # ---- after the timed region (untimed, informational): the same K steps again with the march NOT prefetched, i.e. what a
+    # loop pays whose next batch is not known one step ahead
+    elapsed_np = None
+    if use_trainer and args.prefetch and not args.graph and world == 1:
+        i0 = base + args.warmup + args.steps
+        i0 += (-i0) % 16                                                    # same phase relative to the grid updates ...
+        i0 += (base + args.warmup) % 16                                     # ... as the timed region
+        step(i0 - 1, prefetch=False, log=False)
+        fence()
+        t0 = time.perf_counter()
+        for i in range(i0, i0 + args.steps):
+            step(i, prefetch=False, log=False)
+        fence()
+        elapsed_np = time.perf_counter() - t0
 
     if use_trainer:
-        n_st = (state["k"] + STAT_EVERY - 1) // STAT_EVERY
-        state["rm"] = stat_log[:n_st].sum(dtype=torch.int64) * state["k"] // max(n_st, 1)
-        state["vr"] = vr_log[:n_st].sum(dtype=torch.int64) * state["k"] // max(n_st, 1)
+        n_st = (k_timed + STAT_EVERY - 1) // STAT_EVERY
+        state["rm"] = stat_log[:n_st].sum(dtype=torch.int64) * k_timed // max(n_st, 1)
+        state["vr"] = vr_log[:n_st].sum(dtype=torch.int64) * k_timed // max(n_st, 1)
     rm = int(state["rm"]); vr = int(state["vr"])
     total_rays = args.rays * world * args.steps
     if rank == 0:
         ks = timer.summary()
         rooflines = {}
+        live_avg = None
         if use_trainer:
-            live = rm / max(args.steps, 1)                     # marched samples per step (launches are sized for the arena)
-            live_avg = (float(live_log[:n_st].sum(dtype=torch.int64)) / max(n_st, 1)) if trainer.live_backward else live
+            marched = rm / max(args.steps, 1)                  # marched samples per step (launches are sized for the arena)
+            live_avg = (float(live_log[:n_st].sum(dtype=torch.int64)) / max(n_st, 1)) if trainer.live_backward else marched
+            # the dense Adam pass skips float4 groups that never received a gradient (g = m = v = 0: exact fixed points) after
+            # reading g, m, v; everything else reads p too and writes p, m, v and the zeroed g.  Bytes it really moves:
+            n4 = trainer.table.numel() // 4
+            touched4 = int(((trainer.table_m.view(-1, 4) != 0) | (trainer.table_v.view(-1, 4) != 0)).any(1).sum())
+            adam_bytes = 48.0 * n4 + 80.0 * touched4 + (8.0 * touched4 if (args.half or args.table == "bf16") else 0.0)
             agg = {}                                           # key -> [launches, total_ms, total_work, bound, per_unit, unit, units]
             for name, evs in c_events.items():
                 key, bound, per_unit, unit = TRAINER_KERNELS[name]
@@ -366,11 +445,14 @@ def main():
                     elif unit == "live":
                         units = float(live_avg)
                     else:
-                        # _ex launches: device-side count (the live samples of the step) unless n_dev is NULL
+                        # _ex launches: device-side count (the marched samples of the step) unless n_dev is NULL
                         # (occupancy-update encodes: exact n = arg 3)
                         n_dev = a[4] if name in ("ngp_hash_fwd_f32_ex", "ngp_hash_fwd_bf16_ex", "ngp_hash_fwd_f16_ex", "ngp_mlp_fwd_ex") else None
-                        units = float(a[3]) if (n_dev is not None and getattr(n_dev, "value", 1) is None) else float(live)
-                    work = per_unit * units + (8 * live if key == "march_count" else 0)
+                        units = float(a[3]) if (n_dev is not None and getattr(n_dev, "value", 1) is None) else float(marched)
+                    if unit == "param":
+                        work = adam_bytes
+                    else:
+                        work = per_unit * units + (8 * marched if key == "march_count" else 0)
                     rec = agg.setdefault(key, [0, 0.0, 0.0, bound, per_unit, "sample" if unit in ("n_arg", "live") else unit, 0.0])
                     rec[0] += 1; rec[1] += e0.elapsed_time(e1); rec[2] += work; rec[6] += units
             for key, (n_l, tot_ms, tot_work, bound, per_unit, unit, tot_units) in agg.items():
@@ -381,6 +463,10 @@ def main():
                                   "unit": "GB/s" if bound == "hbm" else "TFLOP/s", "frac": float(ach / peak),
                                   "traffic": None, "work_per_unit": per_unit, "unit_of_work": unit,
                                   "avg_units_per_launch": tot_units / n_l, "avg_launch_ms": tot_ms / n_l, "launches": n_l}
+                if key.startswith("adam"):
+                    rooflines[key]["note"] = ("bytes = what the pass really moves: 48 B per float4 group (g, m, v read) + 80 B per TOUCHED "
+                                              "group (p read; p, m, v, zeroed g written); %d of %d groups touched" % (touched4, n4))
+                    rooflines[key]["work_per_unit"] = adam_bytes / max(tot_units / n_l, 1)
         else:
             for key, k in ks.items():
                 bps = BYTES_PER_SAMPLE[key]
@@ -388,54 +474,73 @@ def main():
                 rooflines[key] = {"kernel": key, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": ach / HBM_PEAK_GBS, "traffic": None, "work_per_unit": bps, "unit_of_work": "sample",
                                   "avg_units_per_launch": k["avg_units"], "avg_launch_ms": k["avg_ms"], "launches": k["launches"]}
-        # PMC traffic (HBM bytes per launch) measured in separate rocprofv3 --pmc passes, see profiles/r01_pmc.json
-        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc.json")
-        if os.path.exists(pmc_path):
+        # PMC traffic (HBM bytes per launch) comes from separate rocprofv3 --pmc passes of THIS command (profiles/r02_pmc.json,
+        # which records the workload state it was taken in); it is attached only if that state matches this run within 10 %,
+        # otherwise traffic stays null -- a counter value from another state says nothing about this one
+        pmc_path = os.path.join(ROOT, "profiles", "r02_pmc.json")
+        traffic_src = None
+        if os.path.exists(pmc_path) and use_trainer:
             pmc = json.load(open(pmc_path))
-            for key, r in rooflines.items():
-                if key in pmc.get("kernels", {}):
-                    r["traffic"] = pmc["kernels"][key]["hbm_bytes_per_launch"]
+            st = pmc.get("state", {})
+            same = (st.get("regime") == args.regime and st.get("rays") == args.rays and not args.half and args.table == "f32"
+                    and abs(st.get("live_samples_per_step", -1) - live_avg) <= 0.1 * max(live_avg, 1)
+                    and abs(st.get("marched_samples_per_step", -1) - marched) <= 0.1 * max(marched, 1))
+            if same:
+                traffic_src = "profiles/r02_pmc.json (separate --pmc passes of this command; state matches this run within 10 %)"
+                for key, r in rooflines.items():
+                    if key in pmc.get("kernels", {}):
+                        r["traffic"] = pmc["kernels"][key]["hbm_bytes_per_launch"]
+                        r["traffic_source"] = traffic_src
         # dominant kernel = largest total time on the step's critical path; with --prefetch the march of the next batch
         # runs on a side stream underneath the other kernels (15 of 16 steps), so it is reported but not eligible
         eligible = [k for k in rooflines if not (k == "march_count" and use_trainer and args.prefetch and not args.graph)]
         dom = max(eligible, key=lambda k: ks[k]["total_ms"], default=None)
         roof = rooflines.get(dom)
-        if roof is not None and dom == "hash_bwd_f32":
-            # transparency: achieved prices EVERY live sample at the SURVEY 8(d) figure (like the reference's autodiff kernel);
-            # samples behind early termination carry exact-zero gradients and are skipped after their 140-byte read
-            # the scatter-add is bound by the chip's float-atomic LINE-REQUEST rate, not by HBM bytes: <= 4 distinct 64-byte lines per
-            # (live sample, level) -- the reference's hash keeps only the x-neighbour on a line -- against ~21 G line requests/s
-            # measured for random lines (profiles/r01_microbench_atomics2.txt).  Upper bound (run merging removes some requests).
-            lines = 4.0 * 16.0 * roof["avg_units_per_launch"]
-            roof = dict(roof, note="the backward runs on the live samples only (those in front of each ray's early-termination point: "
-                                   "%.0f%% of the marched samples in this run); achieved = algorithmic bytes x LIVE samples per launch; "
-                                   "the kernel's real bound is the atomic line-request rate, see atomic_line_rate" % (100.0 * vr / max(rm, 1)),
-                        atomic_line_rate={"line_requests_per_launch_upper_bound": lines,
-                                          "achieved_G_per_s": lines / (roof["avg_launch_ms"] * 1e-3) / 1e9,
-                                          "measured_peak_G_per_s": 21.0,
-                                          "frac": lines / (roof["avg_launch_ms"] * 1e-3) / 21.0e9})
+        workload = {"regime": args.regime, "rm_samples_per_ray": rm / total_rays * world, "vr_samples_per_ray": vr / total_rays * world,
+                    "live_over_marched": vr / max(rm, 1),
+                    "occupied_fraction": float((torch.cat([(model.density_bitfield >> b) & 1 for b in range(8)]) > 0).float().mean())}
+        if scene:
+            workload.update({"targets": "analytic Lego-shape scene (ngp_hip/synthetic.py), dense-integration radiance per ray, white background",
+                             "conditioning_steps": args.condition, "conditioning_seconds": t_cond, "pool_batches": n_pool,
+                             "occupancy": "the model's own grid (update every 16 steps; all-cell warm-up for steps < 256)"})
+            if use_trainer:
+                workload["loss_at_end"] = trainer.last_loss()
+        if garden:
+            text = ("360_v2 Garden shape (BASELINE C3): %d rays/GPU/step, scale 16, 6 cascades 128^3, hash grid L=16 F=2 "
+                    "T=2^19 max_res=4096 (%s table), exp_step_factor 1/256, synthetic ball+slab+far-cells occupancy, random target colours, "
+                    "MSE + 1e-3 distortion loss, full train step (fwd+bwd+GradScaler+Adam, grid update every 16 steps)"
+                    % (args.rays, "f16" if args.half else args.table))
+        else:
+            text = ("Synthetic-NeRF Lego shape (BASELINE C2%s): %d rays/GPU/step, scale 0.5, 1 cascade 128^3, hash grid L=16 F=2 T=2^19 "
+                    "max_res=1024 (%s table), %s, full train step (fwd+bwd+GradScaler+Adam, grid update every 16 steps); "
+                    "%.1f marched / %.1f composited samples per ray" % (
+                        "/C4" if world > 1 else "", args.rays, "f16" if args.half else args.table,
+                        ("analytic-scene targets, model conditioned for %d steps, marching its own occupancy grid" % args.condition)
+                        if scene else ("random target colours, fixed occupancy=%s (diagnostic state)" % args.regime),
+                        rm / total_rays * world, vr / total_rays * world))
         out = {
             "metric": "training rays/sec", "value": total_rays / elapsed, "unit": "rays/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16-table+f16-mlp" if args.half else ("bf16-table(f32 master)+f16-mlp" if args.table == "bf16" else "f32-table+f16-mlp"), "data": "synthetic",
-            "config": {"workload": ("360_v2 Garden shape (BASELINE C3): %d rays/GPU/step, scale 16, 6 cascades 128^3, hash grid L=16 F=2 "
-                                    "T=2^19 max_res=4096 (%s table), exp_step_factor 1/256, synthetic ball+slab+far-cells occupancy, "
-                                    "MSE + 1e-3 distortion loss, full train step (fwd+bwd+GradScaler+Adam, grid update every 16 steps)"
-                                    % (args.rays, "f16" if args.half else args.table)) if garden else
-                                   "Synthetic-NeRF Lego shape (BASELINE C2%s): %d rays/GPU/step, scale 0.5, 1 cascade 128^3, "
-                                   "hash grid L=16 F=2 T=2^19 max_res=1024 (%s table), occupancy=%s, full train step "
-                                   "(fwd+bwd+GradScaler+Adam, grid update every 16 steps)" % (
-                                       "/C4" if world > 1 else "", args.rays, "f16" if args.half else args.table, args.regime),
+            "config": {"workload": text, "workload_state": workload,
                        "rays_per_gpu": args.rays, "global_batch": args.rays * world,
                        "parallelism": "ray-sharded dp%d, RCCL all-reduce of %s" % (world, "one flat %s gradient bucket per step" % args.comm) if world > 1 else "single GPU",
-                       "path": ("FusedTrainer" + ("+hipGraph" if args.graph else "")) if use_trainer else "modules+torch.optim"},
+                       "path": ("FusedTrainer" + ("+hipGraph" if args.graph else "")) if use_trainer else "modules+torch.optim",
+                       "kernel_events_in_timed_region": bool(event_pool) or not use_trainer},
             "samples_per_sec": rm * world / elapsed, "rm_samples_per_ray": rm / total_rays * world, "vr_samples_per_ray": vr / total_rays * world,
+            "live_samples_per_step": live_avg,
+            "ms_per_step_no_prefetch": None if elapsed_np is None else elapsed_np / args.steps * 1e3,
             "kernels": ks, "roofline": roof, "rooflines": rooflines,
         }
         if not args.no_cpu_baseline and world == 1 and not garden:     # the CPU leg restates the C2 workload only
-            out["cpu_baseline"] = cpu_baseline(bits_np if args.regime == "lego" else np.load(golden)["density_bitfield"],
-                                               args.cpu_seconds)
+            if scene:
+                out["cpu_baseline"] = cpu_baseline(model.density_bitfield.cpu().numpy(), args.cpu_seconds,
+                                                   table=model.pos_encoder.hash_table.detach().float().view(-1).cpu().numpy(),
+                                                   weights=[w.detach().cpu() for w in model._mlp_weights()], targets="scene")
+            else:
+                out["cpu_baseline"] = cpu_baseline(bits_np if args.regime == "lego" else np.load(golden)["density_bitfield"],
+                                                   args.cpu_seconds)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -24,45 +24,7 @@ for p in (ROOT, os.path.join(ROOT, "taichi-nerfs_amd")):
 import torch  # noqa: E402
 import torch.nn.functional as F  # noqa: E402
 
-BOXES = [  # (centre, half-size, rgb)
-    ((0.0, 0.0, -0.22), (0.30, 0.20, 0.05), (0.85, 0.10, 0.10)),
-    ((-0.12, 0.0, -0.02), (0.10, 0.10, 0.15), (0.95, 0.80, 0.10)),
-    ((0.14, 0.05, -0.07), (0.08, 0.12, 0.10), (0.10, 0.35, 0.85)),
-    ((0.0, -0.12, 0.16), (0.22, 0.04, 0.04), (0.15, 0.70, 0.25)),
-]
-STUDS = [((-0.2 + 0.1 * i, -0.1 + 0.1 * j, -0.15), (0.025, 0.025, 0.02), (0.85, 0.10, 0.10)) for i in range(5) for j in range(3)]
-
-
-def field(x):
-    """x: [...,3] -> (sigma [...], rgb [...,3])."""
-    sigma = torch.zeros(x.shape[:-1], device=x.device)
-    rgb = torch.ones(x.shape, device=x.device) * 0.5
-    for c, h, col in BOXES + STUDS:
-        inside = ((x - torch.tensor(c, device=x.device)).abs() < torch.tensor(h, device=x.device)).all(-1)
-        sigma = torch.where(inside, torch.full_like(sigma, 400.0), sigma)
-        shade = 0.75 + 0.25 * torch.sin(40.0 * x.sum(-1, keepdim=True))
-        rgb = torch.where(inside[..., None], torch.tensor(col, device=x.device) * shade, rgb)
-    return sigma, rgb
-
-
-@torch.no_grad()
-def render_gt(rays_o, rays_d, n_samples=768, chunk=16384):
-    out = []
-    for i in range(0, rays_o.shape[0], chunk):
-        o, d = rays_o[i:i + chunk], rays_d[i:i + chunk]
-        inv = 1.0 / d
-        t0, t1 = (-0.5 - o) * inv, (0.5 - o) * inv
-        near = torch.minimum(t0, t1).amax(-1).clamp_min(0.01)
-        far = torch.maximum(t0, t1).amin(-1)
-        hit = far > near
-        ts = near[:, None] + (far - near).clamp_min(0)[:, None] * (torch.arange(n_samples, device=o.device) + 0.5) / n_samples
-        dt = ((far - near).clamp_min(0) / n_samples)[:, None] * d.norm(dim=-1, keepdim=True)
-        sigma, rgb = field(o[:, None] + ts[..., None] * d[:, None])
-        alpha = 1 - torch.exp(-sigma * dt)
-        T = torch.cumprod(torch.cat([torch.ones_like(alpha[:, :1]), 1 - alpha[:, :-1]], 1), 1)
-        w = alpha * T * hit[:, None]
-        out.append((w[..., None] * rgb).sum(1) + (1 - w.sum(1, keepdim=True)))       # white background
-    return torch.cat(out)
+from ngp_hip.synthetic import procedural_render_gt as render_gt  # noqa: E402  (the analytic scene lives in ngp_hip/synthetic.py)
 
 
 def cameras(n, radius, seed, device):

@@ -57,13 +57,16 @@ __global__ void __launch_bounds__(256) composite_fwd_kernel(const float* __restr
         float excl = __shfl_up(incl, 1, NGP_WAVE);
         if (lane == 0) excl = 1.0f;
         const float Ts = T * excl;                                                   // T before this sample
-        const bool live = valid && (Ts > thr);
+        // liveness as a PREFIX by construction: the Kogge-Stone product is not guaranteed monotone to the last ulp, and
+        // ngp_live_compact takes the live samples of a ray to be exactly its first vr[r] ones
+        const uint64_t deadm = __ballot(valid && !(Ts > thr));
+        const bool live = valid && (deadm == 0 || lane < __builtin_ctzll(deadm));
         const float w = live ? a * Ts : 0.0f;                                        // :40
         if (valid) ws[s] = w;                                                        // :46
         r0 += w * c[0]; r1 += w * c[1]; r2 += w * c[2];                              // :41-43 (per-lane partials)
         dep += w * tm; op += w;                                                      // :44-45
         cnt += live ? 1 : 0;                                                         // :48
-        T = T * __shfl(incl, NGP_WAVE - 1, NGP_WAVE);
+        T = deadm ? 0.0f : T * __shfl(incl, NGP_WAVE - 1, NGP_WAVE);    // a dead sample in this chunk ends the ray for good
     }
     r0 = wave_sum(r0); r1 = wave_sum(r1); r2 = wave_sum(r2);
     dep = wave_sum(dep); op = wave_sum(op); cnt = wave_sum_i(cnt);
@@ -127,7 +130,10 @@ __global__ void __launch_bounds__(256) composite_bwd_kernel(const float* __restr
         float excl = __shfl_up(incl, 1, NGP_WAVE);
         if (lane == 0) excl = 1.0f;
         const float Ts = T * excl;
-        const bool live = valid && (Ts > thr);
+        // liveness as a PREFIX by construction: the Kogge-Stone product is not guaranteed monotone to the last ulp, and
+        // ngp_live_compact takes the live samples of a ray to be exactly its first vr[r] ones
+        const uint64_t deadm = __ballot(valid && !(Ts > thr));
+        const bool live = valid && (deadm == 0 || lane < __builtin_ctzll(deadm));
         const float w = live ? a * Ts : 0.0f;
         const float Tp = Ts * (1.0f - a);
         const float p0 = cr0 + wave_scan_add(w * c[0], lane);
@@ -153,7 +159,7 @@ __global__ void __launch_bounds__(256) composite_bwd_kernel(const float* __restr
         cr0 = __shfl(p0, NGP_WAVE - 1, NGP_WAVE); cr1 = __shfl(p1, NGP_WAVE - 1, NGP_WAVE);
         cr2 = __shfl(p2, NGP_WAVE - 1, NGP_WAVE); cd = __shfl(pd, NGP_WAVE - 1, NGP_WAVE);
         if (g_ws) cw = __shfl(pw, NGP_WAVE - 1, NGP_WAVE);
-        T = T * __shfl(incl, NGP_WAVE - 1, NGP_WAVE);
+        T = deadm ? 0.0f : T * __shfl(incl, NGP_WAVE - 1, NGP_WAVE);    // a dead sample in this chunk ends the ray for good
     }
 }
 
@@ -186,11 +192,14 @@ __global__ void __launch_bounds__(256) composite_train_fused_kernel(
         float excl = __shfl_up(incl, 1, NGP_WAVE);
         if (lane == 0) excl = 1.0f;
         const float Ts = T * excl;
-        const bool live = valid && (Ts > thr);
+        // liveness as a PREFIX by construction: the Kogge-Stone product is not guaranteed monotone to the last ulp, and
+        // ngp_live_compact takes the live samples of a ray to be exactly its first vr[r] ones
+        const uint64_t deadm = __ballot(valid && !(Ts > thr));
+        const bool live = valid && (deadm == 0 || lane < __builtin_ctzll(deadm));
         const float w = live ? a * Ts : 0.0f;
         if (valid) ws[s] = w;
         r0 += w * c[0]; r1 += w * c[1]; r2 += w * c[2]; dep += w * tm; op += w; cnt += live ? 1 : 0;
-        T = T * __shfl(incl, NGP_WAVE - 1, NGP_WAVE);
+        T = deadm ? 0.0f : T * __shfl(incl, NGP_WAVE - 1, NGP_WAVE);    // a dead sample in this chunk ends the ray for good
     }
     const float R0 = wave_sum(r0), R1 = wave_sum(r1), R2 = wave_sum(r2), D = wave_sum(dep), O = wave_sum(op);
     cnt = wave_sum_i(cnt);
@@ -228,7 +237,10 @@ __global__ void __launch_bounds__(256) composite_train_fused_kernel(
         float excl = __shfl_up(incl, 1, NGP_WAVE);
         if (lane == 0) excl = 1.0f;
         const float Ts = T * excl;
-        const bool live = valid && (Ts > thr);
+        // liveness as a PREFIX by construction: the Kogge-Stone product is not guaranteed monotone to the last ulp, and
+        // ngp_live_compact takes the live samples of a ray to be exactly its first vr[r] ones
+        const uint64_t deadm = __ballot(valid && !(Ts > thr));
+        const bool live = valid && (deadm == 0 || lane < __builtin_ctzll(deadm));
         const float w = live ? a * Ts : 0.0f;
         const float Tp = Ts * (1.0f - a);
         const float p0 = cr0 + wave_scan_add(w * c[0], lane), p1 = cr1 + wave_scan_add(w * c[1], lane),
@@ -246,7 +258,7 @@ __global__ void __launch_bounds__(256) composite_train_fused_kernel(
             else { float* p = (float*)d_rgbs + 3 * s; p[0] = dc0; p[1] = dc1; p[2] = dc2; }
         }
         cr0 = __shfl(p0, NGP_WAVE - 1, NGP_WAVE); cr1 = __shfl(p1, NGP_WAVE - 1, NGP_WAVE); cr2 = __shfl(p2, NGP_WAVE - 1, NGP_WAVE);
-        T = T * __shfl(incl, NGP_WAVE - 1, NGP_WAVE);
+        T = deadm ? 0.0f : T * __shfl(incl, NGP_WAVE - 1, NGP_WAVE);    // a dead sample in this chunk ends the ray for good
     }
 }
 

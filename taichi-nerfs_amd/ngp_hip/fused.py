@@ -44,6 +44,9 @@ class TrainArena:
         self._scratch = {}
         self.live_idx = torch.empty(cap, device=device, dtype=torch.int32)     # compacted backward: indices of the live samples
         self._live_off = torch.empty(n_rays, device=device, dtype=torch.int32)
+        # bumped by every FusedTrainRender.forward that overwrites the per-sample buffers; a backward whose forward is not the
+        # latest one would silently differentiate the WRONG batch's activations, so it checks this stamp and raises instead
+        self.generation = 0
 
     def live_off(self, n):
         return self._live_off
@@ -112,7 +115,8 @@ class FusedTrainRender(torch.autograd.Function):
         check(L.ngp_composite_train_fwd(_ptr(A.sigmas), _ptr(A.rgbs), 1, _ptr(A.deltas), _ptr(A.ts), _ptr(rays_a),
                                         cfg.T_threshold, n, _ptr(vr_per_ray), _ptr(opacity), _ptr(depth), _ptr(rgb), _ptr(A.ws),
                                         st), "ngp_composite_train_fwd")
-        ctx.cfg, ctx.arena, ctx.table_numel = cfg, A, table.numel()
+        A.generation += 1
+        ctx.cfg, ctx.arena, ctx.table_numel, ctx.generation = cfg, A, table.numel(), A.generation
         ctx.save_for_backward(rays_a, total, opacity, depth, rgb)
         ctx.set_materialize_grads(False)
         rm = total[0]
@@ -125,6 +129,11 @@ class FusedTrainRender(torch.autograd.Function):
         L = _lib_mod.load()
         rays_a, total, opacity, depth, rgb = ctx.saved_tensors
         cfg, A = ctx.cfg, ctx.arena
+        if A.generation != ctx.generation:
+            raise RuntimeError(
+                "fused render: backward() of a forward whose per-sample activations were overwritten by a later render() with the "
+                "same ray count (the arena is shared per (device, n_rays)).  Call backward before the next training-mode render of "
+                "that size, or set NGP_FUSED_RENDER=0 to get the reference's per-call buffers (operator path).")
         dev = rgb.device
         n = rays_a.shape[0]
         st = _stream()

@@ -9,7 +9,7 @@ import torch
 
 from . import lib as _lib_mod
 from .lib import check
-from .ops import _ptr, _stream
+from .ops import _ptr, _stream, _touched
 
 
 class OccupancyUpdater:
@@ -93,3 +93,4 @@ class OccupancyUpdater:
         check(L.ngp_occ_merge(_ptr(grid), _ptr(self.tmp), float(decay), C * G3, _ptr(self.stats), st), "ngp_occ_merge")
         check(L.ngp_occ_pack(_ptr(grid), _ptr(self.stats), float(density_threshold), C * G3 // 8, _ptr(m.density_bitfield), st),
               "ngp_occ_pack")
+        _touched(grid, m.density_bitfield)       # written through raw pointers: version-keyed caches (coarse table) must see it

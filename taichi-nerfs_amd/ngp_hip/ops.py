@@ -22,6 +22,14 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
 
+def _touched(*tensors):
+    """A kernel wrote these tensors IN PLACE through their raw pointers: move their torch version counters like any in-place
+    torch op would, so version-keyed caches (the trainer's coarse occupancy table) and autograd's saved-tensor checks see it."""
+    for t in tensors:
+        if t is not None:
+            torch.autograd.graph.increment_version(t)
+
+
 def _dev(t, dtype=None, name="tensor"):
     if not t.is_cuda:
         raise RuntimeError("%s must live on the GPU: libngp_hip has no CPU path (got device %s)" % (name, t.device))
@@ -122,6 +130,7 @@ def march_test(rays_o, rays_d, hits_t, alive_indices, density_bitfield, cascades
                                 int(cascades), int(grid_size), float(scale), float(exp_step_factor), int(max_samples), n,
                                 _ptr(ray_indices), _ptr(valid_mask), _ptr(deltas), _ptr(ts), _ptr(samples_counter), _stream()),
           "ngp_march_test")
+    _touched(hits_t)                                                  # resume state, advanced in place (ray_march.py:262-268)
     return ray_indices, valid_mask, deltas, ts, samples_counter
 
 
@@ -158,6 +167,7 @@ def hash_bwd_f32(xyzs, dout, lv, dtable):
     _dev(xyzs, torch.float32, "xyzs"); _dev(dout, torch.float32, "dout"); _dev(dtable, torch.float32, "dtable")
     check(_lib().ngp_hash_bwd_f32(_ptr(xyzs), _ptr(dout), ctypes.byref(lv), xyzs.shape[0], _ptr(dtable), _stream()),
           "ngp_hash_bwd_f32")
+    _touched(dtable)
     return dtable
 
 
@@ -173,6 +183,7 @@ def hash_bwd_f16(xyzs, dout_h, lv, dtable_h):
     _dev(xyzs, torch.float32, "xyzs"); _dev(dout_h, torch.float16, "dout"); _dev(dtable_h, torch.float16, "dtable")
     check(_lib().ngp_hash_bwd_f16(_ptr(xyzs), _ptr(dout_h), ctypes.byref(lv), xyzs.shape[0], _ptr(dtable_h), _stream()),
           "ngp_hash_bwd_f16")
+    _touched(dtable_h)
     return dtable_h
 
 
@@ -239,6 +250,7 @@ def composite_test(sigmas, rgbs, deltas, ts, pack_info, alive_indices, T_thresho
     check(_lib().ngp_composite_test(_ptr(sigmas), _ptr(rgbs), _rgb_kind(rgbs), _ptr(deltas), _ptr(ts), _ptr(pack_info),
                                     _ptr(alive_indices), float(T_threshold), alive_indices.shape[0], _ptr(opacity), _ptr(depth),
                                     _ptr(rgb), _stream()), "ngp_composite_test")
+    _touched(opacity, depth, rgb, alive_indices)
 
 
 # ---------------------------------------------------------------------------------------------------- a-9
@@ -312,6 +324,7 @@ def packbits(density_grid, threshold, density_bitfield):
     if density_grid.numel() != 8 * n_bytes:
         raise ValueError("density_grid must hold 8 floats per bitfield byte")
     check(_lib().ngp_packbits(_ptr(density_grid), float(threshold), n_bytes, _ptr(density_bitfield), _stream()), "ngp_packbits")
+    _touched(density_bitfield)
     return density_bitfield
 
 

@@ -5,8 +5,56 @@
                reference hands to render() for Lego (un-normalised directions, one origin per ray).
 `garden_rays`: N rays from cameras on a ring inside a scale-16 unbounded scene (360_v2 Garden shape).
 `random_bitfield` / `ball_slab_bitfield`: seeded occupancy bitfields for the initialisation / Garden regimes.
+`procedural_field` / `procedural_render_gt`: an analytic "Lego-shape" scene (base plate, tower, studs inside
+               [-0.35, 0.35]^3, white background) and its dense-integration renderer -- the scene-consistent target
+               colours bench.py and examples/train_procedural.py train against.
 """
 import numpy as np
+
+# ---- analytic scene: axis-aligned boxes (centre, half-size, rgb) ------------------------------------------------------
+PROCEDURAL_BOXES = [
+    ((0.0, 0.0, -0.22), (0.30, 0.20, 0.05), (0.85, 0.10, 0.10)),
+    ((-0.12, 0.0, -0.02), (0.10, 0.10, 0.15), (0.95, 0.80, 0.10)),
+    ((0.14, 0.05, -0.07), (0.08, 0.12, 0.10), (0.10, 0.35, 0.85)),
+    ((0.0, -0.12, 0.16), (0.22, 0.04, 0.04), (0.15, 0.70, 0.25)),
+] + [((-0.2 + 0.1 * i, -0.1 + 0.1 * j, -0.15), (0.025, 0.025, 0.02), (0.85, 0.10, 0.10)) for i in range(5) for j in range(3)]
+
+
+def procedural_field(x):
+    """x: [...,3] torch tensor (world coordinates) -> (sigma [...], rgb [...,3]); density 400 inside the boxes, striped albedo."""
+    import torch
+    sigma = torch.zeros(x.shape[:-1], device=x.device)
+    rgb = torch.ones(x.shape, device=x.device) * 0.5
+    shade = 0.75 + 0.25 * torch.sin(40.0 * x.sum(-1, keepdim=True))
+    for c, h, col in PROCEDURAL_BOXES:
+        inside = ((x - torch.tensor(c, device=x.device)).abs() < torch.tensor(h, device=x.device)).all(-1)
+        sigma = torch.where(inside, torch.full_like(sigma, 400.0), sigma)
+        rgb = torch.where(inside[..., None], torch.tensor(col, device=x.device) * shade, rgb)
+    return sigma, rgb
+
+
+def procedural_render_gt(rays_o, rays_d, n_samples=768, chunk=16384, scale=0.5):
+    """Ground-truth radiance of the analytic scene along rays [N,3] (torch, any device): midpoint-rule integration of
+    n_samples points inside the [-scale, scale]^3 box, white background -> [N,3] float32."""
+    import torch
+    out = []
+    with torch.no_grad():
+        for i in range(0, rays_o.shape[0], chunk):
+            o, d = rays_o[i:i + chunk].float(), rays_d[i:i + chunk].float()
+            inv = 1.0 / d
+            t0, t1 = (-scale - o) * inv, (scale - o) * inv
+            near = torch.minimum(t0, t1).amax(-1).clamp_min(0.01)
+            far = torch.maximum(t0, t1).amin(-1)
+            hit = far > near
+            span = (far - near).clamp_min(0)
+            ts = near[:, None] + span[:, None] * (torch.arange(n_samples, device=o.device) + 0.5) / n_samples
+            dt = (span / n_samples)[:, None] * d.norm(dim=-1, keepdim=True)
+            sigma, rgb = procedural_field(o[:, None] + ts[..., None] * d[:, None])
+            alpha = 1 - torch.exp(-sigma * dt)
+            T = torch.cumprod(torch.cat([torch.ones_like(alpha[:, :1]), 1 - alpha[:, :-1]], 1), 1)
+            w = alpha * T * hit[:, None]
+            out.append((w[..., None] * rgb).sum(1) + (1 - w.sum(1, keepdim=True)))       # white background
+    return torch.cat(out)
 
 
 def _look_at(cam_pos, target, roll):

@@ -111,6 +111,7 @@ class FusedTrainer:
         # (with world > 1 the default is 3: the march then runs underneath the gradient all-reduce)
         self._prefetch_at = int(_os.environ.get("NGP_PREFETCH_AT", "1" if self.world == 1 else "3"))
         self._coarse_ver = None
+        self.sync_occupancy = True            # world > 1: broadcast rank 0's occupancy after every update_density_grid()
         lvs = model.pos_encoder.levels_struct
         self.enc_pairs = 1 if (lvs.n_levels == 16 and lvs.n_features == 2) else 0
         self.wpack = torch.empty(self.L.ngp_mlp_wpack_halfs(), device=dev, dtype=torch.float16)
@@ -149,7 +150,15 @@ class FusedTrainer:
             self.xyzs, self.dirs = torch.empty(cap, 3, **f32), torch.empty(cap, 3, **f32)
             self.deltas, self.ts = torch.empty(cap, **f32), torch.empty(cap, **f32)
             self.ready = None               # event recorded on the side stream when a prefetched march has finished
-            self.key = None                 # (data_ptr of rays_o, rays_d) the set was marched for
+            self.src = None                 # the caller's (rays_o, rays_d) tensor OBJECTS + their versions the set was marched for
+            self.held = None                # the (possibly converted) tensors the side-stream march reads: kept alive until reuse
+
+        def marched_for(self, src):
+            """True if this set holds a (possibly still running) prefetched march of exactly these caller tensors, unmodified
+            since.  Identity + version, not data_ptr: a freed and reallocated tensor at the same address is a different batch."""
+            k = self.src
+            return (self.ready is not None and k is not None and src is not None and k[0] is src[0] and k[1] is src[1]
+                    and k[2] == src[0]._version and k[3] == src[1]._version)
 
 
     def _march_sets(self, n):
@@ -163,6 +172,8 @@ class FusedTrainer:
         """The 8^3-block occupancy shortcut table, rebuilt only when the bitfield tensor was written to (its torch version
         counter moves on every in-place op, e.g. packbits / copy_)."""
         coarse = A.coarse_for(cfg)
+        # every writer of the bitfield moves its version counter: torch in-place ops by themselves, the raw-pointer kernels
+        # (ngp_occ_pack, ngp_packbits) through ops._touched; update_density_grid() additionally drops the cache outright
         ver = (cfg.bitfield.data_ptr(), cfg.bitfield._version)
         if self._coarse_ver != ver:
             check(self.L.ngp_bitfield_coarsen(_ptr(cfg.bitfield), cfg.cascades, cfg.grid_size, _ptr(coarse), _stream()),
@@ -182,19 +193,21 @@ class FusedTrainer:
         check(L.ngp_march_train_scan(_ptr(M.counts), n, _ptr(M.rays_a), _ptr(M.total), st), "ngp_march_train_scan")
         check(L.ngp_march_train_write(_ptr(rays_o), _ptr(rays_d), _ptr(M.rays_a), _ptr(M.stage), cfg.max_samples, n,
                                       _ptr(M.xyzs), _ptr(M.dirs), _ptr(M.deltas), _ptr(M.ts), st), "ngp_march_train_write")
-        M.key = (rays_o.data_ptr(), rays_d.data_ptr())
 
-    def _launch(self, rays_o, rays_d, target, prefetch=None):
+    def _launch(self, rays_o, rays_d, target, prefetch=None, src=None, src_next=None):
         n = rays_o.shape[0]
         cfg = RenderConfig(self.model, self.exp_step_factor, self.T_threshold, self.max_samples)
         A = TrainArena.get(self.dev, n, self.max_samples)
         sets = self._march_sets(n)
         M = sets[self._cur]
-        if M.ready is not None and M.key == (rays_o.data_ptr(), rays_d.data_ptr()):
-            torch.cuda.current_stream().wait_event(M.ready)                 # this batch was marched ahead on the side stream
-        else:
+        hit = M.marched_for(src)
+        if M.ready is not None:
+            # whatever the side stream did to this set has to be finished before the main stream reads OR rewrites it (a stale
+            # prefetch for other rays would otherwise race with the re-march below on M.stage / counts / xyzs)
+            torch.cuda.current_stream().wait_event(M.ready)
+        if not hit:
             self._march(M, rays_o, rays_d, cfg, A)
-        M.ready = None
+        M.ready, M.src, M.held = None, None, None
         hook = None
         if prefetch is not None and (prefetch[0].shape != rays_o.shape or prefetch[1].shape != rays_d.shape):
             raise ValueError("prefetch rays must have the shape of the current batch (the two march buffers are sized per batch size)")
@@ -209,9 +222,13 @@ class FusedTrainer:
                 start.record()                                              # everything that still reads `nxt` is before this
                 with torch.cuda.stream(self._side):
                     self._side.wait_event(start)
+                    if nxt.ready is not None:
+                        self._side.wait_event(nxt.ready)                    # an unconsumed earlier prefetch into the same set
                     self._march(nxt, prefetch[0], prefetch[1], cfg, A)
                     nxt.ready = torch.cuda.Event()
                     nxt.ready.record(self._side)
+                nxt.src = None if src_next is None else (src_next[0], src_next[1], src_next[0]._version, src_next[1]._version)
+                nxt.held = prefetch          # (possibly temporaries of step()): alive until the set is consumed or re-marched
             if self._prefetch_at == 0 or self._graph is not None:
                 hook(); hook = None
         cur, self._cur = self._cur, 1 - self._cur
@@ -363,9 +380,12 @@ class FusedTrainer:
         prefetch=(next_rays_o, next_rays_d): the NEXT step's rays, if already known and if the occupancy grid will not be
         updated in between -- their march then overlaps this step on a side stream (the tensors must stay alive and
         unmodified until that next step() call, which must receive the very same tensors)."""
+        src, src_next = (rays_o, rays_d), None
         if prefetch is not None:
+            src_next = (prefetch[0], prefetch[1])
             prefetch = (prefetch[0].contiguous().float(), prefetch[1].contiguous().float())
-        self.stats = self._launch(rays_o.contiguous().float(), rays_d.contiguous().float(), target.contiguous().float(), prefetch)
+        self.stats = self._launch(rays_o.contiguous().float(), rays_d.contiguous().float(), target.contiguous().float(), prefetch,
+                                  src, src_next)
         return self.stats
 
     def compute_gradients(self, rays_o, rays_d, target):
@@ -404,8 +424,34 @@ class FusedTrainer:
 
     # ------------------------------------------------------------------------------------------------ bookkeeping
     def update_density_grid(self, density_threshold, warmup=False, **kw):
+        """Occupancy-grid maintenance (train.py:178-182).  With world_size > 1 rank 0's freshly updated grid + bitfield are
+        broadcast (8.4 MB + 262 KB per cascade, once per 16 steps): the update samples random cells, and replicas that march
+        different bitfields stop being replicas."""
         with torch.autocast(device_type="cuda", dtype=torch.float16):
             self.model.update_density_grid(density_threshold, warmup=warmup, **kw)
+        if self.world > 1 and self.sync_occupancy:
+            from .dist import broadcast_occupancy
+            broadcast_occupancy(self.model, src=0, group=self.group)
+        self._coarse_ver = None              # the coarse 8^3-block table is rebuilt on the next march, whoever wrote the bitfield
+        for sets in self._sets.values():     # a march prefetched against the old bitfield must not be consumed
+            for M in sets:
+                M.src = None
+
+    def state_dict(self):
+        """Optimizer-side state the model's own state_dict does not hold: Adam moments, loss scale + growth counter, the
+        LR-schedule iteration.  (The reference saves no optimizer state either -- ckpt = model.state_dict(), train.py:285-291 --
+        so a resume without this restarts the moments and the cosine schedule; with it the continuation is exact.)"""
+        return {"table_m": self.table_m.clone(), "table_v": self.table_v.clone(), "mlp_m": self.mlp_m.clone(),
+                "mlp_v": self.mlp_v.clone(), "state_f": self.state_f.clone(), "state_i": self.state_i.clone()}
+
+    def load_state_dict(self, sd):
+        for k in ("table_m", "table_v", "mlp_m", "mlp_v", "state_f", "state_i"):
+            getattr(self, k).copy_(sd[k])
+        self.grad_flat.zero_()
+        if self.half:
+            self.table_grad.zero_()
+        self._coarse_ver = None
+        self.repack()                          # the model's weights were (presumably) loaded alongside: refresh the fp16 images
 
     def last_loss(self):
         """MSE of the last step (host sync: logging only)."""

@@ -278,3 +278,102 @@ def test_checkpoint_roundtrip_through_trainer(hip_lib, lego_bitfield, kind):
         tr2.step(o, d, target)
         l0 = tr2.last_loss() if l0 is None else l0
     assert np.isfinite(tr2.last_loss()) and tr2.last_loss() <= l0 * 1.05
+
+
+def test_coarse_table_follows_grid_update(hip_lib, lego_bitfield):
+    """the 8^3-block coarse occupancy table must be rebuilt after every writer of the bitfield, including the
+    raw-pointer kernels (ngp_occ_pack / ngp_packbits) -- a stale table vetoes cells that became occupied.  Start from an EMPTY
+    bitfield (coarse table all zero), let the trainer's own update fill it, and check the next step's march against the
+    operator path on the same rays and noise."""
+    from modules.networks import NGP
+    from modules.ray_march import raymarching_train
+    from modules.intersection import ray_aabb_intersection
+    from ngp_hip import synthetic
+    from ngp_hip.trainer import FusedTrainer
+    torch.manual_seed(0)
+    m = NGP(scale=0.5, max_res=1024).cuda()
+    o, d = synthetic.lego_rays(2048, seed=4)
+    o, d = torch.from_numpy(o).cuda(), torch.from_numpy(d).cuda()
+    target = torch.rand(2048, 3, device="cuda")
+    tr = FusedTrainer(m)
+    st = tr.step(o, d, target)                                   # empty bitfield: coarse table = 0, nothing marched
+    assert int(st["rm_samples"][0]) == 0
+    tr.update_density_grid(0.01 * 1024 / 3**0.5, warmup=True)    # writes the bitfield through ngp_occ_pack (raw pointer)
+    assert int(m.density_bitfield.count_nonzero()) > 0
+    torch.manual_seed(77)
+    st = tr.step(o, d, target)
+    torch.manual_seed(77)                                        # same jitter noise: first draw after the seed
+    hits = ray_aabb_intersection(o, d, 0.5)
+    rays_a, _x, _d, _dl, _ts, total = raymarching_train(o, d, hits, m.density_bitfield, 1, 0.5, 0.0, 128, 1024)
+    assert int(st["rm_samples"][0]) == int(total) > 0
+    assert torch.equal(st["rays_a"], rays_a)
+    # ... and through modules.utils.packbits (ngp_packbits) as well
+    from modules.utils import packbits
+    v0 = m.density_bitfield._version
+    packbits(m.density_grid.reshape(-1).contiguous(), 1e9, m.density_bitfield)          # threshold above everything: empties it
+    assert m.density_bitfield._version > v0
+    st = tr.step(o, d, target)
+    assert int(st["rm_samples"][0]) == 0
+
+
+def test_stale_prefetch_is_not_consumed(hip_lib, lego_bitfield):
+    """a prefetched march is used only for the very tensors it was issued for, unmodified; anything else
+    re-marches (after waiting for the side stream) and gives the un-prefetched result."""
+    from ngp_hip.trainer import FusedTrainer
+    from ngp_hip import synthetic
+    m, o, d, target = _make(lego_bitfield, n=2048)
+    o2, d2 = [torch.from_numpy(a).cuda() for a in synthetic.lego_rays(2048, seed=10)]
+    o3, d3 = [torch.from_numpy(a).cuda() for a in synthetic.lego_rays(2048, seed=11)]
+    tr = FusedTrainer(m)
+    tr._grads_only = True                                        # keep the parameters fixed: only the march matters here
+    torch.manual_seed(5)
+    tr._launch(o, d, target, (o2, d2), (o, d), (o2, d2))         # prefetches (o2, d2) ...
+    torch.manual_seed(6)
+    got = tr._launch(o3, d3, target, None, (o3, d3), None)       # ... but the next step brings other rays
+    ra = got["rays_a"].clone(); rm = int(got["rm_samples"][0])
+    tr2 = FusedTrainer(_make(lego_bitfield, n=2048)[0]); tr2._grads_only = True
+    torch.manual_seed(6)
+    ref = tr2._launch(o3, d3, target, None, (o3, d3), None)
+    assert rm == int(ref["rm_samples"][0]) and torch.equal(ra, ref["rays_a"])
+    # modified in place after the prefetch -> version moved -> not consumed
+    torch.manual_seed(5)
+    tr._launch(o, d, target, (o2, d2), (o, d), (o2, d2))
+    o2.add_(0.0)
+    M = tr._march_sets(2048)[tr._cur]
+    assert M.ready is not None and not M.marched_for((o2, d2))
+    tr._grads_only = False
+
+
+def test_fused_render_backward_after_second_forward_raises(hip_lib, lego_bitfield):
+    """the fused render keeps activations in a shared arena; differentiating a forward whose
+    activations were overwritten must fail loudly, never silently use the other batch's activations."""
+    from modules.rendering import render
+    m, o, d, target = _make(lego_bitfield, n=1024)
+    with torch.autocast("cuda", dtype=torch.float16):
+        r1 = render(m, o, d, exp_step_factor=0.0)
+        r2 = render(m, o, d, exp_step_factor=0.0)
+        l1, l2 = F.mse_loss(r1["rgb"], target), F.mse_loss(r2["rgb"], target)
+    l2.backward()                                                # latest forward: fine
+    with pytest.raises(RuntimeError, match="overwritten by a later render"):
+        l1.backward()
+
+
+def test_trainer_state_dict_resumes_exactly(hip_lib, lego_bitfield):
+    from ngp_hip.trainer import FusedTrainer
+    m_a, o, d, target = _make(lego_bitfield, n=1024)
+    tr_a = FusedTrainer(m_a, max_steps=100)
+    for i in range(4):
+        torch.manual_seed(i); tr_a.step(o, d, target)
+    sd_model, sd_opt = copy.deepcopy(m_a.state_dict()), tr_a.state_dict()
+    for i in range(4, 7):
+        torch.manual_seed(i); tr_a.step(o, d, target)
+    m_b = _make(lego_bitfield, n=1024)[0]
+    tr_b = FusedTrainer(m_b, max_steps=100)
+    m_b.load_state_dict(sd_model)
+    tr_b.load_state_dict(sd_opt)
+    for i in range(4, 7):
+        torch.manual_seed(i); tr_b.step(o, d, target)
+    assert tr_a.counters() == tr_b.counters()
+    # same kernels, same inputs; only the float-atomic order of the scatter-add differs between the two runs
+    ta, tb = m_a.pos_encoder.hash_table.detach(), m_b.pos_encoder.hash_table.detach()
+    assert ((ta - tb).norm() / ta.norm()).item() < 1e-4
