@@ -44,6 +44,7 @@ TRAINER_KERNELS = {
     "ngp_hash_bwd_f32_ex": ("hash_bwd_f32", "hbm", 12 + 128 + 1024 + 1024, "sample"),
     "ngp_mlp_bwd_live": ("mlp_bwd", "mfma", 37632, "live"),                        # backward kernels run on the live-sample list
     "ngp_hash_bwd_f32_live": ("hash_bwd_f32", "hbm", 12 + 128 + 1024 + 1024, "live"),
+    "ngp_hash_bwd_f32_sliced": ("hash_bwd_f32", "hbm", 12 + 128 + 1024 + 1024, "live"),   # LDS-sliced form (prep + main launch)
     "ngp_hash_bwd_f16_live": ("hash_bwd_f16", "hbm", 12 + 128 + 512 + 512, "live"),
     "ngp_adam_step": ("adam", "hbm", 32, "param"),
     "ngp_adam_all": ("adam", "hbm", 32, "param"),                                  # table pass (+ the MLP block riding along)

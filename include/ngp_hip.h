@@ -185,6 +185,18 @@ int ngp_hash_bwd_f32_live(const float* xyzs, const float* dout, const ngp_hash_l
 int ngp_hash_bwd_f16_live(const float* xyzs, const float* dout, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev,
                           const int32_t* live_idx, int normalize, float lo, float hi, int enc_pairs, uint16_t* dtable,
                           int32_t* found_inf, void* stream);
+/* The same scatter-add (autodiff backward of modules/hash_encoder.py:89-143, call site :269; F = 2) WITHOUT global float
+ * atomics: the gradient table is cut into 16 384-entry slices, each owned by one workgroup that accumulates in its LDS
+ * (csrc/hash_bwd_lds.hip).  Same arguments and semantics as ngp_hash_bwd_f32_live (dtable is accumulated into) plus a
+ * caller-owned scratch buffer of ngp_hash_bwd_sliced_workspace(lv, n_max) bytes (compact positions + one slice-mask word
+ * per (level, sample)).  Returns -2 when the level table does not fit the formulation (F != 2, a level of more than
+ * 32 slices = 2^19 entries): the caller then uses ngp_hash_bwd_f32_live. */
+long long ngp_hash_bwd_sliced_workspace(const ngp_hash_levels* lv, int n_max);
+/* diagnostics: per-block task word + wall-clock stamps into a device buffer of 8 * 1024 uint64 (NULL = off, the default) */
+int ngp_hash_bwd_sliced_debug(void* device_buffer);
+int ngp_hash_bwd_f32_sliced(const float* xyzs, const float* dout, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev,
+                            const int32_t* live_idx, int normalize, float lo, float hi, int enc_pairs, float* dtable,
+                            int32_t* found_inf, void* workspace, long long workspace_bytes, void* stream);
 
 /* ---- a-8  composite_test (modules/volume_render_test.py:4-54) -------------------------------- */
 int ngp_composite_test(const float* sigmas, const void* rgbs, int rgbs_is_half, const float* deltas,

@@ -1,0 +1,670 @@
+// hash_bwd_lds.hip -- hash-grid scatter-add (backward of the fp32 encoder, F = 2) WITHOUT global float atomics.
+//
+// Replaces the Taichi-autodiff backward of modules/hash_encoder.py:89-143 (call site :269): dtable[idx*2+f] += w * dout.
+//
+// Why a second formulation.  Round 1's kernel (hash_bwd_f32x2_kernel, hash_grid.hip) issues one global float atomic per
+// (sample, level, corner pair) and sits at the chip's atomic line-request rate (~21 G 64-byte lines/s, measured in
+// profiles/microbench/atomics*.hip; it executes memory-side, no L2 locality helps): 1.7 ns per live sample, 590-650 us at
+// the 350-400 k live samples of a real training step = 61 % of the step.  But the whole gradient table is only 45.7 MB and
+// the chip has 256 x 160 KB = 40 MB of LDS.  So the table is cut into SLICES of 8192 entries, one workgroup OWNS one slice
+// in its LDS, looks at the live samples of its level, accumulates the contributions that land in its slice with LDS
+// atomics, and adds the slice to the table once, coalesced and non-atomically.
+//
+// What the hardware dictated (profiles/microbench/lds_atomics.hip -> profiles/r02_microbench_lds_atomics.txt):
+//   * ds_add_f32 is processed ONE LANE AT A TIME (~3 clocks per active lane: 80 ns per full wave instruction per CU, 204 G
+//     lane-adds/s chip-wide) -- the first version of this kernel, with f32 accumulators, took 950 us.  ds_add_f64 retires a
+//     conflict-free wave instruction in ~25 clocks (8x faster; ds_add_u64 in ~13).  Hence DOUBLE accumulators: every
+//     contribution w * g is formed in f32 exactly like the reference's product, widened (exact) and summed in f64; the slice is
+//     rounded to f32 once when it is flushed.  The result no longer depends on the order of the adds beyond ~1e-16 relative
+//     (float atomics differ run to run at ~1e-7) and is more accurate than an f32 running sum.
+//   * same-address LDS atomics still serialise (~3 clocks per lane), so on the coarse levels, where consecutive samples of a
+//     ray sit in one cell for many steps, equal-cell runs are pre-summed with a segmented DPP scan inside 16-lane rows.
+//   * the kernel is VALU-bound once the atomics are cheap (PMC: 160 M VALU wave-instructions in the first version), so the
+//     hashed levels use the structure of the hash: the slice of a corner pair depends on (y, z) only (x flips bits below the
+//     slice bits), two multiplies serve all four (y, z) combinations, and a lane only runs the body of the combinations that
+//     actually land in this slice.
+//   * every slice owner has to look at every live sample of its level (64 owners per hashed level), so the filter must be
+//     nearly free: the prepass writes one hit BIT per (level, slice, sample); an owner scans 4096 samples per 8-byte vector
+//     load (one super-chunk ahead), compacts the hits into a per-wave LDS queue and processes them 128 at a time with all
+//     lanes busy, the gathers of the next batch in flight while the current one is accumulated.
+//
+//   prep  : compact normalised positions xyzc[i]; per (level, slice) hit bitmaps
+//   main  : task = (level, slice, replica r of R); looks at samples [r S/R, (r+1) S/R); coarse levels whose few slices would
+//           see every sample are replicated over sample ranges (private LDS copy each, flushed with float atomics: a few
+//           thousand coalesced lines per replica).
+// Task order: blockIdx b lands on XCD b % 8; all slices of one level go to one XCD where possible so that its owners stream
+// the same position / gradient lines out of that XCD's L2.
+#include "ngp_device.h"
+#include "hash_common.h"
+#include <stdlib.h>
+
+namespace ngp {
+
+constexpr int BW_SLICE_LOG2 = 13;
+constexpr int BW_SLICE_ENTRIES = 1 << BW_SLICE_LOG2;          // 8192 entries x 2 features x f64 = 128 KB of LDS
+constexpr int BW_MAX_SLICES = 64;                              // per level: 2^19 entries
+constexpr int BW_THREADS = 1024;
+constexpr int BW_WAVES = BW_THREADS / 64;
+constexpr int BW_Q = 256;                                      // per-wave hit queue (entries)
+constexpr int BW_MAX_TASKS = 1536;
+constexpr int BW_PREP_BLOCKS = 2048;
+constexpr uint16_t BW_NULL_TASK = 0xffffu;
+
+struct BwdPlan {
+    int32_t n_blocks;
+    uint32_t merge_mask;                  // bit l: pre-sum equal-cell runs on level l
+    uint8_t nrep[NGP_MAX_LEVELS];         // replicas (sample ranges) per slice of level l
+    uint16_t task[BW_MAX_TASKS];          // level | slice << 4 | rep << 10, or BW_NULL_TASK
+};
+
+__device__ __forceinline__ uint32_t level_index(bool dense, uint32_t mode, uint32_t size, uint32_t res, uint32_t gx, uint32_t gy,
+                                                uint32_t gz) {
+    uint32_t h = dense ? (gx + gy * res + gz * res * res) : (gx ^ (gy * 2654435761u) ^ (gz * 805459861u));   // :53-60 / :43-51
+    if (mode == 1u) h &= (size - 1u);
+    else if (mode == 0u) { if (h >= size) { h -= size; if (h >= size) h %= size; } }
+    else h = h % size;                                                                                       // :71
+    return h;
+}
+
+// Which slice owns entry h of a level, and where in the owner's LDS image it lives.
+//   hashed levels : contiguous ranges of 8192 entries (slice = h >> 13): the xor hash already spreads space evenly over them, and
+//                   both x corners of a (y, z) combination fall into the same range;
+//   dense levels  : a contiguous range is a z-slab of the grid, and a scene that sits in part of the z range loads a few owners
+//                   with most of the samples (measured: 200 us stragglers on level 5).  Where a level has many slices, blocks
+//                   of about one z-plane (a power of two of entries) are dealt round-robin to the ns owners instead.
+struct SliceMap {
+    uint32_t ns, magic;      // magic = ceil(2^32 / ns): blk / ns = umulhi(blk, magic) for blk < 2^32 / ns^2
+    uint32_t bshift;         // log2 of the interleaving block (entries)
+    bool interleaved;
+};
+__device__ __forceinline__ uint32_t slice_of(const SliceMap M, uint32_t h, uint32_t& local) {
+    if (!M.interleaved) { local = h & (BW_SLICE_ENTRIES - 1); return h >> BW_SLICE_LOG2; }
+    const uint32_t blk = h >> M.bshift, qd = __umulhi(blk, M.magic), r = blk - qd * M.ns;
+    local = (qd << M.bshift) | (h & ((1u << M.bshift) - 1u));
+    return r;
+}
+__device__ __forceinline__ uint32_t entry_of(const SliceMap M, uint32_t sl, uint32_t local) {      // inverse of slice_of
+    if (!M.interleaved) return sl * (uint32_t)BW_SLICE_ENTRIES + local;
+    return (((local >> M.bshift) * M.ns + sl) << M.bshift) | (local & ((1u << M.bshift) - 1u));
+}
+__device__ __forceinline__ SliceMap slice_map(uint32_t size, uint32_t res, bool dense) {
+    SliceMap M;
+    M.ns = (size + BW_SLICE_ENTRIES - 1) >> BW_SLICE_LOG2;
+    // interleave only where there are many slices (and therefore few sample-range replicas to even out the load): a sample of
+    // a dense level touches the z and z + 1 planes, so with blocks of about one z-plane it still falls into 1-2 slices
+    M.interleaved = dense && M.ns >= 8;
+    const uint32_t plane = res * res;
+    M.bshift = min((uint32_t)BW_SLICE_LOG2, (uint32_t)(31 - __clz((int)max(plane, 128u))));
+    M.magic = M.ns > 1 ? (uint32_t)((0x100000000ull + M.ns - 1) / M.ns) : 0u;
+    return M;
+}
+
+__device__ __forceinline__ const float* grad_ptr(const float* dout, int level, size_t i, size_t plane, int enc_pairs, int nl) {
+    return enc_pairs ? dout + ((size_t)(level < 8 ? level : 15 - level) * plane + i) * 4 + (level < 8 ? 0 : 2)
+                     : dout + i * (size_t)(nl * 2) + level * 2;
+}
+
+// ---- prepass: compact positions, per-(level, slice) hit bitmaps -------------------------------------------------------------
+// bitmap[(level * 64 + slice) * wstride + t] bit j = sample 64 t + j has a corner in that slice.  A wave owns 64 consecutive
+// samples.  Levels of many slices: each lane ORs its corners' bits into a 64-word LDS table (one word per slice; random
+// slices, few same-word collisions), lane s then stores word s.  Levels of <= 8 slices (where every lane would hit the same
+// few words and the LDS atomics serialise): one wave ballot per slice.
+__global__ void __launch_bounds__(256) hash_bwd_prep_kernel(const float* __restrict__ xyzs, const int32_t* __restrict__ idx,
+                                                            ngp_hash_levels lv, int n, const int32_t* __restrict__ n_dev, XyzNorm nm,
+                                                            size_t wstride, uint32_t single_slice_levels, float* __restrict__ xyzc,
+                                                            unsigned long long* __restrict__ bitmap) {
+    __shared__ LevelLDS L;
+    __shared__ unsigned long long words[4][BW_MAX_SLICES];
+    load_levels(lv, L);
+    if (n_dev) n = min(n, *n_dev);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nl = lv.n_levels, bfhl = lv.begin_fast_hash_level;
+    const int n_tiles = (n + 63) >> 6;
+    for (int tile = blockIdx.x * 4 + wave; tile < n_tiles; tile += gridDim.x * 4) {
+        const int i = tile * 64 + lane;
+        const bool valid = i < n;
+        float x = 0.f, y = 0.f, z = 0.f;
+        if (valid) {
+            const size_t src = idx ? (size_t)idx[i] : (size_t)i;
+            x = norm01(nm, xyzs[3 * src]); y = norm01(nm, xyzs[3 * src + 1]); z = norm01(nm, xyzs[3 * src + 2]);
+            xyzc[3 * (size_t)i] = x; xyzc[3 * (size_t)i + 1] = y; xyzc[3 * (size_t)i + 2] = z;
+        }
+        for (int level = 0; level < nl; ++level) {
+            if ((single_slice_levels >> level) & 1u) continue;             // every sample is a hit there: no bitmap needed
+            const float scale = L.scale[level];
+            const uint32_t res = L.res[level], size = L.size[level], mode = L.mode[level];
+            const uint32_t cx = f2u_sat(floorf(x * scale + 0.5f)), cy = f2u_sat(floorf(y * scale + 0.5f)),
+                           cz = f2u_sat(floorf(z * scale + 0.5f));
+            const bool dense = level < bfhl;
+            const SliceMap SM = slice_map(size, res, dense);
+            const int ns = (int)SM.ns;
+            unsigned long long* row = bitmap + ((size_t)level * BW_MAX_SLICES) * wstride + tile;
+            if (ns <= 8) {
+                uint32_t m = 0u;
+                if (valid) {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        uint32_t loc;
+                        m |= 1u << slice_of(SM, level_index(dense, mode, size, res, cx + (c & 1), cy + ((c >> 1) & 1), cz + (c >> 2)), loc);
+                    }
+                }
+                for (int s = 0; s < ns; ++s) {
+                    const unsigned long long w = __ballot((m >> s) & 1u);
+                    if (lane == 0) row[(size_t)s * wstride] = w;
+                }
+                continue;
+            }
+            words[wave][lane] = 0ull;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (valid) {
+                if (!dense && mode == 1u && res < (1u << BW_SLICE_LOG2)) {
+                    // xor hash, power-of-two table: x only flips bits below the slice bits -> one slice per (y, z) combination
+                    const uint32_t b0 = cy * 2654435761u, b1 = b0 + 2654435761u, c0 = cz * 805459861u, c1 = c0 + 805459861u;
+                    const uint32_t msk = size - 1u;
+                    atomicOr(&words[wave][((b0 ^ c0) & msk) >> BW_SLICE_LOG2], 1ull << lane);         // ds_or_b64
+                    atomicOr(&words[wave][((b1 ^ c0) & msk) >> BW_SLICE_LOG2], 1ull << lane);
+                    atomicOr(&words[wave][((b0 ^ c1) & msk) >> BW_SLICE_LOG2], 1ull << lane);
+                    atomicOr(&words[wave][((b1 ^ c1) & msk) >> BW_SLICE_LOG2], 1ull << lane);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        uint32_t loc;
+                        const uint32_t h = level_index(dense, mode, size, res, cx + (c & 1), cy + ((c >> 1) & 1), cz + (c >> 2));
+                        atomicOr(&words[wave][slice_of(SM, h, loc)], 1ull << lane);
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (lane < ns) row[(size_t)lane * wstride] = words[wave][lane];
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+// ---- main kernel -------------------------------------------------------------------------------------------------------
+struct LevelParams {
+    float scale;
+    uint32_t res, size, mode, offset;
+    bool dense;
+    SliceMap map;
+    uint32_t diag;           // diagnostics only (NGP_BWD_DIAG): bit 0 = skip the LDS adds, bit 1 = skip the gathers
+};
+struct Hit {
+    float x, y, z, g0, g1;
+};
+struct __attribute__((packed, aligned(4))) F3 {
+    float x, y, z;
+};
+
+__device__ __forceinline__ Hit load_hit(const int level, const int i, const bool valid, const float* __restrict__ xyzc,
+                                        const float* __restrict__ dout, const size_t plane, const int enc_pairs, const int nl,
+                                        int32_t* __restrict__ found_inf, const uint32_t diag = 0u) {
+    Hit h = {0.f, 0.f, 0.f, 0.f, 0.f};
+    if (diag & 2u) { const float t = (float)(i & 1023) * (1.0f / 1024.0f); h.x = t; h.y = 1.0f - t; h.z = 0.5f * t; h.g0 = 1.0f; h.g1 = t; return h; }
+    if (valid) {
+        const F3 p = *reinterpret_cast<const F3*>(xyzc + 3 * (size_t)i);                  // one 12-byte gather
+        h.x = p.x; h.y = p.y; h.z = p.z;
+        const float2 g = *reinterpret_cast<const float2*>(grad_ptr(dout, level, (size_t)i, plane, enc_pairs, nl));
+        h.g0 = g.x; h.g1 = g.y;
+        if (found_inf && !(isfinite(h.g0) && isfinite(h.g1))) *found_inf = 1;  // GradScaler's inf/nan check, where the data passes
+    }
+    return h;
+}
+
+__device__ __forceinline__ void lds_add(double* p, float v) { atomicAdd(p, (double)v); }          // ds_add_f64
+#define LDS_ADD(p, v) do { if (!(P.diag & 1u)) lds_add((p), (v)); else asm volatile("" :: "v"(v), "v"(p)); } while (0)
+
+// DPP row_shr:D inside each 16-lane row; lanes without a source get `fill`
+template <int D>
+__device__ __forceinline__ float row_shr_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x110 + D, 0xf, 0xf, true));
+}
+template <int D>
+__device__ __forceinline__ int row_shr_i(int v, int fill) {
+    return __builtin_amdgcn_update_dpp(fill, v, 0x110 + D, 0xf, 0xf, false);
+}
+
+template <int D>
+__device__ __forceinline__ void seg_step(float (&v0)[8], float (&v1)[8], int& hf) {
+    const int hup = row_shr_i<D>(hf, 1);
+    float u0[8], u1[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { u0[c] = row_shr_f<D>(v0[c]); u1[c] = row_shr_f<D>(v1[c]); }
+    if (!hf) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { v0[c] += u0[c]; v1[c] += u1[c]; }
+        hf = hup;
+    }
+}
+
+enum { KIND_GENERIC = 0, KIND_HASHED = 1, KIND_MERGE = 2 };
+
+// One batch of <= 64 hits (one per lane): accumulate this level's contributions that fall into slice `sl`.
+template <int KIND>
+__device__ __forceinline__ void accumulate(const LevelParams P, const uint32_t sl, const bool single, const Hit H, const bool valid,
+                                           double* __restrict__ slice) {
+    const int lane = threadIdx.x & 63;
+    float g0 = H.g0, g1 = H.g1;
+    const float px = H.x * P.scale + 0.5f, py = H.y * P.scale + 0.5f, pz = H.z * P.scale + 0.5f;
+    uint32_t cx = f2u_sat(floorf(px)), cy = f2u_sat(floorf(py)), cz = f2u_sat(floorf(pz));
+    const float fx = px - (float)cx, fy = py - (float)cy, fz = pz - (float)cz;
+    const bool act = valid && (g0 != 0.0f || g1 != 0.0f);           // exact-zero gradients contribute nothing
+    if (KIND == KIND_HASHED) {
+        // xor hash into a power-of-two table with res < 2^13: h = (gx ^ A) & mask, A = gy P1 ^ gz P2; gx < 2^13 cannot reach the
+        // slice bits, so both x corners of a (y, z) combination share the slice, and two multiplies serve all four combinations
+        const uint32_t msk = P.size - 1u;
+        const uint32_t b0 = cy * 2654435761u, b1 = b0 + 2654435761u, c0 = cz * 805459861u, c1 = c0 + 805459861u;
+        const uint32_t A0 = b0 ^ c0, A1 = b1 ^ c0, A2 = b0 ^ c1, A3 = b1 ^ c1;             // k = (z bit, y bit)
+        uint32_t m = 0u;
+        if (act) {
+            m = (uint32_t)(((A0 & msk) >> BW_SLICE_LOG2) == sl) | ((uint32_t)(((A1 & msk) >> BW_SLICE_LOG2) == sl) << 1) |
+                ((uint32_t)(((A2 & msk) >> BW_SLICE_LOG2) == sl) << 2) | ((uint32_t)(((A3 & msk) >> BW_SLICE_LOG2) == sl) << 3);
+        }
+        const float wx0 = 1.0f * (1.0f - fx), wx1 = 1.0f * fx;                               // same product order as the forward
+        while (__any(m != 0u)) {
+            if (m != 0u) {
+                const int k = __builtin_ctz(m);
+                m &= m - 1u;
+                const uint32_t A = (k & 2) ? ((k & 1) ? A3 : A2) : ((k & 1) ? A1 : A0);
+                const float wy = (k & 1) ? fy : 1.0f - fy, wz = (k & 2) ? fz : 1.0f - fz;
+                const float w0 = (wx0 * wy) * wz, w1 = (wx1 * wy) * wz;
+                double* p0 = slice + 2 * (((cx ^ A) & msk) & (BW_SLICE_ENTRIES - 1));
+                double* p1 = slice + 2 * ((((cx + 1u) ^ A) & msk) & (BW_SLICE_ENTRIES - 1));
+                LDS_ADD(p0, w0 * g0); LDS_ADD(p0 + 1, w0 * g1);
+                LDS_ADD(p1, w1 * g0); LDS_ADD(p1 + 1, w1 * g1);
+            }
+        }
+        return;
+    }
+    if (KIND == KIND_GENERIC) {
+        if (act) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {                               // k = (z bit, y bit)
+                const int yb = k & 1, zb = k >> 1;
+                const float wyz_y = yb ? fy : 1.0f - fy, wyz_z = zb ? fz : 1.0f - fz;
+#pragma unroll
+                for (int xb = 0; xb < 2; ++xb) {
+                    uint32_t loc;
+                    const uint32_t h = level_index(P.dense, P.mode, P.size, P.res, cx + xb, cy + yb, cz + zb);
+                    if (slice_of(P.map, h, loc) == sl) {
+                        const float w = ((1.0f * (xb ? fx : 1.0f - fx)) * wyz_y) * wyz_z;
+                        double* p = slice + 2 * loc;
+                        LDS_ADD(p, w * g0);
+                        LDS_ADD(p + 1, w * g1);
+                    }
+                }
+            }
+        }
+        return;
+    }
+    // KIND_MERGE: consecutive hits are consecutive samples of a ray; on a coarse level they sit in the same cell for many steps.
+    // Sum each equal-cell run (in f32, fixed lane order) with a segmented scan inside 16-lane rows (DPP row shifts: one VALU
+    // instruction per value and step); only a run's last lane touches the LDS.  A run that crosses a row boundary simply
+    // becomes two adds.
+    if (!act) { cx = 0xffffffffu; g0 = 0.f; g1 = 0.f; }
+    float v0[8], v1[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const float w = ((1.0f * ((c & 1) ? fx : 1.0f - fx)) * (((c >> 1) & 1) ? fy : 1.0f - fy)) * ((c >> 2) ? fz : 1.0f - fz);
+        v0[c] = w * g0; v1[c] = w * g1;
+    }
+    const uint32_t pcx = (uint32_t)row_shr_i<1>((int)cx, -1), pcy = (uint32_t)row_shr_i<1>((int)cy, -1), pcz = (uint32_t)row_shr_i<1>((int)cz, -1);
+    const bool head = ((lane & 15) == 0) || !act || cx != pcx || cy != pcy || cz != pcz;
+    const int nhead = __builtin_amdgcn_update_dpp(1, (int)head, 0x101, 0xf, 0xf, false);          // row_shl:1, row end -> 1
+    const bool tail = act && (nhead != 0);
+    int hf = head;
+    seg_step<1>(v0, v1, hf); seg_step<2>(v0, v1, hf); seg_step<4>(v0, v1, hf); seg_step<8>(v0, v1, hf);
+    if (tail) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            uint32_t loc;
+            const uint32_t h = level_index(P.dense, P.mode, P.size, P.res, cx + (c & 1), cy + ((c >> 1) & 1), cz + (c >> 2));
+            if (slice_of(P.map, h, loc) == sl) {
+                double* p = slice + 2 * loc;
+                if (v0[c] != 0.0f) LDS_ADD(p, v0[c]);
+                if (v1[c] != 0.0f) LDS_ADD(p + 1, v1[c]);
+            }
+        }
+    }
+}
+
+// A pair of batches (lane holds hits i0 and i1): the four gathers of a lane are issued together.
+struct Batch {
+    Hit h0, h1;
+    bool v0, v1;
+};
+
+__device__ __forceinline__ Batch load_batch(const int level, const int i0, const bool v0, const int i1, const bool v1,
+                                            const float* __restrict__ xyzc, const float* __restrict__ dout, const size_t plane,
+                                            const int enc_pairs, const int nl, int32_t* __restrict__ found_inf, const uint32_t diag) {
+    Batch b;
+    b.v0 = v0; b.v1 = v1;
+    b.h0 = load_hit(level, i0, v0, xyzc, dout, plane, enc_pairs, nl, found_inf, diag);
+    b.h1 = load_hit(level, i1, v1, xyzc, dout, plane, enc_pairs, nl, found_inf, diag);
+    return b;
+}
+
+template <int KIND>
+__device__ __forceinline__ void accumulate_batch(const LevelParams P, const uint32_t sl, const bool single, const Batch& b,
+                                                 double* __restrict__ slice) {
+    accumulate<KIND>(P, sl, single, b.h0, b.v0, slice);
+    accumulate<KIND>(P, sl, single, b.h1, b.v1, slice);
+}
+
+// One task: software-pipelined.  The wave's share of the hit bitmap is fetched 64 words (4096 samples) per vector load, one
+// super-chunk ahead; the gathers of batch b+1 are issued before batch b is accumulated.
+template <int KIND>
+__device__ __forceinline__ void bwd_task(const LevelParams P, const int level, const uint32_t sl, const bool single, const int n,
+                                         const int rep, const int nrep, const float* __restrict__ xyzc,
+                                         const unsigned long long* __restrict__ brow, const float* __restrict__ dout,
+                                         const size_t plane, const int enc_pairs, const int nl, double* __restrict__ slice,
+                                         uint32_t* __restrict__ q, uint32_t* __restrict__ next_sc, int32_t* __restrict__ found_inf) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // this replica's sample range in 64-sample words, whole 8-word chunks
+    const int n_words = (n + 63) >> 6;
+    int chunk = (n_words + nrep - 1) / nrep;
+    chunk = (chunk + 7) & ~7;
+    const int lo_w = rep * chunk, hi_w = min(n_words, lo_w + chunk);
+    Batch pend;
+    pend.v0 = pend.v1 = false;
+    pend.h0 = pend.h1 = Hit{0.f, 0.f, 0.f, 0.f, 0.f};
+    if (single) {
+        for (int w0 = lo_w + 2 * wave; w0 < hi_w; w0 += 2 * BW_WAVES) {
+            const int i0 = w0 * 64 + lane, i1 = i0 + 64;
+            const Batch nxt = load_batch(level, i0, i0 < n, i1, (w0 + 1 < hi_w) && i1 < n, xyzc, dout, plane, enc_pairs, nl, found_inf, P.diag);
+            accumulate_batch<KIND>(P, sl, true, pend, slice);
+            pend = nxt;
+        }
+        accumulate_batch<KIND>(P, sl, true, pend, slice);
+        return;
+    }
+    int qhead = 0, qlen = 0;
+    // super-chunk c = words [lo_w + SCW c, + SCW): lane l < SCW holds word l.  Waves take super-chunks from a shared LDS counter
+    // (hit density varies along the sample list; a static deal left the slowest wave 15-30 % behind), one ahead of the one in
+    // work.  SCW = 64 words (4096 samples, ~256 hits) where ~6 % of the samples hit (hashed levels); fewer where a larger share
+    // hits (dense levels: ~2 of ns slices per sample, replicated over short sample ranges -- a 4096-sample chunk would leave
+    // most of the 16 waves idle there, a 256-sample chunk of a 32-slice level would be one exposed load latency per 25 hits).
+    int SCW = 64;
+    if (KIND == KIND_MERGE) { SCW = 4; while (SCW < 64 && SCW < 2 * (int)P.map.ns) SCW <<= 1; }
+    const int n_sc = (hi_w - lo_w + SCW - 1) / SCW;
+    auto load_words = [&](int c) -> unsigned long long {
+        const int w = lo_w + c * SCW + lane;
+        return (c < n_sc && lane < SCW && w < hi_w) ? brow[w] : 0ull;
+    };
+    auto grab = [&]() -> int {
+        int c = 0;
+        if (lane == 0) c = (int)atomicAdd(next_sc, 1u);
+        return __builtin_amdgcn_readfirstlane(c);
+    };
+    auto drain = [&]() {          // 128 queued hits: issue their gathers, accumulate the batch whose gathers were issued last time
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int i0 = (int)q[(qhead + lane) & (BW_Q - 1)], i1 = (int)q[(qhead + 64 + lane) & (BW_Q - 1)];
+        const Batch nxt = load_batch(level, i0, true, i1, true, xyzc, dout, plane, enc_pairs, nl, found_inf, P.diag);
+        accumulate_batch<KIND>(P, sl, false, pend, slice);
+        pend = nxt;
+        __builtin_amdgcn_wave_barrier();
+        qhead = (qhead + 128) & (BW_Q - 1); qlen -= 128;
+    };
+    int sc = grab();
+    unsigned long long cur = load_words(sc);
+    while (sc < n_sc) {
+        const int sc_next = grab();
+        const unsigned long long nxtw = load_words(sc_next);
+        const int wbase = lo_w + sc * SCW;
+        if (KIND == KIND_MERGE) {
+            // word-serial: hits enter the queue in sample order (the run pre-summing needs consecutive samples in consecutive
+            // lanes); these levels have few slices, so most bits are set and a word's ~30 instructions buy ~64 hits
+            unsigned long long nonzero = __ballot(cur != 0ull);                // which of the 64 words have any hit
+            while (nonzero) {
+                const int k = __builtin_ctzll(nonzero);
+                nonzero &= nonzero - 1;
+                const unsigned long long b = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(cur >> 32), k) << 32) |
+                                             (uint32_t)__builtin_amdgcn_readlane((int)cur, k);
+                const bool hit = (b >> lane) & 1ull;
+                const int pos = qlen + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0));
+                if (hit) q[(qhead + pos) & (BW_Q - 1)] = (uint32_t)((wbase + k) * 64 + lane);
+                qlen += __popcll(b);
+                if (qlen >= 128) drain();
+            }
+        } else {
+            // lane-parallel: lane l owns word l (64 samples); every round each lane with bits left emits its lowest one, the
+            // emitting lanes are compacted into the queue with one ballot.  Rounds = the largest popcount among the words
+            // (~10 at the 6 % hit density of a hashed level's slice) instead of one serial step per word.  (Unpacking a whole
+            // word per lane behind a prefix sum was tried: the equal-cell runs of the coarser hashed levels then sit in ONE add
+            // instruction and serialise in the LDS -- 333 -> 397 us.)
+            unsigned long long w = cur;
+            unsigned long long live = __ballot(w != 0ull);
+            while (live) {
+                const bool has = w != 0ull;
+                const int pos = qlen + __builtin_amdgcn_mbcnt_hi((uint32_t)(live >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)live, 0));
+                if (has) {
+                    q[(qhead + pos) & (BW_Q - 1)] = (uint32_t)((wbase + lane) * 64 + __builtin_ctzll(w));
+                    w &= w - 1ull;
+                }
+                qlen += __popcll(live);
+                if (qlen >= 128) drain();
+                live = __ballot(w != 0ull);
+            }
+        }
+        cur = nxtw; sc = sc_next;
+    }
+    if (qlen > 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const bool v0 = lane < qlen, v1 = lane + 64 < qlen;
+        const int i0 = v0 ? (int)q[(qhead + lane) & (BW_Q - 1)] : 0, i1 = v1 ? (int)q[(qhead + 64 + lane) & (BW_Q - 1)] : 0;
+        const Batch nxt = load_batch(level, i0, v0, i1, v1, xyzc, dout, plane, enc_pairs, nl, found_inf, P.diag);
+        accumulate_batch<KIND>(P, sl, false, pend, slice);
+        pend = nxt;
+    }
+    accumulate_batch<KIND>(P, sl, false, pend, slice);
+}
+
+__global__ void __launch_bounds__(BW_THREADS) hash_bwd_lds_kernel(const float* __restrict__ xyzc,
+                                                                  const unsigned long long* __restrict__ bitmap, size_t wstride,
+                                                                  const float* __restrict__ dout, ngp_hash_levels lv, int n,
+                                                                  const int32_t* __restrict__ n_dev, int enc_pairs, BwdPlan plan,
+                                                                  float* __restrict__ dtable, int32_t* __restrict__ found_inf,
+                                                                  unsigned long long* __restrict__ dbg) {
+    __shared__ double slice[2 * BW_SLICE_ENTRIES];
+    __shared__ uint32_t queues[BW_WAVES * BW_Q];
+    __shared__ uint32_t next_sc;
+    const uint32_t task = plan.task[blockIdx.x];
+    if (task == BW_NULL_TASK) return;
+    unsigned long long t_begin = 0;
+    if (dbg) t_begin = wall_clock64();
+    const size_t plane = (size_t)n;
+    if (n_dev) n = min(n, *n_dev);
+    if (n <= 0) return;
+    const int level = task & 0xf, rep = (task >> 10) & 0x3f, nrep = plan.nrep[level];
+    const uint32_t sl = (task >> 4) & 0x3f;
+    const int tid = threadIdx.x;
+    LevelParams P;
+    P.scale = lv.scale[level]; P.res = lv.resolution[level]; P.size = lv.map_size[level]; P.offset = lv.offset[level];
+    P.dense = level < lv.begin_fast_hash_level;
+    if (P.dense) { const uint64_t r = P.res; P.mode = ((uint64_t)P.size >= r * r * r && r >= 2) ? 0u : 2u; }
+    else P.mode = (P.size != 0 && (P.size & (P.size - 1)) == 0) ? 1u : 2u;
+    P.map = slice_map(P.size, P.res, P.dense);
+    P.diag = plan.merge_mask >> 30;
+    const bool single = P.size <= (uint32_t)BW_SLICE_ENTRIES;           // one slice: every sample is a hit, no bitmap
+    const bool merge = (plan.merge_mask >> level) & 1u;          // (levels <= 15: bits 30-31 carry the diagnostics flags)
+    const bool hashed = !P.dense && P.mode == 1u && P.res < (1u << BW_SLICE_LOG2) && !single;
+
+    double2* s2 = reinterpret_cast<double2*>(slice);
+    for (int j = tid; j < BW_SLICE_ENTRIES; j += BW_THREADS) s2[j] = make_double2(0.0, 0.0);
+    if (tid == 0) next_sc = 0u;
+    __syncthreads();
+    unsigned long long t_init = 0;
+    if (dbg) t_init = wall_clock64();
+    uint32_t* q = queues + (tid >> 6) * BW_Q;
+    const unsigned long long* brow = bitmap + ((size_t)level * BW_MAX_SLICES + sl) * wstride;
+    if (merge) bwd_task<KIND_MERGE>(P, level, sl, single, n, rep, nrep, xyzc, brow, dout, plane, enc_pairs, lv.n_levels, slice, q, &next_sc, found_inf);
+    else if (hashed) bwd_task<KIND_HASHED>(P, level, sl, single, n, rep, nrep, xyzc, brow, dout, plane, enc_pairs, lv.n_levels, slice, q, &next_sc, found_inf);
+    else bwd_task<KIND_GENERIC>(P, level, sl, single, n, rep, nrep, xyzc, brow, dout, plane, enc_pairs, lv.n_levels, slice, q, &next_sc, found_inf);
+    unsigned long long t_wave = 0;
+    if (dbg) t_wave = wall_clock64();
+    __syncthreads();
+    unsigned long long t_acc = 0;
+    if (dbg) t_acc = wall_clock64();
+    // flush: the slice owner rounds its f64 image to f32 and adds it into the table gradient -- plain (non-atomic)
+    // read-modify-write when it is the only replica, float atomics (coalesced, a few thousand lines) when the level is
+    // replicated over sample ranges
+    float2* dl = reinterpret_cast<float2*>(dtable + 2 * (size_t)P.offset);
+    for (int j = tid; j < BW_SLICE_ENTRIES; j += BW_THREADS) {
+        const double2 a = s2[j];
+        if (a.x == 0.0 && a.y == 0.0) continue;
+        const uint32_t h = entry_of(P.map, sl, (uint32_t)j);          // LDS position j -> table entry
+        const float vx = (float)a.x, vy = (float)a.y;
+        if (nrep == 1) {
+            float2 d = dl[h];
+            d.x += vx; d.y += vy;
+            dl[h] = d;
+        } else {
+            float* dp = reinterpret_cast<float*>(dl + h);
+            if (vx != 0.0f) unsafeAtomicAdd(dp, vx);
+            if (vy != 0.0f) unsafeAtomicAdd(dp + 1, vy);
+        }
+    }
+    if (dbg) {          // diagnostics (ngp_hash_bwd_sliced_debug): 100 MHz wall-clock stamps per block + wave 0's own finish time
+        if (tid == 0) {
+            unsigned long long* o = dbg + 8 * (size_t)blockIdx.x;
+            uint32_t xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            o[0] = task; o[1] = t_begin; o[2] = t_init; o[3] = t_wave; o[4] = t_acc; o[5] = wall_clock64(); o[6] = xcc & 0xf; o[7] = (unsigned long long)n;
+        }
+    }
+}
+
+// ---- host: the task plan -------------------------------------------------------------------------------------------------
+// Returns false when the level table does not fit the formulation (F != 2, or a level of more than 64 slices).
+static bool build_plan(const ngp_hash_levels& lv, BwdPlan& plan, uint32_t& single_mask) {
+    if (lv.n_features != 2 || lv.n_levels < 1 || lv.n_levels > NGP_MAX_LEVELS) return false;
+    struct Lvl { int level, n_slices, nrep, tasks; };
+    Lvl lvls[NGP_MAX_LEVELS];
+    single_mask = 0u;
+    plan.merge_mask = 0u;
+    int rep_target = 64;                  // a replicated level gets ~ rep_target tasks (see the replica comment below)
+    if (const char* e = getenv("NGP_BWD_REP_TARGET")) rep_target = atoi(e) > 0 ? atoi(e) : rep_target;
+    int merge_res = 128;                  // pre-sum equal-cell runs on levels up to this resolution
+    if (const char* e = getenv("NGP_BWD_MERGE_RES")) merge_res = atoi(e);
+    uint32_t level_mask = 0xffffffffu;    // diagnostics (profiles/microbench/hash_bwd_variants.py): only these levels' tasks
+    if (const char* e = getenv("NGP_BWD_LEVELS")) level_mask = (uint32_t)strtoul(e, nullptr, 0);
+    for (int l = 0; l < lv.n_levels; ++l) {
+        const uint32_t size = lv.map_size[l];
+        const int ns = (int)((size + BW_SLICE_ENTRIES - 1) / BW_SLICE_ENTRIES);
+        if (ns < 1 || ns > BW_MAX_SLICES || size % 2 != 0) return false;
+        // a level of few slices sees a large share of the samples in every slice (a sample touches 1-2 z-adjacent slices of a
+        // dense level, and the scene concentrates in a part of the z range): replicate it over sample ranges so that one task
+        // handles no more hits than a hashed level's slice owner (S/16: 4 of 64 slices per sample)
+        int nrep = ns >= BW_MAX_SLICES ? 1 : (rep_target + ns / 2) / ns;
+        if (nrep < 1) nrep = 1;
+        if (nrep > 63) nrep = 63;
+        lvls[l] = {l, ns, nrep, ((level_mask >> l) & 1u) ? ns * nrep : 0};
+        plan.nrep[l] = (uint8_t)nrep;
+        if (ns == 1) single_mask |= 1u << l;
+        if ((int)lv.resolution[l] <= merge_res && l < lv.begin_fast_hash_level) plan.merge_mask |= 1u << l;    // dense coarse levels
+    }
+    for (int l = lv.n_levels; l < NGP_MAX_LEVELS; ++l) plan.nrep[l] = 1;
+    if (const char* e = getenv("NGP_BWD_DIAG")) plan.merge_mask |= ((uint32_t)atoi(e) & 3u) << 30;     // timing experiments only: wrong results
+    // XCD-aware order (block b runs on XCD b % 8, one 1024-thread block per CU): the owners of one level read the same
+    // position / gradient lines, and they only find them in L2 if they run on the same XCD at about the same time (measured:
+    // a hashed level's owners take 52 us when the level has an XCD to itself, 115 us when its 64 owners are spread over all
+    // eight).  So tasks are dealt to XCDs in same-level chunks of up to 32 (one round of an XCD's 32 CUs), largest first, each
+    // chunk to the least loaded XCD.
+    static thread_local uint16_t lists[8][BW_MAX_TASKS];
+    int len[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    float load[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto encode = [](int level, int slice, int rep) { return (uint16_t)(level | (slice << 4) | (rep << 10)); };
+    auto least = [&]() { int b = 0; for (int x = 1; x < 8; ++x) if (load[x] < load[b]) b = x; return b; };
+    // measured task durations relative to a hashed level's slice owner (profiles/r02_hash_bwd_timeline.txt), per replica count
+    auto cost = [&](const Lvl& L) {
+        if (L.level >= lv.begin_fast_hash_level) return 1.0f;
+        const float per_slice = L.n_slices == 1 ? 24.0f : (L.n_slices >= 8 ? 70.0f / L.n_slices * 2.0f : 36.0f);   // whole-level work / slices
+        return per_slice / (float)L.nrep + 0.1f;
+    };
+    int order[NGP_MAX_LEVELS];
+    for (int l = 0; l < lv.n_levels; ++l) order[l] = l;
+    for (int a = 0; a < lv.n_levels; ++a)                       // heaviest levels first (fine levels first on ties)
+        for (int b = a + 1; b < lv.n_levels; ++b) {
+            const float cb = lvls[order[b]].tasks * cost(lvls[order[b]]), ca = lvls[order[a]].tasks * cost(lvls[order[a]]);
+            if (cb > ca || (cb == ca && order[b] > order[a])) { const int t = order[a]; order[a] = order[b]; order[b] = t; }
+        }
+    int total = 0;
+    for (int a = 0; a < lv.n_levels; ++a) total += lvls[order[a]].tasks;
+    if (total > BW_MAX_TASKS - 64) return false;
+    for (int pass = 0; pass < 2; ++pass)                        // full chunks first, then the remainders
+        for (int a = 0; a < lv.n_levels; ++a) {
+            const Lvl& L = lvls[order[a]];
+            if (L.tasks == 0) continue;
+            const int chunk = L.level < lv.begin_fast_hash_level ? 16 : 32;
+            const int full = (L.tasks / chunk) * chunk;
+            int t = 0, x = 0;
+            for (int s = 0; s < L.n_slices; ++s)
+                for (int r = 0; r < L.nrep; ++r, ++t) {
+                    const bool in_full = t < full;
+                    if ((pass == 0) != in_full) continue;
+                    if (pass == 0 ? (t % chunk == 0) : (t == full)) x = least();
+                    lists[x][len[x]++] = encode(L.level, s, r);
+                    load[x] += cost(L);
+                }
+        }
+    int maxlen = 0;
+    for (int x = 0; x < 8; ++x) if (len[x] > maxlen) maxlen = len[x];
+    if (maxlen * 8 > BW_MAX_TASKS) return false;
+    int nb = 0;
+    for (int p = 0; p < maxlen; ++p)
+        for (int x = 0; x < 8; ++x) plan.task[nb++] = p < len[x] ? lists[x][p] : BW_NULL_TASK;
+    plan.n_blocks = nb;
+    return true;
+}
+
+}  // namespace ngp
+
+using namespace ngp;
+
+static unsigned long long* g_bwd_debug = nullptr;
+
+extern "C" {
+
+// diagnostics: when set to a device buffer of 8 * 1024 u64, every main-kernel block records its task word, 100 MHz wall-clock
+// stamps (begin, after LDS init, wave 0 done, all waves done, after flush), its XCC id and the sample count
+int ngp_hash_bwd_sliced_debug(void* device_buffer) { g_bwd_debug = (unsigned long long*)device_buffer; return 0; }
+
+// bytes of scratch the sliced scatter-add needs for buffers of n_max samples: compact positions + one hit bit per
+// (level, slice, sample)
+long long ngp_hash_bwd_sliced_workspace(const ngp_hash_levels* lv, int n_max) {
+    if (!lv || n_max <= 0) return 0;
+    const size_t ms = ((size_t)n_max + 511) & ~(size_t)511;
+    return (long long)(ms * 3 * sizeof(float) + (size_t)lv->n_levels * BW_MAX_SLICES * (ms / 64) * sizeof(unsigned long long));
+}
+
+int ngp_hash_bwd_f32_sliced(const float* xyzs, const float* dout, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev,
+                            const int32_t* live_idx, int normalize, float lo, float hi, int enc_pairs, float* dtable,
+                            int32_t* found_inf, void* workspace, long long workspace_bytes, void* stream) {
+    if (n_max <= 0) return 0;
+    if (enc_pairs && !(lv->n_features == 2 && lv->n_levels == 16)) return -1;
+    if (!workspace || workspace_bytes < ngp_hash_bwd_sliced_workspace(lv, n_max)) return -1;
+    static thread_local BwdPlan plan;
+    uint32_t single_mask;
+    if (!build_plan(*lv, plan, single_mask)) return -2;               // not expressible: the caller falls back to the atomic kernel
+    if (plan.n_blocks <= 0) return 0;
+    const size_t ms = ((size_t)n_max + 511) & ~(size_t)511;
+    float* xyzc = reinterpret_cast<float*>(workspace);
+    unsigned long long* bitmap = reinterpret_cast<unsigned long long*>(xyzc + ms * 3);
+    hipStream_t s = (hipStream_t)stream;
+    const XyzNorm nm = {normalize, lo, hi};
+    hipLaunchKernelGGL(hash_bwd_prep_kernel, dim3(BW_PREP_BLOCKS), dim3(256), 0, s, xyzs, live_idx, *lv, n_max, n_dev, nm, ms / 64,
+                       single_mask, xyzc, bitmap);
+    NGP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(hash_bwd_lds_kernel, dim3(plan.n_blocks), dim3(BW_THREADS), 0, s, (const float*)xyzc,
+                       (const unsigned long long*)bitmap, ms / 64, dout, *lv, n_max, n_dev, enc_pairs, plan, dtable,
+                       found_inf, g_bwd_debug);
+    NGP_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

@@ -48,6 +48,14 @@ class TrainArena:
         # latest one would silently differentiate the WRONG batch's activations, so it checks this stamp and raises instead
         self.generation = 0
 
+    def sliced_ws(self, lv):
+        """Scratch of the LDS-sliced scatter-add (compact positions + slice masks for `cap` samples), allocated on first use."""
+        need = int(_lib_mod.load().ngp_hash_bwd_sliced_workspace(ctypes.byref(lv), self.cap))
+        ws = self._scratch.get("sliced_ws")
+        if ws is None or ws.numel() < need:
+            ws = self._scratch["sliced_ws"] = torch.empty(need, device=self.stage.device, dtype=torch.uint8)
+        return ws
+
     def live_off(self, n):
         return self._live_off
 

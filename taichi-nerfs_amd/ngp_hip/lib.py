@@ -15,8 +15,8 @@ PKG_ROOT = os.path.dirname(_HERE)
 CSRC = os.path.join(PKG_ROOT, "csrc")
 INCLUDE = os.path.join(os.path.dirname(PKG_ROOT), "include")
 LIB_PATH = os.path.join(CSRC, "libngp_hip.so")
-SOURCES = ["march.hip", "hash_grid.hip", "composite.hip", "sh_grid.hip", "mlp.hip", "optim.hip", "distortion.hip", "occupancy.hip", "rays.hip"]
-HEADERS = ["ngp_device.h"]
+SOURCES = ["march.hip", "hash_grid.hip", "hash_bwd_lds.hip", "composite.hip", "sh_grid.hip", "mlp.hip", "optim.hip", "distortion.hip", "occupancy.hip", "rays.hip"]
+HEADERS = ["ngp_device.h", "hash_common.h"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
 
 NGP_MAX_LEVELS = 16
@@ -96,6 +96,9 @@ SIGNATURES = {
     "ngp_mlp_bwd_live": [_P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P],
     "ngp_hash_bwd_f32_live": [_P, _P, _LV, _I, _P, _P, _I, _F, _F, _I, _P, _P, _P],
     "ngp_hash_bwd_f16_live": [_P, _P, _LV, _I, _P, _P, _I, _F, _F, _I, _P, _P, _P],
+    "ngp_hash_bwd_sliced_workspace": [_LV, _I],
+    "ngp_hash_bwd_sliced_debug": [_P],
+    "ngp_hash_bwd_f32_sliced": [_P, _P, _LV, _I, _P, _P, _I, _F, _F, _I, _P, _P, _P, ctypes.c_longlong, _P],
     "ngp_sh16_fwd": [_P, _I, _P, _P],
     "ngp_sh16_bwd": [_P, _P, _I, _P, _P],
     "ngp_composite_train_fwd": [_P, _P, _I, _P, _P, _P, _F, _I, _P, _P, _P, _P, _P, _P],
@@ -132,6 +135,7 @@ SIGNATURES = {
     "ngp_packbits": [_P, _F, _I, _P, _P],
 }
 
+_LONGLONG_RESULT = {"ngp_hash_bwd_sliced_workspace"}       # byte counts; every other entry point returns an int status
 _lib = None
 
 
@@ -149,7 +153,7 @@ def load():
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)     # AttributeError here = header/library mismatch: fail loudly
         fn.argtypes = argtypes
-        fn.restype = ctypes.c_int
+        fn.restype = ctypes.c_longlong if name in _LONGLONG_RESULT else ctypes.c_int
     _lib = lib
     return lib
 

@@ -171,6 +171,31 @@ def hash_bwd_f32(xyzs, dout, lv, dtable):
     return dtable
 
 
+_sliced_ws = {}
+
+
+def sliced_workspace(lv, n_max, device):
+    """Scratch of the LDS-sliced scatter-add for buffers of n_max samples (grown, never shrunk, one per device)."""
+    need = int(_lib().ngp_hash_bwd_sliced_workspace(ctypes.byref(lv), int(n_max)))
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    ws = _sliced_ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _sliced_ws[key] = torch.empty(need, device=device, dtype=torch.uint8)
+    return ws
+
+
+def hash_bwd_f32_sliced(xyzs, dout, lv, dtable, live_idx=None, n_dev=None):
+    """dtable += scatter-add of dout (natural [n, L*2] layout), LDS-sliced formulation; xyzs in [0,1].  Raises if the level table
+    does not fit (use hash_bwd_f32 then)."""
+    _dev(xyzs, torch.float32, "xyzs"); _dev(dout, torch.float32, "dout"); _dev(dtable, torch.float32, "dtable")
+    n = dout.shape[0]
+    ws = sliced_workspace(lv, n, xyzs.device)
+    check(_lib().ngp_hash_bwd_f32_sliced(_ptr(xyzs), _ptr(dout), ctypes.byref(lv), n, _ptr(n_dev), _ptr(live_idx), 0, 0.0, 1.0, 0,
+                                         _ptr(dtable), _ptr(None), _ptr(ws), ws.numel(), _stream()), "ngp_hash_bwd_f32_sliced")
+    _touched(dtable)
+    return dtable
+
+
 def hash_fwd_f16(xyzs, table_h, lv):
     _dev(xyzs, torch.float32, "xyzs"); _dev(table_h, torch.float16, "hash_table(f16)")
     n = xyzs.shape[0]

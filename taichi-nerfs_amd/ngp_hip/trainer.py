@@ -58,6 +58,9 @@ class FusedTrainer:
         self.distortion_loss_w = float(distortion_loss_w)                # train.py:194-195 (0 = off, the reference default)
         # backward over the samples in front of each ray's early-termination point only (NGP_LIVE_BACKWARD=0: over all of them)
         self.live_backward = os.environ.get("NGP_LIVE_BACKWARD", "1") != "0"
+        # fp32 table gradient: "sliced" = LDS-owned table slices, no global float atomics (csrc/hash_bwd_lds.hip; the default
+        # whenever the level table fits: F = 2, levels of <= 2^19 entries), "atomic" = round 1's float-atomic kernel
+        self.hash_bwd = os.environ.get("NGP_HASH_BWD", "sliced")
         self.group = process_group
         self.world = world_size if world_size is not None else (dist.get_world_size(process_group) if dist.is_initialized() else 1)
 
@@ -300,8 +303,18 @@ class FusedTrainer:
             check(L.ngp_hash_bwd_f16_live(_ptr(M.xyzs), _ptr(A.d_enc), ctypes.byref(cfg.levels), A.cap, _ptr(cnt), _ptr(live_idx), 1,
                                           cfg.lo, cfg.hi, P, _ptr(self.table_grad), found, st), "ngp_hash_bwd_f16_live")
         else:
-            check(L.ngp_hash_bwd_f32_live(_ptr(M.xyzs), _ptr(A.d_enc), ctypes.byref(cfg.levels), A.cap, _ptr(cnt), _ptr(live_idx), 1,
-                                          cfg.lo, cfg.hi, P, _ptr(self.table_grad), found, st), "ngp_hash_bwd_f32_live")
+            rc = -2
+            if self.hash_bwd == "sliced":
+                ws = A.sliced_ws(cfg.levels)
+                rc = L.ngp_hash_bwd_f32_sliced(_ptr(M.xyzs), _ptr(A.d_enc), ctypes.byref(cfg.levels), A.cap, _ptr(cnt), _ptr(live_idx), 1,
+                                               cfg.lo, cfg.hi, P, _ptr(self.table_grad), found, _ptr(ws), ws.numel(), st)
+                if rc == -2:
+                    self.hash_bwd = "atomic"                 # level table not expressible as <= 32 LDS slices per level
+                else:
+                    check(rc, "ngp_hash_bwd_f32_sliced")
+            if rc == -2:
+                check(L.ngp_hash_bwd_f32_live(_ptr(M.xyzs), _ptr(A.d_enc), ctypes.byref(cfg.levels), A.cap, _ptr(cnt), _ptr(live_idx), 1,
+                                              cfg.lo, cfg.hi, P, _ptr(self.table_grad), found, st), "ngp_hash_bwd_f32_live")
         if self.world > 1:
             self._all_reduce()
         if self.half:       # f16 sums overflow easily: GradScaler's check must see the ACCUMULATED (and reduced) gradient

@@ -12,7 +12,7 @@ from conftest import ROOT
 def _declared():
     hdr = open(os.path.join(ROOT, "include", "ngp_hip.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    return sorted(set(re.findall(r"\bint\s+(ngp_[a-z0-9_]+)\s*\(", hdr)))
+    return sorted(set(re.findall(r"\b(?:int|long long)\s+(ngp_[a-z0-9_]+)\s*\(", hdr)))
 
 
 def test_header_symbols_exported(hip_lib):

@@ -139,6 +139,54 @@ def test_hash_bwd_f32(oracle, hip_lib):
     np.testing.assert_allclose(got, ref, rtol=2e-5, atol=2e-5)
 
 
+@pytest.mark.parametrize("max_res", [1024, 4096])
+def test_hash_bwd_f32_sliced(oracle, hip_lib, max_res):
+    """The LDS-sliced scatter-add (no global float atomics; csrc/hash_bwd_lds.hip) against the oracle: same touched entries,
+    2e-5; ray-like point runs exercise the equal-cell pre-summing and the per-wave hit queue; plus the live-list / device-count
+    form and the accumulate-into semantics."""
+    lv = ops.make_levels(2**19, 16, 16, max_res, 2)
+    rng = np.random.default_rng(1)
+    n_rays, per_ray = 600, 50
+    o = rng.random((n_rays, 1, 3), dtype=np.float32) * 0.8 + 0.1
+    d = rng.standard_normal((n_rays, 1, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    t = (np.arange(per_ray, dtype=np.float32) * np.float32(0.0017))[None, :, None]
+    x = np.clip(o + d * t, 0.0, 1.0).reshape(-1, 3).astype(np.float32)             # consecutive samples share coarse cells
+    x = np.concatenate([x, rng.random((5003, 3), dtype=np.float32),
+                        np.array([[0, 0, 0], [1, 1, 1], [1, 0, 1], [0.999999, 1e-7, 0.5]], np.float32)])
+    n = x.shape[0]
+    dout = rng.standard_normal((n, 32)).astype(np.float32)
+    dout[::7] = 0.0
+    ref = oracle.hash_bwd_f32(x, dout, lv)
+    dt = torch.zeros(lv.total_entries * 2, device="cuda")
+    ops.hash_bwd_f32_sliced(dev(x), dev(dout), lv, dt)
+    got = dt.cpu().numpy()
+    assert support_matches(ref, got)
+    np.testing.assert_allclose(got, ref, rtol=2e-5, atol=2e-5)
+    # accumulates into what is already there, like ngp_hash_bwd_f32
+    ops.hash_bwd_f32_sliced(dev(x), dev(dout), lv, dt)
+    np.testing.assert_allclose(dt.cpu().numpy(), 2 * ref, rtol=4e-5, atol=4e-5)
+    # live list + device-side count: position j of dout belongs to sample live_idx[j]; only the first n_dev entries count
+    perm = rng.permutation(n).astype(np.int32)
+    m = n - 1234
+    ref_live = oracle.hash_bwd_f32(x[perm[:m]], dout[:m], lv)
+    dt2 = torch.zeros(lv.total_entries * 2, device="cuda")
+    ops.hash_bwd_f32_sliced(dev(x), dev(dout), lv, dt2, live_idx=dev(perm), n_dev=torch.tensor([m], device="cuda", dtype=torch.int32))
+    assert support_matches(ref_live, dt2.cpu().numpy())
+    np.testing.assert_allclose(dt2.cpu().numpy(), ref_live, rtol=2e-5, atol=2e-5)
+    # and it agrees with the float-atomic kernel
+    dt3 = torch.zeros(lv.total_entries * 2, device="cuda")
+    ops.hash_bwd_f32(dev(x), dev(dout), lv, dt3)
+    np.testing.assert_allclose(got, dt3.cpu().numpy(), rtol=2e-5, atol=2e-5)
+
+
+def test_hash_bwd_f32_sliced_refuses_unsupported_tables(hip_lib):
+    lv = ops.make_levels(2**21, 4, 32, 128, 4)             # F = 4: not expressible, the C entry point says so (-2)
+    x = torch.rand(100, 3, device="cuda")
+    with pytest.raises(RuntimeError, match="code -2"):
+        ops.hash_bwd_f32_sliced(x, torch.zeros(100, 16, device="cuda"), lv, torch.zeros(lv.total_entries * 4, device="cuda"))
+
+
 def test_hash_f16(oracle, hip_lib):
     lv = ops.make_levels(2**19, 16, 16, 1024, 2)
     rng = np.random.default_rng(2)
