@@ -86,6 +86,9 @@ def parse():
                     help="do not march the next batch on a side stream underneath the current step")
     ap.add_argument("--comm", default="f32", choices=["f32", "bf16"],
                     help="N>1: dtype the gradient bucket travels in (f32 = exact mean, the default; bf16 halves xGMI bytes)")
+    ap.add_argument("--no-shard", dest="shard", action="store_false",
+                    help="N>1: round 1's exchange (ONE all-reduce of the flat gradient bucket + replicated Adam) instead of the default "
+                         "reduce-scatter -> Adam on the own 1/N of the table -> all-gather")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -260,7 +263,8 @@ def main():
         from ngp_hip.trainer import FusedTrainer
         trainer = FusedTrainer(model, lr=1e-2, max_steps=20000, init_scale=2.0**16 if args.half else 2.0**19, world_size=world,
                                exp_step_factor=esf, distortion_loss_w=w_dist,
-                               grad_comm_dtype=torch.bfloat16 if args.comm == "bf16" else torch.float32)
+                               grad_comm_dtype=torch.bfloat16 if args.comm == "bf16" else torch.float32,
+                               shard_optimizer=args.shard if world > 1 else None)
     else:
         opt = torch.optim.Adam(model.parameters(), 1e-2, eps=1e-15, fused=True)
         sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, 20000, 1e-2 / 30)
@@ -519,6 +523,15 @@ def main():
                         ("analytic-scene targets, model conditioned for %d steps, marching its own occupancy grid" % args.condition)
                         if scene else ("random target colours, fixed occupancy=%s (diagnostic state)" % args.regime),
                         rm / total_rays * world, vr / total_rays * world))
+        if world == 1:
+            parallelism = "single GPU"
+        elif use_trainer and args.shard:
+            parallelism = ("ray-sharded dp%d, RCCL reduce-scatter of the %s table gradient -> Adam on the own 1/%d of the table -> all-gather of "
+                           "the updated %s, + one 37.6 KB all-reduce [MLP gradient | inf flag]" % (
+                               world, "f16" if args.half else args.comm, world,
+                               "f16 table copy" if args.half else ("bf16 table copy" if args.table == "bf16" else "f32 table")))
+        else:
+            parallelism = "ray-sharded dp%d, RCCL all-reduce of one flat %s gradient bucket per step" % (world, args.comm)
         out = {
             "metric": "training rays/sec", "value": total_rays / elapsed, "unit": "rays/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -526,7 +539,7 @@ def main():
             "dtype": "f16-table+f16-mlp" if args.half else ("bf16-table(f32 master)+f16-mlp" if args.table == "bf16" else "f32-table+f16-mlp"), "data": "synthetic",
             "config": {"workload": text, "workload_state": workload,
                        "rays_per_gpu": args.rays, "global_batch": args.rays * world,
-                       "parallelism": "ray-sharded dp%d, RCCL all-reduce of %s" % (world, "one flat %s gradient bucket per step" % args.comm) if world > 1 else "single GPU",
+                       "parallelism": parallelism,
                        "path": ("FusedTrainer" + ("+hipGraph" if args.graph else "")) if use_trainer else "modules+torch.optim",
                        "kernel_events_in_timed_region": bool(event_pool) or not use_trainer},
             "samples_per_sec": rm * world / elapsed, "rm_samples_per_ray": rm / total_rays * world, "vr_samples_per_ray": vr / total_rays * world,

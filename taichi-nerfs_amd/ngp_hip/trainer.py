@@ -39,7 +39,7 @@ class FusedTrainer:
     def __init__(self, model, lr=1e-2, betas=(0.9, 0.999), eps=1e-15, max_steps=20000, eta_min=None, init_scale=2.0**19,
                  growth_factor=2.0, backoff_factor=0.5, growth_interval=2000, exp_step_factor=0.0, T_threshold=1e-4,
                  max_samples=1024, process_group=None, world_size=None, grad_comm_dtype=torch.float32,
-                 distortion_loss_w=0.0):
+                 distortion_loss_w=0.0, shard_optimizer=None):
         if not model.use_fused_mlp:
             raise ValueError("FusedTrainer needs the default architecture (L=16, F=2 hash grid, 64-wide MLPs)")
         self.half = bool(model.half_opt)              # half2 encoder (hash_encoder_half.py): f16 table copy, f16 gradient buffer
@@ -74,27 +74,59 @@ class FusedTrainer:
             w.data = flat[off:off + n].view_as(w)
             off += n
         self.mlp_flat = flat
-        self.table = model.pos_encoder.hash_table.data.view(-1)          # [entries * 2] (the half encoder's parameter is 2-D)
         f32 = dict(device=dev, dtype=torch.float32)
-        # ONE flat gradient bucket [hash-table grad | MLP grad | inf flag]: a single all-reduce per step when world > 1
-        nt = self.table.numel()
+        nt = model.pos_encoder.hash_table.numel()
         assert nt % 8 == 0
+        # world > 1, sharded optimizer (the default): the table gradient is reduce-scattered, every rank runs Adam on ITS 1/world
+        # of the table (the dense 45.7 MB pass shrinks by `world`) and the updated parameters are all-gathered -- as the 16-bit
+        # copy the forward reads when there is one (bf16 / half2 encoder: half the bytes on xGMI).  Same bytes on the wire as
+        # one all-reduce (which IS reduce-scatter + all-gather), no replicated optimizer work.  shard_optimizer=False keeps
+        # round 1's single all-reduce of one flat bucket + replicated Adam.
+        # (shard_optimizer=True with world_size 1 runs the same collectives over a 1-rank group: used to exercise them on RCCL)
+        self.shard = bool(self.world > 1 if shard_optimizer is None else shard_optimizer)
+        if self.shard and not dist.is_initialized():
+            raise RuntimeError("the sharded optimizer needs an initialised torch.distributed process group")
+        self.rank = dist.get_rank(process_group) if (self.shard or self.world > 1) and dist.is_initialized() else 0
+        # shards are whole float4 groups of equal size: parameter, gradient and 16-bit copies live in storage padded to a multiple
+        # of 4 * world elements (the parameters become views of it, exactly like the five MLP weights above)
+        unit = 4 * self.world if self.shard else 4
+        self.nt, self.nt_pad = nt, (nt + unit - 1) // unit * unit
+        self.shard_len = self.nt_pad // self.world if self.shard else self.nt_pad
+        hp = model.pos_encoder.hash_table
+        store = torch.zeros(self.nt_pad, **f32)
+        store[:nt].copy_(hp.detach().reshape(-1))
+        hp.data = store[:nt].view_as(hp)
+        self.table_store = store
+        self.table = store[:nt]                                          # [entries * 2] (the half encoder's parameter is 2-D)
+        # gradient bucket(s).  Unsharded: ONE flat bucket [hash-table grad | MLP grad | inf flag] = a single all-reduce per step.
+        # Sharded: [padded table grad] is reduce-scattered, [MLP grad | inf flag] (37.6 KB) is all-reduced.
         if self.half:
             # the half2 encoder accumulates its table gradient in f16 (one packed atomic per corner): separate f16 buffer
-            self.table_grad = torch.zeros(nt, device=dev, dtype=torch.float16)
+            self.table_grad_store = torch.zeros(self.nt_pad, device=dev, dtype=torch.float16)
+            self.table_grad = self.table_grad_store[:nt]
             self.grad_flat = torch.zeros(MLP_N_WEIGHTS + 4, **f32)
             self.mlp_grad = self.grad_flat[:MLP_N_WEIGHTS]
             self._flag_f = self.grad_flat[MLP_N_WEIGHTS:MLP_N_WEIGHTS + 1]
+            self.small_bucket = self.grad_flat
         else:
-            self.grad_flat = torch.zeros(nt + MLP_N_WEIGHTS + 4, **f32)
-            self.table_grad = self.grad_flat[:nt].view_as(self.table)
-            self.mlp_grad = self.grad_flat[nt:nt + MLP_N_WEIGHTS]
-            self._flag_f = self.grad_flat[nt + MLP_N_WEIGHTS:nt + MLP_N_WEIGHTS + 1]
+            self.grad_flat = torch.zeros(self.nt_pad + MLP_N_WEIGHTS + 4, **f32)
+            self.table_grad_store = self.grad_flat[:self.nt_pad]
+            self.table_grad = self.grad_flat[:nt]
+            self.mlp_grad = self.grad_flat[self.nt_pad:self.nt_pad + MLP_N_WEIGHTS]
+            self._flag_f = self.grad_flat[self.nt_pad + MLP_N_WEIGHTS:self.nt_pad + MLP_N_WEIGHTS + 1]
+            self.small_bucket = self.grad_flat[self.nt_pad:]
+        self.shard_grad = (torch.zeros(self.shard_len, device=dev, dtype=self.table_grad_store.dtype) if self.shard else None)
         # optional 16-bit gradient transport: halves the bytes on xGMI; fp32 (exact mean) is the default
         if grad_comm_dtype not in (torch.float32, torch.bfloat16):
             raise ValueError("grad_comm_dtype must be torch.float32 or torch.bfloat16")
-        self._comm = None if grad_comm_dtype == torch.float32 or self.world == 1 else torch.empty_like(self.grad_flat, dtype=grad_comm_dtype)
-        self.table_m, self.table_v = torch.zeros(nt, **f32), torch.zeros(nt, **f32)
+        self._comm = self._comm_shard = None
+        if grad_comm_dtype != torch.float32 and self.world > 1 and not self.half:
+            if self.shard:
+                self._comm = torch.empty(self.nt_pad, device=dev, dtype=grad_comm_dtype)
+                self._comm_shard = torch.empty(self.shard_len, device=dev, dtype=grad_comm_dtype)
+            else:
+                self._comm = torch.empty_like(self.grad_flat, dtype=grad_comm_dtype)
+        self.table_m, self.table_v = torch.zeros(self.nt_pad, **f32), torch.zeros(self.nt_pad, **f32)
         self.mlp_m, self.mlp_v = torch.zeros(MLP_N_WEIGHTS, **f32), torch.zeros(MLP_N_WEIGHTS, **f32)
         self.state_f = torch.zeros(8, **f32)
         self.state_i = torch.zeros(8, device=dev, dtype=torch.int32)
@@ -119,9 +151,17 @@ class FusedTrainer:
         self.enc_pairs = 1 if (lvs.n_levels == 16 and lvs.n_features == 2) else 0
         self.wpack = torch.empty(self.L.ngp_mlp_wpack_halfs(), device=dev, dtype=torch.float16)
         # bf16 storage copy of the table (HashEncoder(table_dtype=torch.bfloat16)): gathered by the forward, refreshed by Adam
-        self.table_bf16 = (model.pos_encoder.table_bf16()
-                           if getattr(model.pos_encoder, "table_dtype", torch.float32) == torch.bfloat16 else None)
-        self.table_f16 = model.pos_encoder.table_f16().view(-1) if self.half else None
+        enc = model.pos_encoder
+        self.table_bf16 = self.table_f16 = self.copy16_store = None
+        if getattr(enc, "table_dtype", torch.float32) == torch.bfloat16:
+            self.copy16_store = torch.zeros(self.nt_pad, device=dev, dtype=torch.bfloat16)
+            enc._bf16, enc._bf16_ver = self.copy16_store[:nt].view(enc.hash_table.shape), None     # the encoder's copy IS this view
+            self.table_bf16 = enc.table_bf16()
+        elif self.half:
+            self.copy16_store = torch.zeros(self.nt_pad, device=dev, dtype=torch.float16)
+            enc._f16, enc._f16_ver = self.copy16_store[:nt].view(enc.hash_table.shape), None
+            self.table_f16 = enc.table_f16().view(-1)
+        self._master_stale = False            # sharded + 16-bit copy: the fp32 master of the other ranks' shards is gathered lazily
         self.repack()
 
     def repack(self):
@@ -184,10 +224,11 @@ class FusedTrainer:
             self._coarse_ver = ver
         return coarse
 
-    def _march(self, M, rays_o, rays_d, cfg, A, coarse=None):
+    def _march(self, M, rays_o, rays_d, cfg, A, coarse=None, noise=None):
         """ray-AABB + count/scan/write into march set M on the CURRENT stream."""
         L, st, n = self.L, _stream(), rays_o.shape[0]
-        noise = torch.rand(n, device=self.dev, dtype=torch.float32)                         # ray_march.py:138
+        if noise is None:
+            noise = torch.rand(n, device=self.dev, dtype=torch.float32)                     # ray_march.py:138
         if coarse is None:
             coarse = self._coarse_bits(cfg, A)
         check(L.ngp_march_train_count_ex(_ptr(rays_o), _ptr(rays_d), _ptr(None), _ptr(cfg.bitfield), _ptr(coarse), _ptr(noise),
@@ -197,19 +238,19 @@ class FusedTrainer:
         check(L.ngp_march_train_write(_ptr(rays_o), _ptr(rays_d), _ptr(M.rays_a), _ptr(M.stage), cfg.max_samples, n,
                                       _ptr(M.xyzs), _ptr(M.dirs), _ptr(M.deltas), _ptr(M.ts), st), "ngp_march_train_write")
 
-    def _launch(self, rays_o, rays_d, target, prefetch=None, src=None, src_next=None):
+    def _launch(self, rays_o, rays_d, target, prefetch=None, src=None, src_next=None, noise=None):
         n = rays_o.shape[0]
         cfg = RenderConfig(self.model, self.exp_step_factor, self.T_threshold, self.max_samples)
         A = TrainArena.get(self.dev, n, self.max_samples)
         sets = self._march_sets(n)
         M = sets[self._cur]
-        hit = M.marched_for(src)
+        hit = noise is None and M.marched_for(src)               # an explicit jitter vector always re-marches
         if M.ready is not None:
             # whatever the side stream did to this set has to be finished before the main stream reads OR rewrites it (a stale
             # prefetch for other rays would otherwise race with the re-march below on M.stage / counts / xyzs)
             torch.cuda.current_stream().wait_event(M.ready)
         if not hit:
-            self._march(M, rays_o, rays_d, cfg, A)
+            self._march(M, rays_o, rays_d, cfg, A, noise=noise)
         M.ready, M.src, M.held = None, None, None
         hook = None
         if prefetch is not None and (prefetch[0].shape != rays_o.shape or prefetch[1].shape != rays_d.shape):
@@ -315,21 +356,42 @@ class FusedTrainer:
             if rc == -2:
                 check(L.ngp_hash_bwd_f32_live(_ptr(M.xyzs), _ptr(A.d_enc), ctypes.byref(cfg.levels), A.cap, _ptr(cnt), _ptr(live_idx), 1,
                                               cfg.lo, cfg.hi, P, _ptr(self.table_grad), found, st), "ngp_hash_bwd_f32_live")
-        if self.world > 1:
-            self._all_reduce()
-        if self.half:       # f16 sums overflow easily: GradScaler's check must see the ACCUMULATED (and reduced) gradient
-            check(L.ngp_check_finite_f16(_ptr(self.table_grad), self.table_grad.numel(), found, st), "ngp_check_finite_f16")
+        sharded = self.shard and not self._grads_only                      # (gradient diagnostics use the plain all-reduce)
+        if sharded:
+            self._exchange_sharded(found, st)
+        else:
+            if self.world > 1:
+                self._all_reduce()
+            if self.half:   # f16 sums overflow easily: GradScaler's check must see the ACCUMULATED (and reduced) gradient
+                check(L.ngp_check_finite_f16(_ptr(self.table_grad), self.table_grad.numel(), found, st), "ngp_check_finite_f16")
         if self._grads_only:
             return {"rm_samples": total, "vr_per_ray": vr_per_ray, "rgb": rgb, "opacity": opacity, "depth": depth, "rays_a": rays_a,
                     "deltas": M.deltas, "ts": M.ts, "sq_err": sq_err}
         check(L.ngp_train_prologue(_ptr(sf), _ptr(si), self.lr0, self.eta_min, self.t_max, self.beta1,
                                    self.beta2, self.growth, self.backoff, self.growth_interval, st), "ngp_train_prologue")
         # Adam on the table (+ its bf16 copy) and on the MLP weights + the fp16 fragment repack the next step needs: one launch
-        copy16, kind = (self.table_f16, 2) if self.half else ((self.table_bf16, 1) if self.table_bf16 is not None else (None, 0))
-        check(L.ngp_adam_all_ex(_ptr(self.table), _ptr(self.table_grad), int(self.half), _ptr(self.table_m), _ptr(self.table_v),
-                                self.table.numel(), _ptr(copy16), kind, _ptr(self.mlp_flat), _ptr(self.mlp_grad), _ptr(self.mlp_m),
-                                _ptr(self.mlp_v), _ptr(sf), _ptr(si), self.beta1, self.beta2, self.eps, P, _ptr(self.wpack), st),
-              "ngp_adam_all_ex")
+        kind = 2 if self.half else (1 if self.table_bf16 is not None else 0)
+        if sharded:
+            # Adam on THIS rank's 1/world of the table (its gradient shard is already the cross-rank average); the MLP block of the
+            # launch runs replicated on the all-reduced MLP gradient; then the updated parameters travel back
+            lo = self.rank * self.shard_len
+            sl = slice(lo, lo + self.shard_len)
+            c16 = self.copy16_store[sl] if self.copy16_store is not None else None
+            check(L.ngp_adam_all_ex(_ptr(self.table_store[sl]), _ptr(self.shard_grad), int(self.half), _ptr(self.table_m[sl]),
+                                    _ptr(self.table_v[sl]), self.shard_len, _ptr(c16), kind, _ptr(self.mlp_flat), _ptr(self.mlp_grad),
+                                    _ptr(self.mlp_m), _ptr(self.mlp_v), _ptr(sf), _ptr(si), self.beta1, self.beta2, self.eps, P,
+                                    _ptr(self.wpack), st), "ngp_adam_all_ex")
+            if self.copy16_store is not None:
+                self._all_gather(self.copy16_store, sl)          # the forward (and the occupancy update) read the 16-bit copy only
+                self._master_stale = True                        # fp32 master of the other ranks' shards: sync_master() on demand
+            else:
+                self._all_gather(self.table_store, sl)
+        else:
+            copy16 = self.copy16_store[:self.nt] if self.copy16_store is not None else None
+            check(L.ngp_adam_all_ex(_ptr(self.table), _ptr(self.table_grad), int(self.half), _ptr(self.table_m), _ptr(self.table_v),
+                                    self.table.numel(), _ptr(copy16), kind, _ptr(self.mlp_flat), _ptr(self.mlp_grad), _ptr(self.mlp_m),
+                                    _ptr(self.mlp_v), _ptr(sf), _ptr(si), self.beta1, self.beta2, self.eps, P, _ptr(self.wpack), st),
+                  "ngp_adam_all_ex")
         return {"rm_samples": total, "vr_per_ray": vr_per_ray, "rgb": rgb, "opacity": opacity, "depth": depth, "rays_a": rays_a,
                 "deltas": M.deltas, "ts": M.ts, "sq_err": sq_err}
 
@@ -361,6 +423,57 @@ class FusedTrainer:
         self._dist_loss = dist_loss
         return None
 
+    # ---- world > 1, sharded optimizer: reduce-scatter -> Adam on the own shard -> all-gather ------------------------------
+    def _nccl(self):
+        return dist.get_backend(self.group) == "nccl"
+
+    def _exchange_sharded(self, found, st):
+        """(1) reduce-scatter of the padded table gradient: this rank receives the cross-rank AVERAGE of shard `rank` (MSE is a
+        mean over the local ray shard); the local accumulator is cleared for the next step.  (2) one small all-reduce of
+        [MLP gradient | inf flag] (37.6 KB): the MLP Adam runs replicated, and every rank has to take the same skip / step
+        decision (the half2 encoder's f16 gradient shard is scanned for inf first: f16 sums overflow)."""
+        src = self.table_grad_store
+        if self._comm is not None:                                 # 16-bit transport of the fp32 gradient (bench.py --comm bf16)
+            self._comm.copy_(src)
+            self._reduce_scatter(self._comm_shard, self._comm)
+            self.shard_grad.copy_(self._comm_shard)
+        else:
+            self._reduce_scatter(self.shard_grad, src)
+        src.zero_()
+        if self.half:
+            check(self.L.ngp_check_finite_f16(_ptr(self.shard_grad), self.shard_grad.numel(), found, st), "ngp_check_finite_f16")
+        flag_i = self.state_i[_SI_FOUND_INF:_SI_FOUND_INF + 1]
+        self._flag_f.copy_(flag_i)
+        if self._nccl():
+            dist.all_reduce(self.small_bucket, op=dist.ReduceOp.AVG, group=self.group)
+        else:
+            dist.all_reduce(self.small_bucket, op=dist.ReduceOp.SUM, group=self.group)
+            self.small_bucket.div_(self.world)
+        flag_i.copy_(self._flag_f != 0)
+        self._flag_f.zero_()
+
+    def _reduce_scatter(self, out, inp):
+        if self._nccl():
+            dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.AVG, group=self.group)
+        else:                                                       # gloo (functional tests): all-reduce + take the own shard
+            dist.all_reduce(inp, op=dist.ReduceOp.SUM, group=self.group)
+            out.copy_(inp[self.rank * out.numel():(self.rank + 1) * out.numel()]).div_(self.world)
+
+    def _all_gather(self, store, sl):
+        if self._nccl():
+            dist.all_gather_into_tensor(store, store[sl], group=self.group)      # in place: shard r already sits at its offset
+        else:
+            mine = store[sl].clone()
+            dist.all_gather([store[r * self.shard_len:(r + 1) * self.shard_len] for r in range(self.world)], mine, group=self.group)
+
+    def sync_master(self):
+        """Sharded optimizer with a 16-bit table copy: only the copy is exchanged every step; gather the fp32 master table of
+        all shards (for a checkpoint / model.state_dict()).  No-op otherwise."""
+        if self.shard and self._master_stale:
+            lo = self.rank * self.shard_len
+            self._all_gather(self.table_store, slice(lo, lo + self.shard_len))
+            self._master_stale = False
+
     def _all_reduce(self):
         """Average the gradients of the ray shards (MSE is a mean over the local shard) and OR the inf flags: ONE
         collective over the flat bucket [table grad | MLP grad | flag] (the flag rides along as a float; any rank's
@@ -374,7 +487,7 @@ class FusedTrainer:
                 dist.all_reduce(self.table_grad, op=dist.ReduceOp.SUM, group=self.group)
                 self.table_grad.div_(self.world)
         buf = self.grad_flat
-        if self._comm is not None:
+        if self._comm is not None and not self.shard:
             buf = self._comm
             buf.copy_(self.grad_flat)                           # loss-scaled gradients: bf16 keeps the fp32 exponent range
         if dist.get_backend(self.group) == "nccl":
@@ -387,7 +500,7 @@ class FusedTrainer:
         flag_i.copy_(self._flag_f != 0)
         self._flag_f.zero_()
 
-    def step(self, rays_o, rays_d, target, prefetch=None):
+    def step(self, rays_o, rays_d, target, prefetch=None, noise=None):
         """rays_o, rays_d, target: [N,3] contiguous float32 device tensors (this rank's shard).  Returns the per-step
         outputs (device tensors; nothing is synchronised).
         prefetch=(next_rays_o, next_rays_d): the NEXT step's rays, if already known and if the occupancy grid will not be
@@ -398,17 +511,17 @@ class FusedTrainer:
             src_next = (prefetch[0], prefetch[1])
             prefetch = (prefetch[0].contiguous().float(), prefetch[1].contiguous().float())
         self.stats = self._launch(rays_o.contiguous().float(), rays_d.contiguous().float(), target.contiguous().float(), prefetch,
-                                  src, src_next)
+                                  src, src_next, noise)
         return self.stats
 
-    def compute_gradients(self, rays_o, rays_d, target):
+    def compute_gradients(self, rays_o, rays_d, target, noise=None):
         """Forward + backward of one batch WITHOUT the optimizer (diagnostics / gradient tests): returns the outputs plus
         clones of the table and MLP gradients divided by the current loss scale; accumulators and the inf flag are cleared."""
         if self._graph is not None:
             raise RuntimeError("not available after capture()")
         self._grads_only = True
         try:
-            out = self._launch(rays_o.contiguous().float(), rays_d.contiguous().float(), target.contiguous().float())
+            out = self._launch(rays_o.contiguous().float(), rays_d.contiguous().float(), target.contiguous().float(), noise=noise)
         finally:
             self._grads_only = False
         inv = 1.0 / self.state_f[_SF_LOSS_SCALE]
@@ -454,6 +567,7 @@ class FusedTrainer:
         """Optimizer-side state the model's own state_dict does not hold: Adam moments, loss scale + growth counter, the
         LR-schedule iteration.  (The reference saves no optimizer state either -- ckpt = model.state_dict(), train.py:285-291 --
         so a resume without this restarts the moments and the cosine schedule; with it the continuation is exact.)"""
+        self.sync_master()
         return {"table_m": self.table_m.clone(), "table_v": self.table_v.clone(), "mlp_m": self.mlp_m.clone(),
                 "mlp_v": self.mlp_v.clone(), "state_f": self.state_f.clone(), "state_i": self.state_i.clone()}
 

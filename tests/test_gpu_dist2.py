@@ -1,0 +1,120 @@
+"""The code path `bench.py --gpus N` runs, with TWO ranks: two processes share GPU 0 over gloo (RCCL refuses two
+ranks on one device), each runs FusedTrainer on its `shard_rays` half of one global batch.  Checked, for the sharded optimizer
+(reduce-scatter -> Adam on the own shard -> all-gather; the default) and for round 1's single all-reduce, f32 and half2
+encoders:
+  * the exchanged gradient bucket == the single-rank full-batch gradient (compute_gradients, rel 1e-5; f16 gradients: 2e-2);
+  * an inf gradient on ONE rank makes BOTH ranks skip the step and back the loss scale off;
+  * after 5 optimisation steps spanning an occupancy-grid update, table, MLP weights, 16-bit table copy and bitfield are
+    bit-identical across the ranks (and they moved)."""
+import os
+import sys
+import traceback
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, kind, shard_opt, bits_np, out_dir):
+    try:
+        for p in (ROOT, os.path.join(ROOT, "taichi-nerfs_amd")):
+            if p not in sys.path:
+                sys.path.insert(0, p)
+        import torch.distributed as dist
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from modules.networks import NGP
+        from ngp_hip import synthetic
+        from ngp_hip.dist import shard_rays
+        from ngp_hip.trainer import FusedTrainer
+        dev = torch.device("cuda", 0)
+        n = 2048
+
+        def make():
+            torch.manual_seed(0)
+            m = NGP(scale=0.5, max_res=1024, half_opt=kind == "half", table_dtype=torch.bfloat16 if kind == "bf16" else None).to(dev)
+            m.density_bitfield.copy_(torch.from_numpy(bits_np).to(dev))
+            with torch.no_grad():
+                m.pos_encoder.hash_table.mul_(0.2 if kind != "half" else 1.0)
+            return m
+        o, d = synthetic.lego_rays(n, seed=9)
+        o, d = torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev)
+        g = torch.Generator().manual_seed(1)
+        target = torch.rand(n, 3, generator=g).to(dev)
+        noise = torch.rand(n, generator=g).to(dev)
+        a, b = shard_rays(n, rank, world)
+        scale0 = 2.0**10 if kind == "half" else 2.0**15
+        tr = FusedTrainer(make(), world_size=world, init_scale=scale0, shard_optimizer=shard_opt)
+        assert tr.shard == bool(shard_opt) and tr.rank == rank
+
+        # (1) exchanged gradients == single-rank full-batch gradients
+        out = tr.compute_gradients(o[a:b], d[a:b], target[a:b], noise=noise[a:b].contiguous())
+        ref = FusedTrainer(make(), world_size=1, init_scale=scale0).compute_gradients(o, d, target, noise=noise)
+        assert int(ref["rm_samples"][0]) > 10000
+
+        def rel(x, y):
+            return float((x - y).norm() / y.norm())
+        tol = 2e-2 if kind == "half" else 1e-5
+        assert rel(out["table_grad"], ref["table_grad"]) < tol, rel(out["table_grad"], ref["table_grad"])
+        assert rel(out["mlp_grad"], ref["mlp_grad"]) < (1e-3 if kind == "half" else 1e-5), rel(out["mlp_grad"], ref["mlp_grad"])
+
+        # (2) inf on rank 1 only -> both ranks skip
+        before = tr.table.clone()
+        bad = target[a:b].clone()
+        if rank == 1:
+            bad[:, 0] = float("inf")                              # (every ray: a single poisoned ray may well march no sample)
+        tr.step(o[a:b], d[a:b], bad, noise=noise[a:b].contiguous())
+        c = tr.counters()
+        assert c["skipped"] == 1 and c["opt_steps"] == 0, c
+        assert tr.loss_scale() == scale0 / 2
+        assert torch.equal(before, tr.table)
+        assert float(tr.table_grad_store.float().abs().max()) == 0.0
+
+        # (3) 5 steps spanning a grid update: replicas stay bit-identical
+        start = tr.table.clone()
+        for i in range(14, 19):
+            if i % 16 == 0:
+                tr.update_density_grid(0.01 * 1024 / 3**0.5, warmup=False)
+            tr.step(o[a:b], d[a:b], target[a:b])                 # rank-local jitter noise, like bench.py
+        tr.sync_master()
+        assert not torch.equal(start, tr.table) and tr.counters()["opt_steps"] == 5
+        items = {"table": tr.table, "mlp": tr.mlp_flat, "bits": tr.model.density_bitfield, "grid": tr.model.density_grid,
+                 "wpack": tr.wpack.view(torch.int16).int(), "state_f": tr.state_f, "state_i": tr.state_i}
+        if tr.copy16_store is not None:
+            items["copy16"] = tr.copy16_store[:tr.nt].view(torch.int16).int()       # (gloo has no 16-bit integer type)
+        for name, t in items.items():
+            mine = t.detach().cpu().contiguous()
+            both = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(both, mine)
+            assert torch.equal(both[0], both[1]), "replicas differ in %s" % name
+        if tr.copy16_store is not None:                           # the 16-bit copy is the cast of the (synced) master
+            want = tr.table.half() if kind == "half" else tr.table.bfloat16()
+            assert torch.equal(want.view(torch.int16), tr.copy16_store[:tr.nt].view(torch.int16))
+        dist.barrier()
+        dist.destroy_process_group()
+        open(os.path.join(out_dir, "ok_%d" % rank), "w").write("ok")
+    except Exception:
+        open(os.path.join(out_dir, "fail_%d" % rank), "w").write(traceback.format_exc())
+        raise
+
+
+@pytest.mark.parametrize("kind,shard_opt", [("f32", True), ("f32", False), ("half", True), ("half", False), ("bf16", True)])
+def test_two_ranks_on_one_gpu(hip_lib, lego_bitfield, tmp_path, kind, shard_opt):
+    import torch.multiprocessing as mp
+    port = 29600 + (os.getpid() + hash((kind, shard_opt))) % 300
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, kind, shard_opt, lego_bitfield, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+    fails = [f for f in os.listdir(tmp_path) if f.startswith("fail_")]
+    msg = "\n".join(open(os.path.join(tmp_path, f)).read() for f in fails)
+    assert not fails, msg
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert sorted(os.listdir(tmp_path)) == ["ok_0", "ok_1"]

@@ -160,6 +160,49 @@ def test_trainer_allreduce_path_on_rccl_world1(hip_lib, lego_bitfield):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("kind", ["f32", "bf16"])
+def test_sharded_optimizer_on_rccl_world1(hip_lib, lego_bitfield, kind):
+    """reduce-scatter -> Adam on the own shard -> all-gather (the N > 1 default) on the real `nccl` backend with a 1-rank group:
+    the shard is the whole table, so three steps must land where the plain single-GPU trainer lands (same kernels; only the
+    float-atomic flush order of the replicated coarse levels differs run to run)."""
+    import os
+    import socket
+    import torch.distributed as dist
+    from modules.networks import NGP
+    from ngp_hip import synthetic
+    from ngp_hip.trainer import FusedTrainer
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        def make():
+            torch.manual_seed(0)
+            m = NGP(scale=0.5, max_res=1024, table_dtype=torch.bfloat16 if kind == "bf16" else None).cuda()
+            m.density_bitfield.copy_(torch.from_numpy(lego_bitfield).cuda())
+            with torch.no_grad():
+                m.pos_encoder.hash_table.mul_(0.2)
+            return m
+        o, d = [torch.from_numpy(a).cuda() for a in synthetic.lego_rays(2048, seed=9)]
+        target = torch.rand(2048, 3, device="cuda")
+        tr_a = FusedTrainer(make(), world_size=1, shard_optimizer=True, init_scale=2.0**15)
+        tr_b = FusedTrainer(make(), world_size=1, init_scale=2.0**15)
+        assert tr_a.shard and not tr_b.shard and tr_a.shard_len == tr_a.nt_pad
+        for i in range(3):
+            noise = torch.rand(2048, device="cuda")
+            tr_a.step(o, d, target, noise=noise); tr_b.step(o, d, target, noise=noise)
+        tr_a.sync_master()
+        torch.cuda.synchronize()
+        assert tr_a.counters() == tr_b.counters() and tr_a.counters()["opt_steps"] == 3
+        assert ((tr_a.table - tr_b.table).norm() / tr_b.table.norm()).item() < 1e-6
+        assert ((tr_a.mlp_flat - tr_b.mlp_flat).norm() / tr_b.mlp_flat.norm()).item() < 1e-6
+        if kind == "bf16":
+            assert torch.equal(tr_a.table.bfloat16().view(torch.int16), tr_a.copy16_store[:tr_a.nt].view(torch.int16))
+        assert float(tr_a.table_grad_store.abs().max()) == 0.0 and float(tr_a.shard_grad.abs().max()) == 0.0
+    finally:
+        dist.destroy_process_group()
+
+
 @pytest.mark.parametrize("bf16", [False, True])
 def test_adam_all_equals_separate_launches(hip_lib, bf16):
     """ngp_adam_all (table pass + MLP Adam + fragment repack in one launch) == ngp_adam_step[_bf16] + ngp_adam_mlp_pack,
