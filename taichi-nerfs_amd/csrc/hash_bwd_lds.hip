@@ -66,6 +66,13 @@ __device__ __forceinline__ uint32_t level_index(bool dense, uint32_t mode, uint3
     return h;
 }
 
+// dense level whose table holds the whole grid (mode 0: size >= res^3, so x + y res + z res^2 < 2 size and `% size` is one
+// conditional subtract): the eight corner indices from one base index, branch-free
+__device__ __forceinline__ uint32_t dense0_index(uint32_t base, uint32_t res, uint32_t res2, uint32_t size, int c) {
+    uint32_t h = base + (uint32_t)(c & 1) + (((c >> 1) & 1) ? res : 0u) + ((c >> 2) ? res2 : 0u);
+    return h >= size ? h - size : h;
+}
+
 // Which slice owns entry h of a level, and where in the owner's LDS image it lives.
 //   hashed levels : contiguous ranges of 8192 entries (slice = h >> 13): the xor hash already spreads space evenly over them, and
 //                   both x corners of a (y, z) combination fall into the same range;
@@ -139,13 +146,20 @@ __global__ void __launch_bounds__(256) hash_bwd_prep_kernel(const float* __restr
             const SliceMap SM = slice_map(size, res, dense);
             const int ns = (int)SM.ns;
             unsigned long long* row = bitmap + ((size_t)level * BW_MAX_SLICES) * wstride + tile;
+            const bool dense0 = dense && mode == 0u;
+            const uint32_t res2 = res * res, base = cx + cy * res + cz * res2;
             if (ns <= 8) {
                 uint32_t m = 0u;
                 if (valid) {
+                    if (dense0) {
 #pragma unroll
-                    for (int c = 0; c < 8; ++c) {
-                        uint32_t loc;
-                        m |= 1u << slice_of(SM, level_index(dense, mode, size, res, cx + (c & 1), cy + ((c >> 1) & 1), cz + (c >> 2)), loc);
+                        for (int c = 0; c < 8; ++c) { uint32_t loc; m |= 1u << slice_of(SM, dense0_index(base, res, res2, size, c), loc); }
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) {
+                            uint32_t loc;
+                            m |= 1u << slice_of(SM, level_index(dense, mode, size, res, cx + (c & 1), cy + ((c >> 1) & 1), cz + (c >> 2)), loc);
+                        }
                     }
                 }
                 for (int s = 0; s < ns; ++s) {
@@ -166,6 +180,16 @@ __global__ void __launch_bounds__(256) hash_bwd_prep_kernel(const float* __restr
                     atomicOr(&words[wave][((b1 ^ c0) & msk) >> BW_SLICE_LOG2], 1ull << lane);
                     atomicOr(&words[wave][((b0 ^ c1) & msk) >> BW_SLICE_LOG2], 1ull << lane);
                     atomicOr(&words[wave][((b1 ^ c1) & msk) >> BW_SLICE_LOG2], 1ull << lane);
+                } else if (dense0) {
+                    // the x pair is adjacent and stays inside one interleaving block except at a block edge: 4 ORs, + the edge cases
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        uint32_t loc;
+                        const uint32_t s0 = slice_of(SM, dense0_index(base, res, res2, size, 2 * k), loc);
+                        const uint32_t s1 = slice_of(SM, dense0_index(base, res, res2, size, 2 * k + 1), loc);
+                        atomicOr(&words[wave][s0], 1ull << lane);
+                        if (s1 != s0) atomicOr(&words[wave][s1], 1ull << lane);
+                    }
                 } else {
 #pragma unroll
                     for (int c = 0; c < 8; ++c) {
@@ -202,19 +226,24 @@ __device__ __forceinline__ Hit load_hit(const int level, const int i, const bool
                                         const float* __restrict__ dout, const size_t plane, const int enc_pairs, const int nl,
                                         int32_t* __restrict__ found_inf, const uint32_t diag = 0u) {
     Hit h = {0.f, 0.f, 0.f, 0.f, 0.f};
+#ifdef NGP_BWD_DIAG
     if (diag & 2u) { const float t = (float)(i & 1023) * (1.0f / 1024.0f); h.x = t; h.y = 1.0f - t; h.z = 0.5f * t; h.g0 = 1.0f; h.g1 = t; return h; }
+#endif
     if (valid) {
         const F3 p = *reinterpret_cast<const F3*>(xyzc + 3 * (size_t)i);                  // one 12-byte gather
         h.x = p.x; h.y = p.y; h.z = p.z;
         const float2 g = *reinterpret_cast<const float2*>(grad_ptr(dout, level, (size_t)i, plane, enc_pairs, nl));
         h.g0 = g.x; h.g1 = g.y;
-        if (found_inf && !(isfinite(h.g0) && isfinite(h.g1))) *found_inf = 1;  // GradScaler's inf/nan check, where the data passes
     }
     return h;
 }
 
 __device__ __forceinline__ void lds_add(double* p, float v) { atomicAdd(p, (double)v); }          // ds_add_f64
+#ifdef NGP_BWD_DIAG          // timing experiments only (profiles/microbench): lets the LDS adds / the gathers be switched off at run time
 #define LDS_ADD(p, v) do { if (!(P.diag & 1u)) lds_add((p), (v)); else asm volatile("" :: "v"(v), "v"(p)); } while (0)
+#else
+#define LDS_ADD(p, v) lds_add((p), (v))
+#endif
 
 // DPP row_shr:D inside each 16-lane row; lanes without a source get `fill`
 template <int D>
@@ -239,7 +268,7 @@ __device__ __forceinline__ void seg_step(float (&v0)[8], float (&v1)[8], int& hf
     }
 }
 
-enum { KIND_GENERIC = 0, KIND_HASHED = 1, KIND_MERGE = 2 };
+enum { KIND_GENERIC = 0, KIND_HASHED = 1, KIND_MERGE = 2, KIND_MERGE0 = 3 };     // MERGE0: run pre-summing on a mode-0 dense level
 
 // One batch of <= 64 hits (one per lane): accumulate this level's contributions that fall into slice `sl`.
 template <int KIND>
@@ -299,7 +328,7 @@ __device__ __forceinline__ void accumulate(const LevelParams P, const uint32_t s
         }
         return;
     }
-    // KIND_MERGE: consecutive hits are consecutive samples of a ray; on a coarse level they sit in the same cell for many steps.
+    // KIND_MERGE / KIND_MERGE0: consecutive hits are consecutive samples of a ray; on a coarse level they sit in the same cell for many steps.
     // Sum each equal-cell run (in f32, fixed lane order) with a segmented scan inside 16-lane rows (DPP row shifts: one VALU
     // instruction per value and step); only a run's last lane touches the LDS.  A run that crosses a row boundary simply
     // becomes two adds.
@@ -317,14 +346,16 @@ __device__ __forceinline__ void accumulate(const LevelParams P, const uint32_t s
     int hf = head;
     seg_step<1>(v0, v1, hf); seg_step<2>(v0, v1, hf); seg_step<4>(v0, v1, hf); seg_step<8>(v0, v1, hf);
     if (tail) {
+        const uint32_t res2 = P.res * P.res, base = cx + cy * P.res + cz * res2;
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             uint32_t loc;
-            const uint32_t h = level_index(P.dense, P.mode, P.size, P.res, cx + (c & 1), cy + ((c >> 1) & 1), cz + (c >> 2));
+            const uint32_t h = KIND == KIND_MERGE0 ? dense0_index(base, P.res, res2, P.size, c)
+                                                   : level_index(P.dense, P.mode, P.size, P.res, cx + (c & 1), cy + ((c >> 1) & 1), cz + (c >> 2));
             if (slice_of(P.map, h, loc) == sl) {
                 double* p = slice + 2 * loc;
-                if (v0[c] != 0.0f) LDS_ADD(p, v0[c]);
-                if (v1[c] != 0.0f) LDS_ADD(p + 1, v1[c]);
+                LDS_ADD(p, v0[c]);
+                LDS_ADD(p + 1, v1[c]);
             }
         }
     }
@@ -348,7 +379,10 @@ __device__ __forceinline__ Batch load_batch(const int level, const int i0, const
 
 template <int KIND>
 __device__ __forceinline__ void accumulate_batch(const LevelParams P, const uint32_t sl, const bool single, const Batch& b,
-                                                 double* __restrict__ slice) {
+                                                 double* __restrict__ slice, int32_t* __restrict__ found_inf) {
+    // GradScaler's inf/nan check, where the data passes -- here, not at the load: testing a value the moment it is requested
+    // would make the wave wait for the gather it has just issued
+    if (found_inf && !(isfinite(b.h0.g0) && isfinite(b.h0.g1) && isfinite(b.h1.g0) && isfinite(b.h1.g1))) *found_inf = 1;
     accumulate<KIND>(P, sl, single, b.h0, b.v0, slice);
     accumulate<KIND>(P, sl, single, b.h1, b.v1, slice);
 }
@@ -375,10 +409,10 @@ __device__ __forceinline__ void bwd_task(const LevelParams P, const int level, c
         for (int w0 = lo_w + 2 * wave; w0 < hi_w; w0 += 2 * BW_WAVES) {
             const int i0 = w0 * 64 + lane, i1 = i0 + 64;
             const Batch nxt = load_batch(level, i0, i0 < n, i1, (w0 + 1 < hi_w) && i1 < n, xyzc, dout, plane, enc_pairs, nl, found_inf, P.diag);
-            accumulate_batch<KIND>(P, sl, true, pend, slice);
+            accumulate_batch<KIND>(P, sl, true, pend, slice, found_inf);
             pend = nxt;
         }
-        accumulate_batch<KIND>(P, sl, true, pend, slice);
+        accumulate_batch<KIND>(P, sl, true, pend, slice, found_inf);
         return;
     }
     int qhead = 0, qlen = 0;
@@ -388,7 +422,7 @@ __device__ __forceinline__ void bwd_task(const LevelParams P, const int level, c
     // hits (dense levels: ~2 of ns slices per sample, replicated over short sample ranges -- a 4096-sample chunk would leave
     // most of the 16 waves idle there, a 256-sample chunk of a 32-slice level would be one exposed load latency per 25 hits).
     int SCW = 64;
-    if (KIND == KIND_MERGE) { SCW = 4; while (SCW < 64 && SCW < 2 * (int)P.map.ns) SCW <<= 1; }
+    if (KIND == KIND_MERGE || KIND == KIND_MERGE0) { SCW = 4; while (SCW < 64 && SCW < 2 * (int)P.map.ns) SCW <<= 1; }
     const int n_sc = (hi_w - lo_w + SCW - 1) / SCW;
     auto load_words = [&](int c) -> unsigned long long {
         const int w = lo_w + c * SCW + lane;
@@ -404,7 +438,7 @@ __device__ __forceinline__ void bwd_task(const LevelParams P, const int level, c
         __builtin_amdgcn_wave_barrier();
         const int i0 = (int)q[(qhead + lane) & (BW_Q - 1)], i1 = (int)q[(qhead + 64 + lane) & (BW_Q - 1)];
         const Batch nxt = load_batch(level, i0, true, i1, true, xyzc, dout, plane, enc_pairs, nl, found_inf, P.diag);
-        accumulate_batch<KIND>(P, sl, false, pend, slice);
+        accumulate_batch<KIND>(P, sl, false, pend, slice, found_inf);
         pend = nxt;
         __builtin_amdgcn_wave_barrier();
         qhead = (qhead + 128) & (BW_Q - 1); qlen -= 128;
@@ -415,7 +449,7 @@ __device__ __forceinline__ void bwd_task(const LevelParams P, const int level, c
         const int sc_next = grab();
         const unsigned long long nxtw = load_words(sc_next);
         const int wbase = lo_w + sc * SCW;
-        if (KIND == KIND_MERGE) {
+        if (KIND == KIND_MERGE || KIND == KIND_MERGE0) {
             // word-serial: hits enter the queue in sample order (the run pre-summing needs consecutive samples in consecutive
             // lanes); these levels have few slices, so most bits are set and a word's ~30 instructions buy ~64 hits
             unsigned long long nonzero = __ballot(cur != 0ull);                // which of the 64 words have any hit
@@ -458,10 +492,10 @@ __device__ __forceinline__ void bwd_task(const LevelParams P, const int level, c
         const bool v0 = lane < qlen, v1 = lane + 64 < qlen;
         const int i0 = v0 ? (int)q[(qhead + lane) & (BW_Q - 1)] : 0, i1 = v1 ? (int)q[(qhead + 64 + lane) & (BW_Q - 1)] : 0;
         const Batch nxt = load_batch(level, i0, v0, i1, v1, xyzc, dout, plane, enc_pairs, nl, found_inf, P.diag);
-        accumulate_batch<KIND>(P, sl, false, pend, slice);
+        accumulate_batch<KIND>(P, sl, false, pend, slice, found_inf);
         pend = nxt;
     }
-    accumulate_batch<KIND>(P, sl, false, pend, slice);
+    accumulate_batch<KIND>(P, sl, false, pend, slice, found_inf);
 }
 
 __global__ void __launch_bounds__(BW_THREADS) hash_bwd_lds_kernel(const float* __restrict__ xyzc,
@@ -502,7 +536,8 @@ __global__ void __launch_bounds__(BW_THREADS) hash_bwd_lds_kernel(const float* _
     if (dbg) t_init = wall_clock64();
     uint32_t* q = queues + (tid >> 6) * BW_Q;
     const unsigned long long* brow = bitmap + ((size_t)level * BW_MAX_SLICES + sl) * wstride;
-    if (merge) bwd_task<KIND_MERGE>(P, level, sl, single, n, rep, nrep, xyzc, brow, dout, plane, enc_pairs, lv.n_levels, slice, q, &next_sc, found_inf);
+    if (merge && P.dense && P.mode == 0u) bwd_task<KIND_MERGE0>(P, level, sl, single, n, rep, nrep, xyzc, brow, dout, plane, enc_pairs, lv.n_levels, slice, q, &next_sc, found_inf);
+    else if (merge) bwd_task<KIND_MERGE>(P, level, sl, single, n, rep, nrep, xyzc, brow, dout, plane, enc_pairs, lv.n_levels, slice, q, &next_sc, found_inf);
     else if (hashed) bwd_task<KIND_HASHED>(P, level, sl, single, n, rep, nrep, xyzc, brow, dout, plane, enc_pairs, lv.n_levels, slice, q, &next_sc, found_inf);
     else bwd_task<KIND_GENERIC>(P, level, sl, single, n, rep, nrep, xyzc, brow, dout, plane, enc_pairs, lv.n_levels, slice, q, &next_sc, found_inf);
     unsigned long long t_wave = 0;

@@ -23,11 +23,13 @@ namespace ngp {
 __device__ __forceinline__ uint32_t f2u_bits(float x) { return __float_as_uint(x); }
 __device__ __forceinline__ float u2f_bits(uint32_t u) { return __uint_as_float(u); }
 
-// f32 -> u32 truncating, saturating cast (v_cvt_u32_f32 semantics; NaN/negative -> 0).
+// f32 -> u32 truncating, saturating cast: NaN / negative -> 0, >= 2^32 -> 0xffffffff.  That is exactly what the hardware's
+// v_cvt_u32_f32 does; issuing it directly keeps the three-way C definition (two compares + branches per coordinate in every
+// hash / march kernel) out of the instruction stream.
 __device__ __forceinline__ uint32_t f2u_sat(float v) {
-    if (!(v > 0.0f)) return 0u;
-    if (v >= 4294967296.0f) return 0xffffffffu;
-    return (uint32_t)v;
+    uint32_t r;
+    asm("v_cvt_u32_f32 %0, %1" : "=v"(r) : "v"(v));
+    return r;
 }
 
 // modules/utils.py:54-57

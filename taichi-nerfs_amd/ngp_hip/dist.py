@@ -1,7 +1,11 @@
-"""Ray-sharded data parallelism: every rank holds a full replica (hash table, MLPs, occupancy grid), renders its own
-shard of the ray batch, and the gradients are averaged with ONE large + one small RCCL all-reduce per step
-(torch.distributed backend "nccl" == RCCL over xGMI on ROCm).  The reference has no multi-GPU path at all
-(SURVEY.md section 8e); this is the only exchange step the hot path needs."""
+"""Ray-sharded data parallelism: every rank holds a full replica (hash table, MLPs, occupancy grid) and renders its own
+shard of the ray batch (torch.distributed backend "nccl" == RCCL over xGMI on ROCm).  The reference has no multi-GPU path at
+all; the gradient exchange is the only exchange step the hot path needs.  Two forms:
+  * FusedTrainer (what bench.py --gpus N runs), default: reduce-scatter of the table gradient -> Adam on the own 1/N of the
+    table -> all-gather of the updated parameters (`reduce_scatter_avg`, `all_gather_shards` below), plus one 37.6 KB all-reduce
+    of [MLP gradient | inf flag]; `shard_optimizer=False`: ONE all-reduce of one flat bucket [table | MLP | flag];
+  * GradReducer (the reference's loop shape: modules/ + torch.optim): the table gradient all-reduced in place + one small
+    flattened bucket for the 9 408 MLP weights."""
 import torch
 import torch.distributed as dist
 
@@ -56,6 +60,27 @@ class GradReducer:
                 n = p.numel()
                 p.grad.copy_(flat[off:off + n].view_as(p.grad))
                 off += n
+
+
+def reduce_scatter_avg(out, inp, rank, world, group=None):
+    """out <- average over ranks of shard `rank` of inp (inp = world equal shards).  RCCL: one reduce_scatter_tensor(AVG).
+    Other backends (gloo: functional tests; it has no AVG and no CUDA reduce-scatter): all-reduce(SUM) + own shard / world."""
+    if dist.get_backend(group) == "nccl":
+        dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.AVG, group=group)
+    else:
+        dist.all_reduce(inp, op=dist.ReduceOp.SUM, group=group)
+        out.copy_(inp[rank * out.numel():(rank + 1) * out.numel()]).div_(world)
+    return out
+
+
+def all_gather_shards(store, rank, shard_len, world, group=None):
+    """Every rank holds the valid shard [rank * shard_len, (rank + 1) * shard_len) of `store`: fill in everybody else's."""
+    mine = store[rank * shard_len:(rank + 1) * shard_len]
+    if dist.get_backend(group) == "nccl":
+        dist.all_gather_into_tensor(store, mine, group=group)        # in place: the own shard already sits at its offset
+    else:
+        dist.all_gather([store[r * shard_len:(r + 1) * shard_len] for r in range(world)], mine.clone(), group=group)
+    return store
 
 
 def broadcast_occupancy(model, src=0, group=None):

@@ -453,18 +453,12 @@ class FusedTrainer:
         self._flag_f.zero_()
 
     def _reduce_scatter(self, out, inp):
-        if self._nccl():
-            dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.AVG, group=self.group)
-        else:                                                       # gloo (functional tests): all-reduce + take the own shard
-            dist.all_reduce(inp, op=dist.ReduceOp.SUM, group=self.group)
-            out.copy_(inp[self.rank * out.numel():(self.rank + 1) * out.numel()]).div_(self.world)
+        from .dist import reduce_scatter_avg
+        reduce_scatter_avg(out, inp, self.rank, self.world, self.group)
 
     def _all_gather(self, store, sl):
-        if self._nccl():
-            dist.all_gather_into_tensor(store, store[sl], group=self.group)      # in place: shard r already sits at its offset
-        else:
-            mine = store[sl].clone()
-            dist.all_gather([store[r * self.shard_len:(r + 1) * self.shard_len] for r in range(self.world)], mine, group=self.group)
+        from .dist import all_gather_shards
+        all_gather_shards(store, self.rank, self.shard_len, self.world, self.group)
 
     def sync_master(self):
         """Sharded optimizer with a 16-bit table copy: only the copy is exchanged every step; gather the fp32 master table of

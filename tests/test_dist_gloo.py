@@ -72,3 +72,38 @@ def test_shard_rays_covers_batch():
         assert spans[0][0] == 0 and spans[-1][1] == n
         assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
         assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
+
+
+def _sharded_worker(rank, world, port, out_path):
+    import os
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ngp_hip.dist import all_gather_shards, reduce_scatter_avg
+    n, lr = 4096, 0.1
+    g = torch.Generator().manual_seed(0)
+    table = torch.randn(n, generator=g)                       # replicated parameters
+    grads = torch.randn(world, n, generator=g)                # rank r's local gradient = grads[r]
+    sh = n // world
+    shard_grad = torch.empty(sh)
+    reduce_scatter_avg(shard_grad, grads[rank].clone(), rank, world)
+    table[rank * sh:(rank + 1) * sh] -= lr * shard_grad       # the optimizer touches the own shard only
+    all_gather_shards(table, rank, sh, world)
+    want = torch.randn(n, generator=torch.Generator().manual_seed(0)) - lr * grads.mean(0)
+    ok = torch.allclose(table, want, atol=1e-6)
+    both = [torch.empty_like(table) for _ in range(world)]
+    dist.all_gather(both, table)
+    ok = ok and all(torch.equal(both[0], b) for b in both)
+    dist.destroy_process_group()
+    open(out_path + ".%d" % rank, "w").write("ok" if ok else "mismatch")
+
+
+def test_two_rank_sharded_exchange_equals_replicated_update(tmp_path):
+    """reduce-scatter(avg) -> update of the own shard -> all-gather (FusedTrainer's N > 1 exchange, ngp_hip/dist.py) leaves
+    every rank with exactly the parameters a replicated update on the averaged gradient gives (2 ranks, gloo, CPU)."""
+    import torch.multiprocessing as mp
+    port = 29500 + os.getpid() % 400
+    out = str(tmp_path / "res")
+    mp.spawn(_sharded_worker, args=(2, port, out), nprocs=2, join=True)
+    assert open(out + ".0").read() == "ok" and open(out + ".1").read() == "ok"
