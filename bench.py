@@ -45,6 +45,8 @@ TRAINER_KERNELS = {
     "ngp_mlp_bwd_live": ("mlp_bwd", "mfma", 37632, "live"),                        # backward kernels run on the live-sample list
     "ngp_hash_bwd_f32_live": ("hash_bwd_f32", "hbm", 12 + 128 + 1024 + 1024, "live"),
     "ngp_hash_bwd_f32_sliced": ("hash_bwd_f32", "hbm", 12 + 128 + 1024 + 1024, "live"),   # LDS-sliced form (prep + main launch)
+    "ngp_hash_bwd_sliced_main": ("hash_bwd_f32", "hbm", 12 + 128 + 1024 + 1024, "live"),  # ... its main launch (what the trainer issues)
+    "ngp_hash_bwd_sliced_prep": ("hash_bwd_prep", "hbm", 12 + 12 + 16 * 8, "live"),        # ... its prepass, on a side stream under the MLP backward
     "ngp_hash_bwd_f16_live": ("hash_bwd_f16", "hbm", 12 + 128 + 512 + 512, "live"),
     "ngp_adam_step": ("adam", "hbm", 32, "param"),
     "ngp_adam_all": ("adam", "hbm", 32, "param"),                                  # table pass (+ the MLP block riding along)
@@ -432,8 +434,11 @@ def main():
             live_avg = (float(live_log[:n_st].sum(dtype=torch.int64)) / max(n_st, 1)) if trainer.live_backward else marched
             # the dense Adam pass skips float4 groups that never received a gradient (g = m = v = 0: exact fixed points) after
             # reading g, m, v; everything else reads p too and writes p, m, v and the zeroed g.  Bytes it really moves:
-            n4 = trainer.table.numel() // 4
-            touched4 = int(((trainer.table_m.view(-1, 4) != 0) | (trainer.table_v.view(-1, 4) != 0)).any(1).sum())
+            # (sharded optimizer: this rank's pass covers its 1/N of the table only)
+            lo_ = trainer.rank * trainer.shard_len if trainer.shard else 0
+            hi_ = lo_ + trainer.shard_len if trainer.shard else trainer.nt_pad
+            n4 = (hi_ - lo_) // 4
+            touched4 = int(((trainer.table_m[lo_:hi_].view(-1, 4) != 0) | (trainer.table_v[lo_:hi_].view(-1, 4) != 0)).any(1).sum())
             adam_bytes = 48.0 * n4 + 80.0 * touched4 + (8.0 * touched4 if (args.half or args.table == "bf16") else 0.0)
             agg = {}                                           # key -> [launches, total_ms, total_work, bound, per_unit, unit, units]
             for name, evs in c_events.items():
@@ -498,7 +503,8 @@ def main():
                         r["traffic_source"] = traffic_src
         # dominant kernel = largest total time on the step's critical path; with --prefetch the march of the next batch
         # runs on a side stream underneath the other kernels (15 of 16 steps), so it is reported but not eligible
-        eligible = [k for k in rooflines if not (k == "march_count" and use_trainer and args.prefetch and not args.graph)]
+        eligible = [k for k in rooflines if not (k == "march_count" and use_trainer and args.prefetch and not args.graph)
+                    and k != "hash_bwd_prep"]                        # (the prepass runs on a side stream underneath the MLP backward)
         dom = max(eligible, key=lambda k: ks[k]["total_ms"], default=None)
         roof = rooflines.get(dom)
         workload = {"regime": args.regime, "rm_samples_per_ray": rm / total_rays * world, "vr_samples_per_ray": vr / total_rays * world,

@@ -192,6 +192,14 @@ int ngp_hash_bwd_f16_live(const float* xyzs, const float* dout, const ngp_hash_l
  * per (level, sample)).  Returns -2 when the level table does not fit the formulation (F != 2, a level of more than
  * 32 slices = 2^19 entries): the caller then uses ngp_hash_bwd_f32_live. */
 long long ngp_hash_bwd_sliced_workspace(const ngp_hash_levels* lv, int n_max);
+/* The two halves as separate launches: the prepass (compact positions + hit bitmaps) needs only positions and live list and
+ * can run on another stream underneath the MLP backward that produces `dout`; `main` consumes the workspace it filled. */
+int ngp_hash_bwd_sliced_prep(const float* xyzs, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev,
+                             const int32_t* live_idx, int normalize, float lo, float hi, void* workspace,
+                             long long workspace_bytes, void* stream);
+int ngp_hash_bwd_sliced_main(const float* dout, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev, int enc_pairs,
+                             float* dtable, int32_t* found_inf, const void* workspace, long long workspace_bytes,
+                             void* stream);
 /* diagnostics: per-block task word + wall-clock stamps into a device buffer of 8 * 1024 uint64 (NULL = off, the default) */
 int ngp_hash_bwd_sliced_debug(void* device_buffer);
 int ngp_hash_bwd_f32_sliced(const float* xyzs, const float* dout, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev,

@@ -99,6 +99,12 @@ def main():
                 lvl, m.sum(), (r[:, 1].min() - t0) / 100.0, (r[:, 1].max() - t0) / 100.0, np.mean(r[:, 2] - r[:, 1]) / 100.0,
                 np.mean(r[:, 4] - r[:, 2]) / 100.0, np.mean(r[:, 3] - r[:, 2]) / 100.0, np.mean(r[:, 5] - r[:, 4]) / 100.0,
                 (r[:, 5].max() - t0) / 100.0, sorted(set(r[:, 6].tolist()))))
+    for x in range(8):
+        r = d[d[:, 6] == x]
+        if len(r):
+            print("  xcc %d: %3d tasks, busy %7.1f CU-us (%.1f us if spread over 32 CUs), first start %5.1f, last end %6.1f" % (
+                x, len(r), (r[:, 5] - r[:, 1]).sum() / 100.0, (r[:, 5] - r[:, 1]).sum() / 100.0 / 32, (r[:, 1].min() - t0) / 100.0,
+                (r[:, 5].max() - t0) / 100.0))
     if os.environ.get("NGP_VARIANTS_ONLY_TIMELINE"):
         return
     # where the time goes: the same launch with pieces switched off (results are wrong with these flags: timing only)

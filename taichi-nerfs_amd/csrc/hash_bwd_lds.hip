@@ -615,11 +615,14 @@ static bool build_plan(const ngp_hash_levels& lv, BwdPlan& plan, uint32_t& singl
     float load[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     auto encode = [](int level, int slice, int rep) { return (uint16_t)(level | (slice << 4) | (rep << 10)); };
     auto least = [&]() { int b = 0; for (int x = 1; x < 8; ++x) if (load[x] < load[b]) b = x; return b; };
-    // measured task durations relative to a hashed level's slice owner (profiles/r02_hash_bwd_timeline.txt), per replica count
+    // task duration model fitted to the measured timelines (profiles/r02_hash_bwd_timeline.txt; microseconds at 400 k live samples):
+    // 3 + 2.7 per 1000 hits on the run-merging path, 3 + 1.9 per 1000 hits on the hashed path; a sample hits 4 of a hashed
+    // level's 64 slices, ~1.5 of a contiguous dense level's slices (z and z + 1 planes), ~2.7 of an interleaved one's
     auto cost = [&](const Lvl& L) {
-        if (L.level >= lv.begin_fast_hash_level) return 1.0f;
-        const float per_slice = L.n_slices == 1 ? 24.0f : (L.n_slices >= 8 ? 70.0f / L.n_slices * 2.0f : 36.0f);   // whole-level work / slices
-        return per_slice / (float)L.nrep + 0.1f;
+        const float S = 400.0f;                                 // thousands of samples
+        if (L.level >= lv.begin_fast_hash_level) return 3.0f + 1.9f * S * 4.0f / (float)L.n_slices / (float)L.nrep;
+        const float frac = L.n_slices == 1 ? 1.0f : (L.n_slices < 8 ? 1.5f : 2.7f) / (float)L.n_slices;
+        return 3.0f + 2.7f * S * frac / (float)L.nrep;
     };
     int order[NGP_MAX_LEVELS];
     for (int l = 0; l < lv.n_levels; ++l) order[l] = l;
@@ -677,29 +680,51 @@ long long ngp_hash_bwd_sliced_workspace(const ngp_hash_levels* lv, int n_max) {
     return (long long)(ms * 3 * sizeof(float) + (size_t)lv->n_levels * BW_MAX_SLICES * (ms / 64) * sizeof(unsigned long long));
 }
 
-int ngp_hash_bwd_f32_sliced(const float* xyzs, const float* dout, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev,
-                            const int32_t* live_idx, int normalize, float lo, float hi, int enc_pairs, float* dtable,
-                            int32_t* found_inf, void* workspace, long long workspace_bytes, void* stream) {
+// The two halves of ngp_hash_bwd_f32_sliced as separate entry points: the prepass only needs the positions and the live list,
+// so a caller can run it on a second stream underneath the MLP backward that produces `dout` (FusedTrainer does).
+int ngp_hash_bwd_sliced_prep(const float* xyzs, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev, const int32_t* live_idx,
+                             int normalize, float lo, float hi, void* workspace, long long workspace_bytes, void* stream) {
+    if (n_max <= 0) return 0;
+    if (!workspace || workspace_bytes < ngp_hash_bwd_sliced_workspace(lv, n_max)) return -1;
+    static thread_local BwdPlan plan;
+    uint32_t single_mask;
+    if (!build_plan(*lv, plan, single_mask)) return -2;
+    const size_t ms = ((size_t)n_max + 511) & ~(size_t)511;
+    float* xyzc = reinterpret_cast<float*>(workspace);
+    unsigned long long* bitmap = reinterpret_cast<unsigned long long*>(xyzc + ms * 3);
+    const XyzNorm nm = {normalize, lo, hi};
+    hipLaunchKernelGGL(hash_bwd_prep_kernel, dim3(BW_PREP_BLOCKS), dim3(256), 0, (hipStream_t)stream, xyzs, live_idx, *lv, n_max, n_dev, nm,
+                       ms / 64, single_mask, xyzc, bitmap);
+    NGP_LAUNCH_CHECK();
+    return 0;
+}
+
+int ngp_hash_bwd_sliced_main(const float* dout, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev, int enc_pairs, float* dtable,
+                             int32_t* found_inf, const void* workspace, long long workspace_bytes, void* stream) {
     if (n_max <= 0) return 0;
     if (enc_pairs && !(lv->n_features == 2 && lv->n_levels == 16)) return -1;
     if (!workspace || workspace_bytes < ngp_hash_bwd_sliced_workspace(lv, n_max)) return -1;
     static thread_local BwdPlan plan;
     uint32_t single_mask;
-    if (!build_plan(*lv, plan, single_mask)) return -2;               // not expressible: the caller falls back to the atomic kernel
+    if (!build_plan(*lv, plan, single_mask)) return -2;
     if (plan.n_blocks <= 0) return 0;
     const size_t ms = ((size_t)n_max + 511) & ~(size_t)511;
-    float* xyzc = reinterpret_cast<float*>(workspace);
-    unsigned long long* bitmap = reinterpret_cast<unsigned long long*>(xyzc + ms * 3);
-    hipStream_t s = (hipStream_t)stream;
-    const XyzNorm nm = {normalize, lo, hi};
-    hipLaunchKernelGGL(hash_bwd_prep_kernel, dim3(BW_PREP_BLOCKS), dim3(256), 0, s, xyzs, live_idx, *lv, n_max, n_dev, nm, ms / 64,
-                       single_mask, xyzc, bitmap);
-    NGP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(hash_bwd_lds_kernel, dim3(plan.n_blocks), dim3(BW_THREADS), 0, s, (const float*)xyzc,
-                       (const unsigned long long*)bitmap, ms / 64, dout, *lv, n_max, n_dev, enc_pairs, plan, dtable,
-                       found_inf, g_bwd_debug);
+    const float* xyzc = reinterpret_cast<const float*>(workspace);
+    const unsigned long long* bitmap = reinterpret_cast<const unsigned long long*>(xyzc + ms * 3);
+    hipLaunchKernelGGL(hash_bwd_lds_kernel, dim3(plan.n_blocks), dim3(BW_THREADS), 0, (hipStream_t)stream, xyzc, bitmap, ms / 64, dout, *lv,
+                       n_max, n_dev, enc_pairs, plan, dtable, found_inf, g_bwd_debug);
     NGP_LAUNCH_CHECK();
     return 0;
+}
+
+int ngp_hash_bwd_f32_sliced(const float* xyzs, const float* dout, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev,
+                            const int32_t* live_idx, int normalize, float lo, float hi, int enc_pairs, float* dtable,
+                            int32_t* found_inf, void* workspace, long long workspace_bytes, void* stream) {
+    if (n_max <= 0) return 0;
+    if (enc_pairs && !(lv->n_features == 2 && lv->n_levels == 16)) return -1;
+    const int rc = ngp_hash_bwd_sliced_prep(xyzs, lv, n_max, n_dev, live_idx, normalize, lo, hi, workspace, workspace_bytes, stream);
+    if (rc != 0) return rc;                                           // -2: not expressible, the caller falls back to the atomic kernel
+    return ngp_hash_bwd_sliced_main(dout, lv, n_max, n_dev, enc_pairs, dtable, found_inf, workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"
