@@ -108,7 +108,7 @@ def main():
     if os.environ.get("NGP_VARIANTS_ONLY_TIMELINE"):
         return
     # where the time goes: the same launch with pieces switched off (results are wrong with these flags: timing only)
-    for diag, what in ((0, "full"), (1, "no LDS adds"), (2, "no gathers"), (3, "neither")):
+    for diag, what in ((0, "full"), (1, "no LDS adds"), (2, "no gathers"), (3, "no adds, no gathers"), (4, "no accumulate"), (6, "no accumulate, no gathers")):
         os.environ["NGP_BWD_DIAG"] = str(diag)
         med, best = timeit(sliced, 5)
         print("sliced, %-12s: median %.1f us" % (what, med))

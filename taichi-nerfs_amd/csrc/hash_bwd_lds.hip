@@ -53,6 +53,7 @@ constexpr uint16_t BW_NULL_TASK = 0xffffu;
 struct BwdPlan {
     int32_t n_blocks;
     uint32_t merge_mask;                  // bit l: pre-sum equal-cell runs on level l
+    uint32_t diag;                        // timing experiments (-DNGP_BWD_DIAG builds): 1 no LDS adds, 2 no gathers, 4 no accumulate
     uint8_t nrep[NGP_MAX_LEVELS];         // replicas (sample ranges) per slice of level l
     uint16_t task[BW_MAX_TASKS];          // level | slice << 4 | rep << 10, or BW_NULL_TASK
 };
@@ -383,6 +384,9 @@ __device__ __forceinline__ void accumulate_batch(const LevelParams P, const uint
     // GradScaler's inf/nan check, where the data passes -- here, not at the load: testing a value the moment it is requested
     // would make the wave wait for the gather it has just issued
     if (found_inf && !(isfinite(b.h0.g0) && isfinite(b.h0.g1) && isfinite(b.h1.g0) && isfinite(b.h1.g1))) *found_inf = 1;
+#ifdef NGP_BWD_DIAG
+    if (P.diag & 4u) { asm volatile("" :: "v"(b.h0.x), "v"(b.h0.g0), "v"(b.h1.x), "v"(b.h1.g0)); return; }
+#endif
     accumulate<KIND>(P, sl, single, b.h0, b.v0, slice);
     accumulate<KIND>(P, sl, single, b.h1, b.v1, slice);
 }
@@ -466,10 +470,12 @@ __device__ __forceinline__ void bwd_task(const LevelParams P, const int level, c
             }
         } else {
             // lane-parallel: lane l owns word l (64 samples); every round each lane with bits left emits its lowest one, the
-            // emitting lanes are compacted into the queue with one ballot.  Rounds = the largest popcount among the words
-            // (~10 at the 6 % hit density of a hashed level's slice) instead of one serial step per word.  (Unpacking a whole
-            // word per lane behind a prefix sum was tried: the equal-cell runs of the coarser hashed levels then sit in ONE add
-            // instruction and serialise in the LDS -- 333 -> 397 us.)
+            // emitting lanes are compacted into the queue with one ballot.  Rounds = the largest popcount among the words (24 on
+            // average: hits come in runs of consecutive samples), ~350 clocks each (a VALU -> SALU -> branch round trip with
+            // four waves per SIMD).  Two cheaper scans were built and measured (profiles/r02_hash_bwd_timeline.txt): unpacking a
+            // whole word per lane behind a prefix sum, and TRANSPOSED bitmap words (a run spread over 64 lanes: a third of the
+            // rounds, scan -40 us).  Both put the equal-cell runs of the coarser hashed levels into ONE add instruction, where
+            // they serialise in the LDS (+30 us) and the gathers lose their spread (+24 us): no net gain, not shipped.
             unsigned long long w = cur;
             unsigned long long live = __ballot(w != 0ull);
             while (live) {
@@ -523,9 +529,9 @@ __global__ void __launch_bounds__(BW_THREADS) hash_bwd_lds_kernel(const float* _
     if (P.dense) { const uint64_t r = P.res; P.mode = ((uint64_t)P.size >= r * r * r && r >= 2) ? 0u : 2u; }
     else P.mode = (P.size != 0 && (P.size & (P.size - 1)) == 0) ? 1u : 2u;
     P.map = slice_map(P.size, P.res, P.dense);
-    P.diag = plan.merge_mask >> 30;
+    P.diag = plan.diag;
     const bool single = P.size <= (uint32_t)BW_SLICE_ENTRIES;           // one slice: every sample is a hit, no bitmap
-    const bool merge = (plan.merge_mask >> level) & 1u;          // (levels <= 15: bits 30-31 carry the diagnostics flags)
+    const bool merge = (plan.merge_mask >> level) & 1u;
     const bool hashed = !P.dense && P.mode == 1u && P.res < (1u << BW_SLICE_LOG2) && !single;
 
     double2* s2 = reinterpret_cast<double2*>(slice);
@@ -604,7 +610,8 @@ static bool build_plan(const ngp_hash_levels& lv, BwdPlan& plan, uint32_t& singl
         if ((int)lv.resolution[l] <= merge_res && l < lv.begin_fast_hash_level) plan.merge_mask |= 1u << l;    // dense coarse levels
     }
     for (int l = lv.n_levels; l < NGP_MAX_LEVELS; ++l) plan.nrep[l] = 1;
-    if (const char* e = getenv("NGP_BWD_DIAG")) plan.merge_mask |= ((uint32_t)atoi(e) & 3u) << 30;     // timing experiments only: wrong results
+    plan.diag = 0u;
+    if (const char* e = getenv("NGP_BWD_DIAG")) plan.diag = (uint32_t)atoi(e);     // timing experiments only (needs -DNGP_BWD_DIAG): wrong results
     // XCD-aware order (block b runs on XCD b % 8, one 1024-thread block per CU): the owners of one level read the same
     // position / gradient lines, and they only find them in L2 if they run on the same XCD at about the same time (measured:
     // a hashed level's owners take 52 us when the level has an XCD to itself, 115 us when its 64 owners are spread over all

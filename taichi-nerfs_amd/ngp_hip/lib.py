@@ -56,7 +56,8 @@ def build(force=False, verbose=False):
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build libngp_hip.so")
     tmp = LIB_PATH + ".tmp.%d" % os.getpid()
-    cmd = [hipcc] + HIPCC_FLAGS + ["-o", tmp] + _sources()
+    extra = os.environ.get("NGP_HIPCC_EXTRA", "").split()             # e.g. -DNGP_BWD_DIAG for the timing experiments in profiles/microbench
+    cmd = [hipcc] + HIPCC_FLAGS + extra + ["-o", tmp] + _sources()
     if verbose:
         print(" ".join(cmd))
     res = subprocess.run(cmd, capture_output=True, text=True)
