@@ -592,6 +592,8 @@ static bool build_plan(const ngp_hash_levels& lv, BwdPlan& plan, uint32_t& singl
     if (const char* e = getenv("NGP_BWD_REP_TARGET")) rep_target = atoi(e) > 0 ? atoi(e) : rep_target;
     int merge_res = 128;                  // pre-sum equal-cell runs on levels up to this resolution
     if (const char* e = getenv("NGP_BWD_MERGE_RES")) merge_res = atoi(e);
+    int dense_min_rep = 4;
+    if (const char* e = getenv("NGP_BWD_DENSE_MIN_REP")) dense_min_rep = atoi(e) > 0 ? atoi(e) : dense_min_rep;
     uint32_t level_mask = 0xffffffffu;    // diagnostics (profiles/microbench/hash_bwd_variants.py): only these levels' tasks
     if (const char* e = getenv("NGP_BWD_LEVELS")) level_mask = (uint32_t)strtoul(e, nullptr, 0);
     for (int l = 0; l < lv.n_levels; ++l) {
@@ -602,6 +604,11 @@ static bool build_plan(const ngp_hash_levels& lv, BwdPlan& plan, uint32_t& singl
         // dense level, and the scene concentrates in a part of the z range): replicate it over sample ranges so that one task
         // handles no more hits than a hashed level's slice owner (S/16: 4 of 64 slices per sample)
         int nrep = ns >= BW_MAX_SLICES ? 1 : (rep_target + ns / 2) / ns;
+        // a dense level's slice load follows the SCENE (an unbounded scene whose content sits in a fraction of the box puts
+        // every sample into one or two slices of a 44-slice level: measured 637 us at C3): never fewer than `dense_min_rep`
+        // sample ranges per dense slice, so the worst slice is bounded by S / dense_min_rep hits; the owners of the empty
+        // slices cost ~3 us each
+        if (l < lv.begin_fast_hash_level && ns > 1 && nrep < dense_min_rep) nrep = dense_min_rep;
         if (nrep < 1) nrep = 1;
         if (nrep > 63) nrep = 63;
         lvls[l] = {l, ns, nrep, ((level_mask >> l) & 1u) ? ns * nrep : 0};
