@@ -15,6 +15,7 @@ Usage: python bench.py --gpus N --steps K --warmup W   (N>1 via torch.distribute
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -74,6 +75,7 @@ def parse():
     ap.add_argument("--condition", type=int, default=1024,
                     help="--regime scene: untimed, seeded optimisation steps on the scene before the warm-up (multiple of 16)")
     ap.add_argument("--pool", type=int, default=32, help="--regime scene: resident batches the steps cycle through")
+    ap.add_argument("--step-trace", default=None, help="diagnostic: write per-step host/device times of the timed region to FILE")
     ap.add_argument("--no-kernel-events", dest="kernel_events", action="store_false",
                     help="no per-kernel HIP events inside the timed region (A/B for the event overhead)")
     ap.add_argument("--half", action="store_true", help="half2 hash encoder (BASELINE C5)")
@@ -385,19 +387,58 @@ def main():
         fence()
         t_cond = time.perf_counter() - t0
         base = args.condition
+    state["k"] = 0
     for i in range(base, base + args.warmup):
-        step(i, prefetch=args.prefetch, log=False)
+        # warm-up steps are the timed steps, sample-count logging included: the first torch reduction of a process loads its
+        # code object (13-55 ms, host blocked), and since the grid update stopped using torch's scans that first call was the
+        # log of the first timed step
+        step(i, prefetch=args.prefetch, log=True)
     if use_trainer and args.graph and world == 1:
         trainer.capture(args.rays)
     state["rm"] = 0; state["vr"] = 0; state["k"] = 0
     timer.enabled = True
     fence()
+    trace = [] if args.step_trace else None
+    if trace is not None:
+        import cProfile, pstats, io                            # (first timed step is profiled on the host: stalls show up there)
+    gc_log = []
+    if trace is not None:
+        def _gc_cb(phase, info, _s=[0.0]):
+            if phase == "start":
+                _s[0] = time.perf_counter()
+            else:
+                gc_log.append((info["generation"], (time.perf_counter() - _s[0]) * 1e3, len(trace)))
+        gc.callbacks.append(_gc_cb)
+    if not os.environ.get("NGP_BENCH_KEEP_GC"):
+        # a generation-2 pass of the cyclic collector over the process's long-lived objects takes 36 ms here (measured with
+        # --step-trace: the collect() below), 55 steps' worth; where the next one lands depends on the allocation count so far.
+        # Collect now and freeze the survivors so a 20-step timed region cannot contain one (young passes: 0.02-0.6 ms).
+        gc.collect()
+        gc.freeze()
     t0 = time.perf_counter()
     for i in range(base + args.warmup, base + args.warmup + args.steps):
+        if trace is not None:                                   # (diagnostic: one event + one host stamp per step)
+            ev = torch.cuda.Event(enable_timing=True); ev.record(); trace.append((i, time.perf_counter(), ev))
+        if trace is not None and len(trace) == 1 and rank == 0:
+            pr = cProfile.Profile(); pr.enable()
+            step(i, prefetch=args.prefetch)
+            pr.disable()
+            buf = io.StringIO(); pstats.Stats(pr, stream=buf).sort_stats("tottime").print_stats(12)
+            open(args.step_trace + ".first_step_profile.txt", "w").write(buf.getvalue())
+            continue
         step(i, prefetch=args.prefetch)
+    if trace is not None:
+        ev = torch.cuda.Event(enable_timing=True); ev.record(); trace.append((-1, time.perf_counter(), ev))
     fence()
     elapsed = time.perf_counter() - t0
     timer.enabled = False
+    if trace is not None and rank == 0:
+        with open(args.step_trace, "w") as f:
+            f.write("# step  step%16  host_ms(launch loop)  device_ms(event to event)\n")
+            for (i, th, ev), (_, th2, ev2) in zip(trace[:-1], trace[1:]):
+                f.write("%d %d %.4f %.4f\n" % (i, i % 16, (th2 - th) * 1e3, ev.elapsed_time(ev2)))
+            for gen, ms, at in gc_log:
+                f.write("# gc generation %d: %.3f ms during timed step %d\n" % (gen, ms, at - 1))
     if world > 1:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

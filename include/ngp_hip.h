@@ -305,6 +305,10 @@ int ngp_sample_rays(const float* poses /*[n_img,3,4]*/, const float* directions 
  * pack    : bitfield bit = grid > min(stats[0]/stats[1], density_threshold) */
 int ngp_occ_compact(const float* density_grid, float threshold, int n_cells, int32_t* list, int32_t* count,
                     int32_t* scratch /*[1024]*/, void* stream);
+/* m ascending U(0,1) values per set without sorting (normalised partial sums of m + 1 unit exponentials: the order statistics
+ * of m iid uniforms, exact in distribution); u: sets * rows * 1024 uniforms (rows = (m + 1 + 1023) / 1024), work: sets * (rows *
+ * 1024 + rows) floats, out: [sets][m].  Feeds ngp_occ_sample: ascending uniforms -> ascending cells -> coherent encoder queries. */
+int ngp_sorted_uniforms(const float* u, int m, int sets, float* work, float* out, void* stream);
 int ngp_occ_sample(const float* u_cell, const float* u_pick, const float* u_jit, const int32_t* list, const int32_t* count,
                    int m, int grid_size, float s, float half_grid, int32_t* indices, float* xyzs, void* stream);
 int ngp_occ_all_cells(const float* u_jit, int n_cells, int grid_size, float s, float half_grid, float* xyzs, void* stream);

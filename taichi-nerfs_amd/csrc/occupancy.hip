@@ -159,6 +159,57 @@ __global__ void __launch_bounds__(256) occ_pack_kernel(const float4* __restrict_
     }
 }
 
+// ---- ascending uniforms without sorting ----------------------------------------------------------------------------------
+// The order statistics of m iid U(0,1) are distributed like the normalised partial sums of m + 1 unit exponentials
+// E_k = -log(1 - U_k): out[k] = (E_0 + ... + E_k) / (E_0 + ... + E_m).  Two launches (row scans of 1024, then row offsets +
+// normalisation) instead of the ten small torch kernels the same formula took (rand, neg, log1p, neg, 2 x cumsum, copy, 2 x add,
+// div: ~105 us per occupancy update).  u: [sets][rows * 1024] uniforms, work: [sets][rows * 1024 + rows], out: [sets][m].
+__global__ void __launch_bounds__(1024) sorted_uniform_rows_kernel(const float* __restrict__ u, int rows, float* __restrict__ work) {
+    __shared__ float wsum[16];
+    const int row = blockIdx.x, set = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const size_t base = ((size_t)set * rows + row) * 1024;
+    float* c1 = work + (size_t)set * (rows * 1024 + rows);
+    const float e = -log1pf(-u[base + tid]);
+    const float inc = wave_scan_add(e, lane);
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    float woff = 0.0f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) woff += (w < wv) ? wsum[w] : 0.0f;
+    c1[(size_t)row * 1024 + tid] = woff + inc;
+    if (tid == 1023) c1[(size_t)rows * 1024 + row] = woff + inc;          // row total
+}
+__global__ void __launch_bounds__(1024) sorted_uniform_norm_kernel(const float* __restrict__ work, int rows, int m, float* __restrict__ out) {
+    __shared__ double red[2][16];
+    __shared__ double s_off, s_den;
+    const int row = blockIdx.x, set = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const float* c1 = work + (size_t)set * (rows * 1024 + rows);
+    const float* tot = c1 + (size_t)rows * 1024;
+    // offset of this row, and of the row that holds element m (the normaliser).  Summed in f64, where a sum of <= 2^20 f32 row
+    // totals of ~1e3 is EXACT, so every block gets off[r + 1] == off[r] + tot[r] whatever the reduction order and the output is
+    // monotone across row boundaries (an f32 tree reduction differs in the last ulp of ~5e5 and stepped back by 1e-7 there; a
+    // serial f32 sum by one thread is 513 dependent global loads, +45 us per training step)
+    const int rm = m >> 10;
+    double voff = 0.0, vden = 0.0;
+    for (int r = tid; r < rows; r += 1024) {
+        const double t = (double)tot[r];
+        if (r < row) voff += t;
+        if (r < rm) vden += t;
+    }
+    for (int o = 32; o > 0; o >>= 1) { voff += __shfl_down(voff, o); vden += __shfl_down(vden, o); }
+    if (lane == 0) { red[0][wv] = voff; red[1][wv] = vden; }
+    __syncthreads();
+    if (tid == 0) {
+        double a = 0.0, b = 0.0;
+        for (int w = 0; w < 16; ++w) { a += red[0][w]; b += red[1][w]; }
+        s_off = a;
+        s_den = b + (double)c1[(size_t)rm * 1024 + (m & 1023)];
+    }
+    __syncthreads();
+    const int k = row * 1024 + tid;
+    if (k < m) out[(size_t)set * m + k] = (float)(((double)c1[(size_t)row * 1024 + tid] + s_off) / s_den);
+}
+
 }  // namespace ngp
 
 using namespace ngp;
@@ -173,6 +224,17 @@ int ngp_occ_compact(const float* density_grid, float threshold, int n_cells, int
     hipLaunchKernelGGL(occ_count_kernel, dim3(OCC_WAVES / 4), dim3(256), 0, s, density_grid, threshold, n_cells, scratch);
     hipLaunchKernelGGL(occ_scan_kernel, dim3(1), dim3(OCC_WAVES), 0, s, scratch, count);
     hipLaunchKernelGGL(occ_write_kernel, dim3(OCC_WAVES / 4), dim3(256), 0, s, density_grid, threshold, n_cells, scratch, list);
+    NGP_LAUNCH_CHECK();
+    return 0;
+}
+
+// out[set][k], k < m: ascending uniforms (see sorted_uniform_rows_kernel); u holds sets * rows * 1024 uniforms, rows = (m + 1 +
+// 1023) / 1024; work holds sets * (rows * 1024 + rows) floats
+int ngp_sorted_uniforms(const float* u, int m, int sets, float* work, float* out, void* stream) {
+    if (m <= 0 || sets <= 0) return 0;
+    const int rows = (m + 1 + 1023) / 1024;
+    hipLaunchKernelGGL(sorted_uniform_rows_kernel, dim3(rows, sets), dim3(1024), 0, (hipStream_t)stream, u, rows, work);
+    hipLaunchKernelGGL(sorted_uniform_norm_kernel, dim3(rows, sets), dim3(1024), 0, (hipStream_t)stream, (const float*)work, rows, m, out);
     NGP_LAUNCH_CHECK();
     return 0;
 }

@@ -128,6 +128,7 @@ SIGNATURES = {
     "ngp_stage_batch": [_P, _P, _P, _P, _P, _P, _I, _P],
     "ngp_sample_rays": [_P, _P, _P, _I, ctypes.c_longlong, _P, ctypes.c_longlong, _P, _I, _P, _P, _P, _P],
     "ngp_occ_compact": [_P, _F, _I, _P, _P, _P, _P],
+    "ngp_sorted_uniforms": [_P, _I, _I, _P, _P, _P],
     "ngp_occ_sample": [_P, _P, _P, _P, _P, _I, _I, _F, _F, _P, _P, _P],
     "ngp_occ_all_cells": [_P, _I, _I, _F, _F, _P, _P],
     "ngp_occ_scatter": [_P, _P, _I, _P, _P],

@@ -35,6 +35,7 @@ class OccupancyUpdater:
         self.wpack = torch.empty(self.L.ngp_mlp_wpack_halfs(), device=dev, dtype=torch.float16)
         lvs = model.pos_encoder.levels_struct
         self.enc_pairs = 1 if (lvs.n_levels == 16 and lvs.n_features == 2) else 0
+        self._su_work = self._su_out = None
 
     @torch.no_grad()
     def update(self, density_threshold, warmup=False, decay=0.95):
@@ -63,14 +64,14 @@ class OccupancyUpdater:
                 # order statistics of M iid uniforms without sorting: normalised partial sums of M+1 unit exponentials
                 # (exact in distribution).  Ascending uniforms -> ascending Morton codes / list positions -> neighbouring
                 # encoder queries share hash-grid lines (the 1 M-point encode is gather-bound: 900 -> ~540 us).
-                cols = 1024
-                rows = (self.M + 1 + cols - 1) // cols
-                e = -torch.log1p(-torch.rand(2, rows, cols, device=self.dev))
-                c1 = torch.cumsum(e, dim=2)                    # two-level prefix sum: torch's single-row scan of 524 k
-                tot = c1[:, :, -1]                             # elements runs 1.1 ms, 1026 rows of 1024 run in microseconds
-                cs = (c1 + (torch.cumsum(tot, dim=1) - tot)[:, :, None]).reshape(2, -1)
-                u_sorted = (cs[:, :self.M] / cs[:, self.M:self.M + 1]).contiguous()
-                u_cell, u_pick = u_sorted[0], u_sorted[1]
+                # (ngp_sorted_uniforms: row scans of 1024 + row offsets, two launches; the same formula took ten torch kernels)
+                rows = (self.M + 1 + 1023) // 1024
+                u_raw = torch.rand(2 * rows * 1024, device=self.dev)
+                if self._su_work is None:
+                    self._su_work = torch.empty(2 * (rows * 1024 + rows), device=self.dev, dtype=torch.float32)
+                    self._su_out = torch.empty(2, self.M, device=self.dev, dtype=torch.float32)
+                check(L.ngp_sorted_uniforms(_ptr(u_raw), self.M, 2, _ptr(self._su_work), _ptr(self._su_out), st), "ngp_sorted_uniforms")
+                u_cell, u_pick = self._su_out[0], self._su_out[1]
                 u_jit = torch.rand(n * 3, device=self.dev)
                 check(L.ngp_occ_compact(_ptr(grid_c), float(density_threshold), G3, _ptr(self.list), _ptr(self.count), _ptr(self.scratch), st),
                       "ngp_occ_compact")

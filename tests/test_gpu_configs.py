@@ -207,3 +207,30 @@ def test_occupancy_compaction_is_deterministic_and_ordered(hip_lib):
         want = torch.nonzero(grid > thr)[:, 0].to(torch.int32)
         assert int(cnt) == want.numel()
         assert torch.equal(lst[:want.numel()], want) and (lst[want.numel():] == -1).all()
+
+
+def test_sorted_uniforms_are_order_statistics(hip_lib):
+    """ngp_sorted_uniforms: strictly inside (0, 1), ascending, and distributed like sorted iid uniforms (k-th value ~ k / (m + 1),
+    the spacing fluctuations of a uniform sample) -- what the occupancy update feeds ngp_occ_sample (networks.py:193-203 draws
+    iid random cells; sorting them only changes the order of the encoder queries)."""
+    from ngp_hip import lib as L
+    from ngp_hip.ops import _ptr, _stream
+    lib = L.load()
+    torch.manual_seed(3)
+    for m in (524288, 1000, 1023, 1024):
+        rows = (m + 1 + 1023) // 1024
+        u = torch.rand(2 * rows * 1024, device="cuda")
+        work = torch.empty(2 * (rows * 1024 + rows), device="cuda")
+        out = torch.empty(2, m, device="cuda")
+        L.check(lib.ngp_sorted_uniforms(_ptr(u), m, 2, _ptr(work), _ptr(out), _stream()), "ngp_sorted_uniforms")
+        assert float(out.min()) > 0.0 and float(out.max()) < 1.0
+        assert bool((out[:, 1:] >= out[:, :-1]).all())
+        k = torch.arange(1, m + 1, device="cuda", dtype=torch.float64) / (m + 1)
+        dev = (out.double() - k).abs().max().item()
+        assert dev < 4.0 / m**0.5, (m, dev)                      # Kolmogorov-Smirnov scale: sup |F_m - F| ~ 1 / sqrt(m)
+        assert not torch.equal(out[0], out[1])
+        # the closed form, in double
+        e = -torch.log1p(-u.double()).view(2, -1)
+        cs = torch.cumsum(e, 1)
+        want = cs[:, :m] / cs[:, m:m + 1]
+        torch.testing.assert_close(out.double(), want, rtol=2e-4, atol=2e-6)
