@@ -76,6 +76,10 @@ def parse():
                     help="--regime scene: untimed, seeded optimisation steps on the scene before the warm-up (multiple of 16)")
     ap.add_argument("--pool", type=int, default=32, help="--regime scene: resident batches the steps cycle through")
     ap.add_argument("--step-trace", default=None, help="diagnostic: write per-step host/device times of the timed region to FILE")
+    ap.add_argument("--kernel-events-every", type=int, default=4,
+                    help="per-kernel HIP events are recorded on every E-th timed step only (default 4; 1 = every step).  Each "
+                         "event is a barrier packet between two kernels: on every step they cost 50-70 us per step (10 %% of it, "
+                         "A/B in profiles/r02_bench_kernel_events_ab.txt); the per-kernel averages are the same either way")
     ap.add_argument("--no-kernel-events", dest="kernel_events", action="store_false",
                     help="no per-kernel HIP events inside the timed region (A/B for the event overhead)")
     ap.add_argument("--half", action="store_true", help="half2 hash encoder (BASELINE C5)")
@@ -105,13 +109,14 @@ class KernelTimer:
     def __init__(self):
         self.records = {}
         self.enabled = False
+        self.sample = True          # this step's launches get events (bench: every --kernel-events-every-th timed step)
 
     def wrap(self, ops, name, units_of):
         fn = getattr(ops, name)
         timer = self
 
         def timed(*a, **k):
-            if not timer.enabled:
+            if not (timer.enabled and timer.sample):
                 return fn(*a, **k)
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -311,7 +316,7 @@ def main():
             raw = getattr(L, name)
 
             def timed(*a):
-                if not timer.enabled or not event_pool:
+                if not (timer.enabled and timer.sample) or not event_pool:
                     return raw(*a)
                 e0, e1 = event_pool.pop(), event_pool.pop()
                 st = torch.cuda.current_stream()
@@ -335,8 +340,11 @@ def main():
         if not scene:
             model.density_bitfield.copy_(bits)
 
+    ev_every = max(1, args.kernel_events_every)
+
     def trainer_step(i, prefetch=True, log=True):
         rays_o, rays_d, target = pool[i % n_pool]
+        timer.sample = state["k"] % ev_every == ev_every // 2
         if i % 16 == 0:
             grid_update(i)
         nxt = pool[(i + 1) % n_pool]
@@ -588,7 +596,8 @@ def main():
                        "rays_per_gpu": args.rays, "global_batch": args.rays * world,
                        "parallelism": parallelism,
                        "path": ("FusedTrainer" + ("+hipGraph" if args.graph else "")) if use_trainer else "modules+torch.optim",
-                       "kernel_events_in_timed_region": bool(event_pool) or not use_trainer},
+                       "kernel_events_in_timed_region": (("every step" if ev_every == 1 else "every %d-th step" % ev_every)
+                                                         if (bool(event_pool) or not use_trainer) else False)},
             "samples_per_sec": rm * world / elapsed, "rm_samples_per_ray": rm / total_rays * world, "vr_samples_per_ray": vr / total_rays * world,
             "live_samples_per_step": live_avg,
             "ms_per_step_no_prefetch": None if elapsed_np is None else elapsed_np / args.steps * 1e3,

@@ -105,6 +105,8 @@ def main():
             print("  xcc %d: %3d tasks, busy %7.1f CU-us (%.1f us if spread over 32 CUs), first start %5.1f, last end %6.1f" % (
                 x, len(r), (r[:, 5] - r[:, 1]).sum() / 100.0, (r[:, 5] - r[:, 1]).sum() / 100.0 / 32, (r[:, 1].min() - t0) / 100.0,
                 (r[:, 5].max() - t0) / 100.0))
+    if os.environ.get("NGP_VARIANTS_DUMP"):                # raw rows: task word, begin, init, wave0, all waves, end (100 MHz ticks), xcc, n
+        np.save(os.environ["NGP_VARIANTS_DUMP"], d)
     if os.environ.get("NGP_VARIANTS_ONLY_TIMELINE"):
         return
     # where the time goes: the same launch with pieces switched off (results are wrong with these flags: timing only)

@@ -49,13 +49,16 @@ constexpr int BW_Q = 256;                                      // per-wave hit q
 constexpr int BW_MAX_TASKS = 1536;
 constexpr int BW_PREP_BLOCKS = 2048;
 constexpr uint16_t BW_NULL_TASK = 0xffffu;
+constexpr size_t BW_CTR_BYTES = 64;                           // 8 queue heads + the exit counter of the main kernel
+constexpr int BW_PERSISTENT_BLOCKS = 256;                     // one 1024-thread workgroup (147 KB of LDS) per CU
 
 struct BwdPlan {
     int32_t n_blocks;
     uint32_t merge_mask;                  // bit l: pre-sum equal-cell runs on level l
     uint32_t diag;                        // timing experiments (-DNGP_BWD_DIAG builds): 1 no LDS adds, 2 no gathers, 4 no accumulate
     uint8_t nrep[NGP_MAX_LEVELS];         // replicas (sample ranges) per slice of level l
-    uint16_t task[BW_MAX_TASKS];          // level | slice << 4 | rep << 10, or BW_NULL_TASK
+    uint16_t task[BW_MAX_TASKS];          // level | slice << 4 | rep << 10; XCD x owns task[xoff[x] .. xoff[x] + xlen[x])
+    uint16_t xoff[8], xlen[8];
 };
 
 __device__ __forceinline__ uint32_t level_index(bool dense, uint32_t mode, uint32_t size, uint32_t res, uint32_t gx, uint32_t gy,
@@ -120,9 +123,10 @@ __device__ __forceinline__ const float* grad_ptr(const float* dout, int level, s
 __global__ void __launch_bounds__(256) hash_bwd_prep_kernel(const float* __restrict__ xyzs, const int32_t* __restrict__ idx,
                                                             ngp_hash_levels lv, int n, const int32_t* __restrict__ n_dev, XyzNorm nm,
                                                             size_t wstride, uint32_t single_slice_levels, float* __restrict__ xyzc,
-                                                            unsigned long long* __restrict__ bitmap) {
+                                                            unsigned long long* __restrict__ bitmap, uint32_t* __restrict__ ctr) {
     __shared__ LevelLDS L;
     __shared__ unsigned long long words[4][BW_MAX_SLICES];
+    if (blockIdx.x == 0 && threadIdx.x < 16) ctr[threadIdx.x] = 0u;       // the main kernel's queue heads (it also resets them itself)
     load_levels(lv, L);
     if (n_dev) n = min(n, *n_dev);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -469,25 +473,53 @@ __device__ __forceinline__ void bwd_task(const LevelParams P, const int level, c
                 if (qlen >= 128) drain();
             }
         } else {
-            // lane-parallel: lane l owns word l (64 samples); every round each lane with bits left emits its lowest one, the
-            // emitting lanes are compacted into the queue with one ballot.  Rounds = the largest popcount among the words (24 on
-            // average: hits come in runs of consecutive samples), ~350 clocks each (a VALU -> SALU -> branch round trip with
-            // four waves per SIMD).  Two cheaper scans were built and measured (profiles/r02_hash_bwd_timeline.txt): unpacking a
-            // whole word per lane behind a prefix sum, and TRANSPOSED bitmap words (a run spread over 64 lanes: a third of the
-            // rounds, scan -40 us).  Both put the equal-cell runs of the coarser hashed levels into ONE add instruction, where
-            // they serialise in the LDS (+30 us) and the gathers lose their spread (+24 us): no net gain, not shipped.
-            unsigned long long w = cur;
-            unsigned long long live = __ballot(w != 0ull);
-            while (live) {
-                const bool has = w != 0ull;
-                const int pos = qlen + __builtin_amdgcn_mbcnt_hi((uint32_t)(live >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)live, 0));
-                if (has) {
-                    q[(qhead + pos) & (BW_Q - 1)] = (uint32_t)((wbase + lane) * 64 + __builtin_ctzll(w));
-                    w &= w - 1ull;
-                }
-                qlen += __popcll(live);
-                if (qlen >= 128) drain();
-                live = __ballot(w != 0ull);
+            // lane-parallel.  The first form gave lane l word l (64 samples); every round each lane with bits left emitted its
+            // lowest one.  Rounds = the largest popcount among the words (24 on average: hits come in runs of consecutive
+            // samples), ~350 clocks each with four waves per SIMD.  Two cheaper scans were built and measured
+            // (profiles/r02_hash_bwd_timeline.txt): unpacking a whole word per lane behind a prefix sum, and TRANSPOSED bitmap
+            // words (a run spread over 64 lanes: a third of the rounds, scan -40 us).  Both put the equal-cell runs of the coarser
+            // hashed levels into ONE add instruction, where they serialise in the LDS (+30 us) and the gathers lose their spread
+            // (+24 us): no net gain, not shipped.  What is shipped:
+            // The unit a lane owns is an 8-sample PIECE of a word, and only non-empty pieces get a lane: the ~16 non-empty words
+            // of a super-chunk (hits come in runs of ~24 consecutive samples) would otherwise keep 48 lanes idle for
+            // max-popcount (~24) rounds of 64-bit bit twiddling.  The non-empty pieces (~50 of 512) are compacted, piece-major
+            // (neighbouring lanes = different words = different rays), through the free part of this wave's hit queue; a round
+            // then is 32-bit work and there are at most 8 of them.
+            const unsigned long long w = cur;
+            if (__ballot(w != 0ull) != 0ull) {
+                int total = 0, pass = 0;
+                do {
+                    const int sbase = qhead + 128;                   // ring slots [qhead + 128, + 192): free while qlen < 128
+                    int off = 0;
+#pragma unroll
+                    for (int pc = 0; pc < 8; ++pc) {
+                        const uint32_t b8 = (uint32_t)(w >> (8 * pc)) & 0xffu;
+                        const unsigned long long nz = __ballot(b8 != 0u);
+                        const int dst = off - 64 * pass + __builtin_amdgcn_mbcnt_hi((uint32_t)(nz >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nz, 0));
+                        if (b8 != 0u && (uint32_t)dst < 64u) q[(sbase + dst) & (BW_Q - 1)] = b8 | ((uint32_t)lane << 8) | ((uint32_t)pc << 14);
+                        off += __popcll(nz);
+                    }
+                    total = off;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    const uint32_t d = (lane < total - 64 * pass) ? q[(sbase + lane) & (BW_Q - 1)] : 0u;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    uint32_t bits = d & 0xffu;
+                    const uint32_t s0 = (uint32_t)(wbase + (int)((d >> 8) & 63u)) * 64u + 8u * (d >> 14);     // sample of the piece's bit 0
+                    unsigned long long live = __ballot(bits != 0u);
+                    while (live) {
+                        const int pos = qlen + __builtin_amdgcn_mbcnt_hi((uint32_t)(live >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)live, 0));
+                        if (bits != 0u) {
+                            q[(qhead + pos) & (BW_Q - 1)] = s0 + (uint32_t)__builtin_ctz(bits);
+                            bits &= bits - 1u;
+                        }
+                        qlen += __popcll(live);
+                        if (qlen >= 128) drain();
+                        live = __ballot(bits != 0u);
+                    }
+                    ++pass;
+                } while (64 * pass < total);
             }
         }
         cur = nxtw; sc = sc_next;
@@ -504,25 +536,62 @@ __device__ __forceinline__ void bwd_task(const LevelParams P, const int level, c
     accumulate_batch<KIND>(P, sl, false, pend, slice, found_inf);
 }
 
+// Queue heads: ctr[x] = tasks taken from the front of XCD x's queue (low 16 bits, by its own workgroups) and from the back (high
+// 16 bits, by thieves); one atomic add claims one position, a claim is valid while front + back < length.  Returns the index
+// into plan.task or 0xffffffff when every queue is empty.
+__device__ __forceinline__ uint32_t claim_task(const BwdPlan& plan, uint32_t* __restrict__ ctr, uint32_t xcc) {
+    {
+        const uint32_t old = atomicAdd(&ctr[xcc], 1u), f = old & 0xffffu, b = old >> 16;
+        if (f + b < plan.xlen[xcc]) return plan.xoff[xcc] + f;
+    }
+    uint32_t dead = 1u << xcc;
+    for (int tries = 0; tries < 7; ++tries) {
+        int best = -1, best_left = 0;
+        for (uint32_t v = 0; v < 8; ++v) {
+            if ((dead >> v) & 1u) continue;
+            const uint32_t c = __atomic_load_n(&ctr[v], __ATOMIC_RELAXED);
+            const int left = (int)plan.xlen[v] - (int)((c & 0xffffu) + (c >> 16));
+            if (left > best_left) { best_left = left; best = (int)v; }
+        }
+        if (best < 0) break;
+        const uint32_t old = atomicAdd(&ctr[best], 0x10000u), f = old & 0xffffu, b = old >> 16;
+        if (f + b < plan.xlen[best]) return plan.xoff[best] + plan.xlen[best] - 1u - b;
+        dead |= 1u << best;
+    }
+    return 0xffffffffu;
+}
+
 __global__ void __launch_bounds__(BW_THREADS) hash_bwd_lds_kernel(const float* __restrict__ xyzc,
                                                                   const unsigned long long* __restrict__ bitmap, size_t wstride,
                                                                   const float* __restrict__ dout, ngp_hash_levels lv, int n,
                                                                   const int32_t* __restrict__ n_dev, int enc_pairs, BwdPlan plan,
                                                                   float* __restrict__ dtable, int32_t* __restrict__ found_inf,
-                                                                  unsigned long long* __restrict__ dbg) {
+                                                                  uint32_t* __restrict__ ctr, unsigned long long* __restrict__ dbg) {
     __shared__ double slice[2 * BW_SLICE_ENTRIES];
     __shared__ uint32_t queues[BW_WAVES * BW_Q];
     __shared__ uint32_t next_sc;
-    const uint32_t task = plan.task[blockIdx.x];
-    if (task == BW_NULL_TASK) return;
-    unsigned long long t_begin = 0;
-    if (dbg) t_begin = wall_clock64();
+    __shared__ uint32_t s_claim;
     const size_t plane = (size_t)n;
     if (n_dev) n = min(n, *n_dev);
     if (n <= 0) return;
+    const int tid = threadIdx.x;
+    // PERSISTENT workgroups (one per CU) take tasks from the queue of the XCD they actually run on; a workgroup whose XCD has
+    // run dry steals from the BACK of the fullest other queue (the queues are sorted longest task first, so what is stolen
+    // are short coarse-level tasks; a stolen task misses the victim XCD's L2 but would otherwise have waited).  A static deal of
+    // tasks to blockIdx % 8 left the XCDs 165-193 us busy and the launch 218 us long (profiles/r02_hash_bwd_timeline.txt).
+    uint32_t xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc &= 7u;
+  for (;;) {
+    if (tid == 0) s_claim = claim_task(plan, ctr, xcc);
+    __syncthreads();
+    const uint32_t claim = s_claim;
+    if (claim == 0xffffffffu) break;
+    const uint32_t task = plan.task[claim];
+    unsigned long long t_begin = 0;
+    if (dbg) t_begin = wall_clock64();
     const int level = task & 0xf, rep = (task >> 10) & 0x3f, nrep = plan.nrep[level];
     const uint32_t sl = (task >> 4) & 0x3f;
-    const int tid = threadIdx.x;
     LevelParams P;
     P.scale = lv.scale[level]; P.res = lv.resolution[level]; P.size = lv.map_size[level]; P.offset = lv.offset[level];
     P.dense = level < lv.begin_fast_hash_level;
@@ -572,10 +641,18 @@ __global__ void __launch_bounds__(BW_THREADS) hash_bwd_lds_kernel(const float* _
     }
     if (dbg) {          // diagnostics (ngp_hash_bwd_sliced_debug): 100 MHz wall-clock stamps per block + wave 0's own finish time
         if (tid == 0) {
-            unsigned long long* o = dbg + 8 * (size_t)blockIdx.x;
-            uint32_t xcc;
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            unsigned long long* o = dbg + 8 * (size_t)claim;
             o[0] = task; o[1] = t_begin; o[2] = t_init; o[3] = t_wave; o[4] = t_acc; o[5] = wall_clock64(); o[6] = xcc & 0xf; o[7] = (unsigned long long)n;
+        }
+    }
+    __syncthreads();                      // the slice and s_claim are reused by the next task
+  }
+    // the last workgroup to leave resets the queue heads for the next launch
+    if (tid == 0) {
+        __threadfence();
+        if (atomicAdd(&ctr[8], 1u) == gridDim.x - 1u) {
+            for (int x = 0; x < 8; ++x) ctr[x] = 0u;
+            ctr[8] = 0u;
         }
     }
 }
@@ -664,13 +741,22 @@ static bool build_plan(const ngp_hash_levels& lv, BwdPlan& plan, uint32_t& singl
                     load[x] += cost(L);
                 }
         }
-    int maxlen = 0;
-    for (int x = 0; x < 8; ++x) if (len[x] > maxlen) maxlen = len[x];
-    if (maxlen * 8 > BW_MAX_TASKS) return false;
+    // inside an XCD: longest tasks first (stable: a level's owners stay together), so that what is left at the end -- and what a
+    // thief takes from the back -- are the short coarse-level tasks (20-30 us), not 50 us ones
+    float lcost[NGP_MAX_LEVELS];
+    for (int l = 0; l < lv.n_levels; ++l) lcost[l] = cost(lvls[l]);
     int nb = 0;
-    for (int p = 0; p < maxlen; ++p)
-        for (int x = 0; x < 8; ++x) plan.task[nb++] = p < len[x] ? lists[x][p] : BW_NULL_TASK;
-    plan.n_blocks = nb;
+    for (int x = 0; x < 8; ++x) {
+        for (int a = 1; a < len[x]; ++a) {                      // insertion sort, descending cost
+            const uint16_t t = lists[x][a];
+            int b = a - 1;
+            while (b >= 0 && lcost[lists[x][b] & 0xf] < lcost[t & 0xf]) { lists[x][b + 1] = lists[x][b]; --b; }
+            lists[x][b + 1] = t;
+        }
+        plan.xoff[x] = (uint16_t)nb; plan.xlen[x] = (uint16_t)len[x];
+        for (int p = 0; p < len[x]; ++p) plan.task[nb++] = lists[x][p];
+    }
+    plan.n_blocks = nb < BW_PERSISTENT_BLOCKS ? nb : BW_PERSISTENT_BLOCKS;
     return true;
 }
 
@@ -691,7 +777,8 @@ int ngp_hash_bwd_sliced_debug(void* device_buffer) { g_bwd_debug = (unsigned lon
 long long ngp_hash_bwd_sliced_workspace(const ngp_hash_levels* lv, int n_max) {
     if (!lv || n_max <= 0) return 0;
     const size_t ms = ((size_t)n_max + 511) & ~(size_t)511;
-    return (long long)(ms * 3 * sizeof(float) + (size_t)lv->n_levels * BW_MAX_SLICES * (ms / 64) * sizeof(unsigned long long));
+    return (long long)(ms * 3 * sizeof(float) + (size_t)lv->n_levels * BW_MAX_SLICES * (ms / 64) * sizeof(unsigned long long) +
+                       BW_CTR_BYTES);
 }
 
 // The two halves of ngp_hash_bwd_f32_sliced as separate entry points: the prepass only needs the positions and the live list,
@@ -707,8 +794,9 @@ int ngp_hash_bwd_sliced_prep(const float* xyzs, const ngp_hash_levels* lv, int n
     float* xyzc = reinterpret_cast<float*>(workspace);
     unsigned long long* bitmap = reinterpret_cast<unsigned long long*>(xyzc + ms * 3);
     const XyzNorm nm = {normalize, lo, hi};
+    uint32_t* ctr = reinterpret_cast<uint32_t*>(bitmap + (size_t)lv->n_levels * BW_MAX_SLICES * (ms / 64));
     hipLaunchKernelGGL(hash_bwd_prep_kernel, dim3(BW_PREP_BLOCKS), dim3(256), 0, (hipStream_t)stream, xyzs, live_idx, *lv, n_max, n_dev, nm,
-                       ms / 64, single_mask, xyzc, bitmap);
+                       ms / 64, single_mask, xyzc, bitmap, ctr);
     NGP_LAUNCH_CHECK();
     return 0;
 }
@@ -725,8 +813,9 @@ int ngp_hash_bwd_sliced_main(const float* dout, const ngp_hash_levels* lv, int n
     const size_t ms = ((size_t)n_max + 511) & ~(size_t)511;
     const float* xyzc = reinterpret_cast<const float*>(workspace);
     const unsigned long long* bitmap = reinterpret_cast<const unsigned long long*>(xyzc + ms * 3);
+    uint32_t* ctr = reinterpret_cast<uint32_t*>(const_cast<unsigned long long*>(bitmap) + (size_t)lv->n_levels * BW_MAX_SLICES * (ms / 64));
     hipLaunchKernelGGL(hash_bwd_lds_kernel, dim3(plan.n_blocks), dim3(BW_THREADS), 0, (hipStream_t)stream, xyzc, bitmap, ms / 64, dout, *lv,
-                       n_max, n_dev, enc_pairs, plan, dtable, found_inf, g_bwd_debug);
+                       n_max, n_dev, enc_pairs, plan, dtable, found_inf, ctr, g_bwd_debug);
     NGP_LAUNCH_CHECK();
     return 0;
 }
