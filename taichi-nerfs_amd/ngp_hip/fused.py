@@ -10,6 +10,7 @@ The reference reads the sample total back to the host every step to slice its N*
 reservation free), every kernel reads the live count from device memory, and nothing in the step waits for the GPU:
 the step can be replayed from a hipGraph (ngp_hip/graph.py)."""
 import ctypes
+import os
 
 import torch
 
@@ -125,7 +126,7 @@ class FusedTrainRender(torch.autograd.Function):
                                         st), "ngp_composite_train_fwd")
         A.generation += 1
         ctx.cfg, ctx.arena, ctx.table_numel, ctx.generation = cfg, A, table.numel(), A.generation
-        ctx.save_for_backward(rays_a, total, opacity, depth, rgb)
+        ctx.save_for_backward(rays_a, total, opacity, depth, rgb, vr_per_ray)
         ctx.set_materialize_grads(False)
         rm = total[0]
         vr = vr_per_ray.sum()
@@ -135,7 +136,7 @@ class FusedTrainRender(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_rgb, g_opacity, g_depth, g_ws, _g_rm, _g_vr, _g_ra):
         L = _lib_mod.load()
-        rays_a, total, opacity, depth, rgb = ctx.saved_tensors
+        rays_a, total, opacity, depth, rgb, vr_per_ray = ctx.saved_tensors
         cfg, A = ctx.cfg, ctx.arena
         if A.generation != ctx.generation:
             raise RuntimeError(
@@ -159,11 +160,25 @@ class FusedTrainRender(torch.autograd.Function):
               "ngp_composite_train_bwd")
         dW = torch.zeros(MLP_N_WEIGHTS, device=dev, dtype=torch.float32)
         P = cfg.enc_pairs
-        check(L.ngp_mlp_bwd_ex(_ptr(A.enc), _ptr(A.dirs), _ptr(A.wpack), _ptr(A.d_sigmas), _ptr(A.d_rgbs), A.cap, _ptr(total), P,
-                               _ptr(A.d_enc), _ptr(dW), _ptr(None), st), "ngp_mlp_bwd_ex")
         dtable = torch.zeros(ctx.table_numel, device=dev, dtype=torch.float32)
-        check(L.ngp_hash_bwd_f32_ex(_ptr(A.xyzs), _ptr(A.d_enc), ctypes.byref(cfg.levels), A.cap, _ptr(total), 1, cfg.lo, cfg.hi, P,
-                                    _ptr(dtable), _ptr(None), st), "ngp_hash_bwd_f32_ex")
+        # backward over the LIVE samples only (the first vr_per_ray[r] of ray r: everything behind the early-termination point has
+        # exact-zero gradients), compacted into an index list; the scatter-add in its LDS-sliced form (no global float atomics)
+        # when the level table fits it -- the same kernels FusedTrainer runs
+        live_total = torch.empty(1, device=dev, dtype=torch.int32)
+        check(L.ngp_live_compact(_ptr(rays_a), _ptr(vr_per_ray), n, _ptr(A.live_off(n)), _ptr(A.live_idx), _ptr(live_total), st),
+              "ngp_live_compact")
+        check(L.ngp_mlp_bwd_live(_ptr(A.enc), _ptr(A.dirs), _ptr(A.wpack), _ptr(A.d_sigmas), _ptr(A.d_rgbs), A.cap, _ptr(live_total),
+                                 _ptr(A.live_idx), P, _ptr(A.d_enc), _ptr(dW), _ptr(None), st), "ngp_mlp_bwd_live")
+        rc = -2
+        if os.environ.get("NGP_HASH_BWD", "sliced") != "atomic":
+            ws = A.sliced_ws(cfg.levels)
+            rc = L.ngp_hash_bwd_f32_sliced(_ptr(A.xyzs), _ptr(A.d_enc), ctypes.byref(cfg.levels), A.cap, _ptr(live_total), _ptr(A.live_idx),
+                                           1, cfg.lo, cfg.hi, P, _ptr(dtable), _ptr(None), _ptr(ws), ws.numel(), st)
+        if rc == -2:                                                      # level table not expressible as <= 64 LDS slices per level
+            check(L.ngp_hash_bwd_f32_live(_ptr(A.xyzs), _ptr(A.d_enc), ctypes.byref(cfg.levels), A.cap, _ptr(live_total),
+                                          _ptr(A.live_idx), 1, cfg.lo, cfg.hi, P, _ptr(dtable), _ptr(None), st), "ngp_hash_bwd_f32_live")
+        else:
+            check(rc, "ngp_hash_bwd_f32_sliced")
         grads = [g.view(shape) for g, shape in zip(dW.split(MLP_SPLITS), MLP_SHAPES)]
         return (None, None, None, dtable, *grads, None)
 

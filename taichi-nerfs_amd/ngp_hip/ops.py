@@ -2,6 +2,7 @@
 torch HIP stream.  No autograd here (that lives in modules/), no CPU path: every function requires device
 tensors and raises otherwise."""
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -163,9 +164,24 @@ def hash_fwd_bf16(xyzs, table_bf16, lv):
     return out
 
 
+SLICED_MIN_SAMPLES = 65536      # below this the float-atomic kernel wins (the sliced launch has a ~60 us floor: 1 k slice owners)
+
+
 def hash_bwd_f32(xyzs, dout, lv, dtable):
+    """dtable += scatter-add of dout (hash_encoder.py:269, the Taichi-autodiff backward).  Large batches take the LDS-sliced
+    formulation (no global float atomics, f64 accumulation; 3x faster at training batch sizes), small ones -- or level tables
+    it cannot express (F != 2, a level of more than 64 slices) -- the float-atomic kernel.  NGP_HASH_BWD=atomic forces the latter."""
     _dev(xyzs, torch.float32, "xyzs"); _dev(dout, torch.float32, "dout"); _dev(dtable, torch.float32, "dtable")
-    check(_lib().ngp_hash_bwd_f32(_ptr(xyzs), _ptr(dout), ctypes.byref(lv), xyzs.shape[0], _ptr(dtable), _stream()),
+    n = xyzs.shape[0]
+    if n >= SLICED_MIN_SAMPLES and os.environ.get("NGP_HASH_BWD", "sliced") != "atomic" and lv.n_features == 2:
+        ws = sliced_workspace(lv, n, xyzs.device)
+        rc = _lib().ngp_hash_bwd_f32_sliced(_ptr(xyzs), _ptr(dout), ctypes.byref(lv), n, _ptr(None), _ptr(None), 0, 0.0, 1.0, 0,
+                                            _ptr(dtable), _ptr(None), _ptr(ws), ws.numel(), _stream())
+        if rc != -2:
+            check(rc, "ngp_hash_bwd_f32_sliced")
+            _touched(dtable)
+            return dtable
+    check(_lib().ngp_hash_bwd_f32(_ptr(xyzs), _ptr(dout), ctypes.byref(lv), n, _ptr(dtable), _stream()),
           "ngp_hash_bwd_f32")
     _touched(dtable)
     return dtable
