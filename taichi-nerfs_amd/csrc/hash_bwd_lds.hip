@@ -782,7 +782,8 @@ long long ngp_hash_bwd_sliced_workspace(const ngp_hash_levels* lv, int n_max) {
 }
 
 // The two halves of ngp_hash_bwd_f32_sliced as separate entry points: the prepass only needs the positions and the live list,
-// so a caller can run it on a second stream underneath the MLP backward that produces `dout` (FusedTrainer does).
+// so a caller can issue it before the MLP backward that produces `dout` (FusedTrainer does; on a second stream underneath that
+// kernel it was measured slower: the two share the VALU and the cross-stream join costs ~20 us).
 int ngp_hash_bwd_sliced_prep(const float* xyzs, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev, const int32_t* live_idx,
                              int normalize, float lo, float hi, void* workspace, long long workspace_bytes, void* stream) {
     if (n_max <= 0) return 0;

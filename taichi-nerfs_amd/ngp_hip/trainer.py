@@ -138,7 +138,6 @@ class FusedTrainer:
         self._sets = {}
         self._cur = 0
         self._side = torch.cuda.Stream(device=dev)
-        self._side2 = torch.cuda.Stream(device=dev)       # the scatter-add prepass, underneath the MLP backward
         # where in the step the next batch's march is put on the side stream: 0 = at the start, 1 = after the hash gather
         # (default: with the backward running on the live samples only, the ~115 us march chain has to start this early to be
         # done before the step is; A/B on one box: 0.327 ms at 1, 0.331 at 0, 0.342 at 2), 2 = after the MLP forward, 3 = before
@@ -337,22 +336,14 @@ class FusedTrainer:
             cnt = live_total
         else:
             live_idx, cnt = None, total
-        # the scatter-add's prepass (hit bitmaps + compact positions) depends on the positions and the live list only: it runs on
-        # a second stream underneath the MLP backward (~45 us hidden)
+        # the scatter-add's prepass (hit bitmaps + compact positions; needs the positions and the live list only).  It used to run on
+        # a second stream underneath the MLP backward, but the two share the VALU (87 us overlapped vs 43 alone) and the
+        # cross-stream join cost 23 us between the prepass's end and the scatter-add's start: in line it is 17 us per step faster
         sliced = (not self.half) and self.hash_bwd == "sliced"
-        prep_done = None
         if sliced:
             ws = A.sliced_ws(cfg.levels)
-            if self._graph is None:
-                ev = torch.cuda.Event(); ev.record()
-                with torch.cuda.stream(self._side2):
-                    self._side2.wait_event(ev)
-                    rc = L.ngp_hash_bwd_sliced_prep(_ptr(M.xyzs), ctypes.byref(cfg.levels), A.cap, _ptr(cnt), _ptr(live_idx), 1, cfg.lo, cfg.hi,
-                                                    _ptr(ws), ws.numel(), _stream())
-                    prep_done = torch.cuda.Event(); prep_done.record(self._side2)
-            else:                                                        # (graph capture: keep everything on the capturing stream)
-                rc = L.ngp_hash_bwd_sliced_prep(_ptr(M.xyzs), ctypes.byref(cfg.levels), A.cap, _ptr(cnt), _ptr(live_idx), 1, cfg.lo, cfg.hi,
-                                                _ptr(ws), ws.numel(), st)
+            rc = L.ngp_hash_bwd_sliced_prep(_ptr(M.xyzs), ctypes.byref(cfg.levels), A.cap, _ptr(cnt), _ptr(live_idx), 1, cfg.lo, cfg.hi,
+                                            _ptr(ws), ws.numel(), st)
             if rc == -2:
                 self.hash_bwd, sliced = "atomic", False                  # level table not expressible as <= 64 LDS slices per level
             else:
@@ -365,8 +356,6 @@ class FusedTrainer:
             check(L.ngp_hash_bwd_f16_live(_ptr(M.xyzs), _ptr(A.d_enc), ctypes.byref(cfg.levels), A.cap, _ptr(cnt), _ptr(live_idx), 1,
                                           cfg.lo, cfg.hi, P, _ptr(self.table_grad), found, st), "ngp_hash_bwd_f16_live")
         elif sliced:
-            if prep_done is not None:
-                torch.cuda.current_stream().wait_event(prep_done)
             check(L.ngp_hash_bwd_sliced_main(_ptr(A.d_enc), ctypes.byref(cfg.levels), A.cap, _ptr(cnt), P, _ptr(self.table_grad), found,
                                              _ptr(ws), ws.numel(), st), "ngp_hash_bwd_sliced_main")
         else:

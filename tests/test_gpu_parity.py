@@ -180,6 +180,33 @@ def test_hash_bwd_f32_sliced(oracle, hip_lib, max_res):
     np.testing.assert_allclose(got, dt3.cpu().numpy(), rtol=2e-5, atol=2e-5)
 
 
+def test_hash_bwd_operator_dispatch(oracle, hip_lib, monkeypatch):
+    """ops.hash_bwd_f32 (what modules/hash_encoder.py's backward calls) takes the sliced form from SLICED_MIN_SAMPLES up and the
+    float-atomic kernel below / when NGP_HASH_BWD=atomic / when the table does not fit: all three against the oracle."""
+    lv = ops.make_levels(2**19, 16, 16, 1024, 2)
+    rng = np.random.default_rng(11)
+    n = ops.SLICED_MIN_SAMPLES + 1000
+    x = rng.random((n, 3), dtype=np.float32)
+    dout = rng.standard_normal((n, 32)).astype(np.float32)
+    ref = oracle.hash_bwd_f32(x, dout, lv)
+    calls = []
+    L = ops._lib()
+    real = L.ngp_hash_bwd_f32_sliced
+    monkeypatch.setattr(L, "ngp_hash_bwd_f32_sliced", lambda *a: (calls.append(1), real(*a))[1])
+    got = ops.hash_bwd_f32(dev(x), dev(dout), lv, torch.zeros(lv.total_entries * 2, device="cuda")).cpu().numpy()
+    assert calls == [1]
+    np.testing.assert_allclose(got, ref, rtol=2e-5, atol=2e-5)
+    monkeypatch.setenv("NGP_HASH_BWD", "atomic")
+    got = ops.hash_bwd_f32(dev(x), dev(dout), lv, torch.zeros(lv.total_entries * 2, device="cuda")).cpu().numpy()
+    assert calls == [1]
+    np.testing.assert_allclose(got, ref, rtol=2e-5, atol=2e-5)
+    monkeypatch.delenv("NGP_HASH_BWD")
+    m = 5000                                                # a small batch stays on the atomic kernel
+    got = ops.hash_bwd_f32(dev(x[:m]), dev(dout[:m]), lv, torch.zeros(lv.total_entries * 2, device="cuda")).cpu().numpy()
+    assert calls == [1]
+    np.testing.assert_allclose(got, oracle.hash_bwd_f32(x[:m], dout[:m], lv), rtol=2e-5, atol=2e-5)
+
+
 def test_hash_bwd_f32_sliced_refuses_unsupported_tables(hip_lib):
     lv = ops.make_levels(2**21, 4, 32, 128, 4)             # F = 4: not expressible, the C entry point says so (-2)
     x = torch.rand(100, 3, device="cuda")
