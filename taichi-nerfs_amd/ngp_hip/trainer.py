@@ -138,13 +138,15 @@ class FusedTrainer:
         self._sets = {}
         self._cur = 0
         self._side = torch.cuda.Stream(device=dev)
+        self.prefetch_hits = 0                # steps that consumed a march prefetched by the previous step() call
         # where in the step the next batch's march is put on the side stream: 0 = at the start, 1 = after the hash gather
         # (default: with the backward running on the live samples only, the ~115 us march chain has to start this early to be
-        # done before the step is; A/B on one box: 0.327 ms at 1, 0.331 at 0, 0.342 at 2), 2 = after the MLP forward, 3 = before
-        # the scatter-add
+        # done before the step is; A/B on one box: 0.327 ms at 1, 0.331 at 0, 0.342 at 2; round 2: 0.567-0.571 at 1, 0.578-0.583 at
+        # 0, 0.585 at 2, 0.590 at 3), 2 = after the MLP forward, 3 = before the scatter-add, 4 = after the scatter-add
         import os as _os
-        # (with world > 1 the default is 3: the march then runs underneath the gradient all-reduce)
-        self._prefetch_at = int(_os.environ.get("NGP_PREFETCH_AT", "1" if self.world == 1 else "3"))
+        # (with world > 1 the default is 4: the march then runs underneath the gradient exchange -- RCCL's kernels occupy a few
+        # workgroups and wait on xGMI -- instead of competing with the VALU-bound kernels of the step for issue slots)
+        self._prefetch_at = int(_os.environ.get("NGP_PREFETCH_AT", "1" if self.world == 1 else "4"))
         self._coarse_ver = None
         self.sync_occupancy = True            # world > 1: broadcast rank 0's occupancy after every update_density_grid()
         lvs = model.pos_encoder.levels_struct
@@ -245,6 +247,7 @@ class FusedTrainer:
         sets = self._march_sets(n)
         M = sets[self._cur]
         hit = noise is None and M.marched_for(src)               # an explicit jitter vector always re-marches
+        self.prefetch_hits += int(hit)
         if M.ready is not None:
             # whatever the side stream did to this set has to be finished before the main stream reads OR rewrites it (a stale
             # prefetch for other rays would otherwise race with the re-march below on M.stage / counts / xyzs)
@@ -350,7 +353,7 @@ class FusedTrainer:
                 check(rc, "ngp_hash_bwd_sliced_prep")
         check(L.ngp_mlp_bwd_live(_ptr(A.enc), _ptr(M.dirs), _ptr(self.wpack), _ptr(A.d_sigmas), _ptr(A.d_rgbs), A.cap, _ptr(cnt),
                                  _ptr(live_idx), P, _ptr(A.d_enc), _ptr(self.mlp_grad), found, st), "ngp_mlp_bwd_live")
-        if hook is not None:
+        if hook is not None and self._prefetch_at <= 3:
             hook(); hook = None                                             # position 3: under the scatter-add and the optimizer
         if self.half:
             check(L.ngp_hash_bwd_f16_live(_ptr(M.xyzs), _ptr(A.d_enc), ctypes.byref(cfg.levels), A.cap, _ptr(cnt), _ptr(live_idx), 1,
@@ -361,6 +364,8 @@ class FusedTrainer:
         else:
             check(L.ngp_hash_bwd_f32_live(_ptr(M.xyzs), _ptr(A.d_enc), ctypes.byref(cfg.levels), A.cap, _ptr(cnt), _ptr(live_idx), 1,
                                           cfg.lo, cfg.hi, P, _ptr(self.table_grad), found, st), "ngp_hash_bwd_f32_live")
+        if hook is not None:
+            hook(); hook = None                                             # position 4: under the gradient exchange + optimizer
         sharded = self.shard and not self._grads_only                      # (gradient diagnostics use the plain all-reduce)
         if sharded:
             self._exchange_sharded(found, st)

@@ -77,11 +77,15 @@ def _worker(rank, world, port, kind, shard_opt, bits_np, out_dir):
 
         # (3) 5 steps spanning a grid update: replicas stay bit-identical
         start = tr.table.clone()
+        ro, rd = o[a:b].contiguous(), d[a:b].contiguous()
+        hits0 = tr.prefetch_hits
         for i in range(14, 19):
             if i % 16 == 0:
                 tr.update_density_grid(0.01 * 1024 / 3**0.5, warmup=False)
-            tr.step(o[a:b], d[a:b], target[a:b])                 # rank-local jitter noise, like bench.py
+            nxt = (ro, rd) if (i + 1) % 16 != 0 else None         # the next step's march prefetched under this step's exchange
+            tr.step(ro, rd, target[a:b], prefetch=nxt)            # (position 4; rank-local jitter noise, like bench.py)
         tr.sync_master()
+        assert tr.prefetch_hits - hits0 == 3 and tr._prefetch_at == 4      # steps 15, 17, 18 consumed the side-stream march
         assert not torch.equal(start, tr.table) and tr.counters()["opt_steps"] == 5
         items = {"table": tr.table, "mlp": tr.mlp_flat, "bits": tr.model.density_bitfield, "grid": tr.model.density_grid,
                  "wpack": tr.wpack.view(torch.int16).int(), "state_f": tr.state_f, "state_i": tr.state_i}
