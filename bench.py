@@ -49,6 +49,7 @@ TRAINER_KERNELS = {
     "ngp_hash_bwd_sliced_main": ("hash_bwd_f32", "hbm", 12 + 128 + 1024 + 1024, "live"),  # ... its main launch (what the trainer issues)
     "ngp_hash_bwd_sliced_prep": ("hash_bwd_prep", "hbm", 12 + 12 + 16 * 8, "live"),        # ... its prepass (in line, before the MLP backward)
     "ngp_hash_bwd_f16_live": ("hash_bwd_f16", "hbm", 12 + 128 + 512 + 512, "live"),
+    "ngp_hash_bwd_sliced_main_f16": ("hash_bwd_f16", "hbm", 12 + 128 + 512 + 512, "live"),    # half2 encoder, LDS-sliced form
     "ngp_adam_step": ("adam", "hbm", 32, "param"),
     "ngp_adam_all": ("adam", "hbm", 32, "param"),                                  # table pass (+ the MLP block riding along)
     "ngp_hash_fwd_f16_ex": ("hash_fwd_f16", "hbm", 12 + 512 + 128, "sample"),      # --half: 4-byte gathers, f32 output to the arena

@@ -200,6 +200,11 @@ int ngp_hash_bwd_sliced_prep(const float* xyzs, const ngp_hash_levels* lv, int n
 int ngp_hash_bwd_sliced_main(const float* dout, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev, int enc_pairs,
                              float* dtable, int32_t* found_inf, const void* workspace, long long workspace_bytes,
                              void* stream);
+/* the half2 encoder's backward (hash_encoder_half.py:163-213) over the same prepass: dtable_f16 = fp16 pairs [entries][2]; the
+ * encoder's fp16 arithmetic per contribution (cell cast to f16, w * g rounded to f16), the owner's f64 sum rounded to fp16 once */
+int ngp_hash_bwd_sliced_main_f16(const float* dout, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev, int enc_pairs,
+                                 uint16_t* dtable_f16, int32_t* found_inf, const void* workspace, long long workspace_bytes,
+                                 void* stream);
 /* diagnostics: per-block task word + wall-clock stamps into a device buffer of 8 * 1024 uint64 (NULL = off, the default) */
 int ngp_hash_bwd_sliced_debug(void* device_buffer);
 int ngp_hash_bwd_f32_sliced(const float* xyzs, const float* dout, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev,

@@ -227,9 +227,11 @@ struct __attribute__((packed, aligned(4))) F3 {
     float x, y, z;
 };
 
+__device__ __forceinline__ float round16(float v) { return (float)(_Float16)v; }                  // through fp16 (round to nearest even) and back
+
 __device__ __forceinline__ Hit load_hit(const int level, const int i, const bool valid, const float* __restrict__ xyzc,
                                         const float* __restrict__ dout, const size_t plane, const int enc_pairs, const int nl,
-                                        int32_t* __restrict__ found_inf, const uint32_t diag = 0u) {
+                                        int32_t* __restrict__ found_inf, const uint32_t diag = 0u, const bool half = false) {
     Hit h = {0.f, 0.f, 0.f, 0.f, 0.f};
 #ifdef NGP_BWD_DIAG
     if (diag & 2u) { const float t = (float)(i & 1023) * (1.0f / 1024.0f); h.x = t; h.y = 1.0f - t; h.z = 0.5f * t; h.g0 = 1.0f; h.g1 = t; return h; }
@@ -239,6 +241,7 @@ __device__ __forceinline__ Hit load_hit(const int level, const int i, const bool
         h.x = p.x; h.y = p.y; h.z = p.z;
         const float2 g = *reinterpret_cast<const float2*>(grad_ptr(dout, level, (size_t)i, plane, enc_pairs, nl));
         h.g0 = g.x; h.g1 = g.y;
+        if (half) { h.g0 = round16(h.g0); h.g1 = round16(h.g1); }      // half2 encoder: its output gradient is an fp16 tensor
     }
     return h;
 }
@@ -273,19 +276,25 @@ __device__ __forceinline__ void seg_step(float (&v0)[8], float (&v1)[8], int& hf
     }
 }
 
-enum { KIND_GENERIC = 0, KIND_HASHED = 1, KIND_MERGE = 2, KIND_MERGE0 = 3 };     // MERGE0: run pre-summing on a mode-0 dense level
+enum { KIND_GENERIC = 0, KIND_HASHED = 1, KIND_MERGE = 2, KIND_MERGE0 = 3,      // MERGE0: run pre-summing on a mode-0 dense level
+       KIND_HALF = 4 };   // | KIND_HALF: the half2 encoder's arithmetic (hash_encoder_half.py:133,205-208): cell cast to f16 before
+                          // the subtract, every w * g product rounded to f16; the owner's f64 sum is rounded to f16 once, at the flush
 
 // One batch of <= 64 hits (one per lane): accumulate this level's contributions that fall into slice `sl`.
 template <int KIND>
 __device__ __forceinline__ void accumulate(const LevelParams P, const uint32_t sl, const bool single, const Hit H, const bool valid,
                                            double* __restrict__ slice) {
+    constexpr bool HALF = (KIND & KIND_HALF) != 0;
+    constexpr int K = KIND & 3;
     const int lane = threadIdx.x & 63;
     float g0 = H.g0, g1 = H.g1;
     const float px = H.x * P.scale + 0.5f, py = H.y * P.scale + 0.5f, pz = H.z * P.scale + 0.5f;
     uint32_t cx = f2u_sat(floorf(px)), cy = f2u_sat(floorf(py)), cz = f2u_sat(floorf(pz));
-    const float fx = px - (float)cx, fy = py - (float)cy, fz = pz - (float)cz;
+    const float fx = px - (HALF ? round16((float)cx) : (float)cx), fy = py - (HALF ? round16((float)cy) : (float)cy),
+                fz = pz - (HALF ? round16((float)cz) : (float)cz);
+    auto R = [](float v) { return HALF ? round16(v) : v; };
     const bool act = valid && (g0 != 0.0f || g1 != 0.0f);           // exact-zero gradients contribute nothing
-    if (KIND == KIND_HASHED) {
+    if (K == KIND_HASHED) {
         // xor hash into a power-of-two table with res < 2^13: h = (gx ^ A) & mask, A = gy P1 ^ gz P2; gx < 2^13 cannot reach the
         // slice bits, so both x corners of a (y, z) combination share the slice, and two multiplies serve all four combinations
         const uint32_t msk = P.size - 1u;
@@ -306,13 +315,13 @@ __device__ __forceinline__ void accumulate(const LevelParams P, const uint32_t s
                 const float w0 = (wx0 * wy) * wz, w1 = (wx1 * wy) * wz;
                 double* p0 = slice + 2 * (((cx ^ A) & msk) & (BW_SLICE_ENTRIES - 1));
                 double* p1 = slice + 2 * ((((cx + 1u) ^ A) & msk) & (BW_SLICE_ENTRIES - 1));
-                LDS_ADD(p0, w0 * g0); LDS_ADD(p0 + 1, w0 * g1);
-                LDS_ADD(p1, w1 * g0); LDS_ADD(p1 + 1, w1 * g1);
+                LDS_ADD(p0, R(w0 * g0)); LDS_ADD(p0 + 1, R(w0 * g1));
+                LDS_ADD(p1, R(w1 * g0)); LDS_ADD(p1 + 1, R(w1 * g1));
             }
         }
         return;
     }
-    if (KIND == KIND_GENERIC) {
+    if (K == KIND_GENERIC) {
         if (act) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {                               // k = (z bit, y bit)
@@ -325,8 +334,8 @@ __device__ __forceinline__ void accumulate(const LevelParams P, const uint32_t s
                     if (slice_of(P.map, h, loc) == sl) {
                         const float w = ((1.0f * (xb ? fx : 1.0f - fx)) * wyz_y) * wyz_z;
                         double* p = slice + 2 * loc;
-                        LDS_ADD(p, w * g0);
-                        LDS_ADD(p + 1, w * g1);
+                        LDS_ADD(p, R(w * g0));
+                        LDS_ADD(p + 1, R(w * g1));
                     }
                 }
             }
@@ -342,7 +351,7 @@ __device__ __forceinline__ void accumulate(const LevelParams P, const uint32_t s
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
         const float w = ((1.0f * ((c & 1) ? fx : 1.0f - fx)) * (((c >> 1) & 1) ? fy : 1.0f - fy)) * ((c >> 2) ? fz : 1.0f - fz);
-        v0[c] = w * g0; v1[c] = w * g1;
+        v0[c] = R(w * g0); v1[c] = R(w * g1);
     }
     const uint32_t pcx = (uint32_t)row_shr_i<1>((int)cx, -1), pcy = (uint32_t)row_shr_i<1>((int)cy, -1), pcz = (uint32_t)row_shr_i<1>((int)cz, -1);
     const bool head = ((lane & 15) == 0) || !act || cx != pcx || cy != pcy || cz != pcz;
@@ -355,7 +364,7 @@ __device__ __forceinline__ void accumulate(const LevelParams P, const uint32_t s
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             uint32_t loc;
-            const uint32_t h = KIND == KIND_MERGE0 ? dense0_index(base, P.res, res2, P.size, c)
+            const uint32_t h = K == KIND_MERGE0 ? dense0_index(base, P.res, res2, P.size, c)
                                                    : level_index(P.dense, P.mode, P.size, P.res, cx + (c & 1), cy + ((c >> 1) & 1), cz + (c >> 2));
             if (slice_of(P.map, h, loc) == sl) {
                 double* p = slice + 2 * loc;
@@ -374,11 +383,12 @@ struct Batch {
 
 __device__ __forceinline__ Batch load_batch(const int level, const int i0, const bool v0, const int i1, const bool v1,
                                             const float* __restrict__ xyzc, const float* __restrict__ dout, const size_t plane,
-                                            const int enc_pairs, const int nl, int32_t* __restrict__ found_inf, const uint32_t diag) {
+                                            const int enc_pairs, const int nl, int32_t* __restrict__ found_inf, const uint32_t diag,
+                                            const bool half) {
     Batch b;
     b.v0 = v0; b.v1 = v1;
-    b.h0 = load_hit(level, i0, v0, xyzc, dout, plane, enc_pairs, nl, found_inf, diag);
-    b.h1 = load_hit(level, i1, v1, xyzc, dout, plane, enc_pairs, nl, found_inf, diag);
+    b.h0 = load_hit(level, i0, v0, xyzc, dout, plane, enc_pairs, nl, found_inf, diag, half);
+    b.h1 = load_hit(level, i1, v1, xyzc, dout, plane, enc_pairs, nl, found_inf, diag, half);
     return b;
 }
 
@@ -403,6 +413,8 @@ __device__ __forceinline__ void bwd_task(const LevelParams P, const int level, c
                                          const unsigned long long* __restrict__ brow, const float* __restrict__ dout,
                                          const size_t plane, const int enc_pairs, const int nl, double* __restrict__ slice,
                                          uint32_t* __restrict__ q, uint32_t* __restrict__ next_sc, int32_t* __restrict__ found_inf) {
+    constexpr bool HALF = (KIND & KIND_HALF) != 0;
+    constexpr int K = KIND & 3;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // this replica's sample range in 64-sample words, whole 8-word chunks
@@ -416,7 +428,7 @@ __device__ __forceinline__ void bwd_task(const LevelParams P, const int level, c
     if (single) {
         for (int w0 = lo_w + 2 * wave; w0 < hi_w; w0 += 2 * BW_WAVES) {
             const int i0 = w0 * 64 + lane, i1 = i0 + 64;
-            const Batch nxt = load_batch(level, i0, i0 < n, i1, (w0 + 1 < hi_w) && i1 < n, xyzc, dout, plane, enc_pairs, nl, found_inf, P.diag);
+            const Batch nxt = load_batch(level, i0, i0 < n, i1, (w0 + 1 < hi_w) && i1 < n, xyzc, dout, plane, enc_pairs, nl, found_inf, P.diag, HALF);
             accumulate_batch<KIND>(P, sl, true, pend, slice, found_inf);
             pend = nxt;
         }
@@ -430,7 +442,7 @@ __device__ __forceinline__ void bwd_task(const LevelParams P, const int level, c
     // hits (dense levels: ~2 of ns slices per sample, replicated over short sample ranges -- a 4096-sample chunk would leave
     // most of the 16 waves idle there, a 256-sample chunk of a 32-slice level would be one exposed load latency per 25 hits).
     int SCW = 64;
-    if (KIND == KIND_MERGE || KIND == KIND_MERGE0) { SCW = 4; while (SCW < 64 && SCW < 2 * (int)P.map.ns) SCW <<= 1; }
+    if (K == KIND_MERGE || K == KIND_MERGE0) { SCW = 4; while (SCW < 64 && SCW < 2 * (int)P.map.ns) SCW <<= 1; }
     const int n_sc = (hi_w - lo_w + SCW - 1) / SCW;
     auto load_words = [&](int c) -> unsigned long long {
         const int w = lo_w + c * SCW + lane;
@@ -445,7 +457,7 @@ __device__ __forceinline__ void bwd_task(const LevelParams P, const int level, c
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         const int i0 = (int)q[(qhead + lane) & (BW_Q - 1)], i1 = (int)q[(qhead + 64 + lane) & (BW_Q - 1)];
-        const Batch nxt = load_batch(level, i0, true, i1, true, xyzc, dout, plane, enc_pairs, nl, found_inf, P.diag);
+        const Batch nxt = load_batch(level, i0, true, i1, true, xyzc, dout, plane, enc_pairs, nl, found_inf, P.diag, HALF);
         accumulate_batch<KIND>(P, sl, false, pend, slice, found_inf);
         pend = nxt;
         __builtin_amdgcn_wave_barrier();
@@ -457,7 +469,7 @@ __device__ __forceinline__ void bwd_task(const LevelParams P, const int level, c
         const int sc_next = grab();
         const unsigned long long nxtw = load_words(sc_next);
         const int wbase = lo_w + sc * SCW;
-        if (KIND == KIND_MERGE || KIND == KIND_MERGE0) {
+        if (K == KIND_MERGE || K == KIND_MERGE0) {
             // word-serial: hits enter the queue in sample order (the run pre-summing needs consecutive samples in consecutive
             // lanes); these levels have few slices, so most bits are set and a word's ~30 instructions buy ~64 hits
             unsigned long long nonzero = __ballot(cur != 0ull);                // which of the 64 words have any hit
@@ -529,7 +541,7 @@ __device__ __forceinline__ void bwd_task(const LevelParams P, const int level, c
         __builtin_amdgcn_wave_barrier();
         const bool v0 = lane < qlen, v1 = lane + 64 < qlen;
         const int i0 = v0 ? (int)q[(qhead + lane) & (BW_Q - 1)] : 0, i1 = v1 ? (int)q[(qhead + 64 + lane) & (BW_Q - 1)] : 0;
-        const Batch nxt = load_batch(level, i0, v0, i1, v1, xyzc, dout, plane, enc_pairs, nl, found_inf, P.diag);
+        const Batch nxt = load_batch(level, i0, v0, i1, v1, xyzc, dout, plane, enc_pairs, nl, found_inf, P.diag, HALF);
         accumulate_batch<KIND>(P, sl, false, pend, slice, found_inf);
         pend = nxt;
     }
@@ -561,12 +573,14 @@ __device__ __forceinline__ uint32_t claim_task(const BwdPlan& plan, uint32_t* __
     return 0xffffffffu;
 }
 
+template <bool HALF>
 __global__ void __launch_bounds__(BW_THREADS) hash_bwd_lds_kernel(const float* __restrict__ xyzc,
                                                                   const unsigned long long* __restrict__ bitmap, size_t wstride,
                                                                   const float* __restrict__ dout, ngp_hash_levels lv, int n,
                                                                   const int32_t* __restrict__ n_dev, int enc_pairs, BwdPlan plan,
-                                                                  float* __restrict__ dtable, int32_t* __restrict__ found_inf,
-                                                                  uint32_t* __restrict__ ctr, unsigned long long* __restrict__ dbg) {
+                                                                  void* __restrict__ dtable /* f32 pairs; HALF: f16 pairs */,
+                                                                  int32_t* __restrict__ found_inf, uint32_t* __restrict__ ctr,
+                                                                  unsigned long long* __restrict__ dbg) {
     __shared__ double slice[2 * BW_SLICE_ENTRIES];
     __shared__ uint32_t queues[BW_WAVES * BW_Q];
     __shared__ uint32_t next_sc;
@@ -611,10 +625,10 @@ __global__ void __launch_bounds__(BW_THREADS) hash_bwd_lds_kernel(const float* _
     if (dbg) t_init = wall_clock64();
     uint32_t* q = queues + (tid >> 6) * BW_Q;
     const unsigned long long* brow = bitmap + ((size_t)level * BW_MAX_SLICES + sl) * wstride;
-    if (merge && P.dense && P.mode == 0u) bwd_task<KIND_MERGE0>(P, level, sl, single, n, rep, nrep, xyzc, brow, dout, plane, enc_pairs, lv.n_levels, slice, q, &next_sc, found_inf);
-    else if (merge) bwd_task<KIND_MERGE>(P, level, sl, single, n, rep, nrep, xyzc, brow, dout, plane, enc_pairs, lv.n_levels, slice, q, &next_sc, found_inf);
-    else if (hashed) bwd_task<KIND_HASHED>(P, level, sl, single, n, rep, nrep, xyzc, brow, dout, plane, enc_pairs, lv.n_levels, slice, q, &next_sc, found_inf);
-    else bwd_task<KIND_GENERIC>(P, level, sl, single, n, rep, nrep, xyzc, brow, dout, plane, enc_pairs, lv.n_levels, slice, q, &next_sc, found_inf);
+    if (merge && P.dense && P.mode == 0u) bwd_task<KIND_MERGE0 | (HALF ? KIND_HALF : 0)>(P, level, sl, single, n, rep, nrep, xyzc, brow, dout, plane, enc_pairs, lv.n_levels, slice, q, &next_sc, found_inf);
+    else if (merge) bwd_task<KIND_MERGE | (HALF ? KIND_HALF : 0)>(P, level, sl, single, n, rep, nrep, xyzc, brow, dout, plane, enc_pairs, lv.n_levels, slice, q, &next_sc, found_inf);
+    else if (hashed) bwd_task<KIND_HASHED | (HALF ? KIND_HALF : 0)>(P, level, sl, single, n, rep, nrep, xyzc, brow, dout, plane, enc_pairs, lv.n_levels, slice, q, &next_sc, found_inf);
+    else bwd_task<KIND_GENERIC | (HALF ? KIND_HALF : 0)>(P, level, sl, single, n, rep, nrep, xyzc, brow, dout, plane, enc_pairs, lv.n_levels, slice, q, &next_sc, found_inf);
     unsigned long long t_wave = 0;
     if (dbg) t_wave = wall_clock64();
     __syncthreads();
@@ -623,7 +637,22 @@ __global__ void __launch_bounds__(BW_THREADS) hash_bwd_lds_kernel(const float* _
     // flush: the slice owner rounds its f64 image to f32 and adds it into the table gradient -- plain (non-atomic)
     // read-modify-write when it is the only replica, float atomics (coalesced, a few thousand lines) when the level is
     // replicated over sample ranges
-    float2* dl = reinterpret_cast<float2*>(dtable + 2 * (size_t)P.offset);
+    if (HALF) {
+        // half2 encoder: the gradient table is fp16 pairs (hash_encoder_half.py:291-306); the f64 sum is rounded to fp16 here, once
+        typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+        half2v* dh = reinterpret_cast<half2v*>(dtable) + P.offset;
+        for (int j = tid; j < BW_SLICE_ENTRIES; j += BW_THREADS) {
+            const double2 a = s2[j];
+            if (a.x == 0.0 && a.y == 0.0) continue;
+            const uint32_t h = entry_of(P.map, sl, (uint32_t)j);
+            half2v val;
+            val.x = (_Float16)(float)a.x; val.y = (_Float16)(float)a.y;
+            if (nrep == 1) dh[h] = dh[h] + val;
+            else if (!(val.x == (_Float16)0 && val.y == (_Float16)0))
+                __builtin_amdgcn_global_atomic_fadd_v2f16((__attribute__((address_space(1))) half2v*)(dh + h), val);
+        }
+    } else {
+    float2* dl = reinterpret_cast<float2*>(reinterpret_cast<float*>(dtable) + 2 * (size_t)P.offset);
     for (int j = tid; j < BW_SLICE_ENTRIES; j += BW_THREADS) {
         const double2 a = s2[j];
         if (a.x == 0.0 && a.y == 0.0) continue;
@@ -638,6 +667,7 @@ __global__ void __launch_bounds__(BW_THREADS) hash_bwd_lds_kernel(const float* _
             if (vx != 0.0f) unsafeAtomicAdd(dp, vx);
             if (vy != 0.0f) unsafeAtomicAdd(dp + 1, vy);
         }
+    }
     }
     if (dbg) {          // diagnostics (ngp_hash_bwd_sliced_debug): 100 MHz wall-clock stamps per block + wave 0's own finish time
         if (tid == 0) {
@@ -802,8 +832,8 @@ int ngp_hash_bwd_sliced_prep(const float* xyzs, const ngp_hash_levels* lv, int n
     return 0;
 }
 
-int ngp_hash_bwd_sliced_main(const float* dout, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev, int enc_pairs, float* dtable,
-                             int32_t* found_inf, const void* workspace, long long workspace_bytes, void* stream) {
+static int sliced_main(bool half, const float* dout, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev, int enc_pairs,
+                       void* dtable, int32_t* found_inf, const void* workspace, long long workspace_bytes, void* stream) {
     if (n_max <= 0) return 0;
     if (enc_pairs && !(lv->n_features == 2 && lv->n_levels == 16)) return -1;
     if (!workspace || workspace_bytes < ngp_hash_bwd_sliced_workspace(lv, n_max)) return -1;
@@ -815,10 +845,27 @@ int ngp_hash_bwd_sliced_main(const float* dout, const ngp_hash_levels* lv, int n
     const float* xyzc = reinterpret_cast<const float*>(workspace);
     const unsigned long long* bitmap = reinterpret_cast<const unsigned long long*>(xyzc + ms * 3);
     uint32_t* ctr = reinterpret_cast<uint32_t*>(const_cast<unsigned long long*>(bitmap) + (size_t)lv->n_levels * BW_MAX_SLICES * (ms / 64));
-    hipLaunchKernelGGL(hash_bwd_lds_kernel, dim3(plan.n_blocks), dim3(BW_THREADS), 0, (hipStream_t)stream, xyzc, bitmap, ms / 64, dout, *lv,
-                       n_max, n_dev, enc_pairs, plan, dtable, found_inf, ctr, g_bwd_debug);
+    if (half)
+        hipLaunchKernelGGL(hash_bwd_lds_kernel<true>, dim3(plan.n_blocks), dim3(BW_THREADS), 0, (hipStream_t)stream, xyzc, bitmap, ms / 64,
+                           dout, *lv, n_max, n_dev, enc_pairs, plan, dtable, found_inf, ctr, g_bwd_debug);
+    else
+        hipLaunchKernelGGL(hash_bwd_lds_kernel<false>, dim3(plan.n_blocks), dim3(BW_THREADS), 0, (hipStream_t)stream, xyzc, bitmap, ms / 64,
+                           dout, *lv, n_max, n_dev, enc_pairs, plan, dtable, found_inf, ctr, g_bwd_debug);
     NGP_LAUNCH_CHECK();
     return 0;
+}
+
+int ngp_hash_bwd_sliced_main(const float* dout, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev, int enc_pairs, float* dtable,
+                             int32_t* found_inf, const void* workspace, long long workspace_bytes, void* stream) {
+    return sliced_main(false, dout, lv, n_max, n_dev, enc_pairs, dtable, found_inf, workspace, workspace_bytes, stream);
+}
+
+// the half2 encoder's backward (hash_encoder_half.py:163-213) on the same prepass: fp16 gradient table [entries][2], the
+// encoder's fp16 arithmetic per contribution, ONE rounding of the owner's f64 sum instead of one per atomic add
+int ngp_hash_bwd_sliced_main_f16(const float* dout, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev, int enc_pairs,
+                                 uint16_t* dtable_f16, int32_t* found_inf, const void* workspace, long long workspace_bytes,
+                                 void* stream) {
+    return sliced_main(true, dout, lv, n_max, n_dev, enc_pairs, dtable_f16, found_inf, workspace, workspace_bytes, stream);
 }
 
 int ngp_hash_bwd_f32_sliced(const float* xyzs, const float* dout, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev,

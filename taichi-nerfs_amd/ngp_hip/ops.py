@@ -228,6 +228,21 @@ def hash_bwd_f16(xyzs, dout_h, lv, dtable_h):
     return dtable_h
 
 
+def hash_bwd_f16_sliced(xyzs, dout, lv, dtable_h, live_idx=None, n_dev=None):
+    """dtable_h (fp16 [entries, 2]) += the half2 encoder's scatter-add of dout (fp32 [n, L*2], rounded to fp16 like the encoder's
+    output gradient) in the LDS-sliced formulation: prepass + ngp_hash_bwd_sliced_main_f16; xyzs in [0,1]."""
+    _dev(xyzs, torch.float32, "xyzs"); _dev(dout, torch.float32, "dout"); _dev(dtable_h, torch.float16, "dtable")
+    n = dout.shape[0]
+    ws = sliced_workspace(lv, n, xyzs.device)
+    L = _lib()
+    check(L.ngp_hash_bwd_sliced_prep(_ptr(xyzs), ctypes.byref(lv), n, _ptr(n_dev), _ptr(live_idx), 0, 0.0, 1.0, _ptr(ws), ws.numel(),
+                                     _stream()), "ngp_hash_bwd_sliced_prep")
+    check(L.ngp_hash_bwd_sliced_main_f16(_ptr(dout), ctypes.byref(lv), n, _ptr(n_dev), 0, _ptr(dtable_h), _ptr(None), _ptr(ws), ws.numel(),
+                                         _stream()), "ngp_hash_bwd_sliced_main_f16")
+    _touched(dtable_h)
+    return dtable_h
+
+
 # ---------------------------------------------------------------------------------------------------- a-6
 def sh16_fwd(dirs):
     _dev(dirs, torch.float32, "dirs")

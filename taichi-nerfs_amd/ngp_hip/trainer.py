@@ -58,8 +58,9 @@ class FusedTrainer:
         self.distortion_loss_w = float(distortion_loss_w)                # train.py:194-195 (0 = off, the reference default)
         # backward over the samples in front of each ray's early-termination point only (NGP_LIVE_BACKWARD=0: over all of them)
         self.live_backward = os.environ.get("NGP_LIVE_BACKWARD", "1") != "0"
-        # fp32 table gradient: "sliced" = LDS-owned table slices, no global float atomics (csrc/hash_bwd_lds.hip; the default
-        # whenever the level table fits: F = 2, levels of <= 2^19 entries), "atomic" = round 1's float-atomic kernel
+        # table gradient (fp32, or fp16 for the half2 encoder): "sliced" = LDS-owned table slices, no global float atomics
+        # (csrc/hash_bwd_lds.hip; the default whenever the level table fits: F = 2, levels of <= 2^19 entries), "atomic" = round
+        # 1's float-atomic / packed-f16-atomic kernels
         self.hash_bwd = os.environ.get("NGP_HASH_BWD", "sliced")
         self.group = process_group
         self.world = world_size if world_size is not None else (dist.get_world_size(process_group) if dist.is_initialized() else 1)
@@ -342,7 +343,7 @@ class FusedTrainer:
         # the scatter-add's prepass (hit bitmaps + compact positions; needs the positions and the live list only).  It used to run on
         # a second stream underneath the MLP backward, but the two share the VALU (87 us overlapped vs 43 alone) and the
         # cross-stream join cost 23 us between the prepass's end and the scatter-add's start: in line it is 17 us per step faster
-        sliced = (not self.half) and self.hash_bwd == "sliced"
+        sliced = self.hash_bwd == "sliced"          # (half2 encoder: same prepass, main pass with its fp16 arithmetic + fp16 table)
         if sliced:
             ws = A.sliced_ws(cfg.levels)
             rc = L.ngp_hash_bwd_sliced_prep(_ptr(M.xyzs), ctypes.byref(cfg.levels), A.cap, _ptr(cnt), _ptr(live_idx), 1, cfg.lo, cfg.hi,
@@ -355,7 +356,10 @@ class FusedTrainer:
                                  _ptr(live_idx), P, _ptr(A.d_enc), _ptr(self.mlp_grad), found, st), "ngp_mlp_bwd_live")
         if hook is not None and self._prefetch_at <= 3:
             hook(); hook = None                                             # position 3: under the scatter-add and the optimizer
-        if self.half:
+        if self.half and sliced:
+            check(L.ngp_hash_bwd_sliced_main_f16(_ptr(A.d_enc), ctypes.byref(cfg.levels), A.cap, _ptr(cnt), P, _ptr(self.table_grad), found,
+                                                 _ptr(ws), ws.numel(), st), "ngp_hash_bwd_sliced_main_f16")
+        elif self.half:
             check(L.ngp_hash_bwd_f16_live(_ptr(M.xyzs), _ptr(A.d_enc), ctypes.byref(cfg.levels), A.cap, _ptr(cnt), _ptr(live_idx), 1,
                                           cfg.lo, cfg.hi, P, _ptr(self.table_grad), found, st), "ngp_hash_bwd_f16_live")
         elif sliced:

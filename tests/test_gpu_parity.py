@@ -234,6 +234,49 @@ def test_hash_f16(oracle, hip_lib):
     np.testing.assert_allclose(got_g, ref_g, rtol=3e-2, atol=2e-3)
 
 
+def test_hash_bwd_f16_sliced(oracle, hip_lib):
+    """The half2 encoder's scatter-add in the LDS-sliced form (ngp_hash_bwd_sliced_main_f16): same support as the oracle; it sums
+    the fp16-rounded contributions exactly and rounds once, so it sits closer to the oracle (fp32 sum of the same contributions)
+    than the packed-f16-atomic kernel can: one fp16 ulp of the result."""
+    lv = ops.make_levels(2**19, 16, 16, 1024, 2)
+    rng = np.random.default_rng(5)
+    n_rays, per_ray = 700, 48
+    o = rng.random((n_rays, 1, 3), dtype=np.float32) * 0.8 + 0.1
+    d = rng.standard_normal((n_rays, 1, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    t = (np.arange(per_ray, dtype=np.float32) * np.float32(0.0017))[None, :, None]
+    x = np.clip(o + d * t, 0.0, 1.0).reshape(-1, 3).astype(np.float32)
+    x = np.concatenate([x, rng.random((7001, 3), dtype=np.float32)])
+    n = x.shape[0]
+    dout = (rng.standard_normal((n, 16, 2)) * 1e-2).astype(np.float32)
+    dout[::5] = 0
+    ref = oracle.hash_bwd_f16(x, dout.astype(np.float16), lv)
+    g = torch.zeros(lv.total_entries, 2, device="cuda", dtype=torch.float16)
+    ops.hash_bwd_f16_sliced(dev(x), dev(dout.reshape(n, 32)), lv, g)
+    got = g.float().cpu().numpy()
+    assert support_matches(ref, got)
+    # levels owned by ONE workgroup per slice (the hashed ones, 6..15 here): the exact sum, rounded once -- fp16's 2^-11 relative;
+    # the absolute floor is one fp16 ulp of a single summand (|w g| ~ 4e-3..8e-3 -> 3.8e-6..7.6e-6: 1 entry in 1e7 sees one
+    # contribution round the other way).  The coarse dense levels are replicated over sample ranges and their partial sums meet in packed fp16
+    # atomics (<= 63 of them per entry, where the reference's formulation has one per contribution): the f16-atomic tolerance
+    split = int(lv.offset[6])
+    np.testing.assert_allclose(got[split:], ref[split:], rtol=1.5e-3, atol=8e-6)
+    np.testing.assert_allclose(got[:split], ref[:split], rtol=3e-2, atol=2e-3)
+    g_at = torch.zeros(lv.total_entries, 2, device="cuda", dtype=torch.float16)
+    ops.hash_bwd_f16(dev(x), dev(dout.astype(np.float16)), lv, g_at)
+    err_sliced, err_atomic = np.abs(got - ref).max(), np.abs(g_at.float().cpu().numpy() - ref).max()
+    assert err_sliced <= 1.5 * err_atomic, (err_sliced, err_atomic)      # never worse than one packed-f16 atomic per contribution
+    # the live-list / device-count form
+    perm = rng.permutation(n).astype(np.int32)
+    m = n - 999
+    ref_live = oracle.hash_bwd_f16(x[perm[:m]], dout[:m].astype(np.float16), lv)
+    g2 = torch.zeros(lv.total_entries, 2, device="cuda", dtype=torch.float16)
+    ops.hash_bwd_f16_sliced(dev(x), dev(dout.reshape(n, 32)), lv, g2, live_idx=dev(perm), n_dev=torch.tensor([m], device="cuda", dtype=torch.int32))
+    got2 = g2.float().cpu().numpy()
+    np.testing.assert_allclose(got2[split:], ref_live[split:], rtol=1.5e-3, atol=8e-6)
+    np.testing.assert_allclose(got2[:split], ref_live[:split], rtol=3e-2, atol=2e-3)
+
+
 def test_sh16(oracle, hip_lib):
     rng = np.random.default_rng(3)
     d = rng.random((10000, 3), dtype=np.float32)
