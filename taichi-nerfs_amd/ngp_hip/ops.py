@@ -221,7 +221,21 @@ def hash_fwd_f16(xyzs, table_h, lv):
 
 
 def hash_bwd_f16(xyzs, dout_h, lv, dtable_h):
+    """The half2 encoder's scatter-add (hash_encoder_half.py:163-213).  Like hash_bwd_f32: large batches take the LDS-sliced
+    form (exact sum of the fp16 contributions, rounded once), small ones / unsupported tables the packed-f16-atomic kernel."""
     _dev(xyzs, torch.float32, "xyzs"); _dev(dout_h, torch.float16, "dout"); _dev(dtable_h, torch.float16, "dtable")
+    n = xyzs.shape[0]
+    if n >= SLICED_MIN_SAMPLES and os.environ.get("NGP_HASH_BWD", "sliced") != "atomic" and lv.n_features == 2:
+        ws = sliced_workspace(lv, n, xyzs.device)
+        L = _lib()
+        rc = L.ngp_hash_bwd_sliced_prep(_ptr(xyzs), ctypes.byref(lv), n, _ptr(None), _ptr(None), 0, 0.0, 1.0, _ptr(ws), ws.numel(), _stream())
+        if rc != -2:
+            check(rc, "ngp_hash_bwd_sliced_prep")
+            dout = dout_h.float().reshape(n, -1).contiguous()          # fp16 -> fp32 is exact; the kernel rounds back (a no-op)
+            check(L.ngp_hash_bwd_sliced_main_f16(_ptr(dout), ctypes.byref(lv), n, _ptr(None), 0, _ptr(dtable_h), _ptr(None), _ptr(ws),
+                                                 ws.numel(), _stream()), "ngp_hash_bwd_sliced_main_f16")
+            _touched(dtable_h)
+            return dtable_h
     check(_lib().ngp_hash_bwd_f16(_ptr(xyzs), _ptr(dout_h), ctypes.byref(lv), xyzs.shape[0], _ptr(dtable_h), _stream()),
           "ngp_hash_bwd_f16")
     _touched(dtable_h)
