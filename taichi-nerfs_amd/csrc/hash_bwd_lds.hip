@@ -48,7 +48,6 @@ constexpr int BW_WAVES = BW_THREADS / 64;
 constexpr int BW_Q = 256;                                      // per-wave hit queue (entries)
 constexpr int BW_MAX_TASKS = 1536;
 constexpr int BW_PREP_BLOCKS = 2048;
-constexpr uint16_t BW_NULL_TASK = 0xffffu;
 constexpr size_t BW_CTR_BYTES = 64;                           // 8 queue heads + the exit counter of the main kernel
 constexpr int BW_PERSISTENT_BLOCKS = 256;                     // one 1024-thread workgroup (147 KB of LDS) per CU
 
