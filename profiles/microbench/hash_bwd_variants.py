@@ -49,6 +49,9 @@ def main():
     M = tr._march_sets(n)[1 - tr._cur]                      # the set the last step shaded
     cfg = RenderConfig(model, 0.0, 1e-4, 1024)
     live, total = int(tr._live_total[0]), int(M.total[0])
+    if os.environ.get("NGP_VARIANTS_FRACTION"):             # only the first fraction of the live list: T(n) vs T(n / 2) gives the
+        tr._live_total[0] = int(live * float(os.environ["NGP_VARIANTS_FRACTION"]))     # per-task cost that does not scale with hits
+        live = int(tr._live_total[0])
     print("live samples %d, marched %d" % (live, total))
     lv = cfg.levels
     grad = torch.zeros_like(tr.table)

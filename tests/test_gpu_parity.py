@@ -3,6 +3,8 @@
 Bars: bit-exact for everything integer / indexing / orbit (ray-AABB, march counts and samples, Morton, packbits,
 hash corner selection via exact forward equality); tolerance-checked for reductions whose order differs
 (compositing wave-scan: 1e-5 rel; hash backward atomics: 1e-5 rel)."""
+import ctypes
+
 import numpy as np
 import pytest
 import torch
@@ -178,6 +180,53 @@ def test_hash_bwd_f32_sliced(oracle, hip_lib, max_res):
     dt3 = torch.zeros(lv.total_entries * 2, device="cuda")
     ops.hash_bwd_f32(dev(x), dev(dout), lv, dt3)
     np.testing.assert_allclose(got, dt3.cpu().numpy(), rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("n", [1, 63, 65, 4097])
+def test_hash_bwd_f32_sliced_ragged_sizes(oracle, hip_lib, n):
+    """Sample counts that are not multiples of the 64-sample bitmap word / the 4096-sample super-chunk, down to one sample."""
+    lv = ops.make_levels(2**19, 16, 16, 1024, 2)
+    rng = np.random.default_rng(100 + n)
+    x = rng.random((n, 3), dtype=np.float32)
+    dout = rng.standard_normal((n, 32)).astype(np.float32)
+    ref = oracle.hash_bwd_f32(x, dout, lv)
+    dt = torch.zeros(lv.total_entries * 2, device="cuda")
+    ops.hash_bwd_f32_sliced(dev(x), dev(dout), lv, dt)
+    got = dt.cpu().numpy()
+    assert support_matches(ref, got)
+    np.testing.assert_allclose(got, ref, rtol=2e-5, atol=2e-5)
+
+
+def test_hash_bwd_f32_sliced_empty_and_flags(oracle, hip_lib):
+    """Device-side count 0 (every ray terminated at once / no ray hit the box): nothing is added, nothing hangs -- also right
+    after a non-empty launch (the persistent workgroups' queue heads reset themselves).  A non-finite gradient raises the
+    GradScaler flag, and only then."""
+    lv = ops.make_levels(2**19, 16, 16, 1024, 2)
+    rng = np.random.default_rng(7)
+    n = 3000
+    x, dout = dev(rng.random((n, 3), dtype=np.float32)), dev(rng.standard_normal((n, 32)).astype(np.float32))
+    L = ops._lib()
+    ws = ops.sliced_workspace(lv, n, x.device)
+    flag = torch.zeros(1, device="cuda", dtype=torch.int32)
+
+    def run(count, d):
+        dt = torch.zeros(lv.total_entries * 2, device="cuda")
+        cnt = torch.tensor([count], device="cuda", dtype=torch.int32)
+        rc = L.ngp_hash_bwd_f32_sliced(ops._ptr(x), ops._ptr(d), ctypes.byref(lv), n, ops._ptr(cnt), ops._ptr(None), 0, 0.0, 1.0, 0,
+                                       ops._ptr(dt), ops._ptr(flag), ops._ptr(ws), ws.numel(), ops._stream())
+        assert rc == 0
+        return dt
+    assert float(run(0, dout).abs().max()) == 0.0 and int(flag) == 0
+    full = run(n, dout)
+    assert float(full.abs().max()) > 0 and int(flag) == 0
+    assert float(run(0, dout).abs().max()) == 0.0
+    again = run(n, dout)
+    np.testing.assert_allclose(again.cpu().numpy(), full.cpu().numpy(), rtol=1e-6, atol=1e-7)
+    bad = dout.clone(); bad[1234, 7] = float("inf")
+    run(n, bad)
+    assert int(flag) == 1
+    assert L.ngp_hash_bwd_f32_sliced(ops._ptr(x), ops._ptr(dout), ctypes.byref(lv), 0, ops._ptr(None), ops._ptr(None), 0, 0.0, 1.0, 0,
+                                     ops._ptr(full), ops._ptr(None), ops._ptr(ws), ws.numel(), ops._stream()) == 0     # n_max = 0: no-op
 
 
 def test_hash_bwd_operator_dispatch(oracle, hip_lib, monkeypatch):
