@@ -205,6 +205,10 @@ int ngp_hash_bwd_sliced_main(const float* dout, const ngp_hash_levels* lv, int n
 int ngp_hash_bwd_sliced_main_f16(const float* dout, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev, int enc_pairs,
                                  uint16_t* dtable_f16, int32_t* found_inf, const void* workspace, long long workspace_bytes,
                                  void* stream);
+/* host-side introspection of the task plan (no GPU): tasks[k] = level | slice << 4 | replica << 10; XCD x owns
+ * tasks[xoff[x] .. xoff[x] + xlen[x]); returns the number of tasks or -2 when the level table cannot be expressed */
+int ngp_hash_bwd_sliced_plan(const ngp_hash_levels* lv, uint16_t* tasks, int max_tasks, uint16_t* xoff /*[8]*/, uint16_t* xlen /*[8]*/,
+                             uint8_t* nrep /*[NGP_MAX_LEVELS]*/, uint32_t* merge_mask, uint32_t* single_mask);
 /* diagnostics: per-block task word + wall-clock stamps into a device buffer of 8 * 1024 uint64 (NULL = off, the default) */
 int ngp_hash_bwd_sliced_debug(void* device_buffer);
 int ngp_hash_bwd_f32_sliced(const float* xyzs, const float* dout, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev,

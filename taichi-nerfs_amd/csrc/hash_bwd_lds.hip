@@ -801,6 +801,25 @@ extern "C" {
 // stamps (begin, after LDS init, wave 0 done, all waves done, after flush), its XCC id and the sample count
 int ngp_hash_bwd_sliced_debug(void* device_buffer) { g_bwd_debug = (unsigned long long*)device_buffer; return 0; }
 
+// host-side introspection (no GPU needed; tests/test_sliced_plan.py): the task plan the main launch would use for this level
+// table.  tasks[k] = level | slice << 4 | replica << 10 for k < return value; XCD x owns tasks[xoff[x] .. xoff[x] + xlen[x]);
+// nrep[l] = sample-range replicas per slice of level l; bit l of *merge_mask = run pre-summing on level l; bit l of
+// *single_mask = one-slice level (no bitmap).  Returns the number of tasks, or -2 when the table cannot be expressed.
+int ngp_hash_bwd_sliced_plan(const ngp_hash_levels* lv, uint16_t* tasks, int max_tasks, uint16_t* xoff, uint16_t* xlen, uint8_t* nrep,
+                             uint32_t* merge_mask, uint32_t* single_mask) {
+    if (!lv) return -1;
+    static thread_local BwdPlan plan;
+    uint32_t sm = 0;
+    if (!build_plan(*lv, plan, sm)) return -2;
+    int total = 0;
+    for (int x = 0; x < 8; ++x) { total += plan.xlen[x]; if (xoff) xoff[x] = plan.xoff[x]; if (xlen) xlen[x] = plan.xlen[x]; }
+    if (tasks) for (int k = 0; k < total && k < max_tasks; ++k) tasks[k] = plan.task[k];
+    if (nrep) for (int l = 0; l < NGP_MAX_LEVELS; ++l) nrep[l] = plan.nrep[l];
+    if (merge_mask) *merge_mask = plan.merge_mask;
+    if (single_mask) *single_mask = sm;
+    return total;
+}
+
 // bytes of scratch the sliced scatter-add needs for buffers of n_max samples: compact positions + one hit bit per
 // (level, slice, sample)
 long long ngp_hash_bwd_sliced_workspace(const ngp_hash_levels* lv, int n_max) {

@@ -1,0 +1,75 @@
+"""Host logic of the LDS-sliced scatter-add (csrc/hash_bwd_lds.hip: build_plan), no GPU: the task plan covers every
+(level, slice, sample-range replica) exactly once, the per-XCD queues tile the task array, the level classes (one-slice levels,
+run pre-summing, replication) follow the level table -- for the C2 table, the C3 one (max_res 4096), a small table and tables the
+formulation cannot express."""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "taichi-nerfs_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+from ngp_hip import lib, ops  # noqa: E402
+
+SLICE = 8192
+
+
+def plan_of(lv):
+    L = lib.load()
+    tasks = np.zeros(1536, np.uint16)
+    xoff, xlen = np.zeros(8, np.uint16), np.zeros(8, np.uint16)
+    nrep = np.zeros(16, np.uint8)
+    mm, sm = ctypes.c_uint32(0), ctypes.c_uint32(0)
+    n = L.ngp_hash_bwd_sliced_plan(ctypes.byref(lv), tasks.ctypes.data_as(ctypes.c_void_p), tasks.size,
+                                   xoff.ctypes.data_as(ctypes.c_void_p), xlen.ctypes.data_as(ctypes.c_void_p),
+                                   nrep.ctypes.data_as(ctypes.c_void_p), ctypes.byref(mm), ctypes.byref(sm))
+    return n, tasks, xoff, xlen, nrep, mm.value, sm.value
+
+
+@pytest.mark.parametrize("log2_t,max_res", [(19, 1024), (19, 4096), (14, 512), (21, 2048)])
+def test_plan_covers_every_slice_replica_once(log2_t, max_res):
+    lv = ops.make_levels(2**log2_t, 16, 16, max_res, 2)
+    n, tasks, xoff, xlen, nrep, merge_mask, single_mask = plan_of(lv)
+    sizes = [int(lv.map_size[l]) for l in range(16)]
+    if max(sizes) > 64 * SLICE:                                  # a level of more than 64 slices: not expressible
+        assert n == -2
+        return
+    ns = [(s + SLICE - 1) // SLICE for s in sizes]
+    assert n == sum(a * int(b) for a, b in zip(ns, nrep)) and 0 < n <= 1536
+    seen = set()
+    for t in tasks[:n]:
+        level, sl, rep = int(t) & 0xf, (int(t) >> 4) & 0x3f, (int(t) >> 10) & 0x3f
+        assert sl < ns[level] and rep < nrep[level]
+        assert (level, sl, rep) not in seen
+        seen.add((level, sl, rep))
+    assert len(seen) == n
+    # the eight XCD queues tile the task array
+    assert int(xoff[0]) == 0 and int(xlen.sum()) == n
+    for x in range(7):
+        assert int(xoff[x + 1]) == int(xoff[x]) + int(xlen[x])
+    # no XCD is left without work, none holds more than twice its share
+    assert int(xlen.min()) > 0 and int(xlen.max()) <= 2 * ((n + 7) // 8) + 32
+    bfhl = int(lv.begin_fast_hash_level)
+    for l in range(16):
+        assert bool((single_mask >> l) & 1) == (ns[l] == 1)
+        if (merge_mask >> l) & 1:
+            assert l < bfhl and int(lv.resolution[l]) <= 128     # run pre-summing: dense coarse levels only
+        if l >= bfhl and ns[l] == 64:
+            assert nrep[l] == 1                                   # a full hashed level: one owner per slice
+        if l < bfhl and ns[l] > 1:
+            assert nrep[l] >= 4                                   # dense slices follow the scene: never fewer than 4 sample ranges
+    # a level's owners sit together inside an XCD queue (they share position / gradient lines in that XCD's L2)
+    for x in range(8):
+        q = [int(t) & 0xf for t in tasks[int(xoff[x]):int(xoff[x]) + int(xlen[x])]]
+        runs = sum(1 for i in range(1, len(q)) if q[i] != q[i - 1]) + 1
+        assert runs <= len(set(q)) + 2, (x, q)
+
+
+def test_plan_refuses_other_feature_counts():
+    lv = ops.make_levels(2**19, 16, 16, 1024, 4)
+    assert plan_of(lv)[0] == -2
