@@ -123,14 +123,27 @@ def main():
         med, best = timeit(sliced, 5)
         print("sliced level %2d only: median %.1f us" % (l, med))
     os.environ["NGP_BWD_LEVELS"] = "0xffffffff"
-    for rep_t in (64,):
-        for merge in (128,):
-            os.environ["NGP_BWD_REP_TARGET"] = str(rep_t); os.environ["NGP_BWD_MERGE_RES"] = str(merge)
-            grad.zero_(); assert sliced() == 0
-            err = float((grad - ref).abs().max() / ref.abs().max())
-            med, best = timeit(sliced, args.reps)
-            out["variants"]["sliced rep_target=%d merge_res=%d" % (rep_t, merge)] = {"median_us": med, "min_us": best, "max_rel_err_vs_atomic": err}
-            print("sliced rep_target=%2d merge_res=%3d: median %.1f us  min %.1f us   max|d|/max|ref| %.2e" % (rep_t, merge, med, best, err))
+    sweep = os.environ.get("NGP_VARIANTS_SWEEP")           # plan knobs: "rep=32,64;merge=64,128;dmin=2,4"
+    knobs = {"rep": [64], "merge": [128], "dmin": [4]}
+    if sweep:
+        for part in sweep.split(";"):
+            k, v = part.split("=")
+            knobs[k] = [int(x) for x in v.split(",")]
+    for rep_t in knobs["rep"]:
+        for merge in knobs["merge"]:
+            for dmin in knobs["dmin"]:
+                os.environ["NGP_BWD_REP_TARGET"] = str(rep_t); os.environ["NGP_BWD_MERGE_RES"] = str(merge)
+                os.environ["NGP_BWD_DENSE_MIN_REP"] = str(dmin)
+                grad.zero_()
+                if sliced() != 0:
+                    print("sliced rep_target=%2d merge_res=%3d dense_min_rep=%d: plan not expressible" % (rep_t, merge, dmin))
+                    continue
+                err = float((grad - ref).abs().max() / ref.abs().max())
+                med, best = timeit(sliced, args.reps)
+                out["variants"]["sliced rep_target=%d merge_res=%d dense_min_rep=%d" % (rep_t, merge, dmin)] = {
+                    "median_us": med, "min_us": best, "max_rel_err_vs_atomic": err}
+                print("sliced rep_target=%2d merge_res=%3d dense_min_rep=%d: median %.1f us  min %.1f us   max|d|/max|ref| %.2e" % (
+                    rep_t, merge, dmin, med, best, err))
     print(json.dumps(out))
 
 

@@ -688,18 +688,16 @@ __global__ void __launch_bounds__(BW_THREADS) hash_bwd_lds_kernel(const float* _
 
 // ---- host: the task plan -------------------------------------------------------------------------------------------------
 // Returns false when the level table does not fit the formulation (F != 2, or a level of more than 64 slices).
-static bool build_plan(const ngp_hash_levels& lv, BwdPlan& plan, uint32_t& single_mask) {
+static bool build_plan_with(const ngp_hash_levels& lv, BwdPlan& plan, uint32_t& single_mask, int dense_min_rep) {
     if (lv.n_features != 2 || lv.n_levels < 1 || lv.n_levels > NGP_MAX_LEVELS) return false;
     struct Lvl { int level, n_slices, nrep, tasks; };
     Lvl lvls[NGP_MAX_LEVELS];
     single_mask = 0u;
     plan.merge_mask = 0u;
-    int rep_target = 64;                  // a replicated level gets ~ rep_target tasks (see the replica comment below)
+    int rep_target = 48;                  // a replicated level gets ~ rep_target tasks (see the replica comment below)
     if (const char* e = getenv("NGP_BWD_REP_TARGET")) rep_target = atoi(e) > 0 ? atoi(e) : rep_target;
     int merge_res = 128;                  // pre-sum equal-cell runs on levels up to this resolution
     if (const char* e = getenv("NGP_BWD_MERGE_RES")) merge_res = atoi(e);
-    int dense_min_rep = 4;
-    if (const char* e = getenv("NGP_BWD_DENSE_MIN_REP")) dense_min_rep = atoi(e) > 0 ? atoi(e) : dense_min_rep;
     uint32_t level_mask = 0xffffffffu;    // diagnostics (profiles/microbench/hash_bwd_variants.py): only these levels' tasks
     if (const char* e = getenv("NGP_BWD_LEVELS")) level_mask = (uint32_t)strtoul(e, nullptr, 0);
     for (int l = 0; l < lv.n_levels; ++l) {
@@ -787,6 +785,17 @@ static bool build_plan(const ngp_hash_levels& lv, BwdPlan& plan, uint32_t& singl
     }
     plan.n_blocks = nb < BW_PERSISTENT_BLOCKS ? nb : BW_PERSISTENT_BLOCKS;
     return true;
+}
+
+// rep_target 48 / at least 8 sample ranges per dense slice: 252 us against 261 us at 64 / 4 (prepass + main, 390 k live samples; sweep
+// in profiles/r02_hash_bwd_timeline.txt) -- 25 us dense tasks pack better behind the 45 us hashed ones than 50 us ones.  A level
+// table whose plan would not fit the task array gets fewer ranges rather than the float-atomic fallback.
+static bool build_plan(const ngp_hash_levels& lv, BwdPlan& plan, uint32_t& single_mask) {
+    int dense_min_rep = 8;
+    if (const char* e = getenv("NGP_BWD_DENSE_MIN_REP")) dense_min_rep = atoi(e) > 0 ? atoi(e) : dense_min_rep;
+    for (; dense_min_rep >= 1; dense_min_rep >>= 1)
+        if (build_plan_with(lv, plan, single_mask, dense_min_rep)) return true;
+    return false;
 }
 
 }  // namespace ngp
