@@ -396,6 +396,13 @@ def main():
         fence()
         t_cond = time.perf_counter() - t0
         base = args.condition
+    if not os.environ.get("NGP_BENCH_KEEP_GC"):
+        # a generation-2 pass of the cyclic collector over the process's long-lived objects takes 36 ms here (measured with
+        # --step-trace), 55 steps' worth; where the next one lands depends on the allocation count so far.  Collect now and freeze
+        # the survivors so a 20-step timed region cannot contain one (young passes: 0.02-0.6 ms) -- BEFORE the warm-up steps, so
+        # that the GPU does not sit idle for those 36 ms right in front of the timed region
+        gc.collect()
+        gc.freeze()
     state["k"] = 0
     for i in range(base, base + args.warmup):
         # warm-up steps are the timed steps, sample-count logging included: the first torch reduction of a process loads its
@@ -418,12 +425,6 @@ def main():
             else:
                 gc_log.append((info["generation"], (time.perf_counter() - _s[0]) * 1e3, len(trace)))
         gc.callbacks.append(_gc_cb)
-    if not os.environ.get("NGP_BENCH_KEEP_GC"):
-        # a generation-2 pass of the cyclic collector over the process's long-lived objects takes 36 ms here (measured with
-        # --step-trace: the collect() below), 55 steps' worth; where the next one lands depends on the allocation count so far.
-        # Collect now and freeze the survivors so a 20-step timed region cannot contain one (young passes: 0.02-0.6 ms).
-        gc.collect()
-        gc.freeze()
     t0 = time.perf_counter()
     for i in range(base + args.warmup, base + args.warmup + args.steps):
         if trace is not None:                                   # (diagnostic: one event + one host stamp per step)
