@@ -7,6 +7,10 @@ from ngp_hip import ops as _ops
 
 def distortion_loss(results):
     """results: the dictionary render() returns in training mode. -> per-ray loss [N_rays]."""
+    if hasattr(results, 'padded'):
+        # fused training render (rendering.TrainResults): the per-sample rows are read in place from its arena -- rays_a addresses
+        # them exactly like the reference's [S] tensors -- so no host read of the sample count is needed
+        return DistortionLoss.apply(results.padded('ws'), results.padded('deltas'), results.padded('ts'), results['rays_a'])
     return DistortionLoss.apply(results['ws'], results['deltas'], results['ts'], results['rays_a'])
 
 

@@ -13,6 +13,57 @@ MAX_SAMPLES = 1024
 NEAR_DISTANCE = 0.01
 
 
+class TrainResults(dict):
+    """Result dictionary of the fused training render.  The reference returns `deltas`, `ts`, `ws` as fresh [S] tensors
+    (S = rm_samples, rendering.py:181-215); the fused render keeps them in its N*MAX_SAMPLES-row arena and never reads S back
+    to the host.  Reading one of the three through the mapping protocol materialises exactly what the reference returns --
+    a [S] copy (one host read of S, paid only by a caller that asks; `ws` stays attached to the autograd graph) -- which the
+    next render() can no longer overwrite.  This package's own distortion loss reads the arena rows in place (`padded()`):
+    `rays_a` addresses them identically, so train.py with --distortion_loss_w > 0 runs without the host read."""
+
+    def __init__(self, data, padded, arena=None):
+        super().__init__(data)
+        self._padded = padded
+        self._arena, self._generation = arena, (arena.generation if arena is not None else None)
+
+    def padded(self, key):
+        """The arena-backed tensor ([N*MAX_SAMPLES] rows, live rows [0, rm_samples)); valid until the next training render."""
+        return self._padded[key]
+
+    def __missing__(self, key):
+        if key not in self._padded:
+            raise KeyError(key)
+        if self._arena is not None and self._arena.generation != self._generation:
+            raise RuntimeError("render(): results[%r] of a training render was first read after a later training render with the same ray "
+                               "count had reused its sample arena; read it before the next render(), or set NGP_FUSED_RENDER=0 for "
+                               "the reference's per-call buffers" % key)
+        n_live = int(dict.__getitem__(self, 'rm_samples'))
+        value = self._padded[key][:n_live].clone()
+        self[key] = value
+        return value
+
+    def __contains__(self, key):
+        return dict.__contains__(self, key) or key in self._padded
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+    def keys(self):
+        return list(dict.keys(self)) + [k for k in self._padded if not dict.__contains__(self, k)]
+
+    def items(self):
+        return [(k, self[k]) for k in self.keys()]
+
+    def values(self):
+        return [self[k] for k in self.keys()]
+
+    def __iter__(self):
+        return iter(self.keys())
+
+    def __len__(self):
+        return len(self.keys())
+
+
 def _background(exp_step_factor, device):
     # synthetic scenes (exp_step_factor == 0) are composited over white, real scenes over black
     return torch.ones(3, device=device) if exp_step_factor == 0 else torch.zeros(3, device=device)
@@ -103,8 +154,8 @@ def _render_rays_test_oneshot(model, rays_o, rays_d, hits_t, exp_step_factor, T_
 def _render_rays_train(model, rays_o, rays_d, hits_t, exp_step_factor, T_threshold):
     """march (occupancy-skipping, jittered) -> shade -> differentiable front-to-back compositing."""
     if getattr(model, 'fused_train_ok', None) is not None and model.fused_train_ok(rays_o):
-        # one autograd node, no host sync; deltas / ts / ws come back padded to the N*MAX_SAMPLES arena
-        # (only rows [0, rm_samples) are live -- rays_a addresses them exactly like the reference)
+        # one autograd node, no host sync; the per-sample outputs stay in the N*MAX_SAMPLES arena until somebody reads them
+        # through the result dictionary (TrainResults: reference-shaped [S] tensors on first access)
         from ngp_hip.fused import FusedTrainRender, RenderConfig
         cfg = RenderConfig(model, exp_step_factor, T_threshold, MAX_SAMPLES)
         rgb, opacity, depth, ws, rm_samples, vr_samples, rays_a = FusedTrainRender.apply(
@@ -113,8 +164,8 @@ def _render_rays_train(model, rays_o, rays_d, hits_t, exp_step_factor, T_thresho
         rgb = rgb + _background(exp_step_factor, rays_o.device) * (1 - opacity)[:, None]
         from ngp_hip.fused import TrainArena
         A = TrainArena.get(rays_o.device, rays_o.shape[0], MAX_SAMPLES)
-        return {'deltas': A.deltas, 'ts': A.ts, 'rm_samples': rm_samples, 'vr_samples': vr_samples, 'opacity': opacity,
-                'depth': depth, 'rgb': rgb, 'ws': ws, 'rays_a': rays_a}
+        return TrainResults({'rm_samples': rm_samples, 'vr_samples': vr_samples, 'opacity': opacity, 'depth': depth, 'rgb': rgb,
+                             'rays_a': rays_a}, {'deltas': A.deltas, 'ts': A.ts, 'ws': ws}, A)
     rays_a, xyzs, dirs, deltas, ts, rm_samples = raymarching_train(
         rays_o, rays_d, hits_t, model.density_bitfield, model.cascades, model.scale, exp_step_factor, model.grid_size,
         MAX_SAMPLES)

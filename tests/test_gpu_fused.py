@@ -47,6 +47,10 @@ def test_fused_render_matches_operator_path(hip_lib, lego_bitfield):
     r_32, l_32, g_32 = _run(m, o, d, target, fused=False, autocast=False)
     assert torch.equal(r_f["rays_a"], r_o["rays_a"]) and int(r_f["rm_samples"]) == int(r_o["rm_samples"]) > 0
     S = int(r_f["rm_samples"])
+    # on the path the unchanged train.py takes (autocast, fused render) the per-sample results have the
+    # reference's [S] shape (rendering.py:181-215), materialised from the arena on first access
+    assert r_f["ws"].shape[0] == r_f["ts"].shape[0] == r_f["deltas"].shape[0] == S and r_f.padded("ws").shape[0] > S
+    assert set(r_f.keys()) == set(r_o.keys()) and "ws" in r_f and r_f.get("ts") is r_f["ts"]
     assert torch.equal(r_f["ts"][:S], r_o["ts"]) and torch.equal(r_f["deltas"][:S], r_o["deltas"])
     assert abs(int(r_f["vr_samples"]) - int(r_o["vr_samples"])) <= 0.01 * S
     torch.testing.assert_close(r_f["rgb"], r_o["rgb"], rtol=0, atol=4e-3)
