@@ -11,8 +11,11 @@ conditioned, untimed, by --condition seeded optimisation steps on that scene wit
 warm-up for the first 256 steps, update every 16).  From there on the occupancy grid is the model's own, samples per ray
 and the live fraction are stable, and `--steps 20 --warmup 5` measures the same step as `--steps 200 --warmup 20`.
 
-Usage: python bench.py --gpus N --steps K --warmup W   (N>1 via torch.distributed.run, one rank per GPU)
-Prints ONE JSON line on rank 0.
+Usage: python bench.py --gpus N --steps K --warmup W
+N > 1: one rank per GPU over RCCL -- either launched by torch.distributed.run (WORLD_SIZE / RANK / LOCAL_RANK in the environment),
+or, when WORLD_SIZE is not set, bench.py starts the N ranks itself (and fails loudly if the node has fewer than N GPUs); the
+line then carries comm_ms / exposed_comm_ms / comm_breakdown_ms / rccl_version / rccl_env.
+Prints ONE JSON line on rank 0.  At N = 1 the default line also carries `configs`: short runs of the other BASELINE configs.
 """
 import argparse
 import gc
@@ -60,7 +63,7 @@ TRAINER_KERNELS = {
 }
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
@@ -100,7 +103,11 @@ def parse():
                          "reduce-scatter -> Adam on the own 1/N of the table -> all-gather")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    return ap.parse_args()
+    ap.add_argument("--no-configs", dest="configs", action="store_false",
+                    help="N = 1, default headline config only: skip the short runs of the other BASELINE configs that are attached "
+                         "to the line as `configs` (C2 with a bf16 table, C5 half2, C3 Garden shape, 65 536 rays, initialisation regime)")
+    ap.add_argument("--configs-steps", type=int, default=20, help="timed steps of each `configs` entry")
+    return ap.parse_args(argv)
 
 
 class KernelTimer:
@@ -114,6 +121,7 @@ class KernelTimer:
 
     def wrap(self, ops, name, units_of):
         fn = getattr(ops, name)
+        fn = getattr(fn, "_bench_raw", fn)           # measure() may run several times in one process: never nest the wrappers
         timer = self
 
         def timed(*a, **k):
@@ -126,6 +134,7 @@ class KernelTimer:
             timer.records.setdefault(name, []).append((e0, e1, units_of(*a, **k)))
             return out
 
+        timed._bench_raw = fn
         setattr(ops, name, timed)
 
     def summary(self):
@@ -200,18 +209,75 @@ def cpu_baseline(bits, seconds, table=None, weights=None, targets=None):
                          "the bench's conditioned" if targets == "scene" else "random-init", el)}
 
 
+class _Probe:
+    """What the timing wrappers around the C-ABI entry points (installed once per process) currently record into."""
+    timer = None
+    event_pool = []
+    c_events = {}
+    comm = None                 # N > 1: [(e0, e1), ...] around the trainer's collectives on the sampled steps
+
+
+def _install_entry_probes(L):
+    """HIP events around the big kernels' launches, on the stream they are launched on.  Installed once; inactive while
+    _Probe.event_pool is empty."""
+    if getattr(L, "_bench_probed", False):
+        return
+    L._bench_probed = True
+
+    def wrap_entry(name):
+        raw = getattr(L, name)
+
+        def timed(*a):
+            t = _Probe.timer
+            if t is None or not (t.enabled and t.sample) or not _Probe.event_pool:
+                return raw(*a)
+            e0, e1 = _Probe.event_pool.pop(), _Probe.event_pool.pop()
+            st = torch.cuda.current_stream()
+            e0.record(st); rc = raw(*a); e1.record(st)
+            _Probe.c_events.setdefault(name, []).append((e0, e1, a))
+            return rc
+        setattr(L, name, timed)
+    for name in TRAINER_KERNELS:
+        if hasattr(L, name):
+            wrap_entry(name)
+
+
+def _self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script on this node (one per GPU) under
+    torch.distributed.run and relay rank 0's JSON line.  Fails loudly when the node has fewer than N devices."""
+    import socket
+    import subprocess
+    one_dev = os.environ.get("NGP_BENCH_ONE_DEVICE", "0") == "1"
+    n_dev = torch.cuda.device_count()
+    if n_dev < args.gpus and not one_dev:
+        raise SystemExit("bench.py --gpus %d: this node exposes %d GPU(s)" % (args.gpus, n_dev))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        _self_launch(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
+    if args.gpus != world:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     # NGP_BENCH_BACKEND=gloo + NGP_BENCH_ONE_DEVICE=1: run the N > 1 code path with every rank on GPU 0 (RCCL refuses two ranks
     # on one device) -- a functional check of the sharding / barrier / max-over-ranks logic on a 1-GPU box, not a measurement
     backend = os.environ.get("NGP_BENCH_BACKEND", "nccl")
     if os.environ.get("NGP_BENCH_ONE_DEVICE", "0") == "1":
         local_rank = 0
+    elif torch.cuda.device_count() <= local_rank:
+        raise SystemExit("rank %d: no GPU %d on this node (%d visible)" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -220,14 +286,105 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    from ngp_hip import lib, ops, synthetic
-    from ngp_hip.dist import GradReducer
+    from ngp_hip import lib
     if world > 1:                   # one rank (re)builds the extension if it has to; the others wait instead of racing hipcc
         if rank == 0:
             lib.build()
         dist.barrier()
     lib.build()
     lib.load()
+    ctx = {"world": world, "rank": rank, "dev": dev, "backend": backend}
+    out = measure(args, ctx)
+    if rank == 0 and world == 1 and args.configs and _is_headline(args):
+        out["configs"] = other_configs(args, ctx)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def _is_headline(args):
+    return (args.scene == "lego" and args.regime == "scene" and args.path == "trainer" and not args.half and args.table == "f32"
+            and args.rays in (None, 8192) and not args.graph and args.prefetch)
+
+
+# the other BASELINE.json configs (and the initialisation regime of SURVEY 8d), as short runs attached to the headline line
+OTHER_CONFIGS = [
+    ("C2-bf16-table", "BASELINE config 2 as worded: bf16 storage copy of the fp32 master table", ["--table", "bf16"]),
+    ("C5-half2", "BASELINE config 5: half2 encoder (hash_encoder_half semantics) + fp16 MFMA MLP", ["--half"]),
+    ("C3-garden", "BASELINE config 3 shape: scale 16, 6 cascades, max_res 4096, 65 536 rays, distortion loss (synthetic occupancy, random targets)", ["--scene", "garden"]),
+    ("C2-65536-rays", "the per-GPU batch of BASELINE config 4's global batch on one GPU", ["--rays", "65536", "--pool", "8", "--condition", "512"]),
+    ("C2-init-random50", "initialisation regime of SURVEY 8(d): seeded 50 % occupancy, random targets, ~250 samples per ray", ["--regime", "random50"]),
+]
+
+
+def other_configs(args, ctx):
+    res = []
+    for name, what, extra in OTHER_CONFIGS:
+        sub = parse(["--steps", str(args.configs_steps), "--warmup", "5", "--no-cpu-baseline", "--no-configs"] + extra)
+        if os.environ.get("NGP_BENCH_CONFIG_CONDITION"):           # (tests: a short conditioning)
+            sub.condition = int(os.environ["NGP_BENCH_CONFIG_CONDITION"])
+        t0 = time.perf_counter()
+        try:
+            o = measure(sub, ctx, brief=True)
+            roof = o["roofline"] or {}
+            res.append({"name": name, "what": what, "args": " ".join(extra), "value": o["value"], "unit": "rays/s", "ms_per_step": o["ms_per_step"],
+                        "steps": o["steps"], "warmup": o["warmup"], "dtype": o["dtype"], "rays_per_gpu": o["config"]["rays_per_gpu"],
+                        "rm_samples_per_ray": o["rm_samples_per_ray"], "vr_samples_per_ray": o["vr_samples_per_ray"],
+                        "live_samples_per_step": o["live_samples_per_step"], "samples_per_sec": o["samples_per_sec"],
+                        "grid_updates_in_timed_region": o["config"]["grid_updates_in_timed_region"],
+                        "dominant_kernel": roof.get("kernel"), "dominant_kernel_ms": roof.get("avg_launch_ms"), "frac": roof.get("frac"),
+                        "bound": roof.get("bound"), "achieved": roof.get("achieved"), "roofline_unit": roof.get("unit"),
+                        "kernels_avg_us": {k: round(v["avg_ms"] * 1e3, 1) for k, v in o["kernels"].items()},
+                        "wall_seconds_incl_setup": None})
+        except Exception as e:                   # a failing side config must not take the headline line with it
+            res.append({"name": name, "what": what, "args": " ".join(extra), "error": "%s: %s" % (type(e).__name__, e)})
+        res[-1]["wall_seconds_incl_setup"] = time.perf_counter() - t0
+    return res
+
+
+def comm_fields(trainer, ctx, args):
+    """N > 1: what the gradient exchange cost on the sampled steps (HIP events on the step's stream around every collective of
+    FusedTrainer: they are issued in line, so the step waits for each of them -- only the next batch's march, on its side
+    stream, runs underneath), and which RCCL this was."""
+    recs = _Probe.comm or []
+    per = {}
+    for name, e0, e1 in recs:
+        per.setdefault(name, []).append(e0.elapsed_time(e1))
+    n_steps = max((len(v) for v in per.values()), default=0)
+    comm_ms = sum(float(np.sum(v)) for v in per.values()) / n_steps if n_steps else None
+    try:
+        ver = ".".join(str(x) for x in torch.cuda.nccl.version())
+    except Exception:
+        ver = None
+    return {"comm_ms": comm_ms, "exposed_comm_ms": comm_ms,
+            "comm_breakdown_ms": {k: float(np.mean(v)) for k, v in per.items()},
+            "comm_note": "per step, HIP events on the step's stream around each collective (sampled steps); the collectives are issued in "
+                         "line after the scatter-add, so all of it is exposed -- what runs underneath is the next batch's march",
+            "comm_bytes_per_rank_per_step": None if trainer is None else trainer.comm_bytes_per_step(),
+            "rccl_version": ver, "rccl_ranks": ctx["world"], "backend": ctx["backend"],
+            "rccl_env": {k: v for k, v in sorted(os.environ.items()) if k.startswith(("NCCL_", "RCCL_", "HSA_ENABLE_IPC"))}}
+
+
+def measure(args, ctx, brief=False):
+    """One configuration: build the model + trainer, condition, warm up, time args.steps steps.  Returns the line's dictionary on
+    rank 0 (None elsewhere)."""
+    try:
+        return _measure(args, ctx, brief)
+    finally:
+        # several configurations run in one process (`configs`): give the arena-sized buffers of this one back before the next
+        _Probe.timer, _Probe.event_pool, _Probe.c_events, _Probe.comm = None, [], {}, None
+        from ngp_hip.fused import TrainArena
+        TrainArena._cache.clear()
+        gc.unfreeze()
+        gc.collect()
+        torch.cuda.empty_cache()
+
+
+def _measure(args, ctx, brief):
+    world, rank, dev = ctx["world"], ctx["rank"], ctx["dev"]
+    from ngp_hip import lib, ops, synthetic
+    from ngp_hip.dist import GradReducer
     from modules.networks import NGP
     from modules.rendering import MAX_SAMPLES, render
 
@@ -310,24 +467,11 @@ def main():
     # events are created up front (hipEventCreate inside the timed loop costs more than the kernels it would time)
     event_pool = ([torch.cuda.Event(enable_timing=True) for _ in range(2 * 10 * (args.steps + 2))]
                   if use_trainer and not args.graph and args.kernel_events else [])
+    _Probe.timer, _Probe.event_pool, _Probe.c_events, _Probe.comm = timer, event_pool, c_events, []
     if use_trainer and not args.graph:
-        L = lib.load()
-
-        def wrap_entry(name):
-            raw = getattr(L, name)
-
-            def timed(*a):
-                if not (timer.enabled and timer.sample) or not event_pool:
-                    return raw(*a)
-                e0, e1 = event_pool.pop(), event_pool.pop()
-                st = torch.cuda.current_stream()
-                e0.record(st); rc = raw(*a); e1.record(st)
-                c_events.setdefault(name, []).append((e0, e1, a))
-                return rc
-            setattr(L, name, timed)
-        for name in TRAINER_KERNELS:
-            if hasattr(L, name):
-                wrap_entry(name)
+        _install_entry_probes(lib.load())
+    if use_trainer and world > 1:
+        trainer.comm_probe = lambda: (timer.enabled and timer.sample, _Probe.comm)
 
     thr = 0.01 * MAX_SAMPLES / 3**0.5                        # train.py:180
 
@@ -458,7 +602,7 @@ def main():
     # ---- after the timed region (untimed, informational): the same K steps again with the march NOT prefetched, i.e. what a
     # loop pays whose next batch is not known one step ahead
     elapsed_np = None
-    if use_trainer and args.prefetch and not args.graph and world == 1:
+    if use_trainer and args.prefetch and not args.graph and world == 1 and not brief:
         i0 = base + args.warmup + args.steps
         i0 += (-i0) % 16                                                    # same phase relative to the grid updates ...
         i0 += (base + args.warmup) % 16                                     # ... as the timed region
@@ -476,6 +620,8 @@ def main():
         state["vr"] = vr_log[:n_st].sum(dtype=torch.int64) * k_timed // max(n_st, 1)
     rm = int(state["rm"]); vr = int(state["vr"])
     total_rays = args.rays * world * args.steps
+    out = None
+    grid_updates = sum(1 for i in range(base + args.warmup, base + args.warmup + args.steps) if i % 16 == 0)
     if rank == 0:
         ks = timer.summary()
         rooflines = {}
@@ -547,8 +693,15 @@ def main():
         # which records the workload state it was taken in); it is attached only if that state matches this run within 15 %
         # (two runs of the same command end their conditioning 5-12 % apart in live samples per step: float-atomic order in the
         # MLP weight gradients), otherwise traffic stays null -- a counter value from another state says nothing about this one
-        pmc_path = os.path.join(ROOT, "profiles", "r02_pmc.json")
+        pmc_path = next((q for q in (os.path.join(ROOT, "profiles", f) for f in ("r03_pmc.json", "r02_pmc.json")) if os.path.exists(q)),
+                        os.path.join(ROOT, "profiles", "r03_pmc.json"))
+        pmc_name = "profiles/" + os.path.basename(pmc_path)
         traffic_src = None
+        if "hash_bwd_f32" in rooflines and use_trainer and trainer.hash_bwd == "sliced":
+            rooflines["hash_bwd_f32"]["note"] = (
+                "bytes = SURVEY 8(d)'s algorithmic figure for the reference's autodiff scatter (2188 B per live sample: position, "
+                "gradient row, 16 x 8 corner read-modify-writes); the LDS-sliced kernel keeps the read-modify-write in LDS, so its HBM "
+                "traffic (PMC, `traffic`) is below that figure: `frac` is the contract's algorithmic-bytes fraction, not HBM utilisation")
         if os.path.exists(pmc_path) and use_trainer:
             pmc = json.load(open(pmc_path))
             st = pmc.get("state", {})
@@ -556,8 +709,8 @@ def main():
                     and abs(st.get("live_samples_per_step", -1) - live_avg) <= 0.15 * max(live_avg, 1)
                     and abs(st.get("marched_samples_per_step", -1) - marched) <= 0.15 * max(marched, 1))
             if same:
-                traffic_src = ("profiles/r02_pmc.json (separate --pmc passes of this command at %.0f live / %.0f marched samples per step; "
-                               "this run: %.0f / %.0f)" % (st["live_samples_per_step"], st["marched_samples_per_step"], live_avg, marched))
+                traffic_src = ("%s (separate --pmc passes of this command at %.0f live / %.0f marched samples per step; "
+                               "this run: %.0f / %.0f)" % (pmc_name, st["live_samples_per_step"], st["marched_samples_per_step"], live_avg, marched))
                 for key, r in rooflines.items():
                     if key in pmc.get("kernels", {}):
                         r["traffic"] = pmc["kernels"][key]["hbm_bytes_per_launch"]
@@ -607,6 +760,8 @@ def main():
             "config": {"workload": text, "workload_state": workload,
                        "rays_per_gpu": args.rays, "global_batch": args.rays * world,
                        "parallelism": parallelism,
+                       # one or two ~1.1 ms occupancy-update steps in a 20-step window move the average by +-5 %: compare runs by this
+                       "grid_updates_in_timed_region": grid_updates,
                        "path": ("FusedTrainer" + ("+hipGraph" if args.graph else "")) if use_trainer else "modules+torch.optim",
                        "kernel_events_in_timed_region": (("every step" if ev_every == 1 else "every %d-th step" % ev_every)
                                                          if (bool(event_pool) or not use_trainer) else False)},
@@ -615,6 +770,8 @@ def main():
             "ms_per_step_no_prefetch": None if elapsed_np is None else elapsed_np / args.steps * 1e3,
             "kernels": ks, "critical_path_gaps": gaps, "roofline": roof, "rooflines": rooflines,
         }
+        if world > 1:
+            out.update(comm_fields(trainer if use_trainer else None, ctx, args))
         if not args.no_cpu_baseline and world == 1 and not garden:     # the CPU leg restates the C2 workload only
             if scene:
                 out["cpu_baseline"] = cpu_baseline(model.density_bitfield.cpu().numpy(), args.cpu_seconds,
@@ -623,9 +780,7 @@ def main():
             else:
                 out["cpu_baseline"] = cpu_baseline(bits_np if args.regime == "lego" else np.load(golden)["density_bitfield"],
                                                    args.cpu_seconds)
-        print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
+    return out
 
 
 if __name__ == "__main__":

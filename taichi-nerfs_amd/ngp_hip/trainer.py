@@ -150,6 +150,9 @@ class FusedTrainer:
         self._prefetch_at = int(_os.environ.get("NGP_PREFETCH_AT", "1" if self.world == 1 else "4"))
         self._coarse_ver = None
         self.sync_occupancy = True            # world > 1: broadcast rank 0's occupancy after every update_density_grid()
+        # bench.py: callable -> (record this step?, list); every collective of the step is then bracketed by two HIP events on the
+        # step's stream and (name, e0, e1) is appended to the list
+        self.comm_probe = None
         lvs = model.pos_encoder.levels_struct
         self.enc_pairs = 1 if (lvs.n_levels == 16 and lvs.n_features == 2) else 0
         self.wpack = torch.empty(self.L.ngp_mlp_wpack_halfs(), device=dev, dtype=torch.float16)
@@ -458,21 +461,52 @@ class FusedTrainer:
             check(self.L.ngp_check_finite_f16(_ptr(self.shard_grad), self.shard_grad.numel(), found, st), "ngp_check_finite_f16")
         flag_i = self.state_i[_SI_FOUND_INF:_SI_FOUND_INF + 1]
         self._flag_f.copy_(flag_i)
-        if self._nccl():
-            dist.all_reduce(self.small_bucket, op=dist.ReduceOp.AVG, group=self.group)
-        else:
-            dist.all_reduce(self.small_bucket, op=dist.ReduceOp.SUM, group=self.group)
-            self.small_bucket.div_(self.world)
+        def small():
+            if self._nccl():
+                dist.all_reduce(self.small_bucket, op=dist.ReduceOp.AVG, group=self.group)
+            else:
+                dist.all_reduce(self.small_bucket, op=dist.ReduceOp.SUM, group=self.group)
+                self.small_bucket.div_(self.world)
+        self._timed("all_reduce_mlp_grad_and_flag", small)
         flag_i.copy_(self._flag_f != 0)
         self._flag_f.zero_()
 
+    def _timed(self, name, fn):
+        """Run one collective; with a bench probe attached, bracket it with HIP events on the current stream (a synchronous
+        torch.distributed collective makes this stream wait for the RCCL stream, so the bracket contains the transfer)."""
+        probe = self.comm_probe() if self.comm_probe is not None else None
+        if not probe or not probe[0]:
+            return fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = fn()
+        e1.record()
+        probe[1].append((name, e0, e1))
+        return out
+
+    def comm_bytes_per_step(self):
+        """Payload bytes this rank hands to the collectives per step (not the wire bytes: a ring moves (N-1)/N of it per phase)."""
+        if self.world <= 1:
+            return {}
+        small = self.small_bucket.numel() * self.small_bucket.element_size()
+        if self.shard:
+            g = self._comm if self._comm is not None else self.table_grad_store
+            back = self.copy16_store if self.copy16_store is not None else self.table_store
+            return {"reduce_scatter_table_grad": g.numel() * g.element_size(), "all_reduce_mlp_grad_and_flag": small,
+                    "all_gather_table": back.numel() * back.element_size()}
+        buf = self._comm if self._comm is not None else self.grad_flat
+        out = {"all_reduce_flat_bucket": buf.numel() * buf.element_size()}
+        if self.half:
+            out["all_reduce_f16_table_grad"] = self.table_grad.numel() * 2
+        return out
+
     def _reduce_scatter(self, out, inp):
         from .dist import reduce_scatter_avg
-        reduce_scatter_avg(out, inp, self.rank, self.world, self.group)
+        self._timed("reduce_scatter_table_grad", lambda: reduce_scatter_avg(out, inp, self.rank, self.world, self.group))
 
     def _all_gather(self, store, sl):
         from .dist import all_gather_shards
-        all_gather_shards(store, self.rank, self.shard_len, self.world, self.group)
+        self._timed("all_gather_table", lambda: all_gather_shards(store, self.rank, self.shard_len, self.world, self.group))
 
     def sync_master(self):
         """Sharded optimizer with a 16-bit table copy: only the copy is exchanged every step; gather the fp32 master table of
@@ -498,11 +532,13 @@ class FusedTrainer:
         if self._comm is not None and not self.shard:
             buf = self._comm
             buf.copy_(self.grad_flat)                           # loss-scaled gradients: bf16 keeps the fp32 exponent range
-        if dist.get_backend(self.group) == "nccl":
-            dist.all_reduce(buf, op=dist.ReduceOp.AVG, group=self.group)
-        else:
-            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
-            buf.div_(self.world)
+        def flat():
+            if dist.get_backend(self.group) == "nccl":
+                dist.all_reduce(buf, op=dist.ReduceOp.AVG, group=self.group)
+            else:
+                dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+                buf.div_(self.world)
+        self._timed("all_reduce_flat_bucket", flat)
         if buf is not self.grad_flat:
             self.grad_flat.copy_(buf)
         flag_i.copy_(self._flag_f != 0)

@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_bench_line_contract(hip_lib):
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "2", "--condition", "48", "--cpu-seconds", "1",
-           "--kernel-events-every", "2"]
+           "--kernel-events-every", "2", "--no-configs"]
     out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.strip()]
@@ -36,3 +36,51 @@ def test_bench_line_contract(hip_lib):
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["value"] > 0 and c["cores"] >= 1 and isinstance(c["sample"], str)
     assert d["value"] > 10 * c["value"]
+
+
+def test_bench_configs_array(hip_lib):
+    """the default N = 1 line carries short runs of the other BASELINE configs."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--condition", "32", "--no-cpu-baseline",
+           "--configs-steps", "4"]
+    env = dict(os.environ, NGP_BENCH_CONFIG_CONDITION="32")
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["config"]["grid_updates_in_timed_region"] in (0, 1)
+    names = [c["name"] for c in d["configs"]]
+    assert names == ["C2-bf16-table", "C5-half2", "C3-garden", "C2-65536-rays", "C2-init-random50"], names
+    for c in d["configs"]:
+        assert "error" not in c, c
+        assert c["value"] > 0 and c["ms_per_step"] > 0 and 0 < c["frac"] <= 1.0 and c["dominant_kernel"], c
+        assert abs(c["value"] - c["rays_per_gpu"] / (c["ms_per_step"] * 1e-3)) / c["value"] < 1e-6
+
+
+def test_bench_self_launches_two_ranks(hip_lib):
+    """`python bench.py --gpus 2` WITHOUT torchrun starts two ranks by itself (here both on GPU 0 over gloo: a
+    functional run of the N > 1 path, not a measurement) and the line carries the communication fields."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--condition", "32",
+           "--kernel-events-every", "2"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(NGP_BENCH_BACKEND="gloo", NGP_BENCH_ONE_DEVICE="1")
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 2 * 8192 and d["scaling"] == "weak"
+    assert abs(d["value"] - 2 * 8192 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6          # whole-job rays/s
+    assert d["comm_ms"] is not None and d["comm_ms"] > 0 and d["exposed_comm_ms"] == d["comm_ms"] and d["rccl_ranks"] == 2
+    assert set(d["comm_breakdown_ms"]) == {"reduce_scatter_table_grad", "all_reduce_mlp_grad_and_flag", "all_gather_table"}
+    assert d["comm_bytes_per_rank_per_step"]["reduce_scatter_table_grad"] >= 4 * 11420064
+    assert "configs" not in d and "cpu_baseline" not in d
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    import torch
+    n = torch.cuda.device_count() + 1
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "NGP_BENCH_ONE_DEVICE")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "2"], cwd=ROOT, capture_output=True,
+                         text=True, timeout=300, env=env)
+    assert out.returncode != 0 and "exposes" in (out.stderr + out.stdout)
