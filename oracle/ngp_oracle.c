@@ -451,6 +451,36 @@ ORA_API void ora_hash_bwd_f16(const float* xyzs, const uint16_t* dout, const ngp
     }
 }
 
+/* The same kernel (:200-213) in the ONE order the reference's source defines when its struct-for runs serially (sample-major,
+ * then level, then corner -- the order oracle/ti_shim executes it in): every `hash_grad[idx] += w_grad_dy_temp` is an f16 vector
+ * add rounded per feature, skipped when the output gradient or the f16 product vector is all-zero (:209-212).  Bit-exact against
+ * the reference-executed fixtures (tests/golden/ref_hash_f16*.npz) on EVERY row; `count` (optional) receives the number of
+ * contributions per table row, so tests can pick the rows whose value does not depend on the accumulation order. */
+ORA_API void ora_hash_bwd_f16_serial(const float* xyzs, const uint16_t* dout, const ngp_hash_levels* lv, int n, uint16_t* dtable_h,
+                                     int32_t* count) {
+    const int L = lv->n_levels, F = lv->n_features;
+    for (int i = 0; i < n; ++i)
+        for (int level = 0; level < L; ++level) {
+            const uint16_t* g = dout + ((size_t)i * L + level) * F;
+            int any_g = 0;
+            for (int f = 0; f < F; ++f) any_g |= (h2f(g[f]) != 0.0f);
+            if (!any_g) continue;                                                  /* :209 */
+            uint32_t idx[8]; float w[8];
+            hash_corners_half(xyzs + 3 * i, lv, level, idx, w);
+            for (int c = 0; c < 8; ++c) {
+                uint16_t prod[16]; int any_p = 0;
+                for (int f = 0; f < F; ++f) { const float p32 = w[c] * h2f(g[f]); any_p |= (p32 != 0.0f); prod[f] = f2h(p32); }   /* :210; the test
+                of :211 sees the f32 product, the cast to the table's f16 happens inside the atomic add */
+                if (!any_p) continue;                                              /* :211 */
+                for (int f = 0; f < F; ++f) {
+                    uint16_t* d = dtable_h + (size_t)idx[c] * F + f;
+                    *d = d2h((double)h2f(*d) + (double)h2f(prod[f]));             /* :212, f16 add, single rounding */
+                }
+                if (count) count[idx[c]] += 1;
+            }
+        }
+}
+
 /* ------------------------------------------------------------------------------------------------
  * a-6  dir_encoder -- modules/spherical_harmonics.py:16-42 (literal forms kept for rounding)
  * ---------------------------------------------------------------------------------------------- */

@@ -163,6 +163,17 @@ def hash_bwd_f16(xyzs, dout_h, lv):
     return dtable
 
 
+def hash_bwd_f16_serial(xyzs, dout_h, lv):
+    """The half2 encoder's explicit backward in the reference's serial order, f16 accumulation: (grad f16 [entries, F],
+    contributions per row int32 [entries])."""
+    x = _f32(xyzs)
+    g = np.ascontiguousarray(dout_h, dtype=np.float16).view(np.uint16)
+    dtable = np.zeros((lv.total_entries, lv.n_features), np.uint16)
+    count = np.zeros(lv.total_entries, np.int32)
+    lib().ora_hash_bwd_f16_serial(_p(x), _p(g), ctypes.byref(lv), x.shape[0], _p(dtable), _p(count))
+    return dtable.view(np.float16), count
+
+
 def sh16_fwd(dirs):
     d = _f32(dirs)
     out = np.empty((d.shape[0], 16), np.float32)

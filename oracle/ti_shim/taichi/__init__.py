@@ -111,14 +111,23 @@ class Vector:
     def __or__(self, o): return self._wrap(self.a | self._v(o))
     def __and__(self, o): return self._wrap(self.a & self._v(o))
 
+    # Augmented assignment.  Taichi lowers `x op= v` to an AtomicOpStmt whose type check casts `v` to x's element type BEFORE the
+    # operation (its "Atomic add (f32 to f16) may lose precision" warning); the operation then runs in that type.  So an f32
+    # product accumulated into an f16 vector (hash_encoder_half.py:212) is rounded to f16 first and the add rounds once more --
+    # not one rounding of an f32 sum (round 2's shim did that: 1 ulp off on rows with two contributions, -0 instead of +0 for
+    # products that underflow f16).  Same-type operands (every other kernel) are unaffected.
+    def _rhs(self, o):
+        o = self._v(o)
+        return np.asarray(o).astype(self.a.dtype) if isinstance(o, (np.ndarray, np.generic)) else o
+
     def __iadd__(self, o):
-        self.a = (self.a + self._v(o)).astype(self.a.dtype); return self
+        self.a = (self.a + self._rhs(o)).astype(self.a.dtype); return self
 
     def __isub__(self, o):
-        self.a = (self.a - self._v(o)).astype(self.a.dtype); return self
+        self.a = (self.a - self._rhs(o)).astype(self.a.dtype); return self
 
     def __imul__(self, o):
-        self.a = (self.a * self._v(o)).astype(self.a.dtype); return self
+        self.a = (self.a * self._rhs(o)).astype(self.a.dtype); return self
 
     def max(self):
         r = self.a[0]
@@ -309,6 +318,7 @@ math = _Math("taichi.math")
 math.vec2 = _VecType(2, np.float32)
 math.vec3 = _VecType(3, np.float32)
 math.uvec3 = _VecType(3, np.uint32)
+math.ivec3 = _VecType(3, np.int32)        # (modules/triplane.py imports it; the tri-plane kernels themselves are never run)
 math.pow = pow
 math.min = min
 math.max = max

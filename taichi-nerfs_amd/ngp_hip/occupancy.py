@@ -33,20 +33,25 @@ class OccupancyUpdater:
         self.tmp = torch.empty(model.cascades, G3, **f32)
         self.stats = torch.zeros(2, **f32)
         self.wpack = torch.empty(self.L.ngp_mlp_wpack_halfs(), device=dev, dtype=torch.float16)
-        lvs = model.pos_encoder.levels_struct
-        self.enc_pairs = 1 if (lvs.n_levels == 16 and lvs.n_features == 2) else 0
+        lvs = getattr(getattr(model, "pos_encoder", None), "levels_struct", None)     # (None: a grid driven with density_fn only)
+        self.enc_pairs = 1 if (lvs is not None and lvs.n_levels == 16 and lvs.n_features == 2) else 0
         self._su_work = self._su_out = None
 
     @torch.no_grad()
-    def update(self, density_threshold, warmup=False, decay=0.95):
+    def update(self, density_threshold, warmup=False, decay=0.95, jitter=None, uniforms=None, density_fn=None):
+        """One occupancy-grid update.  The three optional hooks exist for the fixture tests (tests/test_gpu_golden.py holds this
+        class to vectors produced by the reference's own NGP.update_density_grid): `jitter(c, n)` -> [n, 3] uniforms replacing
+        torch.rand for cascade c's in-cell jitter; `uniforms(c)` -> (u_cell [M], u_pick [M]) replacing the sorted uniforms that
+        choose the cells; `density_fn(c, xyzs [n, 3], indices [n] or None)` -> sigmas [n] replacing the hash-grid + MLP density."""
         m, L, st = self.model, self.L, _stream()
         G, G3, C = m.grid_size, m.grid_size**3, m.cascades
         grid = m.density_grid
         if not grid.is_contiguous():
             raise ValueError("density_grid must be contiguous")
-        lv = m.pos_encoder.levels_struct
-        ws = m._mlp_weights()
-        check(L.ngp_mlp_pack(*[_ptr(w) for w in ws], self.enc_pairs, _ptr(self.wpack), st), "ngp_mlp_pack")
+        if density_fn is None:
+            lv = m.pos_encoder.levels_struct
+            ws = m._mlp_weights()
+            check(L.ngp_mlp_pack(*[_ptr(w) for w in ws], self.enc_pairs, _ptr(self.wpack), st), "ngp_mlp_pack")
         self.tmp.zero_()                                                       # density_grid_tmp = zeros_like, networks.py:261
         lo, hi = -float(m.scale), float(m.scale)
         for c in range(C):
@@ -56,7 +61,7 @@ class OccupancyUpdater:
             tmp_c = self.tmp[c]
             if warmup:
                 n = G3
-                u_jit = torch.rand(n, 3, device=self.dev)
+                u_jit = torch.rand(n, 3, device=self.dev) if jitter is None else jitter(c, n).contiguous().float()
                 check(L.ngp_occ_all_cells(_ptr(u_jit), n, G, s, hg, _ptr(self.xyzs), st), "ngp_occ_all_cells")
                 idx_ptr = _ptr(None)
             else:
@@ -72,13 +77,17 @@ class OccupancyUpdater:
                     self._su_out = torch.empty(2, self.M, device=self.dev, dtype=torch.float32)
                 check(L.ngp_sorted_uniforms(_ptr(u_raw), self.M, 2, _ptr(self._su_work), _ptr(self._su_out), st), "ngp_sorted_uniforms")
                 u_cell, u_pick = self._su_out[0], self._su_out[1]
-                u_jit = torch.rand(n * 3, device=self.dev)
+                if uniforms is not None:
+                    u_cell, u_pick = [u.contiguous().float() for u in uniforms(c)]
+                u_jit = torch.rand(n * 3, device=self.dev) if jitter is None else jitter(c, n).contiguous().float()
                 check(L.ngp_occ_compact(_ptr(grid_c), float(density_threshold), G3, _ptr(self.list), _ptr(self.count), _ptr(self.scratch), st),
                       "ngp_occ_compact")
                 check(L.ngp_occ_sample(_ptr(u_cell), _ptr(u_pick), _ptr(u_jit), _ptr(self.list), _ptr(self.count), self.M, G, s, hg,
                                        _ptr(self.indices), _ptr(self.xyzs), st), "ngp_occ_sample")
                 idx_ptr = _ptr(self.indices)
-            if getattr(m, "half_opt", False):                                  # half2 encoder: its own arithmetic on the f16 copy
+            if density_fn is not None:
+                self.sigmas[:n].copy_(density_fn(c, self.xyzs[:n], None if warmup else self.indices[:n]))
+            elif getattr(m, "half_opt", False):                                # half2 encoder: its own arithmetic on the f16 copy
                 check(L.ngp_hash_fwd_f16_ex(_ptr(self.xyzs), _ptr(m.pos_encoder.table_f16()), ctypes.byref(lv), n, _ptr(None), 1, lo, hi,
                                             self.enc_pairs, _ptr(self.enc), st), "ngp_hash_fwd_f16_ex")
             elif getattr(m.pos_encoder, "table_dtype", torch.float32) == torch.bfloat16:
@@ -87,8 +96,9 @@ class OccupancyUpdater:
             else:
                 check(L.ngp_hash_fwd_f32_ex(_ptr(self.xyzs), _ptr(m.pos_encoder.hash_table), ctypes.byref(lv), n, _ptr(None), 1, lo, hi,
                                             self.enc_pairs, _ptr(self.enc), st), "ngp_hash_fwd_f32_ex")
-            check(L.ngp_mlp_fwd_ex(_ptr(self.enc), _ptr(None), _ptr(self.wpack), n, _ptr(None), self.enc_pairs, _ptr(self.sigmas),
-                                   _ptr(None), st), "ngp_mlp_fwd_ex")
+            if density_fn is None:
+                check(L.ngp_mlp_fwd_ex(_ptr(self.enc), _ptr(None), _ptr(self.wpack), n, _ptr(None), self.enc_pairs, _ptr(self.sigmas),
+                                       _ptr(None), st), "ngp_mlp_fwd_ex")
             check(L.ngp_occ_scatter(idx_ptr, _ptr(self.sigmas), n, _ptr(tmp_c), st), "ngp_occ_scatter")
         self.stats.zero_()
         check(L.ngp_occ_merge(_ptr(grid), _ptr(self.tmp), float(decay), C * G3, _ptr(self.stats), st), "ngp_occ_merge")

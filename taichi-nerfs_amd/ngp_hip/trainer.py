@@ -174,6 +174,7 @@ class FusedTrainer:
         """Rebuild the fp16 MFMA weight image from the fp32 master weights (call after loading a checkpoint into the
         model; the training step keeps it current by itself)."""
         ws = self.model._mlp_weights()
+        self.sync_master()                    # sharded + 16-bit copy: never re-cast the copy from a master whose other shards are stale
         if self.table_bf16 is not None:
             self.model.pos_encoder._bf16_ver = None                             # force a re-cast of the bf16 table copy
             assert self.model.pos_encoder.table_bf16() is self.table_bf16
@@ -610,19 +611,41 @@ class FusedTrainer:
     def state_dict(self):
         """Optimizer-side state the model's own state_dict does not hold: Adam moments, loss scale + growth counter, the
         LR-schedule iteration.  (The reference saves no optimizer state either -- ckpt = model.state_dict(), train.py:285-291 --
-        so a resume without this restarts the moments and the cosine schedule; with it the continuation is exact.)"""
+        so a resume without this restarts the moments and the cosine schedule; with it the continuation is exact.)
+        Sharded optimizer: every rank only ever updates the moments of its own 1/world of the table, so the shards are gathered
+        here (COLLECTIVE: every rank must call state_dict(), any rank's result is then complete) and the fp32 master table of
+        the other shards is brought up to date (sync_master).  The moments are saved WITHOUT the world-dependent padding
+        ([:nt]): a checkpoint loads into any world size."""
         self.sync_master()
-        return {"table_m": self.table_m.clone(), "table_v": self.table_v.clone(), "mlp_m": self.mlp_m.clone(),
+        if self.shard:
+            lo = self.rank * self.shard_len
+            sl = slice(lo, lo + self.shard_len)
+            self._all_gather(self.table_m, sl)
+            self._all_gather(self.table_v, sl)
+        return {"table_m": self.table_m[:self.nt].clone(), "table_v": self.table_v[:self.nt].clone(), "mlp_m": self.mlp_m.clone(),
                 "mlp_v": self.mlp_v.clone(), "state_f": self.state_f.clone(), "state_i": self.state_i.clone()}
 
     def load_state_dict(self, sd):
-        for k in ("table_m", "table_v", "mlp_m", "mlp_v", "state_f", "state_i"):
+        """Load what state_dict() returned (on every rank, after loading the model's weights into the model).  Accepts the
+        unpadded [:nt] moments of this version and the padded ones of earlier checkpoints written at the same world size."""
+        for k in ("table_m", "table_v"):
+            src, dst = sd[k], getattr(self, k)
+            if src.numel() not in (self.nt, dst.numel()):
+                raise ValueError("%s has %d elements; this trainer expects %d (or %d padded)" % (k, src.numel(), self.nt, dst.numel()))
+            n = min(src.numel(), self.nt)
+            dst[:n].copy_(src[:n])
+            dst[self.nt:].zero_()
+        for k in ("mlp_m", "mlp_v", "state_f", "state_i"):
             getattr(self, k).copy_(sd[k])
         self.grad_flat.zero_()
         if self.half:
             self.table_grad.zero_()
+        if self.shard_grad is not None:
+            self.shard_grad.zero_()
         self._coarse_ver = None
-        self.repack()                          # the model's weights were (presumably) loaded alongside: refresh the fp16 images
+        # the model's weights were loaded alongside: the fp32 master IS the checkpoint now, on every shard -- nothing left to gather
+        self._master_stale = False
+        self.repack()                          # refresh the fp16 MFMA image and the 16-bit table copy from the master
 
     def last_loss(self):
         """MSE of the last step (host sync: logging only)."""

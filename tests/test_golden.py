@@ -83,23 +83,31 @@ def test_hash_f32_vs_reference(oracle, tag):
     assert beq(oracle.hash_fwd_f32(g["xyzs"], table, lv), g["out"])
 
 
-def test_hash_f16_vs_reference(oracle):
-    g = G("ref_hash_f16.npz")
+@pytest.mark.parametrize("fixture", ["ref_hash_f16.npz", "ref_hash_f16_big.npz"])
+def test_hash_f16_vs_reference(oracle, fixture):
+    """a-5, the half2 encoder against the reference's own kernels executed under the shim (Taichi-f16-exact since round 3: every
+    f16 operation of the kernel is one correctly rounded operation, and `+=` casts its right-hand side to the table's f16 first,
+    as Taichi's atomic add does).  Forward: bit-exact.  Backward: the oracle's serial-order form is bit-exact on EVERY row; its
+    order-free form (exact sum, one rounding -- what the HIP kernels are held to) is bit-exact wherever a row receives a single
+    contribution and within f16 accuracy of the serial result elsewhere."""
+    g = G(fixture)
     lv = oracle.make_levels(2**19, 16, 16.0, 1024.0, 2)
     n_ent = int(g["total_entries"])
     table_h = golden_table(n_ent * 2, -0.1, 0.1).astype(np.float16).reshape(-1, 2)
     for l in range(16):
         lv.scale[l] = float(g["scale_used"][l])
     out = oracle.hash_fwd_f16(g["xyzs"], table_h, lv)
-    # numpy adds two f16 through f32 (double rounding on rare ties): allow the last f16 bit on a few entries
-    diff = np.abs(out.astype(np.float32) - g["out"].astype(np.float32))
-    assert (diff == 0).mean() > 0.97 and diff.max() <= 2.5e-4
-    grad = oracle.hash_bwd_f16(g["xyzs"], g["dout"], lv)
-    rows = np.flatnonzero(np.abs(grad).sum(1))
-    # the reference skips contributions that round to zero in f16 and rounds after every add; same touched rows
-    # up to such underflows, same values to f16 accuracy
-    assert len(np.setxor1d(rows, g["grad_rows"])) <= 0.02 * len(rows)
-    np.testing.assert_allclose(grad[g["grad_rows"]], g["grad_vals"].astype(np.float32), rtol=2e-2, atol=2e-5)
+    assert out.dtype == np.float16 and np.array_equal(out.view(np.uint16), g["out"].view(np.uint16))
+    serial, count = oracle.hash_bwd_f16_serial(g["xyzs"], g["dout"], lv)
+    rows = np.flatnonzero(np.abs(serial.astype(np.float32)).sum(1))
+    assert np.array_equal(rows, g["grad_rows"])
+    assert np.array_equal(serial[rows].view(np.uint16), g["grad_vals"].view(np.uint16))
+    grad = oracle.hash_bwd_f16(g["xyzs"], g["dout"], lv)                     # f64 accumulation, one rounding
+    assert np.array_equal(np.flatnonzero(np.abs(grad).sum(1)), rows)
+    one = count[rows] == 1
+    assert one.mean() > 0.8
+    assert np.array_equal(grad[rows][one].astype(np.float16).view(np.uint16), g["grad_vals"][one].view(np.uint16))
+    np.testing.assert_allclose(grad[rows], g["grad_vals"].astype(np.float32), rtol=4e-3, atol=1e-7)     # <= a few f16 ulp on shared rows
 
 
 def test_sh16_vs_reference(oracle):

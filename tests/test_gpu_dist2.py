@@ -99,6 +99,42 @@ def _worker(rank, world, port, kind, shard_opt, bits_np, out_dir):
         if tr.copy16_store is not None:                           # the 16-bit copy is the cast of the (synced) master
             want = tr.table.half() if kind == "half" else tr.table.bfloat16()
             assert torch.equal(want.view(torch.int16), tr.copy16_store[:tr.nt].view(torch.int16))
+        # (4) checkpoint / resume: state_dict() gathers the Adam moments of every shard (each rank only updates its own
+        # 1/world) and saves them unpadded; a fresh 2-rank trainer resumed from RANK 0's checkpoint continues like the original
+        sd = tr.state_dict()
+        model_sd = {k: v.clone() for k, v in tr.model.state_dict().items()}
+        assert sd["table_m"].numel() == tr.nt and sd["table_v"].numel() == tr.nt
+        half_nt = tr.nt // 2
+        for k in ("table_m", "table_v"):
+            assert float(sd[k][:half_nt].abs().max()) > 0 and float(sd[k][half_nt:].abs().max()) > 0, "moments of one shard missing in " + k
+            mine = sd[k].cpu().contiguous()
+            both = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(both, mine)
+            assert torch.equal(both[0], both[1]), "rank checkpoints differ in " + k
+        objs = [(sd, model_sd) if rank == 0 else None]
+        dist.broadcast_object_list(objs, src=0)                    # everybody resumes from rank 0's files
+        sd0, model_sd0 = objs[0]
+        m2 = make()
+        m2.load_state_dict({k: v.to(dev) for k, v in model_sd0.items()})
+        tr2 = FusedTrainer(m2, world_size=world, init_scale=scale0, shard_optimizer=shard_opt)
+        tr2.load_state_dict({k: v.to(dev) for k, v in sd0.items()})
+        assert torch.equal(tr2.table_m[:tr.nt], tr.table_m[:tr.nt]) and torch.equal(tr2.table, tr.table) and tr2.counters() == tr.counters()
+        if tr.copy16_store is not None:
+            assert torch.equal(tr2.copy16_store[:tr.nt].view(torch.int16), tr.copy16_store[:tr.nt].view(torch.int16))
+        nz = noise[a:b].contiguous()
+        for t_ in (tr, tr2):
+            for _ in range(2):
+                t_.step(ro, rd, target[a:b], noise=nz)
+            t_.sync_master()
+        # same inputs, same state: the continuation matches up to the run-to-run float-atomic order of the MLP weight gradients
+        assert rel(tr2.table.float(), tr.table.float()) < (2e-3 if kind == "half" else 1e-5), rel(tr2.table.float(), tr.table.float())
+        assert rel(tr2.mlp_flat, tr.mlp_flat) < 1e-4
+        # a 1-rank trainer loads the same checkpoint (no world-dependent padding in the file)
+        m3 = make()
+        m3.load_state_dict({k: v.to(dev) for k, v in model_sd0.items()})
+        tr3 = FusedTrainer(m3, world_size=1, init_scale=scale0)
+        tr3.load_state_dict({k: v.to(dev) for k, v in sd0.items()})
+        assert torch.equal(tr3.table_v[:tr.nt], sd0["table_v"].to(dev))
         dist.barrier()
         dist.destroy_process_group()
         open(os.path.join(out_dir, "ok_%d" % rank), "w").write("ok")
