@@ -189,16 +189,14 @@ int ngp_hash_bwd_f16_live(const float* xyzs, const float* dout, const ngp_hash_l
  * atomics: the gradient table is cut into slices of 8192 entries (128 KB of f64 pairs), each owned by one workgroup that
  * accumulates in its LDS and adds the slice to the table once (csrc/hash_bwd_lds.hip).  Same arguments and semantics as
  * ngp_hash_bwd_f32_live (dtable is accumulated into) plus a caller-owned scratch buffer of
- * ngp_hash_bwd_sliced_workspace(lv, n_max) bytes: compact positions, one hit BIT per (dense level, slice, sample), and for the
- * xor-hashed levels hit LISTS (4 entries per level and sample, sorted by slice inside 2048-sample chunks, + a 64-word segment
- * table per chunk).  Returns -2 when the level table does not fit the formulation (F != 2, a level of more than 64 slices =
- * 2^19 entries, an odd level size, or more than 2^30 samples): the caller then uses ngp_hash_bwd_f32_live.
- * The workspace is per call sequence: prep -> main of one backward must not be interleaved with another backward's on another
- * stream using the same buffer (the queue heads and the lists live in it). */
+ * ngp_hash_bwd_sliced_workspace(lv, n_max) bytes: compact positions + one hit BIT per (level, slice, sample) + the queue heads
+ * of the persistent workgroups.  Returns -2 when the level table does not fit the formulation (F != 2, a level of more than
+ * 64 slices = 2^19 entries, an odd level size): the caller then uses ngp_hash_bwd_f32_live.
+ * The workspace belongs to ONE call sequence at a time: prep -> main of one backward must not be interleaved with another
+ * backward's on another stream using the same buffer (the bitmaps and the queue heads live in it). */
 long long ngp_hash_bwd_sliced_workspace(const ngp_hash_levels* lv, int n_max);
-/* The two halves as separate entry points: the prepass (compact positions + hit bitmaps of the dense levels, then the hit lists
- * of the hashed levels: two launches) needs only positions and live list, so it can be issued before the MLP backward that
- * produces `dout`; `main` consumes the workspace it filled. */
+/* The two halves as separate entry points: the prepass (compact positions + hit bitmaps) needs only positions and live list, so it
+ * can be issued before the MLP backward that produces `dout`; `main` consumes the workspace it filled. */
 int ngp_hash_bwd_sliced_prep(const float* xyzs, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev,
                              const int32_t* live_idx, int normalize, float lo, float hi, void* workspace,
                              long long workspace_bytes, void* stream);
@@ -214,9 +212,6 @@ int ngp_hash_bwd_sliced_main_f16(const float* dout, const ngp_hash_levels* lv, i
  * tasks[xoff[x] .. xoff[x] + xlen[x]); returns the number of tasks or -2 when the level table cannot be expressed */
 int ngp_hash_bwd_sliced_plan(const ngp_hash_levels* lv, uint16_t* tasks, int max_tasks, uint16_t* xoff /*[8]*/, uint16_t* xlen /*[8]*/,
                              uint8_t* nrep /*[NGP_MAX_LEVELS]*/, uint32_t* merge_mask, uint32_t* single_mask);
-/* bit l set = level l's slice owners are list-driven (xor-hashed power-of-two level of more than one slice; NGP_BWD_LIST=0 in the
- * environment switches the lists off and every level back to round 2's bitmap scan); 0 when the table cannot be expressed */
-int ngp_hash_bwd_sliced_list_levels(const ngp_hash_levels* lv);
 /* diagnostics: per-TASK task word + wall-clock stamps into a device buffer of 8 * 1536 uint64 (one 8-word row per task of the
  * plan, at most 1536 tasks; NULL = off, the default) */
 int ngp_hash_bwd_sliced_debug(void* device_buffer);

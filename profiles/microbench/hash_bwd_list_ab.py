@@ -1,4 +1,7 @@
-"""Round 3 A/B of the scatter-add's hashed levels on REAL backward inputs: hit LISTS (NGP_BWD_LIST=1, the default) against round 2's
+"""(Needs the experiment commit 3017399: the list-driven form it A/B-tests was measured slower and is not in the shipped library; at
+HEAD the script still times the prepass and the main launch separately, prints the per-level task timeline and A/B-tests whatever
+knobs NGP_AB_VARIANTS names.)
+Round 3 A/B of the scatter-add's hashed levels on REAL backward inputs: hit LISTS (NGP_BWD_LIST=1, the default) against round 2's
 bitmap scan (NGP_BWD_LIST=0).  The plan knobs are read once per process, so run it once per setting:
 
     NGP_BWD_LIST=1 python profiles/microbench/hash_bwd_list_ab.py ; NGP_BWD_LIST=0 python profiles/microbench/hash_bwd_list_ab.py
@@ -55,7 +58,7 @@ def main():
     cfg = RenderConfig(model, 0.0, 1e-4, 1024)
     live, total = int(tr._live_total[0]), int(M.total[0])
     lv = cfg.levels
-    list_levels = L.ngp_hash_bwd_sliced_list_levels(ctypes.byref(lv))
+    list_levels = L.ngp_hash_bwd_sliced_list_levels(ctypes.byref(lv)) if hasattr(L, "ngp_hash_bwd_sliced_list_levels") else 0
     print("live samples %d, marched %d, list-driven levels 0x%04x (NGP_BWD_LIST=%s)" % (live, total, list_levels, os.environ.get("NGP_BWD_LIST", "unset")))
     grad = torch.zeros_like(tr.table)
     ws = A.sliced_ws(lv)

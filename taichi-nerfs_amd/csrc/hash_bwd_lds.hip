@@ -28,19 +28,22 @@
 //     load (one super-chunk ahead), compacts the hits into a per-wave LDS queue and processes them 128 at a time with all
 //     lanes busy, the gathers of the next batch in flight while the current one is accumulated.
 //
-//   prep  : compact normalised positions xyzc[i]; per (level, slice) hit bitmaps for the DENSE levels
-//   list  : (round 3) the hashed levels get HIT LISTS instead of bitmaps.  An owner of a hashed slice sees 4 of 64 samples; finding
-//           them in a bitmap cost about as many instructions as accumulating them (the scan was ~40 % of a hashed task), and the
-//           owner then re-derived which of the four (y, z) corner pairs had landed in its slice.  hash_bwd_list_kernel sorts every
-//           2048-sample chunk of a level by slice in LDS (counting sort; an entry = live index | (y, z) combination << 30, exactly
-//           4 per sample and level) and writes the chunk's 8192 entries + a 64-word table (start | count << 16 per slice): an
-//           owner reads ITS segment of every chunk -- coalesced, no search, no capacity question (a chunk's region is fixed) --
-//           and does one corner pair per entry.
+//   prep  : compact normalised positions xyzc[i]; per (level, slice) hit bitmaps
 //   main  : task = (level, slice, replica r of R); looks at samples [r S/R, (r+1) S/R); coarse levels whose few slices would
 //           see every sample are replicated over sample ranges (private LDS copy each, flushed with float atomics: a few
 //           thousand coalesced lines per replica).
 // Task order: blockIdx b lands on XCD b % 8; all slices of one level go to one XCD where possible so that its owners stream
 // the same position / gradient lines out of that XCD's L2.
+//
+// Round 3, measured and NOT shipped (commit 3017399 has the code; profiles/r03_scatter_add_experiments.txt the numbers): hit LISTS
+// instead of bitmaps for the hashed levels (a counting sort of every 2048-sample chunk by slice in the prepass, an owner reads its
+// segment of every chunk and does one corner pair per entry: no scan, no combination test, 70 M instead of ~100 M VALU
+// instructions per launch), with a three-generation software pipeline (8 gathers per lane in flight) and a feature-blocked LDS
+// image.  Correct, prepass +2.5 us -- and the main launch 6 % SLOWER on identical inputs (231-237 vs 218-223 us).  The -DNGP_BWD_DIAG
+// breakdown says why: with the accumulate switched off but the gathers still issued both forms take 177 us, with the gathers off
+// too 123 (bitmaps) / 91 us (lists).  The launch is bound by its two 64-line gathers per 64 hits (48 M vector-L1 accesses, 27 M L2
+// requests per launch = ~27 TB/s of the L2's ~34 TB/s while the hashed levels run), not by instruction issue, LDS banking or
+// memory-level parallelism: LDS, vector L1 and VALU are each 40-50 % busy and the waves sit in s_waitcnt 55 % of their cycles.
 #include "ngp_device.h"
 #include "hash_common.h"
 #include <stdlib.h>
@@ -58,11 +61,6 @@ constexpr int BW_MAX_TASKS = 1536;
 constexpr int BW_PREP_BLOCKS = 2048;
 constexpr size_t BW_CTR_BYTES = 64;                           // 8 queue heads + the exit counter of the main kernel
 constexpr int BW_PERSISTENT_BLOCKS = 256;                     // one 1024-thread workgroup (147 KB of LDS) per CU
-constexpr int BW_LIST_CH = 2048;                               // samples per hit-list chunk (4 * CH entries of 4 bytes: 32 KB of LDS)
-constexpr int BW_LIST_THREADS = 512;
-constexpr int BW_LIST_NB = 4;                                  // sub-batches of 64 entries per pipeline generation of a list-driven owner
-constexpr int BW_LIST_BLOCKS = 1024;                           // grid of hash_bwd_list_kernel (grid-stride over (chunk, level) tasks)
-constexpr uint32_t BW_LIST_IDX_MASK = 0x3fffffffu;             // entry = live index (30 bits) | (z bit, y bit) << 30
 
 struct BwdPlan {
     int32_t n_blocks;
@@ -71,9 +69,6 @@ struct BwdPlan {
     uint8_t nrep[NGP_MAX_LEVELS];         // replicas (sample ranges) per slice of level l
     uint16_t task[BW_MAX_TASKS];          // level | slice << 4 | rep << 10; XCD x owns task[xoff[x] .. xoff[x] + xlen[x])
     uint16_t xoff[8], xlen[8];
-    uint32_t soa;                         // experiment: feature-blocked LDS image
-    uint32_t list_mask;                   // bit l: level l is list-driven (hashed, power-of-two table of > 1 slice, res < 2^13)
-    uint8_t lord[NGP_MAX_LEVELS];         // ordinal of level l among the list-driven levels (its region of the pool / table)
 };
 
 __device__ __forceinline__ uint32_t level_index(bool dense, uint32_t mode, uint32_t size, uint32_t res, uint32_t gx, uint32_t gy,
@@ -227,87 +222,6 @@ __global__ void __launch_bounds__(256) hash_bwd_prep_kernel(const float* __restr
     }
 }
 
-// ---- hit lists of the hashed levels ----------------------------------------------------------------------------------------
-// Task = (chunk c of BW_LIST_CH live samples, list-driven level).  Every sample contributes exactly four entries to its level: one
-// per (y, z) corner combination k = (z bit, y bit), filed under the slice ((cy + yb) P1 ^ (cz + zb) P2) & mask) >> 13 that both of
-// the combination's x corners fall into (x < 2^13 only touches the bits below).  Counting sort by slice in LDS:
-//   pass 1: histogram of the chunk's 4 * CH slice ids -> exclusive scan -> table row tab[level][c][slice] = start | count << 16
-//   pass 2: entry (i | k << 30) to staging[cursor[slice]++]; the chunk's region of the pool is then written as it lies, coalesced.
-// The order of the entries inside one segment depends on the wave schedule; the owner sums in f64 and rounds once, so the
-// gradient does not.  Level-minor task order: the blocks of one chunk run together and share its position lines in L2.
-template <int CH>
-__global__ void __launch_bounds__(BW_LIST_THREADS) hash_bwd_list_kernel(const float* __restrict__ xyzc /* compact, normalised: the prepass's */,
-                                                                        ngp_hash_levels lv, int n, const int32_t* __restrict__ n_dev,
-                                                                        uint32_t list_mask, uint32_t* __restrict__ pool, size_t pool_level,
-                                                                        uint32_t* __restrict__ tab, size_t tab_level) {
-    __shared__ uint32_t hist[BW_MAX_SLICES];
-    __shared__ uint32_t cursor[BW_MAX_SLICES];
-    __shared__ __attribute__((aligned(16))) uint32_t staging[4 * CH];
-    constexpr int NW = BW_LIST_THREADS / 64;                      // waves per block
-    constexpr int SPT = CH / BW_LIST_THREADS;                     // samples per thread
-    // Which samples a thread files: neighbouring lanes take samples CH / 64 apart.  The entries a wave instruction appends to one
-    // segment get consecutive positions, and the owner puts consecutive positions into neighbouring lanes of ONE ds_add_f64:
-    // consecutive samples of a ray sit in the same cell of the coarser hashed levels (7 steps per cell at resolution 85), and
-    // same-address LDS atomics serialise (measured with sample-order segments: level 6 tasks 71 us instead of 41).
-    auto local_sample = [](int tid, int j) { return (tid & 63) * (CH / 64) + (tid >> 6) * SPT + j; };
-    static_assert(CH % BW_LIST_THREADS == 0 && (CH / 64) == NW * SPT, "NW waves x SPT samples = one lane's stride");
-    if (n_dev) n = min(n, *n_dev);
-    if (n <= 0) return;
-    const int n_chunks = (n + CH - 1) / CH, n_list = __popc(list_mask);
-    const int tid = threadIdx.x;
-    for (int task = blockIdx.x; task < n_chunks * n_list; task += gridDim.x) {
-        const int c = task / n_list, lo = task - c * n_list;
-        uint32_t mm = list_mask;
-        for (int k = 0; k < lo; ++k) mm &= mm - 1u;
-        const int level = __builtin_ctz(mm);                      // the lo-th list-driven level
-        const float scale = lv.scale[level];
-        const uint32_t msk = lv.map_size[level] - 1u;
-        if (tid < BW_MAX_SLICES) hist[tid] = 0u;
-        __syncthreads();
-        uint32_t sl4[SPT];                                        // the sample's four slice ids, 6 bits each; ~0 = no sample
-#pragma unroll
-        for (int j = 0; j < SPT; ++j) {
-            const int i = c * CH + local_sample(tid, j);
-            uint32_t packed = 0xffffffffu;
-            if (i < n) {
-                const float y = xyzc[3 * (size_t)i + 1], z = xyzc[3 * (size_t)i + 2];
-                const uint32_t cy = f2u_sat(floorf(y * scale + 0.5f)), cz = f2u_sat(floorf(z * scale + 0.5f));
-                const uint32_t b0 = cy * 2654435761u, b1 = b0 + 2654435761u, c0 = cz * 805459861u, c1 = c0 + 805459861u;
-                const uint32_t s0 = ((b0 ^ c0) & msk) >> BW_SLICE_LOG2, s1 = ((b1 ^ c0) & msk) >> BW_SLICE_LOG2,
-                               s2 = ((b0 ^ c1) & msk) >> BW_SLICE_LOG2, s3 = ((b1 ^ c1) & msk) >> BW_SLICE_LOG2;      // k = 0, 1, 2, 3
-                packed = s0 | (s1 << 6) | (s2 << 12) | (s3 << 18);
-                atomicAdd(&hist[s0], 1u); atomicAdd(&hist[s1], 1u); atomicAdd(&hist[s2], 1u); atomicAdd(&hist[s3], 1u);
-            }
-            sl4[j] = packed;
-        }
-        __syncthreads();
-        if (tid < BW_MAX_SLICES) {                                // wave 0: exclusive scan of the 64 counts
-            const uint32_t cnt = hist[tid];
-            const uint32_t start = (uint32_t)wave_scan_add_i((int)cnt, tid) - cnt;
-            cursor[tid] = start;
-            tab[(size_t)lo * tab_level + (size_t)c * BW_MAX_SLICES + tid] = start | (cnt << 16);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < SPT; ++j) {
-            const uint32_t packed = sl4[j];
-            if (packed != 0xffffffffu) {
-                const uint32_t i = (uint32_t)(c * CH + local_sample(tid, j));
-#pragma unroll
-                for (uint32_t k = 0; k < 4; ++k) {
-                    const uint32_t pos = atomicAdd(&cursor[(packed >> (6 * k)) & 63u], 1u);
-                    staging[pos] = i | (k << 30);
-                }
-            }
-        }
-        __syncthreads();
-        const int total = 4 * min(CH, n - c * CH);                 // a multiple of 4
-        uint32_t* dst = pool + (size_t)lo * pool_level + (size_t)c * (4 * CH);
-        for (int e = 4 * tid; e < total; e += 4 * BW_LIST_THREADS) *reinterpret_cast<uint4*>(dst + e) = *reinterpret_cast<const uint4*>(staging + e);
-        __syncthreads();
-    }
-}
-
 // ---- main kernel -------------------------------------------------------------------------------------------------------
 struct LevelParams {
     float scale;
@@ -315,7 +229,6 @@ struct LevelParams {
     bool dense;
     SliceMap map;
     uint32_t diag;           // diagnostics only (NGP_BWD_DIAG): bit 0 = skip the LDS adds, bit 1 = skip the gathers
-    bool soa;                // experiment: feature-blocked LDS image (lds_f0)
 };
 struct Hit {
     float x, y, z, g0, g1;
@@ -324,7 +237,7 @@ struct __attribute__((packed, aligned(4))) F3 {
     float x, y, z;
 };
 
-__device__ __forceinline__ float round16(float v) { return (float)(_Float16)v; }                  // through fp16 (round to nearest even) and back
+__device__ __forceinline__ float round16(float v) { return f16_round(v); }      // through fp16 (RNE) and back, never fused into the product
 
 __device__ __forceinline__ Hit load_hit(const int level, const int i, const bool valid, const float* __restrict__ xyzc,
                                         const float* __restrict__ dout, const size_t plane, const int enc_pairs, const int nl,
@@ -344,12 +257,6 @@ __device__ __forceinline__ Hit load_hit(const int level, const int i, const bool
 }
 
 __device__ __forceinline__ void lds_add(double* p, float v) { atomicAdd(p, (double)v); }          // ds_add_f64
-
-// LDS image of a slice (indices in doubles).  EXPERIMENT (P.soa): blocks of 32 entries stored as 32 x feature 0 then 32 x feature 1,
-// so that the feature-0 adds of one wave instruction spread over all 64 banks instead of every other bank pair (entry-major:
-// feature f of entry e at 2 e + f).
-__device__ __forceinline__ uint32_t lds_f0(const bool soa, uint32_t loc) { return soa ? (((loc & ~31u) << 1) | (loc & 31u)) : 2u * loc; }
-__device__ __forceinline__ uint32_t lds_f1_off(const bool soa) { return soa ? 32u : 1u; }
 #ifdef NGP_BWD_DIAG          // timing experiments only (profiles/microbench): lets the LDS adds / the gathers be switched off at run time
 #define LDS_ADD(p, v) do { if (!(P.diag & 1u)) lds_add((p), (v)); else asm volatile("" :: "v"(v), "v"(p)); } while (0)
 #else
@@ -416,11 +323,10 @@ __device__ __forceinline__ void accumulate(const LevelParams P, const uint32_t s
                 const uint32_t A = (k & 2) ? ((k & 1) ? A3 : A2) : ((k & 1) ? A1 : A0);
                 const float wy = (k & 1) ? fy : 1.0f - fy, wz = (k & 2) ? fz : 1.0f - fz;
                 const float w0 = (wx0 * wy) * wz, w1 = (wx1 * wy) * wz;
-                double* p0 = slice + lds_f0(P.soa, ((cx ^ A) & msk) & (BW_SLICE_ENTRIES - 1));
-                double* p1 = slice + lds_f0(P.soa, (((cx + 1u) ^ A) & msk) & (BW_SLICE_ENTRIES - 1));
-                const uint32_t o1 = lds_f1_off(P.soa);
-                LDS_ADD(p0, R(w0 * g0)); LDS_ADD(p0 + o1, R(w0 * g1));
-                LDS_ADD(p1, R(w1 * g0)); LDS_ADD(p1 + o1, R(w1 * g1));
+                double* p0 = slice + 2 * (((cx ^ A) & msk) & (BW_SLICE_ENTRIES - 1));
+                double* p1 = slice + 2 * ((((cx + 1u) ^ A) & msk) & (BW_SLICE_ENTRIES - 1));
+                LDS_ADD(p0, R(w0 * g0)); LDS_ADD(p0 + 1, R(w0 * g1));
+                LDS_ADD(p1, R(w1 * g0)); LDS_ADD(p1 + 1, R(w1 * g1));
             }
         }
         return;
@@ -437,9 +343,9 @@ __device__ __forceinline__ void accumulate(const LevelParams P, const uint32_t s
                     const uint32_t h = level_index(P.dense, P.mode, P.size, P.res, cx + xb, cy + yb, cz + zb);
                     if (slice_of(P.map, h, loc) == sl) {
                         const float w = ((1.0f * (xb ? fx : 1.0f - fx)) * wyz_y) * wyz_z;
-                        double* p = slice + lds_f0(P.soa, loc);
+                        double* p = slice + 2 * loc;
                         LDS_ADD(p, R(w * g0));
-                        LDS_ADD(p + lds_f1_off(P.soa), R(w * g1));
+                        LDS_ADD(p + 1, R(w * g1));
                     }
                 }
             }
@@ -471,9 +377,9 @@ __device__ __forceinline__ void accumulate(const LevelParams P, const uint32_t s
             const uint32_t h = K == KIND_MERGE0 ? dense0_index(base, P.res, res2, P.size, c)
                                                    : level_index(P.dense, P.mode, P.size, P.res, cx + (c & 1), cy + ((c >> 1) & 1), cz + (c >> 2));
             if (slice_of(P.map, h, loc) == sl) {
-                double* p = slice + lds_f0(P.soa, loc);
+                double* p = slice + 2 * loc;
                 LDS_ADD(p, v0[c]);
-                LDS_ADD(p + lds_f1_off(P.soa), v1[c]);
+                LDS_ADD(p + 1, v1[c]);
             }
         }
     }
@@ -652,112 +558,6 @@ __device__ __forceinline__ void bwd_task(const LevelParams P, const int level, c
     accumulate_batch<KIND>(P, sl, false, pend, slice, found_inf);
 }
 
-// ---- list-driven owner of a hashed slice ------------------------------------------------------------------------------------------
-// One entry = one (sample, (y, z) combination) whose two x corners live in this slice: no test, no loop over combinations.
-template <bool HALF>
-__device__ __forceinline__ void accumulate_list(const LevelParams P, const Hit H, const uint32_t k, const bool valid, double* __restrict__ slice) {
-    const float g0 = H.g0, g1 = H.g1;
-    if (!(valid && (g0 != 0.0f || g1 != 0.0f))) return;            // exact-zero gradients contribute nothing
-    const float px = H.x * P.scale + 0.5f, py = H.y * P.scale + 0.5f, pz = H.z * P.scale + 0.5f;
-    const uint32_t cx = f2u_sat(floorf(px)), cy = f2u_sat(floorf(py)), cz = f2u_sat(floorf(pz));
-    const float fx = px - (HALF ? round16((float)cx) : (float)cx), fy = py - (HALF ? round16((float)cy) : (float)cy),
-                fz = pz - (HALF ? round16((float)cz) : (float)cz);
-    auto R = [](float v) { return HALF ? round16(v) : v; };
-    const uint32_t yb = k & 1u, zb = k >> 1;
-    const uint32_t msk = P.size - 1u;
-    const uint32_t A = ((cy + yb) * 2654435761u) ^ ((cz + zb) * 805459861u);
-    const float wy = yb ? fy : 1.0f - fy, wz = zb ? fz : 1.0f - fz;
-    const float wx0 = 1.0f * (1.0f - fx), wx1 = 1.0f * fx;        // same product order as the forward
-    const float w0 = (wx0 * wy) * wz, w1 = (wx1 * wy) * wz;
-    double* p0 = slice + lds_f0(P.soa, ((cx ^ A) & msk) & (BW_SLICE_ENTRIES - 1));
-    double* p1 = slice + lds_f0(P.soa, (((cx + 1u) ^ A) & msk) & (BW_SLICE_ENTRIES - 1));
-    const uint32_t o1 = lds_f1_off(P.soa);
-    LDS_ADD(p0, R(w0 * g0)); LDS_ADD(p0 + o1, R(w0 * g1));
-    LDS_ADD(p1, R(w1 * g0)); LDS_ADD(p1 + o1, R(w1 * g1));
-}
-
-// A GENERATION = NB sub-batches of 64 entries (one per lane each).  Three generations are in flight per wave: the entries of
-// generation g + 2 (coalesced loads), the position / gradient gathers of generation g + 1 (2 NB loads per lane), the LDS adds of
-// generation g.  Round 3 counters (profiles/r03_pmc_scatter_add.json): the waves of this kernel sit in s_waitcnt 55 % of their
-// cycles while LDS, vector L1 and VALU are each ~40 % busy -- one workgroup per CU (the 128 KB slice) means four waves per SIMD,
-// so the only way to cover the L2 latency is more independent loads per wave, hence NB = 4 (8 gathers per lane in flight).
-template <int NB>
-struct GenL {
-    Hit h[NB];
-    uint32_t k[NB];
-    bool v[NB];
-};
-
-// The waves of the owner take the chunks round-robin (wave w: chunks w, w + 16, ...: every slice of a hashed level receives a
-// Poisson-equal share of every chunk, so a static deal balances) and read their chunks' segment-table words with ONE vector load
-// per 64 chunks; the stream of sub-batches then runs across segment boundaries without a memory access on the control path.
-template <bool HALF, int NB>
-__device__ __forceinline__ void bwd_task_list(const LevelParams P, const int level, const int n, const float* __restrict__ xyzc,
-                                              const float* __restrict__ dout, const size_t plane, const int enc_pairs, const int nl,
-                                              double* __restrict__ slice, int32_t* __restrict__ found_inf,
-                                              const uint32_t* __restrict__ pool_l, const uint32_t* __restrict__ tab_ls) {
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int n_chunks = (n + BW_LIST_CH - 1) / BW_LIST_CH;
-    const int my_chunks = wave < n_chunks ? (n_chunks - wave + BW_WAVES - 1) / BW_WAVES : 0;
-    int j = 0, jbase = -64, c = 0;                                  // wave-uniform stream state
-    uint32_t tabv = 0u, start = 0u, cnt = 0u, p = 0u;
-    auto next_sub = [&](uint32_t& e, bool& v) {                     // the next <= 64 entries of this wave's stream (v = lane has one)
-        while (p >= cnt) {
-            if (j >= my_chunks) { e = 0u; v = false; return; }
-            if (j >= jbase + 64) {
-                jbase += 64;
-                const int mine = jbase + lane;
-                tabv = mine < my_chunks ? tab_ls[(size_t)(wave + BW_WAVES * mine) * BW_MAX_SLICES] : 0u;
-            }
-            const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)tabv, j - jbase);
-            c = wave + BW_WAVES * j;
-            start = t & 0xffffu; cnt = t >> 16; p = 0u;
-            ++j;
-        }
-        const uint32_t* seg = pool_l + (size_t)c * (4 * BW_LIST_CH) + start + p;
-        v = p + (uint32_t)lane < cnt;
-        e = v ? seg[lane] : 0u;
-        p += 64u;
-    };
-    auto run = [&](const GenL<NB>& g) {
-        if (found_inf) {
-            bool fin = true;
-#pragma unroll
-            for (int b = 0; b < NB; ++b) fin = fin && isfinite(g.h[b].g0) && isfinite(g.h[b].g1);
-            if (!fin) *found_inf = 1;
-        }
-#ifdef NGP_BWD_DIAG
-        if (P.diag & 4u) { asm volatile("" :: "v"(g.h[0].x), "v"(g.h[0].g0)); return; }
-#endif
-#pragma unroll
-        for (int b = 0; b < NB; ++b) accumulate_list<HALF>(P, g.h[b], g.k[b], g.v[b], slice);
-    };
-    uint32_t e[NB];
-    bool v[NB];
-    auto load_entries = [&]() -> bool {                             // false once the stream is exhausted (all lanes invalid)
-#pragma unroll
-        for (int b = 0; b < NB; ++b) next_sub(e[b], v[b]);
-        return p < cnt || j < my_chunks || __any(v[0]);
-    };
-    GenL<NB> pend;
-#pragma unroll
-    for (int b = 0; b < NB; ++b) { pend.v[b] = false; pend.k[b] = 0u; pend.h[b] = Hit{0.f, 0.f, 0.f, 0.f, 0.f}; }
-    bool have = load_entries();
-    while (have) {
-        GenL<NB> nxt;
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            nxt.v[b] = v[b]; nxt.k[b] = e[b] >> 30;
-            nxt.h[b] = load_hit(level, (int)(e[b] & BW_LIST_IDX_MASK), v[b], xyzc, dout, plane, enc_pairs, nl, found_inf, P.diag, HALF);
-        }
-        have = load_entries();
-        run(pend);
-        pend = nxt;
-    }
-    run(pend);
-}
-
 // Queue heads: ctr[x] = tasks taken from the front of XCD x's queue (low 16 bits, by its own workgroups) and from the back (high
 // 16 bits, by thieves); one atomic add claims one position, a claim is valid while front + back < length.  Returns the index
 // into plan.task or 0xffffffff when every queue is empty.
@@ -790,9 +590,7 @@ __global__ void __launch_bounds__(BW_THREADS) hash_bwd_lds_kernel(const float* _
                                                                   const int32_t* __restrict__ n_dev, int enc_pairs, BwdPlan plan,
                                                                   void* __restrict__ dtable /* f32 pairs; HALF: f16 pairs */,
                                                                   int32_t* __restrict__ found_inf, uint32_t* __restrict__ ctr,
-                                                                  unsigned long long* __restrict__ dbg,
-                                                                  const uint32_t* __restrict__ pool, size_t pool_level,
-                                                                  const uint32_t* __restrict__ tab, size_t tab_level) {
+                                                                  unsigned long long* __restrict__ dbg) {
     __shared__ double slice[2 * BW_SLICE_ENTRIES];
     __shared__ uint32_t queues[BW_WAVES * BW_Q];
     __shared__ uint32_t next_sc;
@@ -825,11 +623,9 @@ __global__ void __launch_bounds__(BW_THREADS) hash_bwd_lds_kernel(const float* _
     else P.mode = (P.size != 0 && (P.size & (P.size - 1)) == 0) ? 1u : 2u;
     P.map = slice_map(P.size, P.res, P.dense);
     P.diag = plan.diag;
-    P.soa = plan.soa != 0u;
     const bool single = P.size <= (uint32_t)BW_SLICE_ENTRIES;           // one slice: every sample is a hit, no bitmap
     const bool merge = (plan.merge_mask >> level) & 1u;
     const bool hashed = !P.dense && P.mode == 1u && P.res < (1u << BW_SLICE_LOG2) && !single;
-    const bool listed = (plan.list_mask >> level) & 1u;                 // (implies `hashed`; build_plan applies the same conditions)
 
     double2* s2 = reinterpret_cast<double2*>(slice);
     for (int j = tid; j < BW_SLICE_ENTRIES; j += BW_THREADS) s2[j] = make_double2(0.0, 0.0);
@@ -839,10 +635,7 @@ __global__ void __launch_bounds__(BW_THREADS) hash_bwd_lds_kernel(const float* _
     if (dbg) t_init = wall_clock64();
     uint32_t* q = queues + (tid >> 6) * BW_Q;
     const unsigned long long* brow = bitmap + ((size_t)level * BW_MAX_SLICES + sl) * wstride;
-    if (listed)
-        bwd_task_list<HALF, BW_LIST_NB>(P, level, n, xyzc, dout, plane, enc_pairs, lv.n_levels, slice, found_inf,
-                                        pool + (size_t)plan.lord[level] * pool_level, tab + (size_t)plan.lord[level] * tab_level + sl);
-    else if (merge && P.dense && P.mode == 0u) bwd_task<KIND_MERGE0 | (HALF ? KIND_HALF : 0)>(P, level, sl, single, n, rep, nrep, xyzc, brow, dout, plane, enc_pairs, lv.n_levels, slice, q, &next_sc, found_inf);
+    if (merge && P.dense && P.mode == 0u) bwd_task<KIND_MERGE0 | (HALF ? KIND_HALF : 0)>(P, level, sl, single, n, rep, nrep, xyzc, brow, dout, plane, enc_pairs, lv.n_levels, slice, q, &next_sc, found_inf);
     else if (merge) bwd_task<KIND_MERGE | (HALF ? KIND_HALF : 0)>(P, level, sl, single, n, rep, nrep, xyzc, brow, dout, plane, enc_pairs, lv.n_levels, slice, q, &next_sc, found_inf);
     else if (hashed) bwd_task<KIND_HASHED | (HALF ? KIND_HALF : 0)>(P, level, sl, single, n, rep, nrep, xyzc, brow, dout, plane, enc_pairs, lv.n_levels, slice, q, &next_sc, found_inf);
     else bwd_task<KIND_GENERIC | (HALF ? KIND_HALF : 0)>(P, level, sl, single, n, rep, nrep, xyzc, brow, dout, plane, enc_pairs, lv.n_levels, slice, q, &next_sc, found_inf);
@@ -859,8 +652,7 @@ __global__ void __launch_bounds__(BW_THREADS) hash_bwd_lds_kernel(const float* _
         typedef _Float16 half2v __attribute__((ext_vector_type(2)));
         half2v* dh = reinterpret_cast<half2v*>(dtable) + P.offset;
         for (int j = tid; j < BW_SLICE_ENTRIES; j += BW_THREADS) {
-            const uint32_t jf = lds_f0(P.soa, (uint32_t)j);
-            const double2 a = make_double2(slice[jf], slice[jf + lds_f1_off(P.soa)]);
+            const double2 a = s2[j];
             if (a.x == 0.0 && a.y == 0.0) continue;
             const uint32_t h = entry_of(P.map, sl, (uint32_t)j);
             half2v val;
@@ -872,8 +664,7 @@ __global__ void __launch_bounds__(BW_THREADS) hash_bwd_lds_kernel(const float* _
     } else {
     float2* dl = reinterpret_cast<float2*>(reinterpret_cast<float*>(dtable) + 2 * (size_t)P.offset);
     for (int j = tid; j < BW_SLICE_ENTRIES; j += BW_THREADS) {
-        const uint32_t jf = lds_f0(P.soa, (uint32_t)j);
-        const double2 a = make_double2(slice[jf], slice[jf + lds_f1_off(P.soa)]);
+        const double2 a = s2[j];
         if (a.x == 0.0 && a.y == 0.0) continue;
         const uint32_t h = entry_of(P.map, sl, (uint32_t)j);          // LDS position j -> table entry
         const float vx = (float)a.x, vy = (float)a.y;
@@ -908,17 +699,16 @@ __global__ void __launch_bounds__(BW_THREADS) hash_bwd_lds_kernel(const float* _
 
 // ---- host: the task plan -------------------------------------------------------------------------------------------------
 // Returns false when the level table does not fit the formulation (F != 2, or a level of more than 64 slices).
-// Plan knobs.  Release builds read the environment ONCE (NGP_BWD_LIST=0 switches the hit lists of the hashed levels off and falls
-// back to round 2's bitmap scan; NGP_BWD_REP_TARGET / NGP_BWD_MERGE_RES / NGP_BWD_DENSE_MIN_REP tune the dense levels).  The
-// diagnostic knobs that change RESULTS (NGP_BWD_LEVELS drops levels, NGP_BWD_DIAG switches pieces of the kernel off) exist only in
-// -DNGP_BWD_DIAG builds, which also re-read everything on every call (profiles/microbench sweeps them inside one process).
+// Plan knobs.  Release builds read the environment ONCE (NGP_BWD_REP_TARGET / NGP_BWD_MERGE_RES / NGP_BWD_DENSE_MIN_REP tune the
+// replication of the dense levels); NGP_BWD_KNOBS_DYNAMIC=1 makes them re-read on every call so that one process can A/B them on
+// the same inputs (profiles/microbench).  The diagnostic knobs that change RESULTS (NGP_BWD_LEVELS drops levels, NGP_BWD_DIAG
+// switches pieces of the kernel off) exist only in -DNGP_BWD_DIAG builds (they used to be honoured by every build).
 struct Knobs {
     int rep_target = 48, merge_res = 128, dense_min_rep = 8;
-    bool use_lists = true, soa = false;
     uint32_t level_mask = 0xffffffffu, diag = 0u;
     bool operator==(const Knobs& o) const {
-        return rep_target == o.rep_target && merge_res == o.merge_res && dense_min_rep == o.dense_min_rep && use_lists == o.use_lists &&
-               level_mask == o.level_mask && diag == o.diag && soa == o.soa;
+        return rep_target == o.rep_target && merge_res == o.merge_res && dense_min_rep == o.dense_min_rep && level_mask == o.level_mask &&
+               diag == o.diag;
     }
 };
 static Knobs read_knobs() {
@@ -926,8 +716,6 @@ static Knobs read_knobs() {
     if (const char* e = getenv("NGP_BWD_REP_TARGET")) k.rep_target = atoi(e) > 0 ? atoi(e) : k.rep_target;
     if (const char* e = getenv("NGP_BWD_MERGE_RES")) k.merge_res = atoi(e);
     if (const char* e = getenv("NGP_BWD_DENSE_MIN_REP")) k.dense_min_rep = atoi(e) > 0 ? atoi(e) : k.dense_min_rep;
-    if (const char* e = getenv("NGP_BWD_LIST")) k.use_lists = atoi(e) != 0;
-    if (const char* e = getenv("NGP_BWD_SOA")) k.soa = atoi(e) != 0;
 #ifdef NGP_BWD_DIAG
     if (const char* e = getenv("NGP_BWD_LEVELS")) k.level_mask = (uint32_t)strtoul(e, nullptr, 0);
     if (const char* e = getenv("NGP_BWD_DIAG")) k.diag = (uint32_t)atoi(e);
@@ -935,8 +723,6 @@ static Knobs read_knobs() {
     return k;
 }
 static const Knobs& knobs() {
-    // NGP_BWD_KNOBS_DYNAMIC=1 (read once): re-read the knobs on every call, so that one process can A/B them on the same inputs
-    // (profiles/microbench/hash_bwd_list_ab.py); the plan cache is keyed by the knobs, so this only costs the getenv calls
     static const bool dynamic = getenv("NGP_BWD_KNOBS_DYNAMIC") != nullptr;
     static const Knobs fixed = read_knobs();
 #ifndef NGP_BWD_DIAG
@@ -947,17 +733,6 @@ static const Knobs& knobs() {
     return k;
 }
 
-// levels whose owners can be list-driven: xor-hashed into a power-of-two table of more than one slice, resolution below 2^13 (the x
-// corner pair then shares its slice).  Does not depend on the knobs: the workspace is laid out for these levels either way.
-static uint32_t listable_levels(const ngp_hash_levels& lv) {
-    uint32_t m = 0u;
-    for (int l = lv.begin_fast_hash_level; l < lv.n_levels && l < NGP_MAX_LEVELS; ++l) {
-        const uint32_t size = lv.map_size[l];
-        if (l >= 0 && size > (uint32_t)BW_SLICE_ENTRIES && (size & (size - 1u)) == 0u && lv.resolution[l] < (1u << BW_SLICE_LOG2)) m |= 1u << l;
-    }
-    return m;
-}
-
 static bool build_plan_with(const ngp_hash_levels& lv, BwdPlan& plan, uint32_t& single_mask, int dense_min_rep, const Knobs& K) {
     if (lv.n_features != 2 || lv.n_levels < 1 || lv.n_levels > NGP_MAX_LEVELS) return false;
     struct Lvl { int level, n_slices, nrep, tasks; };
@@ -966,12 +741,7 @@ static bool build_plan_with(const ngp_hash_levels& lv, BwdPlan& plan, uint32_t& 
     plan.merge_mask = 0u;
     const int rep_target = K.rep_target;  // a replicated level gets ~ rep_target tasks (see the replica comment below)
     const int merge_res = K.merge_res;    // pre-sum equal-cell runs on levels up to this resolution
-    const uint32_t level_mask = K.level_mask;
-    plan.list_mask = K.use_lists ? listable_levels(lv) : 0u;
-    {
-        int ord = 0;
-        for (int l = 0; l < NGP_MAX_LEVELS; ++l) plan.lord[l] = (uint8_t)(((listable_levels(lv) >> l) & 1u) ? ord++ : 0);
-    }
+    const uint32_t level_mask = K.level_mask;      // diagnostics (-DNGP_BWD_DIAG): only these levels' tasks
     for (int l = 0; l < lv.n_levels; ++l) {
         const uint32_t size = lv.map_size[l];
         const int ns = (int)((size + BW_SLICE_ENTRIES - 1) / BW_SLICE_ENTRIES);
@@ -994,7 +764,6 @@ static bool build_plan_with(const ngp_hash_levels& lv, BwdPlan& plan, uint32_t& 
     }
     for (int l = lv.n_levels; l < NGP_MAX_LEVELS; ++l) plan.nrep[l] = 1;
     plan.diag = K.diag;                   // timing experiments only (-DNGP_BWD_DIAG builds): wrong results
-    plan.soa = K.soa ? 1u : 0u;
     // XCD-aware order (block b runs on XCD b % 8, one 1024-thread block per CU): the owners of one level read the same
     // position / gradient lines, and they only find them in L2 if they run on the same XCD at about the same time (measured:
     // a hashed level's owners take 52 us when the level has an XCD to itself, 115 us when its 64 owners are spread over all
@@ -1010,7 +779,6 @@ static bool build_plan_with(const ngp_hash_levels& lv, BwdPlan& plan, uint32_t& 
     // level's 64 slices, ~1.5 of a contiguous dense level's slices (z and z + 1 planes), ~2.7 of an interleaved one's
     auto cost = [&](const Lvl& L) {
         const float S = 400.0f;                                 // thousands of samples
-        if ((plan.list_mask >> L.level) & 1u) return 6.0f + 1.0f * S * 4.0f / (float)L.n_slices / (float)L.nrep;      // list-driven: no scan
         if (L.level >= lv.begin_fast_hash_level) return 3.0f + 1.9f * S * 4.0f / (float)L.n_slices / (float)L.nrep;
         const float frac = L.n_slices == 1 ? 1.0f : (L.n_slices < 8 ? 1.5f : 2.7f) / (float)L.n_slices;
         return 3.0f + 2.7f * S * frac / (float)L.nrep;
@@ -1092,25 +860,17 @@ static const BwdPlan* get_plan(const ngp_hash_levels& lv, uint32_t& single_mask)
     return c.ok ? &c.plan : nullptr;
 }
 
-// ---- workspace: compact positions | hit bitmaps (dense levels; all levels with NGP_BWD_LIST=0) | hit-list pool | its segment
-// table | queue heads
+// ---- workspace: compact positions | one hit bit per (level, slice, sample) | queue heads
 struct WsLayout {
-    size_t ms, words, n_chunks, pool_level, tab_level;       // ms: capacity in samples (multiple of BW_LIST_CH); per-level strides (u32)
-    int n_list;
-    size_t off_bitmap, off_pool, off_tab, off_ctr, total;    // bytes
+    size_t ms, words;                          // capacity in samples (a multiple of 512) and in 64-sample bitmap words
+    size_t off_bitmap, off_ctr, total;         // bytes
 };
 static WsLayout ws_layout(const ngp_hash_levels& lv, int n_max) {
     WsLayout w;
-    w.ms = ((size_t)n_max + BW_LIST_CH - 1) / BW_LIST_CH * BW_LIST_CH;
+    w.ms = ((size_t)n_max + 511) & ~(size_t)511;
     w.words = w.ms / 64;
-    w.n_chunks = w.ms / BW_LIST_CH;
-    w.n_list = __builtin_popcount(listable_levels(lv));
-    w.pool_level = 4 * w.ms;
-    w.tab_level = w.n_chunks * BW_MAX_SLICES;
     w.off_bitmap = w.ms * 3 * sizeof(float);
-    w.off_pool = w.off_bitmap + (size_t)lv.n_levels * BW_MAX_SLICES * w.words * sizeof(unsigned long long);
-    w.off_tab = w.off_pool + (size_t)w.n_list * w.pool_level * sizeof(uint32_t);
-    w.off_ctr = w.off_tab + (size_t)w.n_list * w.tab_level * sizeof(uint32_t);
+    w.off_ctr = w.off_bitmap + (size_t)lv.n_levels * BW_MAX_SLICES * w.words * sizeof(unsigned long long);
     w.total = w.off_ctr + BW_CTR_BYTES;
     return w;
 }
@@ -1146,17 +906,8 @@ int ngp_hash_bwd_sliced_plan(const ngp_hash_levels* lv, uint16_t* tasks, int max
     return total;
 }
 
-// bit l = level l's slice owners are list-driven (hashed level, hit lists instead of bitmaps) under the current knobs; 0 when the
-// table cannot be expressed
-int ngp_hash_bwd_sliced_list_levels(const ngp_hash_levels* lv) {
-    if (!lv) return 0;
-    uint32_t sm = 0;
-    const BwdPlan* plan = get_plan(*lv, sm);
-    return plan ? (int)plan->list_mask : 0;
-}
-
-// bytes of scratch the sliced scatter-add needs for buffers of n_max samples: compact positions + one hit bit per (dense level,
-// slice, sample) + 4 list entries per (hashed level, sample) + the segment tables (ws_layout above)
+// bytes of scratch the sliced scatter-add needs for buffers of n_max samples: compact positions + one hit bit per (level, slice,
+// sample) + the queue heads (ws_layout above)
 long long ngp_hash_bwd_sliced_workspace(const ngp_hash_levels* lv, int n_max) {
     if (!lv || n_max <= 0) return 0;
     return (long long)ws_layout(*lv, n_max).total;
@@ -1172,25 +923,15 @@ int ngp_hash_bwd_sliced_prep(const float* xyzs, const ngp_hash_levels* lv, int n
     uint32_t single_mask;
     const BwdPlan* plan = get_plan(*lv, single_mask);
     if (!plan) return -2;
-    if (plan->list_mask && (unsigned)n_max > BW_LIST_IDX_MASK) return -2;          // list entries hold 30-bit sample indices
     const WsLayout W = ws_layout(*lv, n_max);
     char* base = reinterpret_cast<char*>(workspace);
     float* xyzc = reinterpret_cast<float*>(base);
     unsigned long long* bitmap = reinterpret_cast<unsigned long long*>(base + W.off_bitmap);
     uint32_t* ctr = reinterpret_cast<uint32_t*>(base + W.off_ctr);
     const XyzNorm nm = {normalize, lo, hi};
-    // levels without a bitmap: one-slice levels (every sample is a hit) and the list-driven ones
     hipLaunchKernelGGL(hash_bwd_prep_kernel, dim3(BW_PREP_BLOCKS), dim3(256), 0, (hipStream_t)stream, xyzs, live_idx, *lv, n_max, n_dev, nm,
-                       W.words, single_mask | plan->list_mask, xyzc, bitmap, ctr);
+                       W.words, single_mask, xyzc, bitmap, ctr);
     NGP_LAUNCH_CHECK();
-    if (plan->list_mask) {
-        const long tasks = (long)W.n_chunks * __builtin_popcount(plan->list_mask);
-        const int blocks = (int)(tasks < BW_LIST_BLOCKS ? tasks : BW_LIST_BLOCKS);
-        hipLaunchKernelGGL(hash_bwd_list_kernel<BW_LIST_CH>, dim3(blocks), dim3(BW_LIST_THREADS), 0, (hipStream_t)stream, xyzc, *lv, n_max, n_dev,
-                           plan->list_mask, reinterpret_cast<uint32_t*>(base + W.off_pool), W.pool_level,
-                           reinterpret_cast<uint32_t*>(base + W.off_tab), W.tab_level);
-        NGP_LAUNCH_CHECK();
-    }
     return 0;
 }
 
@@ -1202,21 +943,18 @@ static int sliced_main(bool half, const float* dout, const ngp_hash_levels* lv, 
     uint32_t single_mask;
     const BwdPlan* plan = get_plan(*lv, single_mask);
     if (!plan) return -2;
-    if (plan->list_mask && (unsigned)n_max > BW_LIST_IDX_MASK) return -2;
     if (plan->n_blocks <= 0) return 0;
     const WsLayout W = ws_layout(*lv, n_max);
     const char* base = reinterpret_cast<const char*>(workspace);
     const float* xyzc = reinterpret_cast<const float*>(base);
     const unsigned long long* bitmap = reinterpret_cast<const unsigned long long*>(base + W.off_bitmap);
     uint32_t* ctr = reinterpret_cast<uint32_t*>(const_cast<char*>(base) + W.off_ctr);
-    const uint32_t* pool = reinterpret_cast<const uint32_t*>(base + W.off_pool);
-    const uint32_t* tab = reinterpret_cast<const uint32_t*>(base + W.off_tab);
     if (half)
         hipLaunchKernelGGL(hash_bwd_lds_kernel<true>, dim3(plan->n_blocks), dim3(BW_THREADS), 0, (hipStream_t)stream, xyzc, bitmap, W.words,
-                           dout, *lv, n_max, n_dev, enc_pairs, *plan, dtable, found_inf, ctr, g_bwd_debug, pool, W.pool_level, tab, W.tab_level);
+                           dout, *lv, n_max, n_dev, enc_pairs, *plan, dtable, found_inf, ctr, g_bwd_debug);
     else
         hipLaunchKernelGGL(hash_bwd_lds_kernel<false>, dim3(plan->n_blocks), dim3(BW_THREADS), 0, (hipStream_t)stream, xyzc, bitmap, W.words,
-                           dout, *lv, n_max, n_dev, enc_pairs, *plan, dtable, found_inf, ctr, g_bwd_debug, pool, W.pool_level, tab, W.tab_level);
+                           dout, *lv, n_max, n_dev, enc_pairs, *plan, dtable, found_inf, ctr, g_bwd_debug);
     NGP_LAUNCH_CHECK();
     return 0;
 }

@@ -326,9 +326,9 @@ __global__ void __launch_bounds__(256) hash_bwd_f16_kernel(const float* __restri
         corners<true>(L, level, lv.begin_fast_hash_level, x, y, z, c);
 #pragma unroll
         for (int ci = 0; ci < 8; ++ci) {
-            half2v val;
-            val.x = (_Float16)(c.w[ci] * g.x);
-            val.y = (_Float16)(c.w[ci] * g.y);
+            // f32 product, THEN the cast to the table's f16 (two roundings, like the reference: see f16_bits_rn)
+            const uint32_t bits = f16_bits_rn(c.w[ci] * g.x) | (f16_bits_rn(c.w[ci] * g.y) << 16);
+            const half2v val = __builtin_bit_cast(half2v, bits);
             if (val.x == (_Float16)0 && val.y == (_Float16)0) continue;             // :212
             __builtin_amdgcn_global_atomic_fadd_v2f16(
                 (__attribute__((address_space(1))) half2v*)(dtable + c.idx[ci]), val);   // global_atomic_pk_add_f16
@@ -399,7 +399,7 @@ __global__ void __launch_bounds__(256) hash_bwd_f16x2_kernel(const float* __rest
                 else if (mode == 0u) { if (h >= size) { h -= size; if (h >= size) h %= size; } }
                 else h = h % size;
                 e[k] = L.offset[level] + h;
-                const float2 r = __half22float2(__floats2half2_rn(w * g.x, w * g.y));          // cast(w * g, f16) :205-208
+                const float2 r = make_float2(f16_round(w * g.x), f16_round(w * g.y));          // cast(w * g, f16) :205-208 (f32 product first)
                 v0[k] = r.x; v1[k] = r.y;
             }
             bool hf = head;

@@ -32,6 +32,22 @@ __device__ __forceinline__ uint32_t f2u_sat(float v) {
     return r;
 }
 
+// f32 -> f16 (round to nearest even) as ONE instruction the compiler cannot fold into the multiply that produced its operand.
+// clang lowers `(_Float16)(a * b)` -- and __floats2half2_rn(a * b, ...) -- to v_fma_mixlo_f16: the exact product rounded ONCE to
+// f16, even under -ffp-contract=off.  The reference's half2 encoder multiplies in f32 and then casts (hash_encoder_half.py:159,
+// 205-212: two roundings); the two differ on ~1 product in 2000 by one f16 ulp (found by the bit-exact single-contribution rows
+// of tests/golden/ref_hash_f16*.npz).  gfx9-family 16-bit VALU results zero the upper half of the destination register.
+__device__ __forceinline__ uint32_t f16_bits_rn(float v) {
+    uint32_t r;
+    asm("v_cvt_f16_f32 %0, %1" : "=v"(r) : "v"(v));
+    return r & 0xffffu;
+}
+__device__ __forceinline__ float f16_round(float v) {                     // through f16 and back
+    float r;
+    asm("v_cvt_f16_f32 %0, %1\n\tv_cvt_f32_f16 %0, %0" : "=v"(r) : "v"(v));
+    return r;
+}
+
 // modules/utils.py:54-57
 __device__ __forceinline__ float calc_dt(float t, float esf, float dt_min, float dt_max) {
     return fminf(dt_max, fmaxf(dt_min, t * esf));
