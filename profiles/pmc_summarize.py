@@ -1,23 +1,41 @@
-"""Average rocprofv3 --pmc counters per kernel from `*_counter_collection.csv` files (one or several passes).
-usage: pmc_summarize.py <name-filter> <csv> [<csv> ...]   -> JSON {kernel: {counter: mean per dispatch, "dispatches": n}}"""
+"""Per-kernel summary of rocprofv3 --pmc counters from `*_counter_collection.csv` files (one file per pass; several passes may be
+given).  For every kernel whose name contains <name-filter> the LAST `--tail` dispatches are kept (the timed region of a bench run:
+conditioning and warm-up launches come first) and each counter is reported as the mean over them.
+usage: pmc_summarize.py [--tail N] <name-filter> <csv> [<csv> ...]   -> JSON {kernel: {counter: mean, "dispatches": n}}"""
 import csv
 import json
 import sys
 from collections import defaultdict
 
 
-def summarize(paths, flt):
-    acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
+def short_name(name):
+    s = name.split("(")[0].replace("void ", "").replace("ngp::", "")
+    return s.strip()
+
+
+def summarize(paths, flt, tail=None):
+    out = {}
     for p in paths:
+        per = defaultdict(lambda: defaultdict(list))            # kernel -> counter -> [(dispatch id, value)]
         for r in csv.DictReader(open(p)):
             name = r.get("Kernel_Name") or r.get("Name") or ""
             if flt not in name:
                 continue
-            short = name.split("(")[0].replace("void ", "").replace("ngp::", "")
-            a = acc[short][r["Counter_Name"]]
-            a[0] += float(r["Counter_Value"]); a[1] += 1
-    return {k: dict({c: v[0] / v[1] for c, v in cs.items()}, dispatches=max(v[1] for v in cs.values())) for k, cs in acc.items()}
+            per[short_name(name)][r["Counter_Name"]].append((int(r.get("Dispatch_Id") or 0), float(r["Counter_Value"])))
+        for k, cs in per.items():
+            for c, vals in cs.items():
+                vals = [v for _, v in sorted(vals)]
+                if tail:
+                    vals = vals[-tail:]
+                d = out.setdefault(k, {})
+                d[c] = sum(vals) / len(vals)
+                d["dispatches"] = max(d.get("dispatches", 0), len(vals))
+    return out
 
 
 if __name__ == "__main__":
-    print(json.dumps(summarize(sys.argv[2:], sys.argv[1]), indent=1))
+    args = sys.argv[1:]
+    tail = None
+    if args[0] == "--tail":
+        tail = int(args[1]); args = args[2:]
+    print(json.dumps(summarize(args[1:], args[0], tail), indent=1))

@@ -31,6 +31,7 @@
 // Numerics are tolerance-checked against an fp32 torch restatement and against torch's own autocast path
 // (tests/test_gpu_mlp.py); bf16/fp16 MFMA is used because this is the one genuine dense contraction on the path.
 #include "ngp_device.h"
+#include <stdlib.h>
 
 namespace ngp {
 
@@ -648,10 +649,15 @@ int ngp_adam_all(float* table, float* table_g, float* table_m, float* table_v, l
                            state_i, beta1, beta2, eps, enc_pairs, wpack, stream);
 }
 
+// Persistent forward grid = what is RESIDENT at once: 150 VGPRs -> 3 waves per SIMD -> three 256-thread blocks per CU = 768 blocks
+// (the density-only variant fits 5 per CU; 768 blocks still give it 12 waves per CU).  The launch is sized for the buffer
+// capacity (the live count is on the device), and with the former 2048 blocks a training step's ~370 k samples were 1.4 trips per
+// wave in 2.7 rounds of block residency, each block reloading the 20 KB weight image for 4-8 tiles.
 static inline int mlp_grid(int S) {
+    static const int cap = [] { const char* e = getenv("NGP_MLP_FWD_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 768; }();
     const int iters = (S + 31) / 32;
     int blocks = (iters + 3) / 4;
-    if (blocks > 2048) blocks = 2048;
+    if (blocks > cap) blocks = cap;
     return blocks < 1 ? 1 : blocks;
 }
 

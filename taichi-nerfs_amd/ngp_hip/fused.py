@@ -50,7 +50,8 @@ class TrainArena:
         self.generation = 0
 
     def sliced_ws(self, lv):
-        """Scratch of the LDS-sliced scatter-add (compact positions + slice masks for `cap` samples), allocated on first use."""
+        """Scratch of the LDS-sliced scatter-add (compact positions + hit bitmaps for `cap` samples), allocated on first use.  Like
+        every buffer of the arena it belongs to the stream the training step runs on (one step in flight per arena)."""
         need = int(_lib_mod.load().ngp_hash_bwd_sliced_workspace(ctypes.byref(lv), self.cap))
         ws = self._scratch.get("sliced_ws")
         if ws is None or ws.numel() < need:

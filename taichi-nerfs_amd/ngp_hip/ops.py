@@ -191,9 +191,13 @@ _sliced_ws = {}
 
 
 def sliced_workspace(lv, n_max, device):
-    """Scratch of the LDS-sliced scatter-add for buffers of n_max samples (grown, never shrunk, one per device)."""
+    """Scratch of the LDS-sliced scatter-add for buffers of n_max samples: one per (device, stream) -- the prepass's bitmaps and the
+    persistent workgroups' queue heads live in it, so two backward passes in flight on different streams must not share one
+    (on one stream the launches serialise and the buffer is reused).  Grown, never shrunk; a buffer that is replaced is
+    handed back to torch's caching allocator, which keeps it away from other streams until this stream's pending work is done."""
     need = int(_lib().ngp_hash_bwd_sliced_workspace(ctypes.byref(lv), int(n_max)))
-    key = device.index if device.index is not None else torch.cuda.current_device()
+    dev_index = device.index if device.index is not None else torch.cuda.current_device()
+    key = (dev_index, torch.cuda.current_stream(device).cuda_stream)
     ws = _sliced_ws.get(key)
     if ws is None or ws.numel() < need:
         ws = _sliced_ws[key] = torch.empty(need, device=device, dtype=torch.uint8)
