@@ -1,7 +1,4 @@
-"""(Needs the experiment commit 3017399: the list-driven form it A/B-tests was measured slower and is not in the shipped library; at
-HEAD the script still times the prepass and the main launch separately, prints the per-level task timeline and A/B-tests whatever
-knobs NGP_AB_VARIANTS names.)
-Round 3 A/B of the scatter-add's hashed levels on REAL backward inputs: hit LISTS (NGP_BWD_LIST=1, the default) against round 2's
+"""Round 3 A/B of the scatter-add's hashed levels on REAL backward inputs: hit LISTS (NGP_BWD_LIST=1, the default) against round 2's
 bitmap scan (NGP_BWD_LIST=0).  The plan knobs are read once per process, so run it once per setting:
 
     NGP_BWD_LIST=1 python profiles/microbench/hash_bwd_list_ab.py ; NGP_BWD_LIST=0 python profiles/microbench/hash_bwd_list_ab.py
@@ -58,7 +55,9 @@ def main():
     cfg = RenderConfig(model, 0.0, 1e-4, 1024)
     live, total = int(tr._live_total[0]), int(M.total[0])
     lv = cfg.levels
-    list_levels = L.ngp_hash_bwd_sliced_list_levels(ctypes.byref(lv)) if hasattr(L, "ngp_hash_bwd_sliced_list_levels") else 0
+    lm = ctypes.c_uint32(0)
+    L.ngp_hash_bwd_sliced_list_plan(ctypes.byref(lv), _ptr(None), 0, _ptr(None), _ptr(None), ctypes.byref(lm))
+    list_levels = lm.value
     print("live samples %d, marched %d, list-driven levels 0x%04x (NGP_BWD_LIST=%s)" % (live, total, list_levels, os.environ.get("NGP_BWD_LIST", "unset")))
     grad = torch.zeros_like(tr.table)
     ws = A.sliced_ws(lv)
@@ -107,7 +106,7 @@ def main():
             only_g = int(((ga != 0).any(1) & ~(ra != 0).any(1)).sum()); only_r = int((~(ga != 0).any(1) & (ra != 0).any(1)).sum())
             print("  level %2d: %d rows differ in support (only sliced %d, only atomic %d), max|d| %.3e, max|ref| %.3e, sum sliced %.6e sum ref %.6e" % (
                 lvl, sup, only_g, only_r, float(dd.max()), float(ra.abs().max()), float(ga.double().sum()), float(ra.double().sum())))
-    if list_levels and os.environ.get("NGP_AB_CHECK_LISTS", "1") == "1":
+    if list_levels and os.environ.get("NGP_AB_CHECK_LISTS", "0") == "1":        # (written for the 64-slice lists of commit 3017399)
         # integrity of the hit lists of one level: every live sample exactly once per (y, z) combination, filed under the right slice
         CH = 2048
         ms = (A.cap + CH - 1) // CH * CH
@@ -159,17 +158,23 @@ def main():
                 pm, mm = timeit(prep, args.reps), timeit(main_, args.reps, zero=True)
                 out["ab"].append({"variant": ",".join(v), "prep_us": pm[0], "main_us": mm[0], "err": e_})
                 print("  A/B round %d %-32s: prepass %.1f us  main %.1f us  sum %.1f   err %.1e" % (rnd, ",".join(v), pm[0], mm[0], pm[0] + mm[0], e_))
+                if os.environ.get("NGP_AB_TIMELINE") and rnd == 0:
+                    dbg_ = torch.zeros(8 * 3072, device=dev, dtype=torch.int64)
+                    L.ngp_hash_bwd_sliced_debug(_ptr(dbg_)); grad.zero_(); main_(); torch.cuda.synchronize(); L.ngp_hash_bwd_sliced_debug(_ptr(None))
+                    d_ = dbg_.view(3072, 8).cpu().numpy(); d_ = d_[d_[:, 1] > 0]
+                    print("      tasks %d span %.1f | mean task us per level: %s" % (len(d_), (d_[:, 5].max() - d_[:, 1].min()) / 100.0, " ".join(
+                        "%d:%.1f" % (l_, np.mean((d_[(d_[:, 0] & 0xf) == l_][:, 5] - d_[(d_[:, 0] & 0xf) == l_][:, 1])) / 100.0) for l_ in range(16) if ((d_[:, 0] & 0xf) == l_).any())))
         for k, val in saved.items():
             if val is None:
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = val
         prep()                                              # the workspace again holds this mode's lists / bitmaps for the timeline below
-    dbg = torch.zeros(8 * 1536, device=dev, dtype=torch.int64)
+    dbg = torch.zeros(8 * 3072, device=dev, dtype=torch.int64)
     L.ngp_hash_bwd_sliced_debug(_ptr(dbg))
     grad.zero_(); main_(); torch.cuda.synchronize()
     L.ngp_hash_bwd_sliced_debug(_ptr(None))
-    d = dbg.view(1536, 8).cpu().numpy()
+    d = dbg.view(3072, 8).cpu().numpy()
     d = d[d[:, 1] > 0]
     t0 = d[:, 1].min()
     span = (d[:, 5].max() - t0) / 100.0
