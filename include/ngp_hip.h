@@ -186,19 +186,17 @@ int ngp_hash_bwd_f16_live(const float* xyzs, const float* dout, const ngp_hash_l
                           const int32_t* live_idx, int normalize, float lo, float hi, int enc_pairs, uint16_t* dtable,
                           int32_t* found_inf, void* stream);
 /* The same scatter-add (autodiff backward of modules/hash_encoder.py:89-143, call site :269; F = 2) WITHOUT global float
- * atomics: the gradient table is cut into slices, each owned by one workgroup that accumulates in its LDS (f64) and adds the
- * slice to the table once (csrc/hash_bwd_lds.hip).  Dense levels: 8192-entry slices, one owner per CU, found through one hit
- * BIT per (level, slice, sample).  Xor-hashed levels: 4096-entry slices, two owners per CU, driven by hit LISTS the prepass
- * sorts (4 entries per level and sample, by slice, inside 2048-sample chunks, + a 128-word segment table per chunk).
- * Same arguments and semantics as ngp_hash_bwd_f32_live (dtable is accumulated into) plus a caller-owned scratch buffer of
- * ngp_hash_bwd_sliced_workspace(lv, n_max) bytes.  Returns -2 when the level table does not fit the formulation (F != 2, a level
- * of more than 2^19 entries, an odd level size, more than 2^30 samples): the caller then uses ngp_hash_bwd_f32_live.
+ * atomics: the gradient table is cut into slices of 8192 entries (128 KB of f64 pairs), each owned by one workgroup that
+ * accumulates in its LDS and adds the slice to the table once (csrc/hash_bwd_lds.hip).  Same arguments and semantics as
+ * ngp_hash_bwd_f32_live (dtable is accumulated into) plus a caller-owned scratch buffer of
+ * ngp_hash_bwd_sliced_workspace(lv, n_max) bytes: compact positions + one hit BIT per (level, slice, sample) + the queue heads
+ * of the persistent workgroups.  Returns -2 when the level table does not fit the formulation (F != 2, a level of more than
+ * 64 slices = 2^19 entries, an odd level size): the caller then uses ngp_hash_bwd_f32_live.
  * The workspace belongs to ONE call sequence at a time: prep -> main of one backward must not be interleaved with another
- * backward's on another stream using the same buffer (bitmaps, lists and the owners' queue heads live in it). */
+ * backward's on another stream using the same buffer (the bitmaps and the queue heads live in it). */
 long long ngp_hash_bwd_sliced_workspace(const ngp_hash_levels* lv, int n_max);
-/* The two halves as separate entry points: the prepass (compact positions + hit bitmaps, then the hit-list sort: two launches)
- * needs only positions and live list, so it can be issued before the MLP backward that produces `dout`; `main` (list owners,
- * then bitmap owners: two launches) consumes the workspace it filled. */
+/* The two halves as separate entry points: the prepass (compact positions + hit bitmaps) needs only positions and live list, so it
+ * can be issued before the MLP backward that produces `dout`; `main` consumes the workspace it filled. */
 int ngp_hash_bwd_sliced_prep(const float* xyzs, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev,
                              const int32_t* live_idx, int normalize, float lo, float hi, void* workspace,
                              long long workspace_bytes, void* stream);
@@ -214,12 +212,8 @@ int ngp_hash_bwd_sliced_main_f16(const float* dout, const ngp_hash_levels* lv, i
  * tasks[xoff[x] .. xoff[x] + xlen[x]); returns the number of tasks or -2 when the level table cannot be expressed */
 int ngp_hash_bwd_sliced_plan(const ngp_hash_levels* lv, uint16_t* tasks, int max_tasks, uint16_t* xoff /*[8]*/, uint16_t* xlen /*[8]*/,
                              uint8_t* nrep /*[NGP_MAX_LEVELS]*/, uint32_t* merge_mask, uint32_t* single_mask);
-/* the list owners' plan: tasks[k] = level | slice << 4 (4096-entry slices), XCD x owns tasks[xoff[x] .. xoff[x] + xlen[x]);
- * *list_mask = the list-driven levels (0 with NGP_BWD_LIST=0 in the environment: every level then runs on the bitmap owners) */
-int ngp_hash_bwd_sliced_list_plan(const ngp_hash_levels* lv, uint16_t* tasks, int max_tasks, uint16_t* xoff /*[8]*/, uint16_t* xlen /*[8]*/,
-                                  uint32_t* list_mask);
-/* diagnostics: per-TASK task word + wall-clock stamps into a device buffer of 8 * 3072 uint64 (one 8-word row per task: rows
- * [0, 1536) the bitmap owners' plan, rows [1536, 3072) the list owners'; NULL = off, the default) */
+/* diagnostics: per-TASK task word + wall-clock stamps into a device buffer of 8 * 1536 uint64 (one 8-word row per task of the
+ * plan, at most 1536 tasks; NULL = off, the default) */
 int ngp_hash_bwd_sliced_debug(void* device_buffer);
 int ngp_hash_bwd_f32_sliced(const float* xyzs, const float* dout, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev,
                             const int32_t* live_idx, int normalize, float lo, float hi, int enc_pairs, float* dtable,

@@ -1,4 +1,7 @@
-"""Round 3 A/B of the scatter-add's hashed levels on REAL backward inputs: hit LISTS (NGP_BWD_LIST=1, the default) against round 2's
+"""(The list-driven forms this script A/B-tests were measured slower and are not in the shipped library: experiment commits 3017399
+(64 slices, one owner per CU) and 2df8868 (128 slices, two owners per CU).  At HEAD the script still times the prepass and the main
+launch separately, prints the per-level task timeline and A/B-tests whatever knobs NGP_AB_VARIANTS names.)
+Round 3 A/B of the scatter-add's hashed levels on REAL backward inputs: hit LISTS (NGP_BWD_LIST=1, the default) against round 2's
 bitmap scan (NGP_BWD_LIST=0).  The plan knobs are read once per process, so run it once per setting:
 
     NGP_BWD_LIST=1 python profiles/microbench/hash_bwd_list_ab.py ; NGP_BWD_LIST=0 python profiles/microbench/hash_bwd_list_ab.py
@@ -56,7 +59,8 @@ def main():
     live, total = int(tr._live_total[0]), int(M.total[0])
     lv = cfg.levels
     lm = ctypes.c_uint32(0)
-    L.ngp_hash_bwd_sliced_list_plan(ctypes.byref(lv), _ptr(None), 0, _ptr(None), _ptr(None), ctypes.byref(lm))
+    if hasattr(L, "ngp_hash_bwd_sliced_list_plan"):                # (the list owners live in commits 3017399 / 2df8868, not at HEAD)
+        L.ngp_hash_bwd_sliced_list_plan(ctypes.byref(lv), _ptr(None), 0, _ptr(None), _ptr(None), ctypes.byref(lm))
     list_levels = lm.value
     print("live samples %d, marched %d, list-driven levels 0x%04x (NGP_BWD_LIST=%s)" % (live, total, list_levels, os.environ.get("NGP_BWD_LIST", "unset")))
     grad = torch.zeros_like(tr.table)

@@ -85,11 +85,11 @@ def main():
     print("atomic: median %.1f us  min %.1f us" % (med, best))
     os.environ["NGP_BWD_REP_TARGET"] = "64"; os.environ["NGP_BWD_MERGE_RES"] = "128"
     # per-block timeline of one full launch
-    dbg = torch.zeros(8 * 3072, device=dev, dtype=torch.int64)
+    dbg = torch.zeros(8 * 1536, device=dev, dtype=torch.int64)
     L.ngp_hash_bwd_sliced_debug(_ptr(dbg))
     grad.zero_(); sliced(); torch.cuda.synchronize()
     L.ngp_hash_bwd_sliced_debug(_ptr(None))
-    d = dbg.view(3072, 8).cpu().numpy()
+    d = dbg.view(1536, 8).cpu().numpy()
     d = d[d[:, 1] > 0]
     t0 = d[:, 1].min()
     print("timeline (us, 100 MHz clock): %d blocks, span %.1f" % (len(d), (d[:, 5].max() - t0) / 100.0))

@@ -44,6 +44,12 @@
 // too 123 (bitmaps) / 91 us (lists).  The launch is bound by its two 64-line gathers per 64 hits (48 M vector-L1 accesses, 27 M L2
 // requests per launch = ~27 TB/s of the L2's ~34 TB/s while the hashed levels run), not by instruction issue, LDS banking or
 // memory-level parallelism: LDS, vector L1 and VALU are each 40-50 % busy and the waves sit in s_waitcnt 55 % of their cycles.
+// A second form (commit 2df8868) gave the list owners 4096-entry slices so that TWO of them (46 VGPRs, 8 waves per SIMD) share a
+// CU: 58 % slower (333 vs 210 us) -- a task of half the hits takes as long as a task did before.  And a task takes the same time
+// whether 32 or 256 CUs are working.  So the bound is a per-CU THROUGHPUT that neither occupancy nor instruction count moves:
+// ~290 cycles per 64 hits and CU, which is what 128 scattered vector-L1 lane accesses (two gathers, ~55 % missing the L1, each miss
+// a 128-byte fill for 8-12 useful bytes) + 100 LDS cycles of f64 atomics + ~110 VALU cycles add up to when the three serialise
+// inside each wave's gather -> weights -> adds chain.
 #include "ngp_device.h"
 #include "hash_common.h"
 #include <stdlib.h>
@@ -59,29 +65,7 @@ constexpr int BW_WAVES = BW_THREADS / 64;
 constexpr int BW_Q = 256;                                      // per-wave hit queue (entries)
 constexpr int BW_MAX_TASKS = 1536;
 constexpr int BW_PREP_BLOCKS = 2048;
-constexpr size_t BW_CTR_BYTES = 128;                          // 8 queue heads + the exit counter of the main kernel; the same again for the list owners
-// ---- list-driven hashed levels (round 3): 4096-entry slices (64 KB of f64 pairs), TWO 1024-thread owner workgroups per CU
-constexpr int LS_LOG2 = 12;
-constexpr int LS_ENTRIES = 1 << LS_LOG2;
-constexpr int LS_MAX_SLICES = 128;                             // per level: 2^19 entries
-constexpr int LS_THREADS = 1024;
-constexpr int LS_WAVES = LS_THREADS / 64;
-constexpr int LS_CH = 2048;                                    // samples per hit-list chunk (4 entries each: 32 KB of LDS in the sort)
-constexpr int LS_SORT_THREADS = 512;
-constexpr int LS_SORT_BLOCKS = 1024;
-constexpr int LS_PERSISTENT_BLOCKS = 512;                      // two owner workgroups per CU
-constexpr int LS_MAX_TASKS = 1536;
-constexpr int LS_NB = 2;                                       // sub-batches of 64 entries per pipeline generation
-constexpr uint32_t LS_IDX_MASK = 0x3fffffffu;                  // entry = live index (30 bits) | (z bit, y bit) << 30
-
-struct ListPlan {
-    int32_t n_blocks;
-    uint32_t list_mask;                   // bit l: level l is list-driven
-    uint32_t diag;
-    uint8_t lord[NGP_MAX_LEVELS];         // ordinal of level l among the listable levels (its region of the pool / segment table)
-    uint16_t task[LS_MAX_TASKS];          // level | slice << 4; XCD x owns task[xoff[x] .. xoff[x] + xlen[x])
-    uint16_t xoff[8], xlen[8];
-};
+constexpr size_t BW_CTR_BYTES = 64;                           // 8 queue heads + the exit counter of the main kernel
 constexpr int BW_PERSISTENT_BLOCKS = 256;                     // one 1024-thread workgroup (147 KB of LDS) per CU
 
 struct BwdPlan {
@@ -158,7 +142,7 @@ __global__ void __launch_bounds__(256) hash_bwd_prep_kernel(const float* __restr
                                                             unsigned long long* __restrict__ bitmap, uint32_t* __restrict__ ctr) {
     __shared__ LevelLDS L;
     __shared__ unsigned long long words[4][BW_MAX_SLICES];
-    if (blockIdx.x == 0 && threadIdx.x < 32) ctr[threadIdx.x] = 0u;       // the owners' queue heads (the kernels also reset them themselves)
+    if (blockIdx.x == 0 && threadIdx.x < 16) ctr[threadIdx.x] = 0u;       // the main kernel's queue heads (it also resets them itself)
     load_levels(lv, L);
     if (n_dev) n = min(n, *n_dev);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -586,8 +570,7 @@ __device__ __forceinline__ void bwd_task(const LevelParams P, const int level, c
 // Queue heads: ctr[x] = tasks taken from the front of XCD x's queue (low 16 bits, by its own workgroups) and from the back (high
 // 16 bits, by thieves); one atomic add claims one position, a claim is valid while front + back < length.  Returns the index
 // into plan.task or 0xffffffff when every queue is empty.
-template <typename PlanT>
-__device__ __forceinline__ uint32_t claim_task(const PlanT& plan, uint32_t* __restrict__ ctr, uint32_t xcc) {
+__device__ __forceinline__ uint32_t claim_task(const BwdPlan& plan, uint32_t* __restrict__ ctr, uint32_t xcc) {
     {
         const uint32_t old = atomicAdd(&ctr[xcc], 1u), f = old & 0xffffu, b = old >> 16;
         if (f + b < plan.xlen[xcc]) return plan.xoff[xcc] + f;
@@ -723,308 +706,19 @@ __global__ void __launch_bounds__(BW_THREADS) hash_bwd_lds_kernel(const float* _
     }
 }
 
-// =====================================================================================================================
-// List-driven owners for the xor-hashed levels (round 3).
-//
-// What the counters said about the bitmap owners above (profiles/r03_pmc.json, r03_scatter_add_experiments.txt): the waves sit in
-// s_waitcnt 55 % of their cycles while LDS, vector L1 and VALU are each 40-50 % busy; a task takes the same time whether 32 or 256
-// CUs are working (no shared resource is contended); fewer instructions, conflict-free LDS banks, one gather instead of two or
-// more loads in flight per wave do not move it.  It is bound by per-CU LATENCY at four waves per SIMD -- one 147 KB workgroup per
-// CU.  The only lever left is occupancy: 4096-entry slices (64 KB) let TWO 1024-thread owners share a CU, and a data path of <= 64
-// VGPRs lets their 32 waves be resident (8 per SIMD).  Twice as many owners would scan twice as many bitmaps, so these owners
-// do not scan: the prepass SORTS every 2048-sample chunk of a level by slice in LDS (counting sort, 4 entries per sample and
-// level: live index | (y, z) corner combination << 30) and writes the chunk's entries + a 128-word table (start | count << 16 per
-// slice); an owner reads ITS segment of every chunk -- coalesced, no search, no capacity question (a chunk's region is fixed) --
-// and does one corner pair per entry.  Dense levels keep the bitmap owners (run pre-summing needs consecutive samples in
-// consecutive lanes, and their register footprint does not fit 64 VGPRs).
-// =====================================================================================================================
-
-// ---- the sort --------------------------------------------------------------------------------------------------------------
-// Task = (chunk c of LS_CH live samples, list-driven level).  A sample's four entries are filed under the slice
-// (((cy + yb) P1 ^ (cz + zb) P2) & mask) >> 12 that both x corners of the combination k = (zb, yb) fall into (x < 2^12 only touches
-// the bits below).  pass 1: histogram -> exclusive scan -> table row; pass 2: entry to staging[cursor[slice]++]; the chunk's region
-// of the pool is then written as it lies.  Neighbouring lanes take samples LS_CH / 64 apart: the entries one wave instruction appends
-// to a segment get consecutive positions, the owner puts consecutive positions into neighbouring lanes of ONE ds_add_f64, and
-// consecutive samples of a ray sit in the same cell of the coarser hashed levels -- same-address LDS atomics serialise (measured
-// with sample-order segments: level 6 owners 71 us instead of 41).
-__global__ void __launch_bounds__(LS_SORT_THREADS) hash_bwd_sort_kernel(const float* __restrict__ xyzc /* compact, normalised: the prepass's */,
-                                                                        ngp_hash_levels lv, int n, const int32_t* __restrict__ n_dev,
-                                                                        uint32_t list_mask, uint32_t* __restrict__ pool, size_t pool_level,
-                                                                        uint32_t* __restrict__ tab, size_t tab_level) {
-    __shared__ uint32_t hist[LS_MAX_SLICES];
-    __shared__ uint32_t cursor[LS_MAX_SLICES];
-    __shared__ uint32_t tot0;
-    __shared__ __attribute__((aligned(16))) uint32_t staging[4 * LS_CH];
-    constexpr int NW = LS_SORT_THREADS / 64;                      // waves per block
-    constexpr int SPT = LS_CH / LS_SORT_THREADS;                  // samples per thread
-    static_assert(LS_CH % LS_SORT_THREADS == 0 && (LS_CH / 64) == NW * SPT, "NW waves x SPT samples = one lane's stride");
-    auto local_sample = [](int tid, int j) { return (tid & 63) * (LS_CH / 64) + (tid >> 6) * SPT + j; };
-    if (n_dev) n = min(n, *n_dev);
-    if (n <= 0) return;
-    const int n_chunks = (n + LS_CH - 1) / LS_CH, n_list = __popc(list_mask);
-    const int tid = threadIdx.x;
-    for (int task = blockIdx.x; task < n_chunks * n_list; task += gridDim.x) {
-        const int c = task / n_list, lo = task - c * n_list;      // level-minor: the blocks of one chunk run together, its lines stay in L2
-        uint32_t mm = list_mask;
-        for (int k = 0; k < lo; ++k) mm &= mm - 1u;
-        const int level = __builtin_ctz(mm);                      // the lo-th list-driven level
-        const float scale = lv.scale[level];
-        const uint32_t msk = lv.map_size[level] - 1u;
-        if (tid < LS_MAX_SLICES) hist[tid] = 0u;
-        __syncthreads();
-        uint32_t sl4[SPT];                                        // the sample's four slice ids, 7 bits each; ~0 = no sample
-#pragma unroll
-        for (int j = 0; j < SPT; ++j) {
-            const int i = c * LS_CH + local_sample(tid, j);
-            uint32_t packed = 0xffffffffu;
-            if (i < n) {
-                const float y = xyzc[3 * (size_t)i + 1], z = xyzc[3 * (size_t)i + 2];
-                const uint32_t cy = f2u_sat(floorf(y * scale + 0.5f)), cz = f2u_sat(floorf(z * scale + 0.5f));
-                const uint32_t b0 = cy * 2654435761u, b1 = b0 + 2654435761u, c0 = cz * 805459861u, c1 = c0 + 805459861u;
-                const uint32_t s0 = ((b0 ^ c0) & msk) >> LS_LOG2, s1 = ((b1 ^ c0) & msk) >> LS_LOG2, s2 = ((b0 ^ c1) & msk) >> LS_LOG2,
-                               s3 = ((b1 ^ c1) & msk) >> LS_LOG2;                                           // k = 0, 1, 2, 3
-                packed = s0 | (s1 << 7) | (s2 << 14) | (s3 << 21);
-                atomicAdd(&hist[s0], 1u); atomicAdd(&hist[s1], 1u); atomicAdd(&hist[s2], 1u); atomicAdd(&hist[s3], 1u);
-            }
-            sl4[j] = packed;
-        }
-        __syncthreads();
-        uint32_t cnt = 0u, inc = 0u;                              // exclusive scan of the 128 counts: waves 0 and 1
-        if (tid < LS_MAX_SLICES) {
-            cnt = hist[tid];
-            inc = (uint32_t)wave_scan_add_i((int)cnt, tid & 63);
-            if (tid == 63) tot0 = inc;
-        }
-        __syncthreads();
-        if (tid < LS_MAX_SLICES) {
-            const uint32_t start = inc - cnt + (tid >= 64 ? tot0 : 0u);
-            cursor[tid] = start;
-            tab[(size_t)lo * tab_level + (size_t)c * LS_MAX_SLICES + tid] = start | (cnt << 16);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < SPT; ++j) {
-            const uint32_t packed = sl4[j];
-            if (packed != 0xffffffffu) {
-                const uint32_t i = (uint32_t)(c * LS_CH + local_sample(tid, j));
-#pragma unroll
-                for (uint32_t k = 0; k < 4; ++k) {
-                    const uint32_t pos = atomicAdd(&cursor[(packed >> (7 * k)) & 127u], 1u);
-                    staging[pos] = i | (k << 30);
-                }
-            }
-        }
-        __syncthreads();
-        const int total = 4 * min(LS_CH, n - c * LS_CH);           // a multiple of 4
-        uint32_t* dst = pool + (size_t)lo * pool_level + (size_t)c * (4 * LS_CH);
-        for (int e = 4 * tid; e < total; e += 4 * LS_SORT_THREADS) *reinterpret_cast<uint4*>(dst + e) = *reinterpret_cast<const uint4*>(staging + e);
-        __syncthreads();
-    }
-}
-
-// ---- the owner ---------------------------------------------------------------------------------------------------------------
-struct ListLevel {
-    float scale;
-    uint32_t msk, offset, diag;
-};
-
-// One entry = one (sample, (y, z) combination) whose two x corners live in this slice: no test, no loop over combinations.
-template <bool HALF>
-__device__ __forceinline__ void accumulate_entry(const ListLevel P, const Hit H, const uint32_t k, const bool valid, double* __restrict__ slice) {
-    const float g0 = H.g0, g1 = H.g1;
-    if (!(valid && (g0 != 0.0f || g1 != 0.0f))) return;            // exact-zero gradients contribute nothing
-    const float px = H.x * P.scale + 0.5f, py = H.y * P.scale + 0.5f, pz = H.z * P.scale + 0.5f;
-    const uint32_t cx = f2u_sat(floorf(px)), cy = f2u_sat(floorf(py)), cz = f2u_sat(floorf(pz));
-    const float fx = px - (HALF ? round16((float)cx) : (float)cx), fy = py - (HALF ? round16((float)cy) : (float)cy),
-                fz = pz - (HALF ? round16((float)cz) : (float)cz);
-    auto R = [](float v) { return HALF ? round16(v) : v; };
-    const uint32_t yb = k & 1u, zb = k >> 1;
-    const uint32_t A = ((cy + yb) * 2654435761u) ^ ((cz + zb) * 805459861u);
-    const float wy = yb ? fy : 1.0f - fy, wz = zb ? fz : 1.0f - fz;
-    const float wx0 = 1.0f * (1.0f - fx), wx1 = 1.0f * fx;        // same product order as the forward
-    const float w0 = (wx0 * wy) * wz, w1 = (wx1 * wy) * wz;
-    double* p0 = slice + 2 * (((cx ^ A) & P.msk) & (LS_ENTRIES - 1));
-    double* p1 = slice + 2 * ((((cx + 1u) ^ A) & P.msk) & (LS_ENTRIES - 1));
-#ifdef NGP_BWD_DIAG
-    if (P.diag & 1u) { asm volatile("" :: "v"(w0 * g0), "v"(w1 * g1), "v"(p0), "v"(p1)); return; }
-#endif
-    lds_add(p0, R(w0 * g0)); lds_add(p0 + 1, R(w0 * g1));
-    lds_add(p1, R(w1 * g0)); lds_add(p1 + 1, R(w1 * g1));
-}
-
-template <int NB>
-struct Gen {
-    Hit h[NB];
-    uint32_t k[NB];
-    bool v[NB];
-};
-
-// The 16 waves of an owner take chunks from a shared counter (one ahead, its segment-table word with it); the stream of 64-entry
-// sub-batches runs across segment boundaries.  Three generations in flight per wave: the entries of generation g + 2 (coalesced
-// loads), the position / gradient gathers of generation g + 1, the LDS adds of generation g.
-template <bool HALF, int NB>
-__device__ __forceinline__ void list_task(const ListLevel P, const int level, const int n, const float* __restrict__ xyzc,
-                                          const float* __restrict__ dout, const size_t plane, const int enc_pairs, const int nl,
-                                          double* __restrict__ slice, uint32_t* __restrict__ next_chunk, int32_t* __restrict__ found_inf,
-                                          const uint32_t* __restrict__ pool_l, const uint32_t* __restrict__ tab_ls) {
-    const int lane = threadIdx.x & 63;
-    const int n_chunks = (n + LS_CH - 1) / LS_CH;
-    auto grab = [&]() -> int {
-        int c = 0;
-        if (lane == 0) c = (int)atomicAdd(next_chunk, 1u);
-        return __builtin_amdgcn_readfirstlane(c);
-    };
-    auto ldtab = [&](int c) -> uint32_t { return c < n_chunks ? tab_ls[(size_t)c * LS_MAX_SLICES] : 0u; };   // every lane: the same word
-    int c = grab();
-    uint32_t tv = ldtab(c);
-    int cn = grab();
-    uint32_t tnv = ldtab(cn);
-    uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)tv);
-    uint32_t p = 0u;
-    auto next_sub = [&](uint32_t& e, bool& v) {                     // the next <= 64 entries of this wave's stream (wave-uniform control)
-        for (;;) {
-            if (c >= n_chunks) { e = 0u; v = false; return; }
-            if (p < (t >> 16)) break;
-            c = cn; t = (uint32_t)__builtin_amdgcn_readfirstlane((int)tnv); p = 0u;
-            cn = grab(); tnv = ldtab(cn);
-        }
-        const uint32_t start = t & 0xffffu, cnt = t >> 16;
-        const uint32_t* seg = pool_l + (size_t)c * (4 * LS_CH) + start + p;
-        v = p + (uint32_t)lane < cnt;
-        e = v ? seg[lane] : 0u;
-        p += 64u;
-    };
-    auto run = [&](const Gen<NB>& g) {
-        if (found_inf) {
-            bool fin = true;
-#pragma unroll
-            for (int b = 0; b < NB; ++b) fin = fin && isfinite(g.h[b].g0) && isfinite(g.h[b].g1);
-            if (!fin) *found_inf = 1;
-        }
-#ifdef NGP_BWD_DIAG
-        if (P.diag & 4u) { asm volatile("" :: "v"(g.h[0].x), "v"(g.h[0].g0), "v"(g.h[NB - 1].x), "v"(g.h[NB - 1].g0)); return; }
-#endif
-#pragma unroll
-        for (int b = 0; b < NB; ++b) accumulate_entry<HALF>(P, g.h[b], g.k[b], g.v[b], slice);
-    };
-    uint32_t e[NB];
-    bool v[NB];
-    auto load_entries = [&]() -> bool {                             // false once the stream is exhausted (nothing loaded)
-#pragma unroll
-        for (int b = 0; b < NB; ++b) next_sub(e[b], v[b]);
-        return c < n_chunks || __any(v[0]);
-    };
-    Gen<NB> pend;
-#pragma unroll
-    for (int b = 0; b < NB; ++b) { pend.v[b] = false; pend.k[b] = 0u; pend.h[b] = Hit{0.f, 0.f, 0.f, 0.f, 0.f}; }
-    bool have = load_entries();
-    while (have) {
-        Gen<NB> nxt;
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            nxt.v[b] = v[b]; nxt.k[b] = e[b] >> 30;
-            nxt.h[b] = load_hit(level, (int)(e[b] & LS_IDX_MASK), v[b], xyzc, dout, plane, enc_pairs, nl, found_inf, P.diag, HALF);
-        }
-        have = load_entries();
-        run(pend);
-        pend = nxt;
-    }
-    run(pend);
-}
-
-template <bool HALF>
-__global__ void __launch_bounds__(LS_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))
-hash_bwd_list_kernel(const float* __restrict__ xyzc, const float* __restrict__ dout, ngp_hash_levels lv, int n,
-                     const int32_t* __restrict__ n_dev, int enc_pairs, ListPlan plan, void* __restrict__ dtable /* f32 pairs; HALF: f16 pairs */,
-                     int32_t* __restrict__ found_inf, uint32_t* __restrict__ ctr, const uint32_t* __restrict__ pool, size_t pool_level,
-                     const uint32_t* __restrict__ tab, size_t tab_level, unsigned long long* __restrict__ dbg) {
-    __shared__ double slice[2 * LS_ENTRIES];                        // 64 KB: two of these workgroups share a CU
-    __shared__ uint32_t next_chunk;
-    __shared__ uint32_t s_claim;
-    const size_t plane = (size_t)n;
-    if (n_dev) n = min(n, *n_dev);
-    if (n <= 0) return;
-    const int tid = threadIdx.x;
-    uint32_t xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    xcc &= 7u;
-    for (;;) {
-        if (tid == 0) s_claim = claim_task(plan, ctr, xcc);
-        __syncthreads();
-        const uint32_t claim = s_claim;
-        if (claim == 0xffffffffu) break;
-        const uint32_t task = plan.task[claim];
-        unsigned long long t_begin = 0;
-        if (dbg) t_begin = wall_clock64();
-        const int level = task & 0xf;
-        const uint32_t sl = task >> 4;
-        ListLevel P;
-        P.scale = lv.scale[level]; P.msk = lv.map_size[level] - 1u; P.offset = lv.offset[level]; P.diag = plan.diag;
-        double2* s2 = reinterpret_cast<double2*>(slice);
-        for (int j = tid; j < LS_ENTRIES; j += LS_THREADS) s2[j] = make_double2(0.0, 0.0);
-        if (tid == 0) next_chunk = 0u;
-        __syncthreads();
-        unsigned long long t_init = 0;
-        if (dbg) t_init = wall_clock64();
-        list_task<HALF, LS_NB>(P, level, n, xyzc, dout, plane, enc_pairs, lv.n_levels, slice, &next_chunk, found_inf,
-                               pool + (size_t)plan.lord[level] * pool_level, tab + (size_t)plan.lord[level] * tab_level + sl);
-        unsigned long long t_wave = 0;
-        if (dbg) t_wave = wall_clock64();
-        __syncthreads();
-        unsigned long long t_acc = 0;
-        if (dbg) t_acc = wall_clock64();
-        // flush: the only owner of these 4096 entries rounds its f64 image once and adds it to the table gradient (plain
-        // coalesced read-modify-write)
-        const uint32_t base = P.offset + sl * (uint32_t)LS_ENTRIES;
-        if (HALF) {
-            typedef _Float16 half2v __attribute__((ext_vector_type(2)));
-            half2v* dh = reinterpret_cast<half2v*>(dtable) + base;
-            for (int j = tid; j < LS_ENTRIES; j += LS_THREADS) {
-                const double2 a = s2[j];
-                if (a.x == 0.0 && a.y == 0.0) continue;
-                half2v val;
-                val.x = (_Float16)(float)a.x; val.y = (_Float16)(float)a.y;
-                dh[j] = dh[j] + val;
-            }
-        } else {
-            float2* dl = reinterpret_cast<float2*>(reinterpret_cast<float*>(dtable) + 2 * (size_t)base);
-            for (int j = tid; j < LS_ENTRIES; j += LS_THREADS) {
-                const double2 a = s2[j];
-                if (a.x == 0.0 && a.y == 0.0) continue;
-                float2 d = dl[j];
-                d.x += (float)a.x; d.y += (float)a.y;
-                dl[j] = d;
-            }
-        }
-        if (dbg && tid == 0 && claim < (uint32_t)LS_MAX_TASKS) {
-            unsigned long long* o = dbg + 8 * ((size_t)BW_MAX_TASKS + claim);       // rows of the list owners follow the bitmap owners'
-            o[0] = task | 0x8000u; o[1] = t_begin; o[2] = t_init; o[3] = t_wave; o[4] = t_acc; o[5] = wall_clock64(); o[6] = xcc & 0xf; o[7] = (unsigned long long)n;
-        }
-        __syncthreads();                      // the slice and s_claim are reused by the next task
-    }
-    if (tid == 0) {                           // the last workgroup to leave resets the queue heads for the next launch
-        __threadfence();
-        if (atomicAdd(&ctr[8], 1u) == gridDim.x - 1u) {
-            for (int x = 0; x < 8; ++x) ctr[x] = 0u;
-            ctr[8] = 0u;
-        }
-    }
-}
-
 // ---- host: the task plan -------------------------------------------------------------------------------------------------
 // Returns false when the level table does not fit the formulation (F != 2, or a level of more than 64 slices).
-// Plan knobs.  Release builds read the environment ONCE (NGP_BWD_LIST=0 puts the hashed levels back on the bitmap owners;
-// NGP_BWD_REP_TARGET / NGP_BWD_MERGE_RES / NGP_BWD_DENSE_MIN_REP tune the replication of the dense levels); NGP_BWD_KNOBS_DYNAMIC=1 makes them re-read on every call so that one process can A/B them on
+// Plan knobs.  Release builds read the environment ONCE (NGP_BWD_REP_TARGET / NGP_BWD_MERGE_RES / NGP_BWD_DENSE_MIN_REP tune the
+// replication of the dense levels); NGP_BWD_KNOBS_DYNAMIC=1 makes them re-read on every call so that one process can A/B them on
 // the same inputs (profiles/microbench).  The diagnostic knobs that change RESULTS (NGP_BWD_LEVELS drops levels, NGP_BWD_DIAG
 // switches pieces of the kernel off) exist only in -DNGP_BWD_DIAG builds (they used to be honoured by every build).
 struct Knobs {
     int rep_target = 48, merge_res = 128, dense_min_rep = 8;
     uint32_t level_mask = 0xffffffffu, diag = 0u;
-    int blocks = 0;
-    bool use_lists = true;
+    int blocks = 0;                            // -DNGP_BWD_DIAG: fewer persistent workgroups (contention experiment)
     bool operator==(const Knobs& o) const {
         return rep_target == o.rep_target && merge_res == o.merge_res && dense_min_rep == o.dense_min_rep && level_mask == o.level_mask &&
-               diag == o.diag && blocks == o.blocks && use_lists == o.use_lists;
+               diag == o.diag && blocks == o.blocks;
     }
 };
 static Knobs read_knobs() {
@@ -1032,11 +726,10 @@ static Knobs read_knobs() {
     if (const char* e = getenv("NGP_BWD_REP_TARGET")) k.rep_target = atoi(e) > 0 ? atoi(e) : k.rep_target;
     if (const char* e = getenv("NGP_BWD_MERGE_RES")) k.merge_res = atoi(e);
     if (const char* e = getenv("NGP_BWD_DENSE_MIN_REP")) k.dense_min_rep = atoi(e) > 0 ? atoi(e) : k.dense_min_rep;
-    if (const char* e = getenv("NGP_BWD_LIST")) k.use_lists = atoi(e) != 0;        // 0: every level on the bitmap owners (round 2's form)
 #ifdef NGP_BWD_DIAG
     if (const char* e = getenv("NGP_BWD_LEVELS")) k.level_mask = (uint32_t)strtoul(e, nullptr, 0);
     if (const char* e = getenv("NGP_BWD_DIAG")) k.diag = (uint32_t)atoi(e);
-    if (const char* e = getenv("NGP_BWD_BLOCKS")) k.blocks = atoi(e);                  // contention experiment: fewer persistent workgroups
+    if (const char* e = getenv("NGP_BWD_BLOCKS")) k.blocks = atoi(e);
 #endif
     return k;
 }
@@ -1051,20 +744,6 @@ static const Knobs& knobs() {
     return k;
 }
 
-// levels whose owners can be list-driven: xor-hashed into a power-of-two table of 2 .. 128 slices of 4096 entries, resolution + 1
-// below 2^12 (the x corner pair then shares its slice).  Does not depend on the knobs: the workspace is laid out for these levels.
-static uint32_t listable_levels(const ngp_hash_levels& lv) {
-    uint32_t m = 0u;
-    if (lv.n_features != 2) return 0u;
-    for (int l = lv.begin_fast_hash_level < 0 ? 0 : lv.begin_fast_hash_level; l < lv.n_levels && l < NGP_MAX_LEVELS; ++l) {
-        const uint32_t size = lv.map_size[l];
-        if (size > (uint32_t)LS_ENTRIES && size <= (uint32_t)LS_ENTRIES * LS_MAX_SLICES && (size & (size - 1u)) == 0u &&
-            lv.resolution[l] + 1u < (1u << LS_LOG2))
-            m |= 1u << l;
-    }
-    return m;
-}
-
 static bool build_plan_with(const ngp_hash_levels& lv, BwdPlan& plan, uint32_t& single_mask, int dense_min_rep, const Knobs& K) {
     if (lv.n_features != 2 || lv.n_levels < 1 || lv.n_levels > NGP_MAX_LEVELS) return false;
     struct Lvl { int level, n_slices, nrep, tasks; };
@@ -1073,8 +752,7 @@ static bool build_plan_with(const ngp_hash_levels& lv, BwdPlan& plan, uint32_t& 
     plan.merge_mask = 0u;
     const int rep_target = K.rep_target;  // a replicated level gets ~ rep_target tasks (see the replica comment below)
     const int merge_res = K.merge_res;    // pre-sum equal-cell runs on levels up to this resolution
-    // levels that get bitmap-owner tasks: all (diagnostics, -DNGP_BWD_DIAG: NGP_BWD_LEVELS) minus the list-driven ones
-    const uint32_t level_mask = K.level_mask & ~(K.use_lists ? listable_levels(lv) : 0u);
+    const uint32_t level_mask = K.level_mask;      // diagnostics (-DNGP_BWD_DIAG): only these levels' tasks
     for (int l = 0; l < lv.n_levels; ++l) {
         const uint32_t size = lv.map_size[l];
         const int ns = (int)((size + BW_SLICE_ENTRIES - 1) / BW_SLICE_ENTRIES);
@@ -1158,7 +836,7 @@ static bool build_plan_with(const ngp_hash_levels& lv, BwdPlan& plan, uint32_t& 
         for (int p = 0; p < len[x]; ++p) plan.task[nb++] = lists[x][p];
     }
     plan.n_blocks = nb < BW_PERSISTENT_BLOCKS ? nb : BW_PERSISTENT_BLOCKS;
-    if (K.blocks > 0 && K.blocks < plan.n_blocks) plan.n_blocks = K.blocks;          // (-DNGP_BWD_DIAG builds only: contention experiment)
+    if (K.blocks > 0 && K.blocks < plan.n_blocks) plan.n_blocks = K.blocks;
     return true;
 }
 
@@ -1171,76 +849,40 @@ static bool build_plan_uncached(const ngp_hash_levels& lv, BwdPlan& plan, uint32
     return false;
 }
 
-// Tasks of the list-driven levels: (level, slice) dealt to the XCDs in same-level chunks of 64 (one round of an XCD's 64 owner slots),
-// each chunk to the least loaded XCD -- the owners of a level stream the same lists' samples out of that XCD's L2.
-static void build_list_plan(const ngp_hash_levels& lv, ListPlan& lp, const Knobs& K) {
-    const uint32_t able = listable_levels(lv);
-    lp.list_mask = K.use_lists ? (able & K.level_mask) : 0u;
-    lp.diag = K.diag;
-    int ord = 0;
-    for (int l = 0; l < NGP_MAX_LEVELS; ++l) lp.lord[l] = (uint8_t)(((able >> l) & 1u) ? ord++ : 0);
-    static thread_local uint16_t lists[8][LS_MAX_TASKS];
-    int len[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int l = lv.n_levels - 1; l >= 0; --l) {                 // finest first: their flush touches the most entries
-        if (!((lp.list_mask >> l) & 1u)) continue;
-        const int ns = (int)(lv.map_size[l] >> LS_LOG2);
-        for (int s0 = 0; s0 < ns; s0 += 64) {
-            int x = 0;
-            for (int v = 1; v < 8; ++v) if (len[v] < len[x]) x = v;
-            for (int sl = s0; sl < ns && sl < s0 + 64; ++sl) lists[x][len[x]++] = (uint16_t)(l | (sl << 4));
-        }
-    }
-    int nb = 0;
-    for (int x = 0; x < 8; ++x) {
-        lp.xoff[x] = (uint16_t)nb; lp.xlen[x] = (uint16_t)len[x];
-        for (int p = 0; p < len[x]; ++p) lp.task[nb++] = lists[x][p];
-    }
-    lp.n_blocks = nb < LS_PERSISTENT_BLOCKS ? nb : LS_PERSISTENT_BLOCKS;
-    if (K.blocks > 0 && 2 * K.blocks < lp.n_blocks) lp.n_blocks = 2 * K.blocks;      // (-DNGP_BWD_DIAG builds only)
-}
-
-// The plans only depend on the level table and the knobs: they are built once per (thread, level table) and reused by the prepass
-// and the main launches of every step (the plan used to be rebuilt -- getenv, cost model, O(tasks) sort -- twice per step).
+// The plan only depends on the level table and the knobs: it is built once per (thread, level table) and reused by the prepass
+// and the main launch of every step (it used to be rebuilt -- getenv, cost model, O(tasks) sort -- twice per step).
 struct PlanCache {
     bool valid = false, ok = false;
     ngp_hash_levels key;
     Knobs knobs;
     BwdPlan plan;
-    ListPlan lplan;
     uint32_t single_mask = 0u;
 };
-static const PlanCache* get_plans(const ngp_hash_levels& lv) {
+static const BwdPlan* get_plan(const ngp_hash_levels& lv, uint32_t& single_mask) {
     static thread_local PlanCache cache[2];                      // two tables alternate in a process that trains and evaluates
     static thread_local int victim = 0;
     const Knobs& K = knobs();
     for (PlanCache& c : cache)
-        if (c.valid && memcmp(&c.key, &lv, sizeof(lv)) == 0 && c.knobs == K) return c.ok ? &c : nullptr;
+        if (c.valid && memcmp(&c.key, &lv, sizeof(lv)) == 0 && c.knobs == K) { single_mask = c.single_mask; return c.ok ? &c.plan : nullptr; }
     PlanCache& c = cache[victim];
     victim ^= 1;
     c.valid = true; c.key = lv; c.knobs = K;
     c.ok = build_plan_uncached(lv, c.plan, c.single_mask, K);
-    if (c.ok) build_list_plan(lv, c.lplan, K);
-    return c.ok ? &c : nullptr;
+    single_mask = c.single_mask;
+    return c.ok ? &c.plan : nullptr;
 }
 
-// ---- workspace: compact positions | one hit bit per (level, slice, sample) | hit-list pool | its segment tables | queue heads
+// ---- workspace: compact positions | one hit bit per (level, slice, sample) | queue heads
 struct WsLayout {
-    size_t ms, words, n_chunks, pool_level, tab_level;       // capacity in samples (a multiple of LS_CH); per-level strides (u32)
-    int n_list;
-    size_t off_bitmap, off_pool, off_tab, off_ctr, total;    // bytes
+    size_t ms, words;                          // capacity in samples (a multiple of 512) and in 64-sample bitmap words
+    size_t off_bitmap, off_ctr, total;         // bytes
 };
 static WsLayout ws_layout(const ngp_hash_levels& lv, int n_max) {
     WsLayout w;
-    w.ms = ((size_t)n_max + LS_CH - 1) / LS_CH * LS_CH;
+    w.ms = ((size_t)n_max + 511) & ~(size_t)511;
     w.words = w.ms / 64;
-    w.n_chunks = w.ms / LS_CH;
-    w.n_list = __builtin_popcount(listable_levels(lv));
-    w.pool_level = 4 * w.ms;
-    w.tab_level = w.n_chunks * LS_MAX_SLICES;
     w.off_bitmap = w.ms * 3 * sizeof(float);
-    w.off_pool = w.off_bitmap + (size_t)lv.n_levels * BW_MAX_SLICES * w.words * sizeof(unsigned long long);
-    w.off_tab = w.off_pool + (size_t)w.n_list * w.pool_level * sizeof(uint32_t);
-    w.off_ctr = w.off_tab + (size_t)w.n_list * w.tab_level * sizeof(uint32_t);
+    w.off_ctr = w.off_bitmap + (size_t)lv.n_levels * BW_MAX_SLICES * w.words * sizeof(unsigned long long);
     w.total = w.off_ctr + BW_CTR_BYTES;
     return w;
 }
@@ -1253,49 +895,31 @@ static unsigned long long* g_bwd_debug = nullptr;
 
 extern "C" {
 
-// diagnostics: when set to a device buffer of 8 * (BW_MAX_TASKS + LS_MAX_TASKS) (= 8 * 3072) u64, every task records its task
-// word (bit 15 set: a list owner's (level | slice << 4); clear: a bitmap owner's (level | slice << 4 | replica << 10)), 100 MHz
-// wall-clock stamps (begin, after LDS init, wave 0 done, all waves done, after flush), its XCC id and the sample count.  Rows
-// [0, 1536) belong to the bitmap owners' plan, rows [1536, 3072) to the list owners'.
+// diagnostics: when set to a device buffer of 8 * BW_MAX_TASKS (= 8 * 1536) u64, every task of the main kernel records its task
+// word, 100 MHz wall-clock stamps (begin, after LDS init, wave 0 done, all waves done, after flush), its XCC id and the sample count
 int ngp_hash_bwd_sliced_debug(void* device_buffer) { g_bwd_debug = (unsigned long long*)device_buffer; return 0; }
 
-// host-side introspection (no GPU needed; tests/test_sliced_plan.py): the task plan of the BITMAP owners for this level table.
-// tasks[k] = level | slice << 4 | replica << 10 for k < return value; XCD x owns tasks[xoff[x] .. xoff[x] + xlen[x]);
+// host-side introspection (no GPU needed; tests/test_sliced_plan.py): the task plan the main launch would use for this level
+// table.  tasks[k] = level | slice << 4 | replica << 10 for k < return value; XCD x owns tasks[xoff[x] .. xoff[x] + xlen[x]);
 // nrep[l] = sample-range replicas per slice of level l; bit l of *merge_mask = run pre-summing on level l; bit l of
-// *single_mask = one-slice level (no bitmap).  Levels named by ngp_hash_bwd_sliced_list_plan have no tasks here.  Returns the
-// number of tasks, or -2 when the table cannot be expressed.
+// *single_mask = one-slice level (no bitmap).  Returns the number of tasks, or -2 when the table cannot be expressed.
 int ngp_hash_bwd_sliced_plan(const ngp_hash_levels* lv, uint16_t* tasks, int max_tasks, uint16_t* xoff, uint16_t* xlen, uint8_t* nrep,
                              uint32_t* merge_mask, uint32_t* single_mask) {
     if (!lv) return -1;
-    const PlanCache* pc = get_plans(*lv);
-    if (!pc) return -2;
-    const BwdPlan* plan = &pc->plan;
+    uint32_t sm = 0;
+    const BwdPlan* plan = get_plan(*lv, sm);
+    if (!plan) return -2;
     int total = 0;
     for (int x = 0; x < 8; ++x) { total += plan->xlen[x]; if (xoff) xoff[x] = plan->xoff[x]; if (xlen) xlen[x] = plan->xlen[x]; }
     if (tasks) for (int k = 0; k < total && k < max_tasks; ++k) tasks[k] = plan->task[k];
     if (nrep) for (int l = 0; l < NGP_MAX_LEVELS; ++l) nrep[l] = plan->nrep[l];
     if (merge_mask) *merge_mask = plan->merge_mask;
-    if (single_mask) *single_mask = pc->single_mask;
-    return total;
-}
-
-// the LIST owners' plan: tasks[k] = level | slice << 4 (slices of 4096 entries); *list_mask = the list-driven levels (0 with
-// NGP_BWD_LIST=0 in the environment).  Returns the number of tasks, or -2 when the table cannot be expressed.
-int ngp_hash_bwd_sliced_list_plan(const ngp_hash_levels* lv, uint16_t* tasks, int max_tasks, uint16_t* xoff, uint16_t* xlen,
-                                  uint32_t* list_mask) {
-    if (!lv) return -1;
-    const PlanCache* pc = get_plans(*lv);
-    if (!pc) return -2;
-    const ListPlan* lp = &pc->lplan;
-    int total = 0;
-    for (int x = 0; x < 8; ++x) { total += lp->xlen[x]; if (xoff) xoff[x] = lp->xoff[x]; if (xlen) xlen[x] = lp->xlen[x]; }
-    if (tasks) for (int k = 0; k < total && k < max_tasks; ++k) tasks[k] = lp->task[k];
-    if (list_mask) *list_mask = lp->list_mask;
+    if (single_mask) *single_mask = sm;
     return total;
 }
 
 // bytes of scratch the sliced scatter-add needs for buffers of n_max samples: compact positions + one hit bit per (level, slice,
-// sample) + 4 list entries per (listable level, sample) + their segment tables + the queue heads (ws_layout above)
+// sample) + the queue heads (ws_layout above)
 long long ngp_hash_bwd_sliced_workspace(const ngp_hash_levels* lv, int n_max) {
     if (!lv || n_max <= 0) return 0;
     return (long long)ws_layout(*lv, n_max).total;
@@ -1308,28 +932,18 @@ int ngp_hash_bwd_sliced_prep(const float* xyzs, const ngp_hash_levels* lv, int n
                              int normalize, float lo, float hi, void* workspace, long long workspace_bytes, void* stream) {
     if (n_max <= 0) return 0;
     if (!workspace || workspace_bytes < ngp_hash_bwd_sliced_workspace(lv, n_max)) return -1;
-    const PlanCache* pc = get_plans(*lv);
-    if (!pc) return -2;
-    const uint32_t list_mask = pc->lplan.list_mask;
-    if (list_mask && (unsigned)n_max > LS_IDX_MASK) return -2;          // list entries hold 30-bit sample indices
+    uint32_t single_mask;
+    const BwdPlan* plan = get_plan(*lv, single_mask);
+    if (!plan) return -2;
     const WsLayout W = ws_layout(*lv, n_max);
     char* base = reinterpret_cast<char*>(workspace);
     float* xyzc = reinterpret_cast<float*>(base);
     unsigned long long* bitmap = reinterpret_cast<unsigned long long*>(base + W.off_bitmap);
     uint32_t* ctr = reinterpret_cast<uint32_t*>(base + W.off_ctr);
     const XyzNorm nm = {normalize, lo, hi};
-    // levels without a bitmap: one-slice levels (every sample is a hit) and the list-driven ones
     hipLaunchKernelGGL(hash_bwd_prep_kernel, dim3(BW_PREP_BLOCKS), dim3(256), 0, (hipStream_t)stream, xyzs, live_idx, *lv, n_max, n_dev, nm,
-                       W.words, pc->single_mask | list_mask, xyzc, bitmap, ctr);
+                       W.words, single_mask, xyzc, bitmap, ctr);
     NGP_LAUNCH_CHECK();
-    if (list_mask) {
-        const long tasks = (long)W.n_chunks * __builtin_popcount(list_mask);
-        const int blocks = (int)(tasks < LS_SORT_BLOCKS ? tasks : LS_SORT_BLOCKS);
-        hipLaunchKernelGGL(hash_bwd_sort_kernel, dim3(blocks), dim3(LS_SORT_THREADS), 0, (hipStream_t)stream, xyzc, *lv, n_max, n_dev, list_mask,
-                           reinterpret_cast<uint32_t*>(base + W.off_pool), W.pool_level, reinterpret_cast<uint32_t*>(base + W.off_tab),
-                           W.tab_level);
-        NGP_LAUNCH_CHECK();
-    }
     return 0;
 }
 
@@ -1338,37 +952,22 @@ static int sliced_main(bool half, const float* dout, const ngp_hash_levels* lv, 
     if (n_max <= 0) return 0;
     if (enc_pairs && !(lv->n_features == 2 && lv->n_levels == 16)) return -1;
     if (!workspace || workspace_bytes < ngp_hash_bwd_sliced_workspace(lv, n_max)) return -1;
-    const PlanCache* pc = get_plans(*lv);
-    if (!pc) return -2;
-    const BwdPlan* plan = &pc->plan;
-    const ListPlan* lp = &pc->lplan;
-    if (lp->list_mask && (unsigned)n_max > LS_IDX_MASK) return -2;
+    uint32_t single_mask;
+    const BwdPlan* plan = get_plan(*lv, single_mask);
+    if (!plan) return -2;
+    if (plan->n_blocks <= 0) return 0;
     const WsLayout W = ws_layout(*lv, n_max);
     const char* base = reinterpret_cast<const char*>(workspace);
     const float* xyzc = reinterpret_cast<const float*>(base);
     const unsigned long long* bitmap = reinterpret_cast<const unsigned long long*>(base + W.off_bitmap);
     uint32_t* ctr = reinterpret_cast<uint32_t*>(const_cast<char*>(base) + W.off_ctr);
-    // the list owners of the hashed levels first (two workgroups per CU), then the bitmap owners of the other levels (one per CU)
-    if (lp->list_mask && lp->n_blocks > 0) {
-        const uint32_t* pool = reinterpret_cast<const uint32_t*>(base + W.off_pool);
-        const uint32_t* tab = reinterpret_cast<const uint32_t*>(base + W.off_tab);
-        if (half)
-            hipLaunchKernelGGL(hash_bwd_list_kernel<true>, dim3(lp->n_blocks), dim3(LS_THREADS), 0, (hipStream_t)stream, xyzc, dout, *lv, n_max,
-                               n_dev, enc_pairs, *lp, dtable, found_inf, ctr + 16, pool, W.pool_level, tab, W.tab_level, g_bwd_debug);
-        else
-            hipLaunchKernelGGL(hash_bwd_list_kernel<false>, dim3(lp->n_blocks), dim3(LS_THREADS), 0, (hipStream_t)stream, xyzc, dout, *lv, n_max,
-                               n_dev, enc_pairs, *lp, dtable, found_inf, ctr + 16, pool, W.pool_level, tab, W.tab_level, g_bwd_debug);
-        NGP_LAUNCH_CHECK();
-    }
-    if (plan->n_blocks > 0) {
-        if (half)
-            hipLaunchKernelGGL(hash_bwd_lds_kernel<true>, dim3(plan->n_blocks), dim3(BW_THREADS), 0, (hipStream_t)stream, xyzc, bitmap, W.words,
-                               dout, *lv, n_max, n_dev, enc_pairs, *plan, dtable, found_inf, ctr, g_bwd_debug);
-        else
-            hipLaunchKernelGGL(hash_bwd_lds_kernel<false>, dim3(plan->n_blocks), dim3(BW_THREADS), 0, (hipStream_t)stream, xyzc, bitmap, W.words,
-                               dout, *lv, n_max, n_dev, enc_pairs, *plan, dtable, found_inf, ctr, g_bwd_debug);
-        NGP_LAUNCH_CHECK();
-    }
+    if (half)
+        hipLaunchKernelGGL(hash_bwd_lds_kernel<true>, dim3(plan->n_blocks), dim3(BW_THREADS), 0, (hipStream_t)stream, xyzc, bitmap, W.words,
+                           dout, *lv, n_max, n_dev, enc_pairs, *plan, dtable, found_inf, ctr, g_bwd_debug);
+    else
+        hipLaunchKernelGGL(hash_bwd_lds_kernel<false>, dim3(plan->n_blocks), dim3(BW_THREADS), 0, (hipStream_t)stream, xyzc, bitmap, W.words,
+                           dout, *lv, n_max, n_dev, enc_pairs, *plan, dtable, found_inf, ctr, g_bwd_debug);
+    NGP_LAUNCH_CHECK();
     return 0;
 }
 

@@ -19,16 +19,6 @@ from ngp_hip import lib, ops  # noqa: E402
 SLICE = 8192
 
 
-def list_plan_of(lv):
-    L = lib.load()
-    tasks = np.zeros(1536, np.uint16)
-    xoff, xlen = np.zeros(8, np.uint16), np.zeros(8, np.uint16)
-    lm = ctypes.c_uint32(0)
-    n = L.ngp_hash_bwd_sliced_list_plan(ctypes.byref(lv), tasks.ctypes.data_as(ctypes.c_void_p), tasks.size,
-                                        xoff.ctypes.data_as(ctypes.c_void_p), xlen.ctypes.data_as(ctypes.c_void_p), ctypes.byref(lm))
-    return n, tasks, xoff, xlen, lm.value
-
-
 def plan_of(lv):
     L = lib.load()
     tasks = np.zeros(1536, np.uint16)
@@ -50,28 +40,11 @@ def test_plan_covers_every_slice_replica_once(log2_t, max_res):
         assert n == -2
         return
     ns = [(s + SLICE - 1) // SLICE for s in sizes]
-    bfhl = int(lv.begin_fast_hash_level)
-    # round 3: the xor-hashed power-of-two levels of 2 .. 128 slices of 4096 entries (resolution + 1 < 4096) are LIST-driven:
-    # they have no bitmap-owner tasks, and the list plan covers each of their 4096-entry slices exactly once
-    n_l, tasks_l, xoff_l, xlen_l, list_mask = list_plan_of(lv)
-    want_list = 0
-    for l in range(bfhl, 16):
-        if sizes[l] > 4096 and sizes[l] <= 128 * 4096 and sizes[l] & (sizes[l] - 1) == 0 and int(lv.resolution[l]) + 1 < 4096:
-            want_list |= 1 << l
-    assert list_mask == want_list
-    seen_l = set()
-    for t in tasks_l[:n_l]:
-        level, sl = int(t) & 0xf, int(t) >> 4
-        assert (list_mask >> level) & 1 and sl < sizes[level] // 4096 and (level, sl) not in seen_l
-        seen_l.add((level, sl))
-    assert n_l == sum(sizes[l] // 4096 for l in range(16) if (list_mask >> l) & 1) == len(seen_l) <= 1536
-    assert int(xoff_l[0]) == 0 and int(xlen_l.sum()) == n_l and all(int(xoff_l[x + 1]) == int(xoff_l[x]) + int(xlen_l[x]) for x in range(7))
-    bitmap_levels = [l for l in range(16) if not (list_mask >> l) & 1]
-    assert n == sum(ns[l] * int(nrep[l]) for l in bitmap_levels) and 0 < n <= 1536
+    assert n == sum(a * int(b) for a, b in zip(ns, nrep)) and 0 < n <= 1536
     seen = set()
     for t in tasks[:n]:
         level, sl, rep = int(t) & 0xf, (int(t) >> 4) & 0x3f, (int(t) >> 10) & 0x3f
-        assert level in bitmap_levels and sl < ns[level] and rep < nrep[level]
+        assert sl < ns[level] and rep < nrep[level]
         assert (level, sl, rep) not in seen
         seen.add((level, sl, rep))
     assert len(seen) == n
@@ -79,15 +52,15 @@ def test_plan_covers_every_slice_replica_once(log2_t, max_res):
     assert int(xoff[0]) == 0 and int(xlen.sum()) == n
     for x in range(7):
         assert int(xoff[x + 1]) == int(xoff[x]) + int(xlen[x])
-    # no XCD is left without work (when there is a chunk for each: idle workgroups steal from the others anyway), none holds more
-    # than twice its share
-    assert (int(xlen.min()) > 0 or n < 256) and int(xlen.max()) <= 2 * ((n + 7) // 8) + 32
+    # no XCD is left without work, none holds more than twice its share
+    assert int(xlen.min()) > 0 and int(xlen.max()) <= 2 * ((n + 7) // 8) + 32
+    bfhl = int(lv.begin_fast_hash_level)
     for l in range(16):
         assert bool((single_mask >> l) & 1) == (ns[l] == 1)
         if (merge_mask >> l) & 1:
             assert l < bfhl and int(lv.resolution[l]) <= 128     # run pre-summing: dense coarse levels only
-        if l >= bfhl and ns[l] == 64 and l in bitmap_levels:
-            assert nrep[l] == 1                                   # a full hashed level on the bitmap owners: one owner per slice
+        if l >= bfhl and ns[l] == 64:
+            assert nrep[l] == 1                                   # a full hashed level: one owner per slice
         if l < bfhl and ns[l] > 1:
             assert nrep[l] >= 4                                   # dense slices follow the scene: never fewer than 4 sample ranges
     # a level's owners sit together inside an XCD queue (they share position / gradient lines in that XCD's L2)
