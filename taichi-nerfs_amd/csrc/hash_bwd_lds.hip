@@ -569,23 +569,37 @@ __device__ __forceinline__ void bwd_task(const LevelParams P, const int level, c
 
 // Queue heads: ctr[x] = tasks taken from the front of XCD x's queue (low 16 bits, by its own workgroups) and from the back (high
 // 16 bits, by thieves); one atomic add claims one position, a claim is valid while front + back < length.  Returns the index
-// into plan.task or 0xffffffff when every queue is empty.
-__device__ __forceinline__ uint32_t claim_task(const BwdPlan& plan, uint32_t* __restrict__ ctr, uint32_t xcc) {
-    {
-        const uint32_t old = atomicAdd(&ctr[xcc], 1u), f = old & 0xffffu, b = old >> 16;
+// into plan.task or 0xffffffff when every queue is empty.  Called by the whole of WAVE 0 (round 3): lanes 0..7 read the eight
+// heads with ONE load and the fullest queue is picked with a wave reduction -- the serial form (one thread, eight dependent
+// atomic loads per try) took ~10 us per stolen task, which the per-task timeline never showed because it sat between two tasks.
+// `own_empty` (wave-uniform, kept by the caller) skips the doomed attempt on the own queue once it has failed.
+__device__ __forceinline__ uint32_t claim_task(const BwdPlan& plan, uint32_t* __restrict__ ctr, uint32_t xcc, bool& own_empty) {
+    const int lane = threadIdx.x & 63;
+    if (!own_empty) {
+        uint32_t old = 0u;
+        if (lane == 0) old = atomicAdd(&ctr[xcc], 1u);
+        old = (uint32_t)__builtin_amdgcn_readfirstlane((int)old);
+        const uint32_t f = old & 0xffffu, b = old >> 16;
         if (f + b < plan.xlen[xcc]) return plan.xoff[xcc] + f;
+        own_empty = true;
     }
     uint32_t dead = 1u << xcc;
     for (int tries = 0; tries < 7; ++tries) {
-        int best = -1, best_left = 0;
-        for (uint32_t v = 0; v < 8; ++v) {
-            if ((dead >> v) & 1u) continue;
-            const uint32_t c = __atomic_load_n(&ctr[v], __ATOMIC_RELAXED);
-            const int left = (int)plan.xlen[v] - (int)((c & 0xffffu) + (c >> 16));
-            if (left > best_left) { best_left = left; best = (int)v; }
+        int left = 0;
+        if (lane < 8 && !((dead >> lane) & 1u)) {
+            const uint32_t c = __atomic_load_n(&ctr[lane], __ATOMIC_RELAXED);
+            left = (int)plan.xlen[lane] - (int)((c & 0xffffu) + (c >> 16));
         }
-        if (best < 0) break;
-        const uint32_t old = atomicAdd(&ctr[best], 0x10000u), f = old & 0xffffu, b = old >> 16;
+        int key = left > 0 ? (left << 3) | (7 - lane) : 0;                 // fullest queue, lowest index on ties
+#pragma unroll
+        for (int d = 1; d < 8; d <<= 1) key = max(key, __shfl_xor(key, d, NGP_WAVE));
+        key = __builtin_amdgcn_readfirstlane(key);
+        if (key <= 0) break;
+        const int best = 7 - (key & 7);
+        uint32_t old = 0u;
+        if (lane == 0) old = atomicAdd(&ctr[best], 0x10000u);
+        old = (uint32_t)__builtin_amdgcn_readfirstlane((int)old);
+        const uint32_t f = old & 0xffffu, b = old >> 16;
         if (f + b < plan.xlen[best]) return plan.xoff[best] + plan.xlen[best] - 1u - b;
         dead |= 1u << best;
     }
@@ -615,11 +629,19 @@ __global__ void __launch_bounds__(BW_THREADS) hash_bwd_lds_kernel(const float* _
     uint32_t xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     xcc &= 7u;
-  for (;;) {
-    if (tid == 0) s_claim = claim_task(plan, ctr, xcc);
+    // Task loop, two barriers per task: the NEXT task is claimed (global atomic round trips) by wave 0 while the others flush the
+    // current slice, the flush leaves every slot it read at zero (no separate 128 KB zero pass per task), and the super-chunk
+    // counter is reset before the flush barrier.  (Round 3: -15 us on the launch at ~390 k live samples.)
+    double2* s2 = reinterpret_cast<double2*>(slice);
+    for (int j = tid; j < BW_SLICE_ENTRIES; j += BW_THREADS) s2[j] = make_double2(0.0, 0.0);
+    bool own_empty = false;                                               // (wave 0's: its own XCD queue has run dry)
+    if (tid < 64) {
+        const uint32_t c0 = claim_task(plan, ctr, xcc, own_empty);
+        if (tid == 0) { s_claim = c0; next_sc = 0u; }
+    }
     __syncthreads();
-    const uint32_t claim = s_claim;
-    if (claim == 0xffffffffu) break;
+    uint32_t claim = s_claim;
+  while (claim != 0xffffffffu) {
     const uint32_t task = plan.task[claim];
     unsigned long long t_begin = 0;
     if (dbg) t_begin = wall_clock64();
@@ -636,10 +658,6 @@ __global__ void __launch_bounds__(BW_THREADS) hash_bwd_lds_kernel(const float* _
     const bool merge = (plan.merge_mask >> level) & 1u;
     const bool hashed = !P.dense && P.mode == 1u && P.res < (1u << BW_SLICE_LOG2) && !single;
 
-    double2* s2 = reinterpret_cast<double2*>(slice);
-    for (int j = tid; j < BW_SLICE_ENTRIES; j += BW_THREADS) s2[j] = make_double2(0.0, 0.0);
-    if (tid == 0) next_sc = 0u;
-    __syncthreads();
     unsigned long long t_init = 0;
     if (dbg) t_init = wall_clock64();
     uint32_t* q = queues + (tid >> 6) * BW_Q;
@@ -653,6 +671,10 @@ __global__ void __launch_bounds__(BW_THREADS) hash_bwd_lds_kernel(const float* _
     __syncthreads();
     unsigned long long t_acc = 0;
     if (dbg) t_acc = wall_clock64();
+    if (tid < 64) {                                                       // wave 0 claims the next task, then joins the flush
+        const uint32_t c1 = claim_task(plan, ctr, xcc, own_empty);
+        if (tid == 0) { s_claim = c1; next_sc = 0u; }                     // (s_claim was read by everybody before the barrier above)
+    }
     // flush: the slice owner rounds its f64 image to f32 and adds it into the table gradient -- plain (non-atomic)
     // read-modify-write when it is the only replica, float atomics (coalesced, a few thousand lines) when the level is
     // replicated over sample ranges
@@ -663,6 +685,7 @@ __global__ void __launch_bounds__(BW_THREADS) hash_bwd_lds_kernel(const float* _
         for (int j = tid; j < BW_SLICE_ENTRIES; j += BW_THREADS) {
             const double2 a = s2[j];
             if (a.x == 0.0 && a.y == 0.0) continue;
+            s2[j] = make_double2(0.0, 0.0);                              // the next task starts from a clean slice
             const uint32_t h = entry_of(P.map, sl, (uint32_t)j);
             half2v val;
             val.x = (_Float16)(float)a.x; val.y = (_Float16)(float)a.y;
@@ -675,6 +698,7 @@ __global__ void __launch_bounds__(BW_THREADS) hash_bwd_lds_kernel(const float* _
     for (int j = tid; j < BW_SLICE_ENTRIES; j += BW_THREADS) {
         const double2 a = s2[j];
         if (a.x == 0.0 && a.y == 0.0) continue;
+        s2[j] = make_double2(0.0, 0.0);                                // the next task starts from a clean slice
         const uint32_t h = entry_of(P.map, sl, (uint32_t)j);          // LDS position j -> table entry
         const float vx = (float)a.x, vy = (float)a.y;
         if (nrep == 1) {
@@ -694,7 +718,8 @@ __global__ void __launch_bounds__(BW_THREADS) hash_bwd_lds_kernel(const float* _
             o[0] = task; o[1] = t_begin; o[2] = t_init; o[3] = t_wave; o[4] = t_acc; o[5] = wall_clock64(); o[6] = xcc & 0xf; o[7] = (unsigned long long)n;
         }
     }
-    __syncthreads();                      // the slice and s_claim are reused by the next task
+    __syncthreads();                      // flush done (slice clean again), next claim visible
+    claim = s_claim;
   }
     // the last workgroup to leave resets the queue heads for the next launch
     if (tid == 0) {

@@ -77,11 +77,18 @@ def test_hash_f16_golden(hip_lib, oracle, fixture, monkeypatch):
     n = g["xyzs"].shape[0]
     sliced = torch.zeros(table_h.shape[0], 2, device="cuda", dtype=torch.float16)
     ops.hash_bwd_f16_sliced(dev(g["xyzs"]), dev(g["dout"]).float().reshape(n, -1).contiguous(), lv, sliced)
+    # rows shared by several contributions depend on the order of the f16 adds (the reference's atomics, the HIP kernel's, the
+    # fixture's serial order): every add rounds to f16, i.e. loses at most 2^-11 of the running sum, which never exceeds the sum of
+    # the |contributions| -- the oracle's exact scatter-add of |dout| (the weights are non-negative).  Two such results differ by
+    # at most twice count * 2^-11 * sum|contributions|.
+    sum_abs = oracle.hash_bwd_f16(g["xyzs"], np.abs(g["dout"].astype(np.float32)).astype(np.float16), lv)[rows]
+    bound = 2.0 * count[rows][:, None] * 2.0**-11 * sum_abs + 1e-7
     for name, t in (("atomic", grad), ("sliced", sliced)):
         got = t.cpu().numpy()
         assert np.array_equal(np.flatnonzero(np.abs(got.astype(np.float32)).sum(1)), rows), name
         assert np.array_equal(got[rows][one].view(np.uint16), g["grad_vals"][one].view(np.uint16)), name
-        np.testing.assert_allclose(got[rows].astype(np.float32), g["grad_vals"].astype(np.float32), rtol=4e-3, atol=1e-7, err_msg=name)
+        err = np.abs(got[rows].astype(np.float32) - g["grad_vals"].astype(np.float32))
+        assert (err <= bound).all(), (name, float((err / bound).max()))
 
 
 def test_sh16_and_grid_utils_golden(hip_lib):
