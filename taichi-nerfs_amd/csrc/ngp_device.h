@@ -12,6 +12,12 @@
 
 #define NGP_WAVE 64
 
+// One target, no dual paths: the kernels use gfx950 instructions and registers directly (v_cvt_u32_f32 saturation semantics,
+// s_getreg HW_REG_XCC_ID, ds_read_b64_tr_b16, v_mfma_f32_16x16x32_f16, the 160 KB LDS).  Fail the build, not the run, elsewhere.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "libngp_hip is written for gfx950 (MI355X / CDNA4): build with --offload-arch=gfx950"
+#endif
+
 #define NGP_LAUNCH_CHECK()                                   \
     do {                                                     \
         hipError_t e__ = hipGetLastError();                  \

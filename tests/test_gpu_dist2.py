@@ -158,3 +158,73 @@ def test_two_ranks_on_one_gpu(hip_lib, lego_bitfield, tmp_path, kind, shard_opt)
     assert not fails, msg
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     assert sorted(os.listdir(tmp_path)) == ["ok_0", "ok_1"]
+
+
+def _comm_worker(rank, world, port, out_dir):
+    """Train the analytic scene for 240 steps on two ranks twice -- fp32 and bf16 gradient transport -- from the same initial model."""
+    try:
+        for p in (ROOT, os.path.join(ROOT, "taichi-nerfs_amd")):
+            if p not in sys.path:
+                sys.path.insert(0, p)
+        import torch.distributed as dist
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from modules.networks import NGP
+        from ngp_hip import synthetic
+        from ngp_hip.trainer import FusedTrainer
+        dev = torch.device("cuda", 0)
+        n = 4096
+        batches = []
+        for b in range(8):
+            o, d = synthetic.lego_rays(n, seed=300 + 17 * b + rank)              # rank-dependent shards, like bench.py
+            o, d = torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev)
+            batches.append((o, d, synthetic.procedural_render_gt(o, d).contiguous()))
+        eval_o, eval_d = synthetic.lego_rays(n, seed=999)
+        eval_o, eval_d = torch.from_numpy(eval_o).to(dev), torch.from_numpy(eval_d).to(dev)
+        eval_t = synthetic.procedural_render_gt(eval_o, eval_d).contiguous()
+        losses = {}
+        for comm in (torch.float32, torch.bfloat16):
+            torch.manual_seed(0)
+            m = NGP(scale=0.5, max_res=1024).to(dev)
+            tr = FusedTrainer(m, world_size=world, grad_comm_dtype=comm, lr=1e-2, max_steps=2000)
+            assert (tr._comm is not None) == (comm == torch.bfloat16)
+            for i in range(240):
+                if i % 16 == 0:
+                    tr.update_density_grid(0.01 * 1024 / 3**0.5, warmup=True)
+                torch.manual_seed(1000 + i)                                      # same jitter noise in both runs
+                tr.step(*batches[i % 8])
+            tr.sync_master()
+            noise = torch.zeros(n, device=dev)
+            out = tr.compute_gradients(eval_o, eval_d, eval_t, noise=noise)      # forward on a held-out batch (no optimizer step)
+            losses[str(comm)] = float(out["sq_err"].sum()) / (3.0 * n)
+            assert tr.counters()["skipped"] == 0
+        l32, l16 = losses["torch.float32"], losses["torch.bfloat16"]
+        assert l32 < 0.03, l32                                                   # it learned the scene (initial MSE ~0.1)
+        assert abs(l16 - l32) < 0.25 * l32, (l32, l16)                           # 8 mantissa bits on the wire do not change where it gets to
+        both = [None, None]
+        dist.all_gather_object(both, (l32, l16))
+        assert both[0] == both[1], both                                          # replicas agree bit for bit in both modes
+        dist.barrier()
+        dist.destroy_process_group()
+        open(os.path.join(out_dir, "ok_%d" % rank), "w").write("%r" % (losses,))
+    except Exception:
+        open(os.path.join(out_dir, "fail_%d" % rank), "w").write(traceback.format_exc())
+        raise
+
+
+def test_bf16_gradient_transport_converges_like_f32(hip_lib, tmp_path):
+    """`bench.py --comm bf16` (FusedTrainer(grad_comm_dtype=torch.bfloat16)) halves the reduce-scatter bytes; two
+    ranks trained on the analytic scene with it reach the held-out loss of the fp32 exchange (within 25 %), with identical replicas."""
+    import torch.multiprocessing as mp
+    port = 29950 + os.getpid() % 40
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_comm_worker, args=(r, 2, port, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+    fails = [f for f in os.listdir(tmp_path) if f.startswith("fail_")]
+    msg = "\n".join(open(os.path.join(tmp_path, f)).read() for f in fails)
+    assert not fails, msg
+    assert all(p.exitcode == 0 for p in procs) and sorted(os.listdir(tmp_path)) == ["ok_0", "ok_1"]
