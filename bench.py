@@ -80,8 +80,8 @@ def parse(argv=None):
                     help="--regime scene: untimed, seeded optimisation steps on the scene before the warm-up (multiple of 16)")
     ap.add_argument("--pool", type=int, default=32, help="--regime scene: resident batches the steps cycle through")
     ap.add_argument("--step-trace", default=None, help="diagnostic: write per-step host/device times of the timed region to FILE")
-    ap.add_argument("--kernel-events-every", type=int, default=4,
-                    help="per-kernel HIP events are recorded on every E-th timed step only (default 4; 1 = every step).  Each "
+    ap.add_argument("--kernel-events-every", type=int, default=8,
+                    help="per-kernel HIP events are recorded on every E-th timed step only (default 8, at most steps / 3; 1 = every step).  Each "
                          "event is a barrier packet between two kernels: on every step they cost 50-70 us per step (10 %% of it, "
                          "A/B in profiles/r02_bench_kernel_events_ab.txt); the per-kernel averages are the same either way")
     ap.add_argument("--no-kernel-events", dest="kernel_events", action="store_false",
@@ -485,7 +485,7 @@ def _measure(args, ctx, brief):
         if not scene:
             model.density_bitfield.copy_(bits)
 
-    ev_every = max(1, args.kernel_events_every)
+    ev_every = max(1, min(args.kernel_events_every, args.steps // 3))        # (a short run still samples three steps)
 
     def trainer_step(i, prefetch=True, log=True):
         rays_o, rays_d, target = pool[i % n_pool]

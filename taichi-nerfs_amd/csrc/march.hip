@@ -118,11 +118,12 @@ __global__ void __launch_bounds__(256) ray_aabb_kernel(const float* __restrict__
 // ------------------------------------------------------------------------------------------------------
 // a-2  training march, count + stage.
 // MARCH_GROUP lanes cooperate on one ray: the orbit t_{k+1} = t_k + calc_dt(t_k) does not depend on occupancy, so
-// the 16 lanes of a group probe 16 consecutive orbit points at once (cell index, bitfield byte, skip target), park
-// the results in LDS, and every lane then replays the reference's examined / skipped / emitted logic over the 16
-// points from LDS broadcasts (same address for the whole group: conflict-free).  8192 rays give 2048 waves instead of
-// the 128 single-lane-per-ray waves that left 7/8 of the SIMDs idle and each ray with a ~2000-instruction serial
-// chain per 8 steps.
+// the lanes of a group probe G consecutive orbit points at once (cell index, bitfield byte, skip target) and then resolve
+// the reference's examined / skipped / emitted logic over the batch IN PARALLEL: the orbit ascends, so every "t_u < x"
+// question is a prefix of the batch (a ballot + popcount or a 6-probe binary search over the lanes' t), each point knows
+// its successor on the chain of examined points, and log2(G) rounds of pointer doubling mark that chain.  (Rounds 1-2
+// replayed the batch serially from LDS broadcasts: ~2000 of the kernel's ~2600 instructions per batch; 109 -> 47 us.)
+// 8192 rays give 4096 waves instead of the 128 single-lane-per-ray waves that left 7/8 of the SIMDs idle.
 // ------------------------------------------------------------------------------------------------------
 constexpr int MARCH_GROUP = 32;
 constexpr int MARCH_MAX_COARSE_WORDS = 1024;            // 32 768 coarse blocks: up to 8 cascades of a 128^3 grid
@@ -136,7 +137,7 @@ __global__ void __launch_bounds__(64) march_count_kernel(const float* __restrict
                                                          const uint32_t* __restrict__ coarse /*nullable*/,
                                                          float2* __restrict__ stage, int32_t* __restrict__ counts) {
     constexpr int GROUPS = 64 / G;                          // one wave per block: the barriers below are wave-local
-    __shared__ float4 pts[GROUPS][G];                       // (t, dt, skip target, occupied)
+    __shared__ unsigned long long chain[GROUPS];            // bit u: orbit point u of the batch is examined (replay below)
     // coarse occupancy: one bit per 8^3 block of cells == per 512 consecutive Morton codes (64 bitfield bytes).
     // A clear bit proves the cell empty without touching the bitfield: most batches of a trained scene never issue a
     // global load at all, which is what this latency-bound kernel is waiting on.
@@ -217,29 +218,54 @@ __global__ void __launch_bounds__(64) march_count_kernel(const float* __restrict
             }
         }
         if (interesting != 0ull) {
-            pts[grp][sub] = make_float4(tu, dtu, targ, occ ? 1.0f : 0.0f);
-            __syncthreads();
-            int my_slot = -1;
-            if (need) {
+            // Replay of the reference's examined / skipped / emitted logic (ray_march.py:46-74) over the batch, in parallel.
+            // The orbit ascends, so "t_u < x" holds on a prefix of the batch and every question below is a population count:
+            //   nv  = points still inside the box; e0 = first point not inside the incoming skip;
+            //   c_u = first point not inside the skip point u would start  ->  successor of u on the chain of EXAMINED points
+            //         j_u = u + 1 (occupied) or max(u + 1, c_u) (empty).
+            // The examined set is the chain e0, j(e0), j(j(e0)), ...: log2(G) rounds of pointer doubling mark it in an LDS word.
+            const unsigned long long GM = (G == 64) ? ~0ull : ((1ull << (G & 63)) - 1ull);
+            const int gbase = grp * G;
+            const int gsh = gbase & 63;
+            const bool act = live && need;                                            // group-uniform
+            const int nv = __popcll((__ballot(tu < t2) >> gsh) & GM);
+            const int e0 = __popcll((__ballot(tu < t_target) >> gsh) & GM);
+            const unsigned long long occm = (__ballot(occ) >> gsh) & GM;
+            int c = 0;
 #pragma unroll
-                for (int u = 0; u < G; ++u) {
-                    const float4 q = pts[grp][u];
-                    if (live) {
-                        if (!(q.x < t2)) live = false;                               // loop head, ray_march.py:46
-                        else if (!(q.x < t_target)) {                                // examined (not inside a skip)
-                            if (q.w != 0.0f) {                                       // occupied: emit, ray_march.py:63-65
-                                if (u == sub) my_slot = n;
-                                n += 1;
-                                t_target = -INFINITY;
-                                if (n >= max_samples) live = false;
-                            } else {
-                                t_target = q.z;                                      // empty: skip, ray_march.py:66-74
-                            }
-                        }
-                    }
+            for (int s = G / 2; s >= 1; s >>= 1) {
+                const float tv = __shfl(tu, gbase + c + s - 1);
+                if (tv < targ) c += s;
+            }
+            if (__shfl(tu, gbase + G - 1) < targ) c = G;
+            int j = occ ? sub + 1 : max(sub + 1, c);
+            if (sub == 0) chain[grp] = (e0 < G) ? (1ull << e0) : 0ull;
+            bool on_chain = sub == e0;
+#pragma unroll
+            for (int k = 1; k < G; k <<= 1) {                                         // chain members at distance < k are marked
+                __syncthreads();
+                if (on_chain && j < G) atomicOr(&chain[grp], 1ull << j);
+                __syncthreads();
+                on_chain = (chain[grp] >> sub) & 1ull;
+                if (2 * k < G) {
+                    const int jj = __shfl(j, gbase + min(j, G - 1));
+                    j = (j >= G) ? G : jj;
                 }
             }
-            if (my_slot >= 0) row[my_slot] = make_float2(tu, dtu);
+            const unsigned long long inside = (nv >= 64) ? ~0ull : ((1ull << nv) - 1ull);
+            const unsigned long long X = act ? (chain[grp] & inside) : 0ull;          // examined points
+            const unsigned long long E = X & occm;                                    // ... that are occupied: emitted, :63-65
+            const int cnt = __popcll(E), cap = max_samples - n;                       // cap >= 1 while live
+            const int rank = __popcll(E & ((1ull << sub) - 1ull));
+            if (((E >> sub) & 1ull) && rank < cap) row[n + rank] = make_float2(tu, dtu);
+            const int last = X ? 63 - __clzll(X) : 0;
+            const float targ_last = __shfl(targ, gbase + last);
+            if (act) {
+                if (X) t_target = ((occm >> last) & 1ull) ? -INFINITY : targ_last;    // what the last examined point left behind
+                const bool full = cnt >= cap;                                         // n reached max_samples inside the batch
+                n = full ? max_samples : n + cnt;
+                live = !full && nv == G;                                              // loop head, ray_march.py:46
+            }
             __syncthreads();
         }
         t = t_next_batch;
@@ -452,8 +478,8 @@ int ngp_march_train_count_ex(const float* rays_o, const float* rays_d, const flo
     MarchParams p = make_march_params(cascades, grid_size, scale, exp_step_factor);
     // lanes per ray: more lanes = more resident waves for this latency-bound kernel, at the price of a longer replay when
     // a batch contains occupied cells or real skips.  NGP_MARCH_GROUP overrides (16 / 32 / 64) for experiments.
-    static int group = -1;
-    if (group < 0) { const char* e = getenv("NGP_MARCH_GROUP"); group = e ? atoi(e) : MARCH_GROUP; }
+    const char* ge = getenv("NGP_MARCH_GROUP");
+    const int group = ge ? atoi(ge) : MARCH_GROUP;
     hipStream_t s = (hipStream_t)stream;
 #define NGP_LAUNCH_MARCH(CD, GG, C1)                                                                                           \
     hipLaunchKernelGGL((march_count_kernel<CD, GG, C1>), dim3((n_rays + 64 / GG - 1) / (64 / GG)), dim3(64), 0, s, rays_o,     \

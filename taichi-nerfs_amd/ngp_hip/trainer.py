@@ -143,11 +143,14 @@ class FusedTrainer:
         # where in the step the next batch's march is put on the side stream: 0 = at the start, 1 = after the hash gather
         # (default: with the backward running on the live samples only, the ~115 us march chain has to start this early to be
         # done before the step is; A/B on one box: 0.327 ms at 1, 0.331 at 0, 0.342 at 2; round 2: 0.567-0.571 at 1, 0.578-0.583 at
-        # 0, 0.585 at 2, 0.590 at 3), 2 = after the MLP forward, 3 = before the scatter-add, 4 = after the scatter-add
+        # 0, 0.585 at 2, 0.590 at 3), 2 = after the MLP forward, 3 = before the scatter-add, 4 = after the scatter-add.
+        # Round 3: the count kernel's replay became parallel (109 -> 47 us, ~75 us chain), so the chain no longer has to start that
+        # early and is best kept off the gather-bound encoder: at 350 k live samples, 3 runs x 400 steps each: 0.554 ms at 2,
+        # 0.556 at 3, 0.560 at 0, 0.564 at 1 (not prefetched: 0.570)
         import os as _os
         # (with world > 1 the default is 4: the march then runs underneath the gradient exchange -- RCCL's kernels occupy a few
         # workgroups and wait on xGMI -- instead of competing with the VALU-bound kernels of the step for issue slots)
-        self._prefetch_at = int(_os.environ.get("NGP_PREFETCH_AT", "1" if self.world == 1 else "4"))
+        self._prefetch_at = int(_os.environ.get("NGP_PREFETCH_AT", "2" if self.world == 1 else "4"))
         self._coarse_ver = None
         self.sync_occupancy = True            # world > 1: broadcast rank 0's occupancy after every update_density_grid()
         # bench.py: callable -> (record this step?, list); every collective of the step is then bracketed by two HIP events on the

@@ -90,6 +90,48 @@ def test_march_train_cascades_exp_step(oracle, hip_lib):
         assert bits_equal(xyzs, g[1].cpu().numpy())
 
 
+@pytest.mark.parametrize("group", [16, 32, 64])
+def test_march_train_replay_stress(oracle, lego_batch, group, monkeypatch):
+    """The count kernel resolves a batch of G orbit points in parallel (chain of examined points by pointer doubling): hold it to
+    the serial oracle on sparse .. nearly full grids (short and long skips, chains of every length), with max_samples reached in
+    the middle of a batch, for every lanes-per-ray variant."""
+    monkeypatch.setenv("NGP_MARCH_GROUP", str(group))
+    o, d, noise, _ = lego_batch
+    n = 1024
+    o, d, noise = o[:n].copy(), d[:n].copy(), noise[:n]
+    hits = oracle.ray_aabb(o, d, 0.5)
+    for fraction in (0.02, 0.3, 0.97):
+        bits = synthetic.random_bitfield(1, fraction=fraction, seed=int(fraction * 100))
+        for max_samples in (1, 7, 64, 1024):
+            ref = oracle.march_train(o, d, hits, bits, noise, 1, 0.5, 0.0, 128, max_samples)
+            g = ops.march_train(dev(o), dev(d), dev(hits), dev(bits), dev(noise), 1, 0.5, 0.0, 128, max_samples)
+            assert int(g[5]) == ref[5], (fraction, max_samples)
+            assert np.array_equal(ref[0], g[0].cpu().numpy())
+            assert bits_equal(ref[4], g[4].cpu().numpy()) and bits_equal(ref[3], g[3].cpu().numpy())
+            assert bits_equal(ref[1], g[1].cpu().numpy())
+    # two cascades, exponential stepping, coarse cells: skips that span several batches
+    o2, d2 = synthetic.garden_rays(n, seed=11)
+    hits2 = oracle.ray_aabb(o2, d2, 1.0)
+    for fraction in (0.05, 0.6):
+        bits = synthetic.random_bitfield(2, fraction=fraction, seed=9)
+        for max_samples in (5, 256):
+            ref = oracle.march_train(o2, d2, hits2, bits, noise, 2, 1.0, 1 / 256, 128, max_samples)
+            g = ops.march_train(dev(o2), dev(d2), dev(hits2), dev(bits), dev(noise), 2, 1.0, 1 / 256, 128, max_samples)
+            assert int(g[5]) == ref[5], (fraction, max_samples)
+            assert np.array_equal(ref[0], g[0].cpu().numpy())
+            assert bits_equal(ref[4], g[4].cpu().numpy()) and bits_equal(ref[3], g[3].cpu().numpy())
+    # Garden shape (six cascades, cells up to 64 steps long): one skip covers several batches
+    o3, d3 = synthetic.garden_rays(n, seed=7)
+    bits = synthetic.ball_slab_bitfield(6, 16.0, seed=7)
+    hits3 = oracle.ray_aabb(o3, d3, 16.0)
+    for max_samples in (37, 1024):
+        ref = oracle.march_train(o3, d3, hits3, bits, noise, 6, 16.0, 1 / 256, 128, max_samples)
+        g = ops.march_train(dev(o3), dev(d3), dev(hits3), dev(bits), dev(noise), 6, 16.0, 1 / 256, 128, max_samples)
+        assert int(g[5]) == ref[5] and ref[5] > 0
+        assert np.array_equal(ref[0], g[0].cpu().numpy())
+        assert bits_equal(ref[4], g[4].cpu().numpy()) and bits_equal(ref[3], g[3].cpu().numpy())
+
+
 def test_march_test_bit_exact(oracle, lego_batch):
     o, d, _, bits = lego_batch
     o, d = o[:4096], d[:4096]
