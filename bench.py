@@ -489,7 +489,11 @@ def _measure(args, ctx, brief):
 
     def trainer_step(i, prefetch=True, log=True):
         rays_o, rays_d, target = pool[i % n_pool]
-        timer.sample = state["k"] % ev_every == ev_every // 2
+        # per-kernel events on every ev_every-th step; an occupancy-update step (its 1 M-point encodes go through the same entry
+        # points) hands its turn to the next step, so that the per-kernel averages are those of the training step's launches
+        due = state["k"] % ev_every == ev_every // 2 or state.get("ev_owed", False)
+        timer.sample = due and i % 16 != 0
+        state["ev_owed"] = due and i % 16 == 0
         if i % 16 == 0:
             grid_update(i)
         nxt = pool[(i + 1) % n_pool]

@@ -350,12 +350,12 @@ __global__ void __launch_bounds__(256) mlp_fwd_kernel(const float* __restrict__ 
 // Stores: a 16-lane ds_write_b64 group holds 16 sample rows of ONE granule (4 halfs) column, which would land 4-way on the
 // same banks; granule gi of a block is therefore kept at slot gi ^ (rb & 3) -- the group then covers all 32 banks once.
 constexpr int IMG_TILE = 8 * 64;          // halfs per feature tile (8 row blocks x 128 B)
-constexpr int IMG_TILES = 11;             // up to 176 feature columns are live at a time
-constexpr int IMG_HALFS = IMG_TILES * IMG_TILE;     // 11 KB per group
+constexpr int IMG_TILES = 13;             // up to 208 feature columns are live at a time
+constexpr int IMG_HALFS = IMG_TILES * IMG_TILE;     // 13 KB per group
 // tile map of the three dW phases
-constexpr int A_DZ4 = 0, A_A3 = 4;                                  // phase A: layer 4
+constexpr int A_DZ5 = 0, A_DZ4 = 1, A_A4 = 5, A_A3 = 9;            // phase A: layers 5 and 4
 constexpr int B_DZ3 = 0, B_DZ2 = 4, B_IN3 = 5, B_A1 = 7;           // phase B: layers 3 and 2
-constexpr int C_DZ1 = 0, C_ENC = 4, C_DZ5 = 6, C_A4 = 7;           // phase C: layers 1 and 5
+constexpr int C_DZ1 = 0, C_ENC = 4;                                // phase C: layer 1
 constexpr int N_W = 2048 + 1024 + 2048 + 4096 + 192;    // 9408 weights
 constexpr int OFF_W1 = 0, OFF_W2 = 2048, OFF_W3 = 3072, OFF_W4 = 5120, OFF_W5 = 9216;
 
@@ -374,23 +374,22 @@ __device__ __forceinline__ half8 img_load_tr(const half_t* img, int tile, int q,
     return cat_h4(__builtin_bit_cast(half4, lo), __builtin_bit_cast(half4, hi));
 }
 
-// Block = 6 waves, TWO blocks per CU (77 KB of LDS each: the packed weights + three group images; 3 waves per SIMD in total).
-// Every wave runs the data path (forward recompute + dX chain) of ONE 16-sample tile; waves 2k and 2k+1 form the 32-sample
-// group k (image rows 16 * (wave & 1) + n).  The 40 dW output tiles (16x16 each) are DISTRIBUTED over the 6 waves; each wave
-// accumulates its tiles over the images of all 3 groups (K = 96 samples per round).  Three store -> barrier -> accumulate ->
-// barrier phases per round:
-//     phase A: layer 4 (waves 0..3: tile row w, all four tile columns: 5 fragment reads per 4 MFMAs)
-//     phase B: layer 3 (waves 0..3: tile row w, two columns)  + layer 2 (waves 4, 5: two tiles each)
-//     phase C: layer 1 (waves 0..3: tile row w, two columns)  + layer 5 (waves 4, 5: two tiles each)
-// A phase uses one resource at a time (LDS stores, then transposing reads feeding a few MFMAs) and the data path between the
-// phases uses none of the LDS bandwidth: two independent blocks per CU drift apart and fill each other's gaps, which one
-// 12-wave block per CU with its six block-wide barriers per round could not (rounds 1-2: 64-75 us at 350-400 k samples,
-// MFMA 14 % / LDS 27 % / VALU 25 % busy, waves waiting 52 % of their cycles: profiles/r03_pmc.json).
+// Block = 12 waves (3 per SIMD).  Every wave runs the data path (forward recompute + dX chain) of ONE 16-sample tile; waves
+// 2k and 2k+1 form the 32-sample group k (image rows 16 * (wave & 1) + n).  The 40 dW output tiles (16x16 each) are
+// DISTRIBUTED over the 12 waves (4 accumulators per wave instead of 160 in a wave-private scheme); each wave accumulates its
+// tiles over the images of all 6 groups (K = 192 samples per round).  Three store -> barrier -> accumulate -> barrier phases
+// per round, two layers at a time so that both wave classes have work in a phase:
+//     phase A: layer 4 (waves 0..7, two tiles each)  + layer 5 (waves 8..11)
+//     phase B: layer 3 (waves 0..7)                  + layer 2 (waves 8..11)
+//     phase C: layer 1 (waves 0..7)
 // A block's waves own disjoint dW tiles, so nothing is reduced across waves at the end.
-#ifndef NGP_MLP_DW_UNROLL
-#define NGP_MLP_DW_UNROLL 3
-#endif
-constexpr int BW = 6;                      // waves per block
+// Round 3 (profiles/r03_mlp_bwd_experiments.txt): at 350-400 k samples a round of 192 samples takes ~8.3 us, 62 % of it in the
+// three dW phases, with the LDS 27 %, the VALU 25 % and the MFMA pipe 14 % busy -- a phase uses one resource at a time and six
+// block-wide barriers per round keep all 12 waves in the same phase.  Two independent 6-wave blocks per CU (77 KB of LDS each)
+// would interleave, but do not become co-resident: a workgroup's waves go to the SIMDs in cyclic order (2,2,1,1), and at
+// 164 VGPRs (3 waves per SIMD) a second such workgroup finds no complementary slots (profiles/microbench/occupancy_probe.hip:
+// 384-thread blocks pair up per CU at <= 128 VGPRs only) -- measured 98 us instead of 75.  8-wave blocks would need 86 KB.
+constexpr int BW = 12;                     // waves per block
 constexpr int BG = BW / 2;                 // 32-sample groups per round
 
 struct BwdIn {                             // prefetched per-round inputs of one lane
@@ -423,14 +422,16 @@ __device__ __forceinline__ void bwd_load(BwdIn& in, const float* __restrict__ en
 }
 
 #ifdef NGP_MLP_DIAG
-__device__ unsigned long long ngp_mlp_dbg[16 * 8];      // [wave][segment]: cycles summed over the rounds of block 0 (timing builds only)
+// Timing builds only (-DNGP_MLP_DIAG, profiles/microbench/mlp_time.py): s_memtime ticks per segment of a round, summed over the
+// rounds of block 0, per wave.  The counter update is a global read-modify-write, i.e. every stamp also drains the wave's
+// outstanding global loads / stores: the prefetch below shows up in the segment that follows it.
+__device__ unsigned long long ngp_mlp_dbg[16 * 8];
 #define MLP_T(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); if (blockIdx.x == 0 && lane == 0) ngp_mlp_dbg[wv * 8 + (k)] += now_ - t_prev; t_prev = now_; } while (0)
 #else
 #define MLP_T(k) do { } while (0)
 #endif
 
-template <bool PF>
-__global__ void __launch_bounds__(64 * BW, 2) mlp_bwd_kernel(const float* __restrict__ enc, const float* __restrict__ dirs,
+__global__ void __launch_bounds__(768) mlp_bwd_kernel(const float* __restrict__ enc, const float* __restrict__ dirs,
                                                        const half_t* __restrict__ wpack, const float* __restrict__ dsigmas,
                                                        const half_t* __restrict__ drgbs, int S,
                                                        const int32_t* __restrict__ n_dev, const int32_t* __restrict__ idx, int pairs,
@@ -452,27 +453,28 @@ __global__ void __launch_bounds__(64 * BW, 2) mlp_bwd_kernel(const float* __rest
     const floatx4 zero = {0.f, 0.f, 0.f, 0.f};
     const half4 hzero = {(half_t)0, (half_t)0, (half_t)0, (half_t)0};
 
-    // dW tile ownership (40 tiles of 16x16 over 6 waves):
-    //   waves 0..3 (w)     : L4 tiles (mt = w, nt = 0..3) -> acc4[] ;  L3 tiles (mt = w, nt = 0, 1) -> accB[] ;
-    //                        L1 tiles (mt = w, nt = 0, 1) -> accC[]
-    //   waves 4, 5 (v=w-4) : L2 tiles (nt = 2v, 2v+1) -> accB[] ;  L5 tiles (nt = 2v, 2v+1) -> accC[]
-    floatx4 acc4[4] = {zero, zero, zero, zero}, accB[2] = {zero, zero}, accC[2] = {zero, zero};
+    // dW tile ownership (40 tiles of 16x16 over 12 waves):
+    //   waves 0..7  (w)    : L4 tiles (mt = w>>1, nt = 2(w&1), 2(w&1)+1) -> accA0/accA1 ;  L3 tile (mt = w>>1, nt = w&1) -> accB ;
+    //                        L1 tile (mt = w>>1, nt = w&1) -> accC
+    //   waves 8..11 (v=w-8): L2 tile (nt = v) -> accB ;  L5 tile (nt = v) -> accC
+    floatx4 accA0 = zero, accA1 = zero, accB = zero, accC = zero;
     bool bad_denc = false;             // a non-finite d_enc value: the same condition the scatter-add flags on its input
-    const bool lo4 = wv < 4;
-    const int v2 = 2 * (wv - 4);
+    const bool lo8 = wv < 8;
+    const int v4 = wv - 8;
+    const int mtL = wv >> 1, ntL = wv & 1;         // lo8: tile row / column of the L3 and L1 tiles, tile row of the L4 pair
     // image row 16 par + n -> row block 4 par + (n >> 2), row n & 3, swizzle key n >> 2; this lane's D-layout granule is g
     const int lrow = (4 * par + (n >> 2)) * 64 + (n & 3) * 16;
     const int lofs = lrow + 4 * (g ^ (n >> 2));
 
     BwdIn in;
-    if (PF) bwd_load(in, enc, dirs, dsigmas, drgbs, bwd_src((blockIdx.x * BG + grp) * 32 + col, S, idx), g, pairs, plane);
+    bwd_load(in, enc, dirs, dsigmas, drgbs, bwd_src((blockIdx.x * BG + grp) * 32 + col, S, idx), g, pairs, plane);
     for (int round = blockIdx.x; round < n_round; round += gridDim.x) {
         const int smp = (round * BG + grp) * 32 + col;
-        if (!PF) bwd_load(in, enc, dirs, dsigmas, drgbs, bwd_src(smp, S, idx), g, pairs, plane);
-        // the next round's list entry now, its inputs once this round's data path has consumed `in` (below): the dependent
-        // idx -> enc load chain then runs underneath the three dW phases instead of in front of the next round
+        // The next round's list entry is requested now and its inputs once this round's data path has consumed `in` (below):
+        // the dependent idx -> enc load chain then runs underneath the three dW phases instead of in front of the next round
+        // (74.5 -> 72.5 us at 400 k live samples, +10 VGPRs; with the uncompacted list of rounds 1-2 it measured no gain)
         int src_next = -1;
-        if (PF && round + (int)gridDim.x < n_round) src_next = bwd_src(((round + (int)gridDim.x) * BG + grp) * 32 + col, S, idx);
+        if (round + (int)gridDim.x < n_round) src_next = bwd_src(((round + (int)gridDim.x) * BG + grp) * 32 + col, S, idx);
         TileFwd t;
         half4 dz5 = hzero, dz4[4], dz3[4], dz2, dz1[4];
 #ifdef NGP_MLP_DIAG
@@ -530,22 +532,30 @@ __global__ void __launch_bounds__(64 * BW, 2) mlp_bwd_kernel(const float* __rest
         }
 
         MLP_T(2);
-        if (PF) bwd_load(in, enc, dirs, dsigmas, drgbs, src_next, g, pairs, plane);
+        bwd_load(in, enc, dirs, dsigmas, drgbs, src_next, g, pairs, plane);
         // ---- weight gradients: every wave publishes its dZ / X rows, then accumulates ITS dW tiles over all BG group images ----
-        // phase A: layer 4 (dZ4 [64] x a3 [64])
+        // phase A: layer 5 (dZ5 [16] x a4 [64]) and layer 4 (dZ4 [64] x a3 [64])
+        img_store(img, A_DZ5, lofs, dz5);
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
             img_store(img, A_DZ4 + mt, lofs, dz4[mt]);
+            img_store(img, A_A4 + mt, lofs, t.a4[mt]);
             img_store(img, A_A3 + mt, lofs, t.a3[mt]);
         }
         __syncthreads();
-        if (lo4) {
-#pragma unroll NGP_MLP_DW_UNROLL
+        if (lo8) {
+#pragma unroll 3
             for (int k = 0; k < BG; ++k) {
                 const half_t* Ik = Iall + k * IMG_HALFS;
-                const half8 a = img_load_tr(Ik, A_DZ4 + wv, g, n);
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) acc4[nt] = NGP_MFMA(a, img_load_tr(Ik, A_A3 + nt, g, n), acc4[nt]);
+                const half8 a = img_load_tr(Ik, A_DZ4 + mtL, g, n);
+                accA0 = NGP_MFMA(a, img_load_tr(Ik, A_A3 + 2 * ntL, g, n), accA0);
+                accA1 = NGP_MFMA(a, img_load_tr(Ik, A_A3 + 2 * ntL + 1, g, n), accA1);
+            }
+        } else {
+#pragma unroll 3
+            for (int k = 0; k < BG; ++k) {
+                const half_t* Ik = Iall + k * IMG_HALFS;
+                accC = NGP_MFMA(img_load_tr(Ik, A_DZ5, g, n), img_load_tr(Ik, A_A4 + v4, g, n), accC);
             }
         }
         __syncthreads();
@@ -560,40 +570,36 @@ __global__ void __launch_bounds__(64 * BW, 2) mlp_bwd_kernel(const float* __rest
             img_store(img, B_A1 + mt, lofs, t.a1[mt]);
         }
         __syncthreads();
-        {
-            const int ta = lo4 ? B_DZ3 + wv : B_DZ2, tb = lo4 ? B_IN3 : B_A1 + v2;
-#pragma unroll NGP_MLP_DW_UNROLL
+        if (lo8) {
+#pragma unroll 3
             for (int k = 0; k < BG; ++k) {
                 const half_t* Ik = Iall + k * IMG_HALFS;
-                const half8 a = img_load_tr(Ik, ta, g, n);
-                accB[0] = NGP_MFMA(a, img_load_tr(Ik, tb, g, n), accB[0]);
-                accB[1] = NGP_MFMA(a, img_load_tr(Ik, tb + 1, g, n), accB[1]);
+                accB = NGP_MFMA(img_load_tr(Ik, B_DZ3 + mtL, g, n), img_load_tr(Ik, B_IN3 + ntL, g, n), accB);
+            }
+        } else {
+#pragma unroll 3
+            for (int k = 0; k < BG; ++k) {
+                const half_t* Ik = Iall + k * IMG_HALFS;
+                accB = NGP_MFMA(img_load_tr(Ik, B_DZ2, g, n), img_load_tr(Ik, B_A1 + v4, g, n), accB);
             }
         }
         __syncthreads();
         MLP_T(4);
-        // phase C: layer 1 (dZ1 [64] x enc [32]) and layer 5 (dZ5 [16] x a4 [64]); X column c of layer 1 = its k-slot
-        // (g' = c>>3, j' = c&7): this lane's 8g..8g+7 are granules 2(g&1), 2(g&1)+1 of tile g>>1
-        img_store(img, C_DZ5, lofs, dz5);
+        // phase C: layer 1 (dZ1 [64] x enc [32]); X column c = k-slot (g' = c>>3, j' = c&7) of layer 1: this lane's 8g..8g+7
+        // are granules 2(g&1), 2(g&1)+1 of tile g>>1
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            img_store(img, C_DZ1 + mt, lofs, dz1[mt]);
-            img_store(img, C_A4 + mt, lofs, t.a4[mt]);
-        }
+        for (int mt = 0; mt < 4; ++mt) img_store(img, C_DZ1 + mt, lofs, dz1[mt]);
         {
             const int te = C_ENC + (g >> 1), sw = n >> 2, gi = 2 * (g & 1);
             img_store(img, te, lrow + 4 * (gi ^ sw), __builtin_shufflevector(t.b_enc, t.b_enc, 0, 1, 2, 3));
             img_store(img, te, lrow + 4 * ((gi + 1) ^ sw), __builtin_shufflevector(t.b_enc, t.b_enc, 4, 5, 6, 7));
         }
         __syncthreads();
-        {
-            const int ta = lo4 ? C_DZ1 + wv : C_DZ5, tb = lo4 ? C_ENC : C_A4 + v2;
-#pragma unroll NGP_MLP_DW_UNROLL
+        if (lo8) {
+#pragma unroll 3
             for (int k = 0; k < BG; ++k) {
                 const half_t* Ik = Iall + k * IMG_HALFS;
-                const half8 a = img_load_tr(Ik, ta, g, n);
-                accC[0] = NGP_MFMA(a, img_load_tr(Ik, tb, g, n), accC[0]);
-                accC[1] = NGP_MFMA(a, img_load_tr(Ik, tb + 1, g, n), accC[1]);
+                accC = NGP_MFMA(img_load_tr(Ik, C_DZ1 + mtL, g, n), img_load_tr(Ik, C_ENC + ntL, g, n), accC);
             }
         }
         __syncthreads();
@@ -605,26 +611,19 @@ __global__ void __launch_bounds__(64 * BW, 2) mlp_bwd_kernel(const float* __rest
     bool bad = false;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int o = 16 * wv + 4 * g + r, o2 = 4 * g + r;          // output row of this lane's accumulator element r
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            const float a = acc4[nt][r];
-            if (lo4 && a != 0.0f) unsafeAtomicAdd(dW + OFF_W4 + o * 64 + 16 * nt + n, a);
-            bad |= !isfinite(a);
+        const int o = 16 * mtL + 4 * g + r, o2 = 4 * g + r;
+        const float a0 = accA0[r], a1 = accA1[r], b = accB[r], c = accC[r];
+        if (lo8) {
+            if (a0 != 0.0f) unsafeAtomicAdd(dW + OFF_W4 + o * 64 + 32 * ntL + n, a0);
+            if (a1 != 0.0f) unsafeAtomicAdd(dW + OFF_W4 + o * 64 + 32 * ntL + 16 + n, a1);
+            if (b != 0.0f) unsafeAtomicAdd(dW + OFF_W3 + o * 32 + 16 * ntL + n, b);
+            // column c of a dW1 tile is the c-th enc column = k-slot (g' = c>>3, j' = c&7) of layer 1
+            if (c != 0.0f) unsafeAtomicAdd(dW + OFF_W1 + o * 32 + enc_feat(pairs, (16 * ntL + n) >> 3, n & 7), c);
+        } else {
+            if (b != 0.0f) unsafeAtomicAdd(dW + OFF_W2 + o2 * 64 + 16 * v4 + n, b);
+            if (o2 < 3 && c != 0.0f) unsafeAtomicAdd(dW + OFF_W5 + o2 * 64 + 16 * v4 + n, c);
         }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const float b = accB[j][r], c = accC[j][r];
-            if (lo4) {
-                if (b != 0.0f) unsafeAtomicAdd(dW + OFF_W3 + o * 32 + 16 * j + n, b);
-                // column c of a dW1 tile is the c-th enc column = k-slot (g' = c>>3, j' = c&7) of layer 1
-                if (c != 0.0f) unsafeAtomicAdd(dW + OFF_W1 + o * 32 + enc_feat(pairs, (16 * j + n) >> 3, n & 7), c);
-            } else {
-                if (b != 0.0f) unsafeAtomicAdd(dW + OFF_W2 + o2 * 64 + 16 * (v2 + j) + n, b);
-                if (o2 < 3 && c != 0.0f) unsafeAtomicAdd(dW + OFF_W5 + o2 * 64 + 16 * (v2 + j) + n, c);
-            }
-            bad |= !isfinite(b) || !isfinite(c);
-        }
+        bad |= !isfinite(a0) || !isfinite(a1) || !isfinite(b) || !isfinite(c);
     }
     if (found_inf && (bad || bad_denc)) *found_inf = 1;
 }
@@ -636,11 +635,6 @@ using namespace ngp;
 extern "C" {
 
 #ifdef NGP_MLP_DIAG
-int ngp_mlp_bwd_occupancy(void) {
-    int nb = -1;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, mlp_bwd_kernel<true>, 64 * BW, 0) != hipSuccess) return -1;
-    return nb;
-}
 int ngp_mlp_debug_read(unsigned long long* host128, int reset) {
     if (hipMemcpyFromSymbol(host128, HIP_SYMBOL(ngp_mlp_dbg), sizeof(ngp_mlp_dbg)) != hipSuccess) return -1;
     if (reset) { unsigned long long z[16 * 8] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(ngp_mlp_dbg), z, sizeof(z)) != hipSuccess) return -1; }
@@ -732,15 +726,10 @@ int ngp_mlp_bwd_live(const float* enc, const float* dirs, const uint16_t* wpack,
                      int32_t* found_inf, void* stream) {
     if (n_max <= 0) return 0;
     int blocks = ((n_max + 31) / 32 + BG - 1) / BG;
-    if (blocks > 512) blocks = 512;                       // two 6-wave blocks per CU: 3 waves per SIMD
+    if (blocks > 256) blocks = 256;                       // one 12-wave block per CU: 3 waves per SIMD
     if (blocks < 1) blocks = 1;
-    const char* pf = getenv("NGP_MLP_BWD_PF");
-    if (pf && atoi(pf) == 0)
-        hipLaunchKernelGGL(mlp_bwd_kernel<false>, dim3(blocks), dim3(64 * BW), 0, (hipStream_t)stream, enc, dirs, (const half_t*)wpack, dsigmas,
-                           (const half_t*)drgbs, n_max, n_dev, live_idx, enc_pairs, d_enc, dW, found_inf);
-    else
-        hipLaunchKernelGGL(mlp_bwd_kernel<true>, dim3(blocks), dim3(64 * BW), 0, (hipStream_t)stream, enc, dirs, (const half_t*)wpack, dsigmas,
-                           (const half_t*)drgbs, n_max, n_dev, live_idx, enc_pairs, d_enc, dW, found_inf);
+    hipLaunchKernelGGL(mlp_bwd_kernel, dim3(blocks), dim3(64 * BW), 0, (hipStream_t)stream, enc, dirs, (const half_t*)wpack, dsigmas,
+                       (const half_t*)drgbs, n_max, n_dev, live_idx, enc_pairs, d_enc, dW, found_inf);
     NGP_LAUNCH_CHECK();
     return 0;
 }
