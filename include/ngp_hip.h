@@ -169,6 +169,17 @@ int ngp_composite_train_fused(const float* sigmas, const void* rgbs, int rgbs_is
                               const float* loss_scale, float T_threshold, int n_rays, int32_t* vr_per_ray,
                               float* opacity, float* depth, float* rgb, float* ws, float* d_sigmas, void* d_rgbs,
                               float* sq_err, void* stream);
+/* The same launch, and the compacted live-sample list of ngp_live_compact as a by-product: every 16-ray block appends its rays'
+ * first vr[r] samples to live_idx at an offset it takes from live_total with ONE atomic add, so the list is in block-completion
+ * order (each ray contiguous) -- the *_live kernels do not depend on the order.  live_total[0] must be 0 at launch; live_zero
+ * (nullable) is set to 0 by the kernel: a caller alternating two counters gets the next step's counter cleared for free.
+ * live_idx == NULL: plain ngp_composite_train_fused. */
+int ngp_composite_train_fused_live(const float* sigmas, const void* rgbs, int rgbs_is_half, const float* deltas,
+                                   const float* ts, const int32_t* rays_a, const float* target, float bg,
+                                   const float* loss_scale, float T_threshold, int n_rays, int32_t* vr_per_ray,
+                                   float* opacity, float* depth, float* rgb, float* ws, float* d_sigmas, void* d_rgbs,
+                                   float* sq_err, int32_t* live_idx, int32_t* live_total, int32_t* live_zero,
+                                   void* stream);
 
 /* Live-sample list for the backward pass: the first vr_per_ray[r] samples of ray r (those in front of the early-termination
  * point, volume_train.py:31-47) are the only ones with a non-zero gradient.  live_idx[j] = sample index of the j-th live

@@ -30,6 +30,19 @@ def main(path, count, condition, warmup):
     for name, d in sorted(per.items(), key=lambda kv: -sum(kv[1])):
         short = name.split("(")[0].replace("void ", "")
         print("%-72s %5d launches  avg %8.2f us  per step %8.2f us" % (short[-72:], len(d), sum(d) / len(d), sum(d) / count))
+    # one ordinary step of the region on the timeline (the 6th: no occupancy update in it): start relative to the previous step's
+    # optimizer end, duration, queue, and the idle time of that queue in front of the launch
+    k0, k1 = ends[first + 4], ends[first + 5]
+    print("\ntimeline of timed step 6 (us after the previous optimizer launch ended; %.1f us long):" % ((k1 - k0) / 1e3))
+    last_end = {}
+    for r in rows:
+        s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+        q = r.get("Queue_Id", "?")
+        if e > k0 and s < k1 + 1:
+            short = r["Kernel_Name"].split("(")[0].replace("void ", "")
+            gap = (s - last_end[q]) / 1e3 if q in last_end else float("nan")
+            print("  %8.1f  +%7.1f us  queue %-4s gap %6.1f  %s" % ((s - k0) / 1e3, (e - s) / 1e3, q, gap, short[-60:]))
+        last_end[q] = max(last_end.get(q, 0), e)
 
 
 if __name__ == "__main__":

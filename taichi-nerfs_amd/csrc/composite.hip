@@ -168,16 +168,24 @@ __global__ void __launch_bounds__(256) composite_bwd_kernel(const float* __restr
 // gradient of a ray's outputs only needs that ray's own radiance, so the three launches (composite fwd, loss, composite
 // bwd) collapse into one: pass 1 composites and leaves R/D/O in registers, pass 2 re-walks the ray (its samples are
 // still in L2) with the closed-form backward.  The per-ray squared error goes to sq_err[ray] (nullable) for logging.
-template <bool HALF>
-__global__ void __launch_bounds__(256) composite_train_fused_kernel(
+// LIVE: the block also appends its rays' live samples (the first vr[r] of each ray: exactly the samples with a non-zero
+// gradient) to the compacted list the backward kernels run over -- one returning atomic per 16-ray block on live_total, the
+// list is then in block-completion order (rays contiguous), which none of its consumers depends on.  live_zero (the OTHER
+// step's counter) is cleared for the next step.  This replaces the separate scan + fill launch (ngp_live_compact, ~20 us on
+// the step's critical path) between this kernel and the MLP backward.
+template <bool HALF, bool LIVE>
+__global__ void __launch_bounds__(LIVE ? 1024 : 256) composite_train_fused_kernel(
     const float* __restrict__ sigmas, const void* __restrict__ rgbs, const float* __restrict__ deltas, const float* __restrict__ ts,
     const int32_t* __restrict__ rays_a, const float* __restrict__ target, float bg, const float* __restrict__ loss_scale, float thr,
     int n_rays, int32_t* __restrict__ vr_per_ray, float* __restrict__ opacity, float* __restrict__ depth, float* __restrict__ rgb,
-    float* __restrict__ ws, float* __restrict__ d_sigmas, void* __restrict__ d_rgbs, float* __restrict__ sq_err) {
-    const int n = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (n >= n_rays) return;
+    float* __restrict__ ws, float* __restrict__ d_sigmas, void* __restrict__ d_rgbs, float* __restrict__ sq_err,
+    int32_t* __restrict__ live_idx, int32_t* __restrict__ live_total, int32_t* __restrict__ live_zero) {
+    const int n_raw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (!LIVE && n_raw >= n_rays) return;
+    const bool has_ray = n_raw < n_rays;                       // LIVE: every wave reaches the block barriers at the end
+    const int n = has_ray ? n_raw : 0;
     const int lane = lane_id();
-    const int ray_idx = rays_a[3 * n], start = rays_a[3 * n + 1], N = rays_a[3 * n + 2];
+    const int ray_idx = rays_a[3 * n], start = rays_a[3 * n + 1], N = has_ray ? rays_a[3 * n + 2] : 0;
     // ---- pass 1: forward (same arithmetic as composite_fwd_kernel)
     float T = 1.0f, r0 = 0.f, r1 = 0.f, r2 = 0.f, dep = 0.f, op = 0.f;
     int cnt = 0;
@@ -209,7 +217,7 @@ __global__ void __launch_bounds__(256) composite_train_fused_kernel(
     const float e0 = (R0 + b) - target[3 * ray_idx], e1 = (R1 + b) - target[3 * ray_idx + 1], e2 = (R2 + b) - target[3 * ray_idx + 2];
     const float gr0 = k * e0, gr1 = k * e1, gr2 = k * e2;
     const float go = -bg * (gr0 + gr1 + gr2);
-    if (lane == 0) {
+    if (lane == 0 && has_ray) {
         rgb[3 * ray_idx] = R0; rgb[3 * ray_idx + 1] = R1; rgb[3 * ray_idx + 2] = R2;
         depth[ray_idx] = D; opacity[ray_idx] = O; vr_per_ray[ray_idx] = cnt;
         // per-ray squared error for logging; summing it here would be 8192 same-address atomics (~12 ns each, measured:
@@ -259,6 +267,26 @@ __global__ void __launch_bounds__(256) composite_train_fused_kernel(
         }
         cr0 = __shfl(p0, NGP_WAVE - 1, NGP_WAVE); cr1 = __shfl(p1, NGP_WAVE - 1, NGP_WAVE); cr2 = __shfl(p2, NGP_WAVE - 1, NGP_WAVE);
         T = deadm ? 0.0f : T * __shfl(incl, NGP_WAVE - 1, NGP_WAVE);    // a dead sample in this chunk ends the ray for good
+    }
+    if (LIVE) {
+        __shared__ int s_off[16];
+        const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+        if (lane == 0) s_off[wave] = has_ray ? cnt : 0;
+        __syncthreads();
+        if (wave == 0) {
+            const int c = lane < nw ? s_off[lane] : 0;
+            const int inc = wave_scan_add_i(c, lane);
+            int base = 0;
+            if (lane == NGP_WAVE - 1 && inc > 0) base = atomicAdd(live_total, inc);
+            base = __shfl(base, NGP_WAVE - 1, NGP_WAVE);
+            if (lane < nw) s_off[lane] = base + inc - c;
+        }
+        __syncthreads();
+        if (has_ray) {
+            const int b = s_off[wave];
+            for (int k = lane; k < cnt; k += NGP_WAVE) live_idx[b + k] = start + k;
+        }
+        if (live_zero && blockIdx.x == 0 && threadIdx.x == 0) *live_zero = 0;
     }
 }
 
@@ -330,20 +358,44 @@ int ngp_composite_train_bwd(const float* dL_dopacity, const float* dL_ddepth, co
     return 0;
 }
 
+int ngp_composite_train_fused_live(const float* sigmas, const void* rgbs, int rgbs_is_half, const float* deltas, const float* ts,
+                                   const int32_t* rays_a, const float* target, float bg, const float* loss_scale, float T_threshold,
+                                   int n_rays, int32_t* vr_per_ray, float* opacity, float* depth, float* rgb, float* ws,
+                                   float* d_sigmas, void* d_rgbs, float* sq_err, int32_t* live_idx, int32_t* live_total,
+                                   int32_t* live_zero, void* stream) {
+    if (n_rays <= 0) return 0;
+    if (!live_idx) {
+        dim3 grid((n_rays + 3) / 4), block(256);
+        if (rgbs_is_half)
+            hipLaunchKernelGGL((composite_train_fused_kernel<true, false>), grid, block, 0, (hipStream_t)stream, sigmas, rgbs, deltas, ts,
+                               rays_a, target, bg, loss_scale, T_threshold, n_rays, vr_per_ray, opacity, depth, rgb, ws, d_sigmas, d_rgbs,
+                               sq_err, nullptr, nullptr, nullptr);
+        else
+            hipLaunchKernelGGL((composite_train_fused_kernel<false, false>), grid, block, 0, (hipStream_t)stream, sigmas, rgbs, deltas, ts,
+                               rays_a, target, bg, loss_scale, T_threshold, n_rays, vr_per_ray, opacity, depth, rgb, ws, d_sigmas, d_rgbs,
+                               sq_err, nullptr, nullptr, nullptr);
+    } else {
+        if (!live_total) return -1;
+        dim3 grid((n_rays + 15) / 16), block(1024);
+        if (rgbs_is_half)
+            hipLaunchKernelGGL((composite_train_fused_kernel<true, true>), grid, block, 0, (hipStream_t)stream, sigmas, rgbs, deltas, ts,
+                               rays_a, target, bg, loss_scale, T_threshold, n_rays, vr_per_ray, opacity, depth, rgb, ws, d_sigmas, d_rgbs,
+                               sq_err, live_idx, live_total, live_zero);
+        else
+            hipLaunchKernelGGL((composite_train_fused_kernel<false, true>), grid, block, 0, (hipStream_t)stream, sigmas, rgbs, deltas, ts,
+                               rays_a, target, bg, loss_scale, T_threshold, n_rays, vr_per_ray, opacity, depth, rgb, ws, d_sigmas, d_rgbs,
+                               sq_err, live_idx, live_total, live_zero);
+    }
+    NGP_LAUNCH_CHECK();
+    return 0;
+}
+
 int ngp_composite_train_fused(const float* sigmas, const void* rgbs, int rgbs_is_half, const float* deltas, const float* ts,
                               const int32_t* rays_a, const float* target, float bg, const float* loss_scale, float T_threshold,
                               int n_rays, int32_t* vr_per_ray, float* opacity, float* depth, float* rgb, float* ws,
                               float* d_sigmas, void* d_rgbs, float* sq_err, void* stream) {
-    if (n_rays <= 0) return 0;
-    dim3 grid((n_rays + 3) / 4), block(256);
-    if (rgbs_is_half)
-        hipLaunchKernelGGL(composite_train_fused_kernel<true>, grid, block, 0, (hipStream_t)stream, sigmas, rgbs, deltas, ts, rays_a,
-                           target, bg, loss_scale, T_threshold, n_rays, vr_per_ray, opacity, depth, rgb, ws, d_sigmas, d_rgbs, sq_err);
-    else
-        hipLaunchKernelGGL(composite_train_fused_kernel<false>, grid, block, 0, (hipStream_t)stream, sigmas, rgbs, deltas, ts, rays_a,
-                           target, bg, loss_scale, T_threshold, n_rays, vr_per_ray, opacity, depth, rgb, ws, d_sigmas, d_rgbs, sq_err);
-    NGP_LAUNCH_CHECK();
-    return 0;
+    return ngp_composite_train_fused_live(sigmas, rgbs, rgbs_is_half, deltas, ts, rays_a, target, bg, loss_scale, T_threshold, n_rays,
+                                          vr_per_ray, opacity, depth, rgb, ws, d_sigmas, d_rgbs, sq_err, nullptr, nullptr, nullptr, stream);
 }
 
 int ngp_composite_test(const float* sigmas, const void* rgbs, int rgbs_is_half, const float* deltas, const float* ts,

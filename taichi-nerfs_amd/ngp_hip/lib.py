@@ -109,6 +109,7 @@ SIGNATURES = {
     "ngp_composite_train_fwd": [_P, _P, _I, _P, _P, _P, _F, _I, _P, _P, _P, _P, _P, _P],
     "ngp_composite_train_bwd": [_P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _F, _I, _P, _P, _P],
     "ngp_composite_train_fused": [_P, _P, _I, _P, _P, _P, _P, _F, _P, _F, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "ngp_composite_train_fused_live": [_P, _P, _I, _P, _P, _P, _P, _F, _P, _F, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "ngp_composite_test": [_P, _P, _I, _P, _P, _P, _P, _F, _I, _P, _P, _P, _P],
     "ngp_mlp_wpack_halfs": [],
     "ngp_mlp_pack": [_P, _P, _P, _P, _P, _I, _P, _P],

@@ -132,7 +132,9 @@ class FusedTrainer:
         self.state_f = torch.zeros(8, **f32)
         self.state_i = torch.zeros(8, device=dev, dtype=torch.int32)
         self.state_f[_SF_LOSS_SCALE] = float(init_scale)
-        self._live_total = torch.zeros(1, device=dev, dtype=torch.int32)
+        # live-sample counters, one per step parity: the fused composite kernel appends to the current step's counter (which has
+        # to be 0 at launch) and clears the other one for the next step -- no memset launch on the step's critical path
+        self._live_pair = torch.zeros(2, device=dev, dtype=torch.int32)    # (parity = which of the two march sets the step shades)
         self._graph = None
         self._grads_only = False
         self.stats = {}
@@ -214,11 +216,18 @@ class FusedTrainer:
                     and k[2] == src[0]._version and k[3] == src[1]._version)
 
 
+    @property
+    def _live_total(self):
+        """[1] int32 view: the live-sample count of the most recent step (diagnostics, bench.py)."""
+        par = 1 - self._cur                                       # _launch flips _cur after choosing the step's set
+        return self._live_pair[par:par + 1]
+
     def _march_sets(self, n):
         key = n
         sets = self._sets.get(key)
         if sets is None:
             sets = self._sets[key] = [self._MarchSet(self.dev, n, self.max_samples) for _ in range(2)]
+            sets[0].index, sets[1].index = 0, 1
         return sets
 
     def _coarse_bits(self, cfg, A):
@@ -330,20 +339,28 @@ class FusedTrainer:
               "ngp_mlp_fwd_ex")
         if hook is not None and self._prefetch_at == 2:
             hook(); hook = None
+        par = M.index
+        live_total, live_next = self._live_pair[par:par + 1], self._live_pair[1 - par:2 - par]
+        fused_live = False
         if self.distortion_loss_w > 0:
             sq_err = self._composite_with_distortion(A, M, target, cfg, n, vr_per_ray, opacity, depth, rgb)
         else:
-            # composite forward + MSE gradient + composite backward, one launch
-            check(L.ngp_composite_train_fused(_ptr(A.sigmas), _ptr(A.rgbs), 1, _ptr(M.deltas), _ptr(M.ts), _ptr(rays_a), _ptr(target),
-                                              self.bg, _ptr(sf), cfg.T_threshold, n, _ptr(vr_per_ray), _ptr(opacity), _ptr(depth),
-                                              _ptr(rgb), _ptr(A.ws), _ptr(A.d_sigmas), _ptr(A.d_rgbs), _ptr(sq_err), st),
-                  "ngp_composite_train_fused")
-        # backward on the LIVE samples only (those in front of each ray's early-termination point; the rest have exact-zero
-        # gradients): a compacted index list, then the MLP backward and the scatter-add run over it
-        live_idx, live_total = A.live_idx, self._live_total
-        if self.live_backward:
+            # composite forward + MSE gradient + composite backward, one launch -- and, as a by-product, the compacted list of
+            # the LIVE samples (those in front of each ray's early-termination point; the rest have exact-zero gradients) that
+            # the MLP backward and the scatter-add run over
+            fused_live = self.live_backward
+            check(L.ngp_composite_train_fused_live(_ptr(A.sigmas), _ptr(A.rgbs), 1, _ptr(M.deltas), _ptr(M.ts), _ptr(rays_a),
+                                                   _ptr(target), self.bg, _ptr(sf), cfg.T_threshold, n, _ptr(vr_per_ray), _ptr(opacity),
+                                                   _ptr(depth), _ptr(rgb), _ptr(A.ws), _ptr(A.d_sigmas), _ptr(A.d_rgbs), _ptr(sq_err),
+                                                   _ptr(A.live_idx if fused_live else None), _ptr(live_total if fused_live else None),
+                                                   _ptr(live_next if fused_live else None), st), "ngp_composite_train_fused_live")
+        live_idx = A.live_idx
+        if self.live_backward and not fused_live:                 # (distortion-loss path: its composite is the operator chain)
             check(L.ngp_live_compact(_ptr(rays_a), _ptr(vr_per_ray), n, _ptr(A.live_off(n)), _ptr(live_idx), _ptr(live_total), st),
                   "ngp_live_compact")
+        if not fused_live:
+            live_next.zero_()
+        if self.live_backward:
             cnt = live_total
         else:
             live_idx, cnt = None, total

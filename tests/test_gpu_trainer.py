@@ -259,25 +259,43 @@ def test_live_backward_equals_full_backward(hip_lib, lego_bitfield):
         with torch.no_grad():
             m.xyz_encoder.output_layer.weight.mul_(3.0)
         tr.repack()
+    from ngp_hip.fused import TrainArena
     outs = []
     for live in (True, False):
         tr.live_backward = live
         torch.manual_seed(77)
         outs.append(tr.compute_gradients(o, d, target))
+        if live:
+            n_live = int(tr._live_total)
+            got_list = TrainArena.get(o.device, o.shape[0], 1024).live_idx[:n_live].cpu().numpy().copy()
     a, b = outs
-    n_live, n_all = int(tr._live_total), int(a["rm_samples"][0])
+    n_all = int(a["rm_samples"][0])
     assert 0 < n_live < 0.8 * n_all and n_live == int(a["vr_per_ray"].sum())
     assert torch.equal(a["rays_a"], b["rays_a"]) and torch.equal(a["rgb"], b["rgb"])
     for k in ("table_grad", "mlp_grad"):
         ga, gb = a[k], b[k]
         assert torch.equal(ga != 0, gb != 0) or ((ga != 0) == (gb != 0)).float().mean().item() > 0.9999
         assert ((ga - gb).norm() / gb.norm()).item() < 1e-5      # float-atomic / MFMA accumulation order only
-    # the live list is the per-ray prefixes, in ray order
-    from ngp_hip.fused import TrainArena
-    A = TrainArena.get(o.device, o.shape[0], 1024)
+    # the live list is the per-ray prefixes: every ray's run contiguous and ascending, the rays in the order their 16-ray blocks
+    # of the fused composite kernel finished (ngp_composite_train_fused_live), i.e. a permutation of the ray-order list
     ra, vr = a["rays_a"].cpu().numpy(), a["vr_per_ray"].cpu().numpy()
     want = np.concatenate([np.arange(s, s + vr[r]) for r, s, c in ra]) if n_live else np.zeros(0)
-    assert np.array_equal(A.live_idx[:n_live].cpu().numpy(), want)
+    assert np.array_equal(np.sort(got_list), want)                       # (sample indices ascend with the ray index)
+    run_start = {int(s): int(vr[r]) for r, s, c in ra if vr[r] > 0}
+    pos = 0
+    while pos < n_live:
+        length = run_start[int(got_list[pos])]
+        assert np.array_equal(got_list[pos:pos + length], np.arange(got_list[pos], got_list[pos] + length))
+        pos += length
+    # the operator (two-pass scan + fill, ray order) over the same per-ray counts
+    from ngp_hip import lib as _lib
+    from ngp_hip.ops import _ptr, _stream
+    L = _lib.load()
+    n_rays = ra.shape[0]
+    off = torch.empty(n_rays, dtype=torch.int32, device="cuda"); lst = torch.empty(n_all, dtype=torch.int32, device="cuda")
+    tot = torch.zeros(1, dtype=torch.int32, device="cuda")
+    assert L.ngp_live_compact(_ptr(a["rays_a"]), _ptr(a["vr_per_ray"]), n_rays, _ptr(off), _ptr(lst), _ptr(tot), _stream()) == 0
+    assert int(tot) == n_live and np.array_equal(lst[:n_live].cpu().numpy(), want)
 
 
 @pytest.mark.parametrize("kind", ["f32", "bf16", "half"])
