@@ -77,6 +77,17 @@ int ngp_march_train_count_ex(const float* rays_o, const float* rays_d, const flo
                              const uint8_t* density_bitfield, const uint32_t* coarse, const float* noise,
                              int cascades, int grid_size, float scale, float exp_step_factor, int max_samples,
                              int n_rays, float* stage, int32_t* counts, void* stream);
+/* The whole training march in ONE launch (count + allocation + expansion): a 16-wave block marches 32 rays, takes its output
+ * range from ctr[0] with one atomic add and writes its rays' samples itself.  Per ray the samples are those of the chain above
+ * (bit for bit, contiguous, in march order); the rays follow each other in the order their blocks finished, as in the reference
+ * (ray_march.py:76-80: N_eff_samples / counter atomic adds) -- rays_a[r] = (r, start, count) says where.  ctr = [2] int32 scratch,
+ * zero before the FIRST launch only (the kernel leaves it zero); total[0] = number of samples.  hits_t / coarse nullable as in
+ * ngp_march_train_count_ex; stage = [n_rays * max_samples * 2] scratch. */
+int ngp_march_train_fused(const float* rays_o, const float* rays_d, const float* hits_t,
+                          const uint8_t* density_bitfield, const uint32_t* coarse, const float* noise, int cascades,
+                          int grid_size, float scale, float exp_step_factor, int max_samples, int n_rays,
+                          float* stage, int32_t* ctr, int32_t* rays_a, int32_t* total, float* xyzs, float* dirs,
+                          float* deltas, float* ts, void* stream);
 int ngp_march_train_scan(const int32_t* counts, int n_rays, int32_t* rays_a /*[n,3]*/,
                          int32_t* total /*[1]*/, void* stream);
 int ngp_march_train_write(const float* rays_o, const float* rays_d, const int32_t* rays_a,

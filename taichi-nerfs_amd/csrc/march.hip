@@ -129,30 +129,27 @@ constexpr int MARCH_GROUP = 32;
 constexpr int MARCH_MAX_COARSE_WORDS = 1024;            // 32 768 coarse blocks: up to 8 cascades of a 128^3 grid
 constexpr int ORBIT_BATCH = 8;      // used by the test-time kernel (one lane per ray)
 
+// LDS traffic between the lanes of ONE wave: order it for the compiler and the memory pipeline, no block barrier
+__device__ __forceinline__ void wave_sync_lds() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// One wave marches 64 / G rays (r = first_ray + lane / G); returns the ray's sample count on all of its lanes and leaves the
+// (t, dt) pairs in the ray's staging row.  `chain` = the wave's own 64 / G words of LDS, `coarse_s` the block's copy of the
+// coarse occupancy bits; every synchronisation inside is wave-local, so blocks of any number of waves can call it.
 template <bool CONST_DT, int G, bool CASC1>
-__global__ void __launch_bounds__(64) march_count_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
-                                                         const float2* __restrict__ hits_t,
-                                                         const uint8_t* __restrict__ bits, const float* __restrict__ noise,
-                                                         MarchParams p, int max_samples, int n_rays,
-                                                         const uint32_t* __restrict__ coarse /*nullable*/,
-                                                         float2* __restrict__ stage, int32_t* __restrict__ counts) {
-    constexpr int GROUPS = 64 / G;                          // one wave per block: the barriers below are wave-local
-    __shared__ unsigned long long chain[GROUPS];            // bit u: orbit point u of the batch is examined (replay below)
-    // coarse occupancy: one bit per 8^3 block of cells == per 512 consecutive Morton codes (64 bitfield bytes).
-    // A clear bit proves the cell empty without touching the bitfield: most batches of a trained scene never issue a
-    // global load at all, which is what this latency-bound kernel is waiting on.
-    __shared__ uint32_t coarse_s[MARCH_MAX_COARSE_WORDS];
-    const int coarse_words = coarse ? (int)((p.grid_size3 >> 9) * (uint32_t)p.cascades + 31u) >> 5 : 0;
-    const bool use_coarse = coarse != nullptr && coarse_words <= MARCH_MAX_COARSE_WORDS;
-    if (use_coarse) {
-        for (int k = threadIdx.x; k < coarse_words; k += 64) coarse_s[k] = coarse[k];
-        __syncthreads();
-    }
-    const int grp = threadIdx.x / G, sub = threadIdx.x % G;
-    const int r = blockIdx.x * GROUPS + grp;
+__device__ __forceinline__ int march_rays_of_wave(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                  const float2* __restrict__ hits_t, const uint8_t* __restrict__ bits,
+                                                  const float* __restrict__ noise, const MarchParams& p, int max_samples, int n_rays,
+                                                  const uint32_t* __restrict__ coarse_s, bool use_coarse, float2* __restrict__ stage,
+                                                  unsigned long long* __restrict__ chain, int first_ray, float o[3], float d[3]) {
+    const int lane = threadIdx.x & 63;
+    const int grp = lane / G, sub = lane % G;
+    const int r = first_ray + grp;
     const bool has_ray = r < n_rays;
     const int rr = has_ray ? r : 0;
-    float o[3], d[3], d_inv[3];
+    float d_inv[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) { o[k] = rays_o[3 * rr + k]; d[k] = rays_d[3 * rr + k]; d_inv[k] = 1.0f / d[k]; }
     float2 h;
@@ -243,9 +240,9 @@ __global__ void __launch_bounds__(64) march_count_kernel(const float* __restrict
             bool on_chain = sub == e0;
 #pragma unroll
             for (int k = 1; k < G; k <<= 1) {                                         // chain members at distance < k are marked
-                __syncthreads();
+                wave_sync_lds();
                 if (on_chain && j < G) atomicOr(&chain[grp], 1ull << j);
-                __syncthreads();
+                wave_sync_lds();
                 on_chain = (chain[grp] >> sub) & 1ull;
                 if (2 * k < G) {
                     const int jj = __shfl(j, gbase + min(j, G - 1));
@@ -266,11 +263,108 @@ __global__ void __launch_bounds__(64) march_count_kernel(const float* __restrict
                 n = full ? max_samples : n + cnt;
                 live = !full && nv == G;                                              // loop head, ray_march.py:46
             }
-            __syncthreads();
+            wave_sync_lds();
         }
         t = t_next_batch;
     }
-    if (has_ray && sub == 0) counts[r] = n;
+    return n;
+}
+
+
+// coarse occupancy: one bit per 8^3 block of cells == per 512 consecutive Morton codes (64 bitfield bytes).
+// A clear bit proves the cell empty without touching the bitfield: most batches of a trained scene never issue a
+// global load at all, which is what this latency-bound kernel is waiting on.
+__device__ __forceinline__ bool load_coarse(const MarchParams& p, const uint32_t* __restrict__ coarse, uint32_t* __restrict__ coarse_s) {
+    const int coarse_words = coarse ? (int)((p.grid_size3 >> 9) * (uint32_t)p.cascades + 31u) >> 5 : 0;
+    const bool use_coarse = coarse != nullptr && coarse_words <= MARCH_MAX_COARSE_WORDS;
+    if (use_coarse) {
+        for (int k = threadIdx.x; k < coarse_words; k += blockDim.x) coarse_s[k] = coarse[k];
+        __syncthreads();
+    }
+    return use_coarse;
+}
+
+template <bool CONST_DT, int G, bool CASC1>
+__global__ void __launch_bounds__(64) march_count_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                         const float2* __restrict__ hits_t,
+                                                         const uint8_t* __restrict__ bits, const float* __restrict__ noise,
+                                                         MarchParams p, int max_samples, int n_rays,
+                                                         const uint32_t* __restrict__ coarse /*nullable*/,
+                                                         float2* __restrict__ stage, int32_t* __restrict__ counts) {
+    constexpr int GROUPS = 64 / G;
+    __shared__ unsigned long long chain[GROUPS];            // bit u: orbit point u of the batch is examined
+    __shared__ uint32_t coarse_s[MARCH_MAX_COARSE_WORDS];
+    const bool use_coarse = load_coarse(p, coarse, coarse_s);
+    float o[3], d[3];
+    const int n = march_rays_of_wave<CONST_DT, G, CASC1>(rays_o, rays_d, hits_t, bits, noise, p, max_samples, n_rays, coarse_s, use_coarse,
+                                                         stage, chain, blockIdx.x * GROUPS, o, d);
+    const int r = blockIdx.x * GROUPS + (int)threadIdx.x / G;
+    if (r < n_rays && threadIdx.x % G == 0) counts[r] = n;
+}
+
+// ---- the whole training march in ONE launch: count, allocate, expand -------------------------------------------------------
+// A 16-wave block marches 16 * 64 / G rays, takes its output range with one atomic add on a device counter (block-local
+// prefix inside it) and expands its rays' staged (t, dt) pairs into xyzs / dirs / deltas / ts itself.  The samples of a ray are
+// contiguous and in march order; the RAYS follow each other in the order their blocks finished -- like the reference, whose
+// rays take their ranges with atomic adds (ray_march.py:76-80), and unlike the count / scan / write chain above, which packs
+// in ray order and costs two more launches (14 + 15-24 us) behind the count.  ctr[0] = allocation counter, ctr[1] = finished
+// blocks: the last block publishes total = ctr[0] and clears both, so the pair needs zeroing only once, at allocation.
+template <bool CONST_DT, int G, bool CASC1>
+__global__ void __launch_bounds__(1024) march_fused_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                           const float2* __restrict__ hits_t, const uint8_t* __restrict__ bits,
+                                                           const float* __restrict__ noise, MarchParams p, int max_samples, int n_rays,
+                                                           const uint32_t* __restrict__ coarse, float2* __restrict__ stage,
+                                                           int32_t* __restrict__ ctr, int32_t* __restrict__ rays_a,
+                                                           int32_t* __restrict__ total, float* __restrict__ xyzs,
+                                                           float* __restrict__ dirs, float* __restrict__ deltas, float* __restrict__ ts) {
+    constexpr int GROUPS = 64 / G, RPB = 16 * GROUPS;      // rays per block: 32 at G = 32
+    __shared__ unsigned long long chain[16][GROUPS];
+    __shared__ uint32_t coarse_s[MARCH_MAX_COARSE_WORDS];
+    __shared__ int s_off[RPB];
+    const bool use_coarse = load_coarse(p, coarse, coarse_s);
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, grp = lane / G, sub = lane % G;
+    const int first = blockIdx.x * RPB + wv * GROUPS, r = first + grp;
+    float o[3], d[3];
+    const int n = march_rays_of_wave<CONST_DT, G, CASC1>(rays_o, rays_d, hits_t, bits, noise, p, max_samples, n_rays, coarse_s, use_coarse,
+                                                         stage, chain[wv], first, o, d);
+    const bool has_ray = r < n_rays;
+    if (sub == 0) s_off[wv * GROUPS + grp] = has_ray ? n : 0;
+    __threadfence_block();                                  // the staging rows are read back by other lanes below
+    __syncthreads();
+    if (wv == 0) {
+        const int c = lane < RPB ? s_off[lane] : 0;
+        const int inc = wave_scan_add_i(c, lane);
+        int base = 0;
+        if (lane == NGP_WAVE - 1) base = atomicAdd(&ctr[0], inc);
+        base = __shfl(base, NGP_WAVE - 1, NGP_WAVE);
+        if (lane < RPB) s_off[lane] = base + inc - c;
+    }
+    __syncthreads();
+    if (has_ray) {
+        const int start = s_off[wv * GROUPS + grp];
+        if (sub == 0) { rays_a[3 * r] = r; rays_a[3 * r + 1] = start; rays_a[3 * r + 2] = n; }
+        const float2* row = stage + (size_t)r * (size_t)max_samples;
+        for (int k = sub; k < n; k += G) {
+            const float2 s = row[k];
+            const size_t g = (size_t)start + k;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                xyzs[3 * g + a] = o[a] + s.x * d[a];                               // ray_march.py:88
+                dirs[3 * g + a] = d[a];
+            }
+            ts[g] = s.x;
+            deltas[g] = s.y;
+        }
+    }
+    // Last block out publishes the total and clears the counters.  No device-scope fence: on gfx950 that is an L2 write-back per
+    // block (measured: the kernel 4x slower); nothing but the two counters travels between blocks, both are device-scope atomics
+    // on one cache line, and every block's allocation precedes its own "finished" increment in program order.
+    if (threadIdx.x == 0) {
+        if (atomicAdd(&ctr[1], 1) == (int)gridDim.x - 1) {
+            total[0] = atomicExch(&ctr[0], 0);
+            atomicExch(&ctr[1], 0);
+        }
+    }
 }
 
 // coarse[k] bit = any occupied cell among Morton codes [512 k, 512 k + 512) = bitfield bytes [64 k, 64 k + 64)
@@ -501,6 +595,27 @@ int ngp_march_train_count_ex(const float* rays_o, const float* rays_d, const flo
         if (cd && c1) NGP_LAUNCH_MARCH(true, 32, true); else if (cd) NGP_LAUNCH_MARCH(true, 32, false);
         else if (c1) NGP_LAUNCH_MARCH(false, 32, true); else NGP_LAUNCH_MARCH(false, 32, false);
     }
+#undef NGP_LAUNCH_MARCH
+    NGP_LAUNCH_CHECK();
+    return 0;
+}
+
+int ngp_march_train_fused(const float* rays_o, const float* rays_d, const float* hits_t, const uint8_t* density_bitfield,
+                          const uint32_t* coarse, const float* noise, int cascades, int grid_size, float scale, float exp_step_factor,
+                          int max_samples, int n_rays, float* stage, int32_t* ctr, int32_t* rays_a, int32_t* total, float* xyzs,
+                          float* dirs, float* deltas, float* ts, void* stream) {
+    if (n_rays <= 0) return 0;
+    if (!ctr || !rays_a || !total) return -1;
+    MarchParams p = make_march_params(cascades, grid_size, scale, exp_step_factor);
+    hipStream_t s = (hipStream_t)stream;
+    constexpr int RPB = 16 * (64 / MARCH_GROUP);
+#define NGP_LAUNCH_MARCH(CD, C1)                                                                                                   \
+    hipLaunchKernelGGL((march_fused_kernel<CD, MARCH_GROUP, C1>), dim3((n_rays + RPB - 1) / RPB), dim3(1024), 0, s, rays_o, rays_d,    \
+                       (const float2*)hits_t, density_bitfield, noise, p, max_samples, n_rays, coarse, (float2*)stage, ctr, rays_a,     \
+                       total, xyzs, dirs, deltas, ts)
+    const bool cd = exp_step_factor == 0.0f, c1 = cascades == 1;
+    if (cd && c1) NGP_LAUNCH_MARCH(true, true); else if (cd) NGP_LAUNCH_MARCH(true, false);
+    else if (c1) NGP_LAUNCH_MARCH(false, true); else NGP_LAUNCH_MARCH(false, false);
 #undef NGP_LAUNCH_MARCH
     NGP_LAUNCH_CHECK();
     return 0;

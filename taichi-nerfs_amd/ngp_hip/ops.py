@@ -115,6 +115,31 @@ def march_train(rays_o, rays_d, hits_t, density_bitfield, noise, cascades, scale
     return rays_a, xyzs, dirs, deltas, ts, total[0]
 
 
+def march_train_fused(rays_o, rays_d, hits_t, density_bitfield, noise, cascades, scale, exp_step_factor, grid_size, max_samples,
+                      capacity=None):
+    """ngp_march_train_fused: the same samples per ray as march_train() in ONE launch, the rays packed in block-completion order
+    (rays_a[r] = (r, start, count)); outputs are sized for `capacity` samples (default n * max_samples), the first `total` valid.
+    hits_t may be None (slab test inline)."""
+    _dev(rays_o, torch.float32, "rays_o"); _dev(rays_d, torch.float32, "rays_d")
+    _dev(density_bitfield, torch.uint8, "density_bitfield"); _dev(noise, torch.float32, "noise")
+    n = rays_o.shape[0]
+    dev = rays_o.device
+    L = _lib()
+    stage = MarchArena.get(dev, n, int(max_samples))
+    cap = n * int(max_samples) if capacity is None else int(capacity)
+    rays_a = torch.empty(n, 3, device=dev, dtype=torch.int32)
+    total = torch.zeros(1, device=dev, dtype=torch.int32)
+    ctr = torch.zeros(2, device=dev, dtype=torch.int32)
+    xyzs, dirs = torch.empty(cap, 3, device=dev, dtype=torch.float32), torch.empty(cap, 3, device=dev, dtype=torch.float32)
+    deltas, ts = torch.empty(cap, device=dev, dtype=torch.float32), torch.empty(cap, device=dev, dtype=torch.float32)
+    coarse = coarse_bitfield(density_bitfield, cascades, grid_size)
+    check(L.ngp_march_train_fused(_ptr(rays_o), _ptr(rays_d), _ptr(hits_t), _ptr(density_bitfield), _ptr(coarse), _ptr(noise),
+                                  int(cascades), int(grid_size), float(scale), float(exp_step_factor), int(max_samples), n,
+                                  _ptr(stage), _ptr(ctr), _ptr(rays_a), _ptr(total), _ptr(xyzs), _ptr(dirs), _ptr(deltas), _ptr(ts),
+                                  _stream()), "ngp_march_train_fused")
+    return rays_a, xyzs, dirs, deltas, ts, total[0], ctr
+
+
 # ---------------------------------------------------------------------------------------------------- a-3
 def march_test(rays_o, rays_d, hits_t, alive_indices, density_bitfield, cascades, scale, exp_step_factor, grid_size,
                max_samples):

@@ -58,6 +58,7 @@ class FusedTrainer:
         self.distortion_loss_w = float(distortion_loss_w)                # train.py:194-195 (0 = off, the reference default)
         # backward over the samples in front of each ray's early-termination point only (NGP_LIVE_BACKWARD=0: over all of them)
         self.live_backward = os.environ.get("NGP_LIVE_BACKWARD", "1") != "0"
+        self.march_fused = os.environ.get("NGP_MARCH_FUSED", "1") != "0"
         # table gradient (fp32, or fp16 for the half2 encoder): "sliced" = LDS-owned table slices, no global float atomics
         # (csrc/hash_bwd_lds.hip; the default whenever the level table fits: F = 2, levels of <= 2^19 entries), "atomic" = round
         # 1's float-atomic / packed-f16-atomic kernels
@@ -148,11 +149,13 @@ class FusedTrainer:
         # 0, 0.585 at 2, 0.590 at 3), 2 = after the MLP forward, 3 = before the scatter-add, 4 = after the scatter-add.
         # Round 3: the count kernel's replay became parallel (109 -> 47 us, ~75 us chain), so the chain no longer has to start that
         # early and is best kept off the gather-bound encoder: at 350 k live samples, 3 runs x 400 steps each: 0.554 ms at 2,
-        # 0.556 at 3, 0.560 at 0, 0.564 at 1 (not prefetched: 0.570)
+        # 0.556 at 3, 0.560 at 0, 0.564 at 1 (not prefetched: 0.570).  Then the march became ONE launch (ngp_march_train_fused,
+        # ~55 us) and the live list a by-product of the composite kernel; 3 runs x 400 steps each, no per-kernel events, at
+        # 350 k live: 0.525 ms at 3 (under the scatter-add), 0.532 at 0, 0.538 at 2, 0.553 at 1, not prefetched 0.548
         import os as _os
         # (with world > 1 the default is 4: the march then runs underneath the gradient exchange -- RCCL's kernels occupy a few
         # workgroups and wait on xGMI -- instead of competing with the VALU-bound kernels of the step for issue slots)
-        self._prefetch_at = int(_os.environ.get("NGP_PREFETCH_AT", "2" if self.world == 1 else "4"))
+        self._prefetch_at = int(_os.environ.get("NGP_PREFETCH_AT", "3" if self.world == 1 else "4"))
         self._coarse_ver = None
         self.sync_occupancy = True            # world > 1: broadcast rank 0's occupancy after every update_density_grid()
         # bench.py: callable -> (record this step?, list); every collective of the step is then bracketed by two HIP events on the
@@ -201,6 +204,7 @@ class FusedTrainer:
             self.counts = torch.empty(n, device=dev, dtype=torch.int32)
             self.rays_a = torch.empty(n, 3, device=dev, dtype=torch.int32)
             self.total = torch.zeros(1, device=dev, dtype=torch.int32)
+            self.ctr = torch.zeros(2, device=dev, dtype=torch.int32)        # ngp_march_train_fused's counters (self-resetting)
             self.hits_t = torch.empty(n, 2, **f32)
             self.xyzs, self.dirs = torch.empty(cap, 3, **f32), torch.empty(cap, 3, **f32)
             self.deltas, self.ts = torch.empty(cap, **f32), torch.empty(cap, **f32)
@@ -250,6 +254,14 @@ class FusedTrainer:
             noise = torch.rand(n, device=self.dev, dtype=torch.float32)                     # ray_march.py:138
         if coarse is None:
             coarse = self._coarse_bits(cfg, A)
+        if self.march_fused:
+            # one launch: count, block-wise allocation of the output ranges (rays in block-completion order, like the reference's
+            # atomic packing), expansion.  NGP_MARCH_FUSED=0: the count / scan / write chain (rays packed in ray order)
+            check(L.ngp_march_train_fused(_ptr(rays_o), _ptr(rays_d), _ptr(None), _ptr(cfg.bitfield), _ptr(coarse), _ptr(noise),
+                                          cfg.cascades, cfg.grid_size, cfg.scale, cfg.exp_step_factor, cfg.max_samples, n,
+                                          _ptr(M.stage), _ptr(M.ctr), _ptr(M.rays_a), _ptr(M.total), _ptr(M.xyzs), _ptr(M.dirs),
+                                          _ptr(M.deltas), _ptr(M.ts), st), "ngp_march_train_fused")
+            return
         check(L.ngp_march_train_count_ex(_ptr(rays_o), _ptr(rays_d), _ptr(None), _ptr(cfg.bitfield), _ptr(coarse), _ptr(noise),
                                          cfg.cascades, cfg.grid_size, cfg.scale, cfg.exp_step_factor, cfg.max_samples, n,
                                          _ptr(M.stage), _ptr(M.counts), st), "ngp_march_train_count_ex")   # slab test inline

@@ -130,7 +130,8 @@ def test_trainer_forward_matches_oracle_on_content(oracle, conditioned, kind):
     assert nonempty.sum() > 200 and op_hit >= 0.5 and early.sum() > 0.5 * nonempty.sum() and vr.sum() < rm
     # indexing / compaction: bit-exact
     assert rm == ref["total"]
-    assert np.array_equal(out["rays_a"].cpu().numpy(), ref["rays_a"])
+    # (ray id and sample count per ray; the ranges' starts depend on the order the fused march kernel's blocks finish in)
+    assert np.array_equal(out["rays_a"].cpu().numpy()[:, [0, 2]], ref["rays_a"][:, [0, 2]])
     dv = np.abs(vr.astype(np.int64) - ref["vr"].astype(np.int64))
     # the early-termination sample is decided by T <= 1e-4 on a product of ~10 f32 factors: allow the boundary sample to differ
     # on a handful of rays (summation order of the wave scan), never more than one sample
@@ -163,7 +164,7 @@ def test_render_operator_and_fused_match_oracle_on_content(oracle, conditioned):
             os.environ["NGP_FUSED_RENDER"] = "1"
         ref = _oracle_forward(oracle, [w.detach().cpu().numpy() for w in m._mlp_weights()], table, o, d, conditioned["bits"], noise,
                               0.5, 1, 0.0, 1.0, 1024)
-        assert int(res["rm_samples"]) == ref["total"] and np.array_equal(res["rays_a"].cpu().numpy(), ref["rays_a"])
+        assert int(res["rm_samples"]) == ref["total"] and np.array_equal(res["rays_a"].cpu().numpy()[:, [0, 2]], ref["rays_a"][:, [0, 2]])
         assert int(res["vr_samples"]) < int(res["rm_samples"])
         err = np.abs(res["rgb"].float().detach().cpu().numpy() - ref["rgb"])
         print("render fused=%s on content: max |d rgb| %.2e" % (fused, err.max()))
@@ -203,7 +204,8 @@ def test_c3_garden_shape_matches_oracle(oracle, hip_lib):
     rm = int(out["rm_samples"][0])
     print("e2e C3: %d samples (%.1f per ray), %d composited, mean opacity %.2f" % (rm, rm / n, int(out["vr_per_ray"].sum()), ref["opacity"].mean()))
     assert rm == ref["total"] > 50 * n // 4
-    assert np.array_equal(out["rays_a"].cpu().numpy(), ref["rays_a"])
+    # (ray id and sample count per ray; the ranges' starts depend on the order the fused march kernel's blocks finish in)
+    assert np.array_equal(out["rays_a"].cpu().numpy()[:, [0, 2]], ref["rays_a"][:, [0, 2]])
     assert int(out["vr_per_ray"].sum()) < 0.8 * rm and ref["opacity"].mean() > 0.3       # content; early termination is exercised
     dv = np.abs(out["vr_per_ray"].cpu().numpy().astype(np.int64) - ref["vr"].astype(np.int64))
     assert dv.max() <= 1 and (dv > 0).mean() < 0.01
@@ -286,6 +288,11 @@ def test_end_to_end_gradients_vs_fp32_cpu_chain(oracle, conditioned):
     assert np.linalg.norm(r_table) > 0 and all(np.linalg.norm(r) > 0 for r in r_mlp)
     # same support as the oracle's scatter-add (identical indexing); up to entries whose sum cancels / underflows
     touched_ref, touched_hip = r_table != 0, g_table != 0
-    assert (touched_ref != touched_hip).mean() < 2e-3
+    # (which sums cancel depends on the summation order, and the order of the live list / of the rays' ranges is the order blocks
+    # finish in: 0.18-0.23 % over runs.  What has to hold: the entries in question carry nothing.)
+    bad = touched_ref != touched_hip
+    worst = max(float(np.abs(r_table[bad]).max(initial=0.0)), float(np.abs(g_table[bad]).max(initial=0.0)))
+    print("support mismatch fraction %.5f, largest |value| there %.3e of max |grad| %.3e" % (bad.mean(), worst, np.abs(r_table).max()))
+    assert bad.mean() < 4e-3 and worst <= 1e-4 * np.abs(r_table).max()      # (fp16 underflow of tiny output gradients: ~1e-5 of the largest)
     for nm, e1, e3 in zip(names, hip, auto):
         assert e1 <= max(1.5 * e3, 2e-3), (nm, e1, e3)      # no worse than torch's own fp16 autocast (plus a small floor)

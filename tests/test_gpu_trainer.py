@@ -271,7 +271,8 @@ def test_live_backward_equals_full_backward(hip_lib, lego_bitfield):
     a, b = outs
     n_all = int(a["rm_samples"][0])
     assert 0 < n_live < 0.8 * n_all and n_live == int(a["vr_per_ray"].sum())
-    assert torch.equal(a["rays_a"], b["rays_a"]) and torch.equal(a["rgb"], b["rgb"])
+    # (same samples per ray; where a ray's range starts is decided by the order the march kernel's blocks finish in)
+    assert torch.equal(a["rays_a"][:, [0, 2]], b["rays_a"][:, [0, 2]]) and torch.equal(a["rgb"], b["rgb"])
     for k in ("table_grad", "mlp_grad"):
         ga, gb = a[k], b[k]
         assert torch.equal(ga != 0, gb != 0) or ((ga != 0) == (gb != 0)).float().mean().item() > 0.9999
@@ -279,8 +280,8 @@ def test_live_backward_equals_full_backward(hip_lib, lego_bitfield):
     # the live list is the per-ray prefixes: every ray's run contiguous and ascending, the rays in the order their 16-ray blocks
     # of the fused composite kernel finished (ngp_composite_train_fused_live), i.e. a permutation of the ray-order list
     ra, vr = a["rays_a"].cpu().numpy(), a["vr_per_ray"].cpu().numpy()
-    want = np.concatenate([np.arange(s, s + vr[r]) for r, s, c in ra]) if n_live else np.zeros(0)
-    assert np.array_equal(np.sort(got_list), want)                       # (sample indices ascend with the ray index)
+    want = np.sort(np.concatenate([np.arange(s, s + vr[r]) for r, s, c in ra])) if n_live else np.zeros(0)
+    assert np.array_equal(np.sort(got_list), want)
     run_start = {int(s): int(vr[r]) for r, s, c in ra if vr[r] > 0}
     pos = 0
     while pos < n_live:
@@ -295,7 +296,8 @@ def test_live_backward_equals_full_backward(hip_lib, lego_bitfield):
     off = torch.empty(n_rays, dtype=torch.int32, device="cuda"); lst = torch.empty(n_all, dtype=torch.int32, device="cuda")
     tot = torch.zeros(1, dtype=torch.int32, device="cuda")
     assert L.ngp_live_compact(_ptr(a["rays_a"]), _ptr(a["vr_per_ray"]), n_rays, _ptr(off), _ptr(lst), _ptr(tot), _stream()) == 0
-    assert int(tot) == n_live and np.array_equal(lst[:n_live].cpu().numpy(), want)
+    want_ray_order = np.concatenate([np.arange(s, s + vr[r]) for r, s, c in ra])
+    assert int(tot) == n_live and np.array_equal(lst[:n_live].cpu().numpy(), want_ray_order)
 
 
 @pytest.mark.parametrize("kind", ["f32", "bf16", "half"])
@@ -367,7 +369,7 @@ def test_coarse_table_follows_grid_update(hip_lib, lego_bitfield):
     hits = ray_aabb_intersection(o, d, 0.5)
     rays_a, _x, _d, _dl, _ts, total = raymarching_train(o, d, hits, m.density_bitfield, 1, 0.5, 0.0, 128, 1024)
     assert int(st["rm_samples"][0]) == int(total) > 0
-    assert torch.equal(st["rays_a"], rays_a)
+    assert torch.equal(st["rays_a"][:, [0, 2]], rays_a[:, [0, 2]])          # (the trainer's march packs the rays in block order)
     # ... and through modules.utils.packbits (ngp_packbits) as well
     from modules.utils import packbits
     v0 = m.density_bitfield._version
@@ -395,7 +397,7 @@ def test_stale_prefetch_is_not_consumed(hip_lib, lego_bitfield):
     tr2 = FusedTrainer(_make(lego_bitfield, n=2048)[0]); tr2._grads_only = True
     torch.manual_seed(6)
     ref = tr2._launch(o3, d3, target, None, (o3, d3), None)
-    assert rm == int(ref["rm_samples"][0]) and torch.equal(ra, ref["rays_a"])
+    assert rm == int(ref["rm_samples"][0]) and torch.equal(ra[:, [0, 2]], ref["rays_a"][:, [0, 2]])
     # modified in place after the prefetch -> version moved -> not consumed
     torch.manual_seed(5)
     tr._launch(o, d, target, (o2, d2), (o, d), (o2, d2))
