@@ -29,6 +29,7 @@ class TrainArena:
         self.cap, self.n_rays, self.max_samples = cap, n_rays, max_samples
         self.stage = torch.empty(cap, 2, **f32)
         self.counts = torch.empty(n_rays, device=device, dtype=torch.int32)
+        self.march_ctr = torch.zeros(2, device=device, dtype=torch.int32)      # ngp_march_train_fused's self-resetting counters
         self.xyzs = torch.empty(cap, 3, **f32)
         self.dirs = torch.empty(cap, 3, **f32)
         self.deltas = torch.empty(cap, **f32)
@@ -102,12 +103,12 @@ class FusedTrainRender(torch.autograd.Function):
         noise = torch.rand(n, **f32)                                            # ray_march.py:138
         coarse = A.coarse_for(cfg)
         check(L.ngp_bitfield_coarsen(_ptr(cfg.bitfield), cfg.cascades, cfg.grid_size, _ptr(coarse), st), "ngp_bitfield_coarsen")
-        check(L.ngp_march_train_count_ex(_ptr(rays_o), _ptr(rays_d), _ptr(hits_t), _ptr(cfg.bitfield), _ptr(coarse), _ptr(noise),
-                                         cfg.cascades, cfg.grid_size, cfg.scale, cfg.exp_step_factor, cfg.max_samples, n,
-                                         _ptr(A.stage), _ptr(A.counts), st), "ngp_march_train_count_ex")
-        check(L.ngp_march_train_scan(_ptr(A.counts), n, _ptr(rays_a), _ptr(total), st), "ngp_march_train_scan")
-        check(L.ngp_march_train_write(_ptr(rays_o), _ptr(rays_d), _ptr(rays_a), _ptr(A.stage), cfg.max_samples, n,
-                                      _ptr(A.xyzs), _ptr(A.dirs), _ptr(A.deltas), _ptr(A.ts), st), "ngp_march_train_write")
+        # the whole march in one launch; the rays' ranges are packed in block-completion order (rays_a says where), like the
+        # reference's own atomic packing (ray_march.py:76-80)
+        check(L.ngp_march_train_fused(_ptr(rays_o), _ptr(rays_d), _ptr(hits_t), _ptr(cfg.bitfield), _ptr(coarse), _ptr(noise),
+                                      cfg.cascades, cfg.grid_size, cfg.scale, cfg.exp_step_factor, cfg.max_samples, n,
+                                      _ptr(A.stage), _ptr(A.march_ctr), _ptr(rays_a), _ptr(total), _ptr(A.xyzs), _ptr(A.dirs),
+                                      _ptr(A.deltas), _ptr(A.ts), st), "ngp_march_train_fused")
         P = cfg.enc_pairs
         if cfg.table_bf16 is not None:
             check(L.ngp_hash_fwd_bf16_ex(_ptr(A.xyzs), _ptr(cfg.table_bf16), ctypes.byref(cfg.levels), A.cap, _ptr(total), 1, cfg.lo,

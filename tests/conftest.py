@@ -36,3 +36,13 @@ def hip_lib():
     from ngp_hip import lib
     lib.build()
     return lib.load()
+
+
+def ray_order(rays_a):
+    """Index array that brings per-sample arrays laid out as rays_a says (row = (ray, start, count), ranges in ANY order: the
+    reference packs with atomic adds, ngp_march_train_fused in block-completion order) into ray order: x[ray_order(rays_a)] is
+    what a ray-ordered packing (the oracle's serial loop, the count / scan / write chain) holds."""
+    ra = rays_a.detach().cpu().numpy() if hasattr(rays_a, "detach") else np.asarray(rays_a)
+    ra = ra[np.argsort(ra[:, 0], kind="stable")]
+    parts = [np.arange(s, s + c, dtype=np.int64) for _, s, c in ra]
+    return np.concatenate(parts) if parts else np.zeros(0, np.int64)

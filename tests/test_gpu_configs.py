@@ -45,7 +45,7 @@ def test_garden_config_fused_matches_operator_path_with_distortion(hip_lib):
     m, o, d, target = _garden()
     r_f, l_f, g_f = _step(m, o, d, target, True, 1e-3)
     r_o, l_o, g_o = _step(m, o, d, target, False, 1e-3)
-    assert torch.equal(r_f["rays_a"], r_o["rays_a"]) and int(r_f["rm_samples"]) == int(r_o["rm_samples"]) > 10000
+    assert torch.equal(r_f["rays_a"][:, [0, 2]], r_o["rays_a"][:, [0, 2]]) and int(r_f["rm_samples"]) == int(r_o["rm_samples"]) > 10000
     torch.testing.assert_close(r_f["rgb"], r_o["rgb"], rtol=0, atol=5e-3)
     assert abs(l_f - l_o) < 2e-3
     for a, b in zip(g_f, g_o):

@@ -65,7 +65,10 @@ def test_render_matches_oracle_pipeline(oracle, hip_lib, lego_bitfield, fused):
     rays_a, total, rgb, op, dep, vr = _oracle_render(oracle, m, o, d, lego_bitfield, noise)
     # indexing / compaction: bit-exact
     assert int(res["rm_samples"]) == total > 20000
-    assert np.array_equal(res["rays_a"].cpu().numpy(), rays_a)
+    ra = res["rays_a"].cpu().numpy()
+    assert np.array_equal(ra[:, [0, 2]], rays_a[:, [0, 2]])
+    if not fused:
+        assert np.array_equal(ra, rays_a)        # the operator chain packs in ray order; the fused march in block order
     assert int(res["vr_samples"]) == vr
     # radiance: within 1e-3 (mean), and no outlier beyond a few fp16 ulps of the accumulated colour
     got = res["rgb"].float().detach().cpu().numpy()

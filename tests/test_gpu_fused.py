@@ -45,19 +45,22 @@ def test_fused_render_matches_operator_path(hip_lib, lego_bitfield):
     r_f, l_f, g_f = _run(m, o, d, target, fused=True)
     r_o, l_o, g_o = _run(m, o, d, target, fused=False)
     r_32, l_32, g_32 = _run(m, o, d, target, fused=False, autocast=False)
-    assert torch.equal(r_f["rays_a"], r_o["rays_a"]) and int(r_f["rm_samples"]) == int(r_o["rm_samples"]) > 0
+    assert torch.equal(r_f["rays_a"][:, [0, 2]], r_o["rays_a"][:, [0, 2]]) and int(r_f["rm_samples"]) == int(r_o["rm_samples"]) > 0
     S = int(r_f["rm_samples"])
+    from conftest import ray_order
+    # the fused path packs the rays' sample ranges in block-completion order, the operator chain in ray order: compare per ray
+    pf, po = [torch.from_numpy(ray_order(r["rays_a"])).cuda() for r in (r_f, r_o)]
     # on the path the unchanged train.py takes (autocast, fused render) the per-sample results have the
     # reference's [S] shape (rendering.py:181-215), materialised from the arena on first access
     assert r_f["ws"].shape[0] == r_f["ts"].shape[0] == r_f["deltas"].shape[0] == S and r_f.padded("ws").shape[0] > S
     assert set(r_f.keys()) == set(r_o.keys()) and "ws" in r_f and r_f.get("ts") is r_f["ts"]
-    assert torch.equal(r_f["ts"][:S], r_o["ts"]) and torch.equal(r_f["deltas"][:S], r_o["deltas"])
+    assert torch.equal(r_f["ts"][pf], r_o["ts"][po]) and torch.equal(r_f["deltas"][pf], r_o["deltas"][po])
     assert abs(int(r_f["vr_samples"]) - int(r_o["vr_samples"])) <= 0.01 * S
     torch.testing.assert_close(r_f["rgb"], r_o["rgb"], rtol=0, atol=4e-3)
     torch.testing.assert_close(r_f["rgb"], r_32["rgb"], rtol=0, atol=1e-2)
     torch.testing.assert_close(r_f["opacity"], r_o["opacity"], rtol=0, atol=4e-3)
     torch.testing.assert_close(r_f["depth"], r_o["depth"], rtol=0, atol=6e-3)
-    torch.testing.assert_close(r_f["ws"][:S], r_o["ws"], rtol=0, atol=2e-3)
+    torch.testing.assert_close(r_f["ws"][pf], r_o["ws"][po], rtol=0, atol=2e-3)
     assert abs(l_f - l_32) < 1e-3
 
     def rel(a, b):
