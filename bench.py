@@ -41,6 +41,7 @@ BYTES_PER_SAMPLE = {"hash_fwd_f32": 12 + 1024 + 128, "hash_bwd_f32": 12 + 128 + 
 # kernel (C-ABI entry) -> (key, bound, work per unit, unit, which argument is the unit count)
 TRAINER_KERNELS = {
     "ngp_march_train_count_ex": ("march_count", "hbm", 24 + 8 + 4 + 12, "ray"),      # + 8 B per staged sample, added below
+    "ngp_march_train_fused": ("march_count", "hbm", 24 + 8 + 4 + 12, "ray"),         # one-launch march: + (8 + 32) B per sample, added below
     "ngp_hash_fwd_f32_ex": ("hash_fwd_f32", "hbm", 12 + 1024 + 128, "sample"),
     "ngp_hash_fwd_f32": ("hash_fwd_f32", "hbm", 12 + 1024 + 128, "n_arg"),       # occupancy-update encodes (exact n = arg 3)
     "ngp_mlp_fwd_ex": ("mlp_fwd", "mfma", 18816, "sample"),
@@ -80,8 +81,8 @@ def parse(argv=None):
                     help="--regime scene: untimed, seeded optimisation steps on the scene before the warm-up (multiple of 16)")
     ap.add_argument("--pool", type=int, default=32, help="--regime scene: resident batches the steps cycle through")
     ap.add_argument("--step-trace", default=None, help="diagnostic: write per-step host/device times of the timed region to FILE")
-    ap.add_argument("--kernel-events-every", type=int, default=8,
-                    help="per-kernel HIP events are recorded on every E-th timed step only (default 8, at most steps / 3; 1 = every step).  Each "
+    ap.add_argument("--kernel-events-every", type=int, default=4,
+                    help="HIP events around the dominant kernel are recorded on every E-th timed step only (default 4, at most steps / 3; 1 = every step).  Each "
                          "event is a barrier packet between two kernels: on every step they cost 50-70 us per step (10 %% of it, "
                          "A/B in profiles/r02_bench_kernel_events_ab.txt); the per-kernel averages are the same either way")
     ap.add_argument("--no-kernel-events", dest="kernel_events", action="store_false",
@@ -215,6 +216,7 @@ class _Probe:
     event_pool = []
     c_events = {}
     comm = None                 # N > 1: [(e0, e1), ...] around the trainer's collectives on the sampled steps
+    only = None                 # entry points that get events (None = all): inside the timed region, the dominant kernel's only
 
 
 def _install_entry_probes(L):
@@ -229,7 +231,7 @@ def _install_entry_probes(L):
 
         def timed(*a):
             t = _Probe.timer
-            if t is None or not (t.enabled and t.sample) or not _Probe.event_pool:
+            if t is None or not (t.enabled and t.sample) or not _Probe.event_pool or (_Probe.only is not None and name not in _Probe.only):
                 return raw(*a)
             e0, e1 = _Probe.event_pool.pop(), _Probe.event_pool.pop()
             st = torch.cuda.current_stream()
@@ -373,7 +375,7 @@ def measure(args, ctx, brief=False):
         return _measure(args, ctx, brief)
     finally:
         # several configurations run in one process (`configs`): give the arena-sized buffers of this one back before the next
-        _Probe.timer, _Probe.event_pool, _Probe.c_events, _Probe.comm = None, [], {}, None
+        _Probe.timer, _Probe.event_pool, _Probe.c_events, _Probe.comm, _Probe.only = None, [], {}, None, None
         from ngp_hip.fused import TrainArena
         TrainArena._cache.clear()
         gc.unfreeze()
@@ -465,7 +467,7 @@ def _measure(args, ctx, brief):
     # the trainer launches go straight through the C ABI: HIP events around the big kernels, on the launch stream
     c_events = {}
     # events are created up front (hipEventCreate inside the timed loop costs more than the kernels it would time)
-    event_pool = ([torch.cuda.Event(enable_timing=True) for _ in range(2 * 10 * (args.steps + 2))]
+    event_pool = ([torch.cuda.Event(enable_timing=True) for _ in range(2 * 10 * (args.steps + args.warmup + 2))]
                   if use_trainer and not args.graph and args.kernel_events else [])
     _Probe.timer, _Probe.event_pool, _Probe.c_events, _Probe.comm = timer, event_pool, c_events, []
     if use_trainer and not args.graph:
@@ -491,7 +493,8 @@ def _measure(args, ctx, brief):
         rays_o, rays_d, target = pool[i % n_pool]
         # per-kernel events on every ev_every-th step; an occupancy-update step (its 1 M-point encodes go through the same entry
         # points) hands its turn to the next step, so that the per-kernel averages are those of the training step's launches
-        due = state["k"] % ev_every == ev_every // 2 or state.get("ev_owed", False)
+        ee = state.get("ev_every", ev_every)
+        due = state["k"] % ee == ee // 2 or state.get("ev_owed", False)
         timer.sample = due and i % 16 != 0
         state["ev_owed"] = due and i % 16 == 0
         if i % 16 == 0:
@@ -552,6 +555,12 @@ def _measure(args, ctx, brief):
         gc.collect()
         gc.freeze()
     state["k"] = 0
+    # Per-kernel HIP events cost a barrier packet each (~6 us of queue time): with all seven kernels bracketed, a sampled step is
+    # ~80 us longer.  So: the WARM-UP steps (untimed, same state) carry events on every kernel -- the `kernels` / `rooflines`
+    # tables come from them -- and the kernel that dominates there is the only one bracketed inside the timed region, whose
+    # events give `roofline` (the contract's live measurement over the timed region).
+    timer.enabled = True
+    state["ev_every"] = 1
     for i in range(base, base + args.warmup):
         # warm-up steps are the timed steps, sample-count logging included: the first torch reduction of a process loads its
         # code object (13-55 ms, host blocked), and since the grid update stopped using torch's scans that first call was the
@@ -559,9 +568,21 @@ def _measure(args, ctx, brief):
         step(i, prefetch=args.prefetch, log=True)
     if use_trainer and args.graph and world == 1:
         trainer.capture(args.rays)
-    state["rm"] = 0; state["vr"] = 0; state["k"] = 0
-    timer.enabled = True
+    state["rm"] = 0; state["vr"] = 0; state["k"] = 0; state["ev_every"] = ev_every; state["ev_owed"] = False
     fence()
+    warm_events = {k_: list(v_) for k_, v_ in c_events.items()}
+    warm_live = int(trainer._live_total[0]) if (use_trainer and trainer.live_backward) else None
+    c_events.clear()
+    if use_trainer and warm_events:
+        tot_ms = {}
+        for name_, evs_ in warm_events.items():
+            key_ = TRAINER_KERNELS[name_][0]
+            if key_ == "march_count" and args.prefetch and not args.graph:
+                continue                                      # runs on the side stream underneath the step: not on the critical path
+            tot_ms[key_] = tot_ms.get(key_, 0.0) + sum(e0.elapsed_time(e1) for e0, e1, _ in evs_)
+        dom_key = max(tot_ms, key=tot_ms.get)
+        _Probe.only = {n_ for n_ in TRAINER_KERNELS if TRAINER_KERNELS[n_][0] == dom_key}
+    timer.enabled = True
     trace = [] if args.step_trace else None
     if trace is not None:
         import cProfile, pstats, io                            # (first timed step is profiled on the host: stalls show up there)
@@ -644,13 +665,19 @@ def _measure(args, ctx, brief):
             adam_bytes = 48.0 * n4 + 80.0 * touched4 + (8.0 * touched4 if (args.half or args.table == "bf16") else 0.0)
             # critical-path gaps on the sampled steps (each includes the two event packets in between): prepass end -> MLP backward
             # start, MLP backward end -> scatter-add start
-            ev_b = c_events.get("ngp_mlp_bwd_live", []); ev_m = c_events.get("ngp_hash_bwd_sliced_main", [])
-            ev_p = c_events.get("ngp_hash_bwd_sliced_prep", [])
+            ev_b = warm_events.get("ngp_mlp_bwd_live", []); ev_m = warm_events.get("ngp_hash_bwd_sliced_main", [])
+            ev_p = warm_events.get("ngp_hash_bwd_sliced_prep", [])
             if ev_b and len(ev_b) == len(ev_m) == len(ev_p):
                 gaps["mlp_bwd_end_to_scatter_start_us"] = float(np.mean([b[1].elapsed_time(m[0]) for b, m in zip(ev_b, ev_m)])) * 1e3
                 gaps["prep_end_to_mlp_bwd_start_us"] = float(np.mean([p_[1].elapsed_time(b[0]) for p_, b in zip(ev_p, ev_b)])) * 1e3
             agg = {}                                           # key -> [launches, total_ms, total_work, bound, per_unit, unit, units]
-            for name, evs in c_events.items():
+            timed_names = {n_ for n_, e_ in c_events.items() if e_}
+            all_events = dict(warm_events)
+            all_events.update({n_: c_events[n_] for n_ in timed_names})        # the dominant kernel: its timed-region events
+            measured_in = {}
+            for name, evs in all_events.items():
+                measured_in[TRAINER_KERNELS[name][0]] = ("timed region" if name in timed_names else
+                                                         "warm-up steps (untimed, same state, every kernel bracketed)")
                 key, bound, per_unit, unit = TRAINER_KERNELS[name]
                 for e0, e1, a in evs:
                     if name == "ngp_adam_step" and a[4] < 1000000:
@@ -671,7 +698,7 @@ def _measure(args, ctx, brief):
                     if unit == "param":
                         work = adam_bytes
                     else:
-                        work = per_unit * units + (8 * marched if key == "march_count" else 0)
+                        work = per_unit * units + ((40 if name == "ngp_march_train_fused" else 8) * marched if key == "march_count" else 0)
                     rec = agg.setdefault(key, [0, 0.0, 0.0, bound, per_unit, "sample" if unit in ("n_arg", "live") else unit, 0.0])
                     rec[0] += 1; rec[1] += e0.elapsed_time(e1); rec[2] += work; rec[6] += units
             for key, (n_l, tot_ms, tot_work, bound, per_unit, unit, tot_units) in agg.items():
@@ -681,7 +708,8 @@ def _measure(args, ctx, brief):
                 rooflines[key] = {"kernel": key, "bound": bound, "achieved": float(ach), "peak": peak,
                                   "unit": "GB/s" if bound == "hbm" else "TFLOP/s", "frac": float(ach / peak),
                                   "traffic": None, "work_per_unit": per_unit, "unit_of_work": unit,
-                                  "avg_units_per_launch": tot_units / n_l, "avg_launch_ms": tot_ms / n_l, "launches": n_l}
+                                  "avg_units_per_launch": tot_units / n_l, "avg_launch_ms": tot_ms / n_l, "launches": n_l,
+                                  "measured_in": measured_in.get(key)}
                 if key.startswith("adam"):
                     rooflines[key]["note"] = ("bytes = what the pass really moves: 48 B per float4 group (g, m, v read) + 80 B per TOUCHED "
                                               "group (p read; p, m, v, zeroed g written); %d of %d groups touched" % (touched4, n4))
@@ -723,7 +751,7 @@ def _measure(args, ctx, brief):
         # runs on a side stream underneath the other kernels (15 of 16 steps), so it is reported but not eligible
         eligible = [k for k in rooflines if not (k == "march_count" and use_trainer and args.prefetch and not args.graph)
                     ]
-        dom = max(eligible, key=lambda k: ks[k]["total_ms"], default=None)
+        dom = max(eligible, key=lambda k: ks[k]["avg_ms"], default=None)     # (one launch of each per step: the per-launch average ranks them)
         roof = rooflines.get(dom)
         workload = {"regime": args.regime, "rm_samples_per_ray": rm / total_rays * world, "vr_samples_per_ray": vr / total_rays * world,
                     "live_over_marched": vr / max(rm, 1),
@@ -767,7 +795,9 @@ def _measure(args, ctx, brief):
                        # one or two ~1.1 ms occupancy-update steps in a 20-step window move the average by +-5 %: compare runs by this
                        "grid_updates_in_timed_region": grid_updates,
                        "path": ("FusedTrainer" + ("+hipGraph" if args.graph else "")) if use_trainer else "modules+torch.optim",
-                       "kernel_events_in_timed_region": (("every step" if ev_every == 1 else "every %d-th step" % ev_every)
+                       "kernel_events_in_timed_region": ((("every step" if ev_every == 1 else "every %d-th step" % ev_every)
+                                                          + (", around %s only (the kernel that dominated the warm-up steps, where every "
+                                                             "kernel is bracketed)" % sorted(_Probe.only) if _Probe.only else ""))
                                                          if (bool(event_pool) or not use_trainer) else False)},
             "samples_per_sec": rm * world / elapsed, "rm_samples_per_ray": rm / total_rays * world, "vr_samples_per_ray": vr / total_rays * world,
             "live_samples_per_step": live_avg,
