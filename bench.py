@@ -43,6 +43,7 @@ TRAINER_KERNELS = {
     "ngp_march_train_count_ex": ("march_count", "hbm", 24 + 8 + 4 + 12, "ray"),      # + 8 B per staged sample, added below
     "ngp_march_train_fused": ("march_count", "hbm", 24 + 8 + 4 + 12, "ray"),         # one-launch march: + (8 + 32) B per sample, added below
     "ngp_hash_fwd_f32_ex": ("hash_fwd_f32", "hbm", 12 + 1024 + 128, "sample"),
+    "ngp_hash_fwd_f32_emit": ("hash_fwd_f32", "hbm", 12 + 1024 + 128, "sample"),     # + the scatter-add's prepass as a by-product (not counted)
     "ngp_hash_fwd_f32": ("hash_fwd_f32", "hbm", 12 + 1024 + 128, "n_arg"),       # occupancy-update encodes (exact n = arg 3)
     "ngp_mlp_fwd_ex": ("mlp_fwd", "mfma", 18816, "sample"),
     "ngp_mlp_bwd_ex": ("mlp_bwd", "mfma", 37632, "sample"),
@@ -54,7 +55,6 @@ TRAINER_KERNELS = {
     "ngp_hash_bwd_sliced_main": ("hash_bwd_f32", "hbm", 12 + 128 + 1024 + 1024, "live"),  # ... its main launch (what the trainer issues)
     "ngp_hash_bwd_sliced_main_marched": ("hash_bwd_f32", "hbm", 12 + 128 + 1024 + 1024, "live"),   # ... prepass folded into the forward
     "ngp_hash_bwd_sliced_prep": ("hash_bwd_prep", "hbm", 12 + 12 + 16 * 8, "live"),        # ... its prepass (in line, before the MLP backward)
-    "ngp_hash_bwd_sliced_prep_marched": ("hash_bwd_prep", "hbm", 12 + 12 + 16 * 8, "marched"),   # ... over all marched samples, behind the march
     "ngp_hash_bwd_f16_live": ("hash_bwd_f16", "hbm", 12 + 128 + 512 + 512, "live"),
     "ngp_hash_bwd_sliced_main_f16": ("hash_bwd_f16", "hbm", 12 + 128 + 512 + 512, "live"),    # half2 encoder, LDS-sliced form
     "ngp_adam_step": ("adam", "hbm", 32, "param"),
@@ -693,18 +693,16 @@ def _measure(args, ctx, brief):
                         units = float(a[3])
                     elif unit == "live":
                         units = float(live_avg)
-                    elif unit == "marched":
-                        units = float(marched)
                     else:
                         # _ex launches: device-side count (the marched samples of the step) unless n_dev is NULL
                         # (occupancy-update encodes: exact n = arg 3)
-                        n_dev = a[4] if name in ("ngp_hash_fwd_f32_ex", "ngp_hash_fwd_bf16_ex", "ngp_hash_fwd_f16_ex", "ngp_mlp_fwd_ex") else None
+                        n_dev = a[4] if name in ("ngp_hash_fwd_f32_ex", "ngp_hash_fwd_f32_emit", "ngp_hash_fwd_bf16_ex", "ngp_hash_fwd_f16_ex", "ngp_mlp_fwd_ex") else None
                         units = float(a[3]) if (n_dev is not None and getattr(n_dev, "value", 1) is None) else float(marched)
                     if unit == "param":
                         work = adam_bytes
                     else:
                         work = per_unit * units + ((40 if name == "ngp_march_train_fused" else 8) * marched if key == "march_count" else 0)
-                    rec = agg.setdefault(key, [0, 0.0, 0.0, bound, per_unit, "sample" if unit in ("n_arg", "live", "marched") else unit, 0.0])
+                    rec = agg.setdefault(key, [0, 0.0, 0.0, bound, per_unit, "sample" if unit in ("n_arg", "live") else unit, 0.0])
                     rec[0] += 1; rec[1] += e0.elapsed_time(e1); rec[2] += work; rec[6] += units
             for key, (n_l, tot_ms, tot_work, bound, per_unit, unit, tot_units) in agg.items():
                 ks[key] = {"launches": n_l, "avg_ms": tot_ms / n_l, "total_ms": tot_ms, "avg_units": tot_units / n_l}

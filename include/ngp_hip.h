@@ -234,18 +234,19 @@ int ngp_hash_bwd_sliced_main(const float* dout, const ngp_hash_levels* lv, int n
 int ngp_hash_bwd_sliced_main_f16(const float* dout, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev, int enc_pairs,
                                  uint16_t* dtable_f16, int32_t* found_inf, const void* workspace, long long workspace_bytes,
                                  void* stream);
-/* The same scatter-add with the prepass OFF the critical path ("marched-sample form", what FusedTrainer issues for the fp32 table):
- *   ngp_hash_bwd_sliced_prep_marched the prepass over ALL n_dev[0] samples of the buffers (no live list): it needs the positions
- *                                    only, so it can run right behind the march, one step ahead on a side stream; it also clears
- *                                    one LIVE bit per sample (64-bit words at byte offset ngp_hash_bwd_sliced_live_offset() of the
- *                                    workspace);
+/* The same scatter-add WITHOUT the prepass launch ("marched-sample form", what FusedTrainer issues for the fp32 table):
+ *   ngp_hash_fwd_f32_emit            the forward gather of ngp_hash_fwd_f32_ex (16 levels x 2 features, pair-major output, bit-identical
+ *                                    encodings) that also leaves in `workspace` what the prepass computes -- compact positions, hit
+ *                                    words per (level, slice) -- over ALL n_dev[0] samples of the buffers, and clears one LIVE bit per
+ *                                    sample (64-bit words at byte offset ngp_hash_bwd_sliced_live_offset() of the workspace);
  *   ngp_composite_train_fused_live   sets the bits of the samples that carry a gradient (live_words argument);
  *   ngp_mlp_bwd_live_ex              d_enc_by_sample = 1: the gradient row of list position p is written at row live_idx[p];
- *   ngp_hash_bwd_sliced_main_marched the owners scan hit & live words; dout rows are indexed by sample; n_dev = the prepass's.
- * Same sums as the live-list form (f64 accumulation per table entry, one rounding). */
+ *   ngp_hash_bwd_sliced_main_marched the owners scan hit & live words; dout rows are indexed by sample.  n_dev = the sample count
+ *                                    the forward ran with.  Same sums as the prepass form (f64 accumulation, one rounding). */
 long long ngp_hash_bwd_sliced_live_offset(const ngp_hash_levels* lv, int n_max);
-int ngp_hash_bwd_sliced_prep_marched(const float* xyzs, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev, int normalize,
-                                     float lo, float hi, void* workspace, long long workspace_bytes, void* stream);
+int ngp_hash_fwd_f32_emit(const float* xyzs, const float* table, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev,
+                          int normalize, float lo, float hi, float* out_pairs, void* workspace, long long workspace_bytes,
+                          void* stream);
 int ngp_hash_bwd_sliced_main_marched(const float* dout, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev, int enc_pairs,
                                      float* dtable, int32_t* found_inf, const void* workspace, long long workspace_bytes,
                                      void* stream);

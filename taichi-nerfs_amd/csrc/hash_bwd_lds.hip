@@ -139,8 +139,7 @@ __device__ __forceinline__ const float* grad_ptr(const float* dout, int level, s
 __global__ void __launch_bounds__(256) hash_bwd_prep_kernel(const float* __restrict__ xyzs, const int32_t* __restrict__ idx,
                                                             ngp_hash_levels lv, int n, const int32_t* __restrict__ n_dev, XyzNorm nm,
                                                             size_t wstride, uint32_t single_slice_levels, float* __restrict__ xyzc,
-                                                            unsigned long long* __restrict__ bitmap, uint32_t* __restrict__ ctr,
-                                                            unsigned long long* __restrict__ live_words /*nullable: cleared per tile*/) {
+                                                            unsigned long long* __restrict__ bitmap, uint32_t* __restrict__ ctr) {
     __shared__ LevelLDS L;
     __shared__ unsigned long long words[4][BW_MAX_SLICES];
     if (blockIdx.x == 0 && threadIdx.x < 16) ctr[threadIdx.x] = 0u;       // the main kernel's queue heads (it also resets them itself)
@@ -152,7 +151,6 @@ __global__ void __launch_bounds__(256) hash_bwd_prep_kernel(const float* __restr
     for (int tile = blockIdx.x * 4 + wave; tile < n_tiles; tile += gridDim.x * 4) {
         const int i = tile * 64 + lane;
         const bool valid = i < n;
-        if (live_words && lane == 0) live_words[tile] = 0ull;
         float x = 0.f, y = 0.f, z = 0.f;
         if (valid) {
             const size_t src = idx ? (size_t)idx[i] : (size_t)i;
@@ -227,6 +225,107 @@ __global__ void __launch_bounds__(256) hash_bwd_prep_kernel(const float* __restr
             if (lane < ns) row[(size_t)lane * wstride] = words[wave][lane];
             __builtin_amdgcn_wave_barrier();
         }
+    }
+}
+
+// ---- the prepass as a by-product of the FORWARD gather (round 3) --------------------------------------------------------------
+// The forward encoder (hash_grid.hip, hash_fwd_f32_xcd_kernel: block b gathers level pair (b % 8, 15 - b % 8) for 128 consecutive
+// samples, lanes (2s, 2s + 1) = the two levels of sample s) already holds every sample's cell coordinates per level while it waits
+// on the L2.  This variant also emits what hash_bwd_prep_kernel computes -- the per-(level, slice) hit words and the compact
+// normalised positions -- over ALL marched samples, tile t = samples [64 t, 64 t + 64), and clears one LIVE word per tile; the
+// trainer's composite kernel then sets a bit per live sample (ngp_composite_train_fused_live) and the owners of the main launch
+// scan hit & live.  The 40-50 us prepass launch between compositing and the MLP backward disappears from the step.
+// Same gather arithmetic and output as hash_fwd_f32_xcd_kernel<0> with the pair-major layout (bit-identical encodings).
+// Block barrier that orders LDS traffic only: __syncthreads() also drains the wave's outstanding GLOBAL loads (its fence is a
+// s_waitcnt vmcnt(0)), which here would make every wave wait for its eight gathers before the hit words are even started.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__global__ void __launch_bounds__(256) hash_fwd_emit_kernel(const float* __restrict__ xyzs, const float* __restrict__ table,
+                                                            ngp_hash_levels lv, int n, const int32_t* __restrict__ n_dev, XyzNorm nm,
+                                                            float* __restrict__ out, size_t wstride, uint32_t single_slice_levels,
+                                                            float* __restrict__ xyzc, unsigned long long* __restrict__ bitmap,
+                                                            unsigned long long* __restrict__ live_words, uint32_t* __restrict__ ctr) {
+    __shared__ LevelLDS L;
+    __shared__ unsigned long long words[2][2][2][BW_MAX_SLICES];          // [buffer][tile of the block][which level][slice]
+    load_levels(lv, L);
+    const size_t plane = (size_t)n;
+    if (n_dev) n = min(n, *n_dev);
+    if (blockIdx.x == 0 && threadIdx.x < 16) ctr[threadIdx.x] = 0u;       // the main launch's queue heads
+    const int tid = threadIdx.x;
+    const int pair = blockIdx.x & 7, which = tid & 1;
+    const int level = which ? 15 - pair : pair;
+    const int bfhl = lv.begin_fast_hash_level;
+    // this lane's level is fixed for the whole launch
+    const uint32_t res = L.res[level], size = L.size[level], mode = L.mode[level];
+    const bool dense = level < bfhl, dense0 = dense && mode == 0u;
+    const SliceMap SM = slice_map(size, res, dense);
+    const bool need_bits = !((single_slice_levels >> level) & 1u);
+    const bool fast_hash = !dense && mode == 1u && res < (1u << BW_SLICE_LOG2);
+    // the (tile, level, slice) word this thread stores after the ORs
+    const int st_tile = tid >> 7, st_which = (tid >> 6) & 1, st_slice = tid & 63;
+    const int st_level = st_which ? 15 - pair : pair;
+    const bool st_on = !((single_slice_levels >> st_level) & 1u) &&
+                       st_slice < (int)slice_map(L.size[st_level], L.res[st_level], st_level < bfhl).ns;
+    unsigned long long* st_row = bitmap + ((size_t)st_level * BW_MAX_SLICES + st_slice) * wstride;
+    const int tiles = gridDim.x >> 3;
+    int buf = 0;
+    for (int base = (blockIdx.x >> 3) * 128; base < n; base += tiles * 128) {
+        const int i = base + (tid >> 1);
+        const bool valid = i < n;
+        words[buf][st_tile][st_which][st_slice] = 0ull;
+        float x = 0.f, y = 0.f, z = 0.f;
+        if (valid) { x = norm01(nm, xyzs[3 * (size_t)i]); y = norm01(nm, xyzs[3 * (size_t)i + 1]); z = norm01(nm, xyzs[3 * (size_t)i + 2]); }
+        Corners c;
+        corners<false>(L, level, bfhl, x, y, z, c);
+        float2 v[8];
+#pragma unroll
+        for (int ci = 0; ci < 8; ++ci) v[ci] = valid ? *reinterpret_cast<const float2*>(table + (size_t)c.idx[ci] * 2) : make_float2(0.f, 0.f);
+        if (pair == 0) {
+            if (valid && which == 0) { xyzc[3 * (size_t)i] = x; xyzc[3 * (size_t)i + 1] = y; xyzc[3 * (size_t)i + 2] = z; }
+            if (tid < 2 && base + 64 * tid < n) live_words[(base >> 6) + tid] = 0ull;
+        }
+        lds_barrier();
+        if (valid && need_bits) {
+            unsigned long long* W = words[buf][tid >> 7][which];
+            const unsigned long long bit = 1ull << ((tid >> 1) & 63);
+            const float scale = L.scale[level];
+            const uint32_t cx = f2u_sat(floorf(x * scale + 0.5f)), cy = f2u_sat(floorf(y * scale + 0.5f)),
+                           cz = f2u_sat(floorf(z * scale + 0.5f));
+            if (fast_hash) {
+                // xor hash, power-of-two table: x only flips bits below the slice bits -> one slice per (y, z) combination
+                const uint32_t b0 = cy * 2654435761u, b1 = b0 + 2654435761u, c0 = cz * 805459861u, c1 = c0 + 805459861u;
+                const uint32_t msk = size - 1u;
+                atomicOr(&W[((b0 ^ c0) & msk) >> BW_SLICE_LOG2], bit);
+                atomicOr(&W[((b1 ^ c0) & msk) >> BW_SLICE_LOG2], bit);
+                atomicOr(&W[((b0 ^ c1) & msk) >> BW_SLICE_LOG2], bit);
+                atomicOr(&W[((b1 ^ c1) & msk) >> BW_SLICE_LOG2], bit);
+            } else {
+                // few distinct slices per sample (dense levels: 1-2): OR each distinct one once
+                const uint32_t res2 = res * res, cbase = cx + cy * res + cz * res2;
+                unsigned long long mask = 0ull;                                  // slices of this sample (ns <= 64)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    uint32_t loc;
+                    const uint32_t h = dense0 ? dense0_index(cbase, res, res2, size, k)
+                                              : level_index(dense, mode, size, res, cx + (k & 1), cy + ((k >> 1) & 1), cz + (k >> 2));
+                    mask |= 1ull << slice_of(SM, h, loc);
+                }
+                while (mask) {
+                    const int sl = __builtin_ctzll(mask);
+                    mask &= mask - 1ull;
+                    atomicOr(&W[sl], bit);
+                }
+            }
+        }
+        lds_barrier();
+        if (st_on && base + 64 * st_tile < n) st_row[(base >> 6) + st_tile] = words[buf][st_tile][st_which][st_slice];
+        if (valid) {
+            float a0 = 0.0f, a1 = 0.0f;
+#pragma unroll
+            for (int ci = 0; ci < 8; ++ci) { a0 += c.w[ci] * v[ci].x; a1 += c.w[ci] * v[ci].y; }    // same order as the generic kernel
+            *reinterpret_cast<float2*>(out + ((size_t)pair * plane + i) * 4 + which * 2) = make_float2(a0, a1);
+        }
+        buf ^= 1;
     }
 }
 
@@ -963,8 +1062,8 @@ long long ngp_hash_bwd_sliced_workspace(const ngp_hash_levels* lv, int n_max) {
 // The two halves of ngp_hash_bwd_f32_sliced as separate entry points: the prepass only needs the positions and the live list,
 // so a caller can issue it before the MLP backward that produces `dout` (FusedTrainer does; on a second stream underneath that
 // kernel it was measured slower: the two share the VALU and the cross-stream join costs ~20 us).
-static int sliced_prep(bool marched, const float* xyzs, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev, const int32_t* live_idx,
-                       int normalize, float lo, float hi, void* workspace, long long workspace_bytes, void* stream) {
+int ngp_hash_bwd_sliced_prep(const float* xyzs, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev, const int32_t* live_idx,
+                             int normalize, float lo, float hi, void* workspace, long long workspace_bytes, void* stream) {
     if (n_max <= 0) return 0;
     if (!workspace || workspace_bytes < ngp_hash_bwd_sliced_workspace(lv, n_max)) return -1;
     uint32_t single_mask;
@@ -977,24 +1076,9 @@ static int sliced_prep(bool marched, const float* xyzs, const ngp_hash_levels* l
     uint32_t* ctr = reinterpret_cast<uint32_t*>(base + W.off_ctr);
     const XyzNorm nm = {normalize, lo, hi};
     hipLaunchKernelGGL(hash_bwd_prep_kernel, dim3(BW_PREP_BLOCKS), dim3(256), 0, (hipStream_t)stream, xyzs, live_idx, *lv, n_max, n_dev, nm,
-                       W.words, single_mask, xyzc, bitmap, ctr,
-                       marched ? reinterpret_cast<unsigned long long*>(base + W.off_live) : nullptr);
+                       W.words, single_mask, xyzc, bitmap, ctr);
     NGP_LAUNCH_CHECK();
     return 0;
-}
-
-int ngp_hash_bwd_sliced_prep(const float* xyzs, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev, const int32_t* live_idx,
-                             int normalize, float lo, float hi, void* workspace, long long workspace_bytes, void* stream) {
-    return sliced_prep(false, xyzs, lv, n_max, n_dev, live_idx, normalize, lo, hi, workspace, workspace_bytes, stream);
-}
-
-// The prepass over ALL samples of the buffers (no live list) + one cleared LIVE word per 64 samples: it depends on the positions
-// only, so a trainer can run it right behind the march -- on the side stream, one step ahead -- and take it off the step's
-// critical path; ngp_composite_train_fused_live then marks the samples that carry a gradient and
-// ngp_hash_bwd_sliced_main_marched scans hit & live.
-int ngp_hash_bwd_sliced_prep_marched(const float* xyzs, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev, int normalize,
-                                     float lo, float hi, void* workspace, long long workspace_bytes, void* stream) {
-    return sliced_prep(true, xyzs, lv, n_max, n_dev, nullptr, normalize, lo, hi, workspace, workspace_bytes, stream);
 }
 
 static int sliced_main(bool half, bool marched, const float* dout, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev, int enc_pairs,
@@ -1040,6 +1124,26 @@ int ngp_hash_bwd_sliced_main_f16(const float* dout, const ngp_hash_levels* lv, i
 long long ngp_hash_bwd_sliced_live_offset(const ngp_hash_levels* lv, int n_max) {
     if (!lv || n_max <= 0) return -1;
     return (long long)ws_layout(*lv, n_max).off_live;
+}
+
+int ngp_hash_fwd_f32_emit(const float* xyzs, const float* table, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev,
+                          int normalize, float lo, float hi, float* out_pairs, void* workspace, long long workspace_bytes, void* stream) {
+    if (n_max <= 0) return 0;
+    if (!(lv->n_features == 2 && lv->n_levels == 16)) return -1;
+    if (!workspace || workspace_bytes < ngp_hash_bwd_sliced_workspace(lv, n_max)) return -1;
+    uint32_t single_mask;
+    const BwdPlan* plan = get_plan(*lv, single_mask);
+    if (!plan) return -2;
+    const WsLayout W = ws_layout(*lv, n_max);
+    char* base = reinterpret_cast<char*>(workspace);
+    int tiles = (n_max + 127) / 128;
+    if (tiles > 512) tiles = 512;
+    const XyzNorm nm = {normalize, lo, hi};
+    hipLaunchKernelGGL(hash_fwd_emit_kernel, dim3(8 * tiles), dim3(256), 0, (hipStream_t)stream, xyzs, table, *lv, n_max, n_dev, nm, out_pairs,
+                       W.words, single_mask, reinterpret_cast<float*>(base), reinterpret_cast<unsigned long long*>(base + W.off_bitmap),
+                       reinterpret_cast<unsigned long long*>(base + W.off_live), reinterpret_cast<uint32_t*>(base + W.off_ctr));
+    NGP_LAUNCH_CHECK();
+    return 0;
 }
 
 int ngp_hash_bwd_sliced_main_marched(const float* dout, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev, int enc_pairs,

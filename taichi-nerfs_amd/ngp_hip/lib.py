@@ -106,7 +106,7 @@ SIGNATURES = {
     "ngp_hash_bwd_sliced_main": [_P, _LV, _I, _P, _I, _P, _P, _P, ctypes.c_longlong, _P],
     "ngp_hash_bwd_sliced_main_f16": [_P, _LV, _I, _P, _I, _P, _P, _P, ctypes.c_longlong, _P],
     "ngp_hash_bwd_sliced_main_marched": [_P, _LV, _I, _P, _I, _P, _P, _P, ctypes.c_longlong, _P],
-    "ngp_hash_bwd_sliced_prep_marched": [_P, _LV, _I, _P, _I, _F, _F, _P, ctypes.c_longlong, _P],
+    "ngp_hash_fwd_f32_emit": [_P, _P, _LV, _I, _P, _I, _F, _F, _P, _P, ctypes.c_longlong, _P],
     "ngp_hash_bwd_sliced_live_offset": [_LV, _I],
     "ngp_hash_bwd_f32_sliced": [_P, _P, _LV, _I, _P, _P, _I, _F, _F, _I, _P, _P, _P, ctypes.c_longlong, _P],
     "ngp_sh16_fwd": [_P, _I, _P, _P],

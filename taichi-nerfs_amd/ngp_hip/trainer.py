@@ -206,8 +206,6 @@ class FusedTrainer:
             self.rays_a = torch.empty(n, 3, device=dev, dtype=torch.int32)
             self.total = torch.zeros(1, device=dev, dtype=torch.int32)
             self.ctr = torch.zeros(2, device=dev, dtype=torch.int32)        # ngp_march_train_fused's counters (self-resetting)
-            self.ws = None                  # the sliced scatter-add's workspace of THIS set (marched-sample form), on first use
-            self.prepped = False            # ... holds the prepass of the set's current march
             self.hits_t = torch.empty(n, 2, **f32)
             self.xyzs, self.dirs = torch.empty(cap, 3, **f32), torch.empty(cap, 3, **f32)
             self.deltas, self.ts = torch.empty(cap, **f32), torch.empty(cap, **f32)
@@ -264,7 +262,6 @@ class FusedTrainer:
                                           cfg.cascades, cfg.grid_size, cfg.scale, cfg.exp_step_factor, cfg.max_samples, n,
                                           _ptr(M.stage), _ptr(M.ctr), _ptr(M.rays_a), _ptr(M.total), _ptr(M.xyzs), _ptr(M.dirs),
                                           _ptr(M.deltas), _ptr(M.ts), st), "ngp_march_train_fused")
-            self._prep_marched(M, cfg, A, st)
             return
         check(L.ngp_march_train_count_ex(_ptr(rays_o), _ptr(rays_d), _ptr(None), _ptr(cfg.bitfield), _ptr(coarse), _ptr(noise),
                                          cfg.cascades, cfg.grid_size, cfg.scale, cfg.exp_step_factor, cfg.max_samples, n,
@@ -272,24 +269,6 @@ class FusedTrainer:
         check(L.ngp_march_train_scan(_ptr(M.counts), n, _ptr(M.rays_a), _ptr(M.total), st), "ngp_march_train_scan")
         check(L.ngp_march_train_write(_ptr(rays_o), _ptr(rays_d), _ptr(M.rays_a), _ptr(M.stage), cfg.max_samples, n,
                                       _ptr(M.xyzs), _ptr(M.dirs), _ptr(M.deltas), _ptr(M.ts), st), "ngp_march_train_write")
-        self._prep_marched(M, cfg, A, st)
-
-    def _prep_marched(self, M, cfg, A, st):
-        """The scatter-add's prepass (hit words per (level, slice), compact positions, cleared live words) over the set's marched
-        samples, right behind its march: it needs nothing but the positions."""
-        M.prepped = False
-        if not (self.marched_form and self.hash_bwd == "sliced" and not self.half and self.table_bf16 is None and self.enc_pairs == 1
-                and self.live_backward and self.distortion_loss_w == 0):
-            return
-        if M.ws is None:
-            M.ws = torch.empty(int(self.L.ngp_hash_bwd_sliced_workspace(ctypes.byref(cfg.levels), A.cap)), device=self.dev, dtype=torch.uint8)
-        rc = self.L.ngp_hash_bwd_sliced_prep_marched(_ptr(M.xyzs), ctypes.byref(cfg.levels), A.cap, _ptr(M.total), 1, cfg.lo, cfg.hi,
-                                                     _ptr(M.ws), M.ws.numel(), st)
-        if rc == -2:
-            self.hash_bwd = "atomic"                                 # level table not expressible as <= 64 LDS slices per level
-            return
-        check(rc, "ngp_hash_bwd_sliced_prep_marched")
-        M.prepped = True
 
     def _launch(self, rays_o, rays_d, target, prefetch=None, src=None, src_next=None, noise=None):
         n = rays_o.shape[0]
@@ -358,15 +337,24 @@ class FusedTrainer:
         sq_err = torch.empty(n, **f32)
         found = ctypes.c_void_p(si.data_ptr() + 4 * _SI_FOUND_INF)
         P = self.enc_pairs
-        # "marched-sample form" of the LDS-sliced scatter-add (fp32 table, MSE-only loss): its prepass ran behind the march (over ALL
-        # marched samples, into the march set's own workspace: one step ahead on the side stream when the march was prefetched),
-        # the composite kernel marks the live samples, the MLP backward writes its gradient rows by sample -- no prepass launch
-        # between compositing and the MLP backward
-        marched_form = M.prepped and self.marched_form and self.live_backward and self.distortion_loss_w == 0
-        ws = M.ws if marched_form else None
-        live_words = (ctypes.c_void_p(ws.data_ptr() + L.ngp_hash_bwd_sliced_live_offset(ctypes.byref(cfg.levels), A.cap))
-                      if marched_form else None)
-        if self.half:
+        # "marched-sample form" of the LDS-sliced scatter-add (fp32 table, MSE-only loss): the forward gather leaves the prepass
+        # results (hit words, compact positions) for ALL marched samples, the composite kernel marks the live ones, the MLP
+        # backward writes its gradient rows by sample -- no prepass launch between compositing and the MLP backward
+        marched_form = (self.marched_form and self.hash_bwd == "sliced" and not self.half and self.table_bf16 is None and P == 1
+                        and self.live_backward and self.distortion_loss_w == 0)
+        ws = live_words = None
+        if marched_form:
+            ws = A.sliced_ws(cfg.levels)
+            rc = L.ngp_hash_fwd_f32_emit(_ptr(M.xyzs), _ptr(self.table), ctypes.byref(cfg.levels), A.cap, _ptr(total), 1, cfg.lo, cfg.hi,
+                                         _ptr(A.enc), _ptr(ws), ws.numel(), st)
+            if rc == -2:
+                self.hash_bwd, marched_form = "atomic", False           # level table not expressible as <= 64 LDS slices per level
+            else:
+                check(rc, "ngp_hash_fwd_f32_emit")
+                live_words = ctypes.c_void_p(ws.data_ptr() + L.ngp_hash_bwd_sliced_live_offset(ctypes.byref(cfg.levels), A.cap))
+        if marched_form:
+            pass
+        elif self.half:
             check(L.ngp_hash_fwd_f16_ex(_ptr(M.xyzs), _ptr(self.table_f16), ctypes.byref(cfg.levels), A.cap, _ptr(total), 1, cfg.lo,
                                         cfg.hi, P, _ptr(A.enc), st), "ngp_hash_fwd_f16_ex")
         elif self.table_bf16 is not None:
