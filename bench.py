@@ -43,17 +43,14 @@ TRAINER_KERNELS = {
     "ngp_march_train_count_ex": ("march_count", "hbm", 24 + 8 + 4 + 12, "ray"),      # + 8 B per staged sample, added below
     "ngp_march_train_fused": ("march_count", "hbm", 24 + 8 + 4 + 12, "ray"),         # one-launch march: + (8 + 32) B per sample, added below
     "ngp_hash_fwd_f32_ex": ("hash_fwd_f32", "hbm", 12 + 1024 + 128, "sample"),
-    "ngp_hash_fwd_f32_emit": ("hash_fwd_f32", "hbm", 12 + 1024 + 128, "sample"),     # + the scatter-add's prepass as a by-product (not counted)
     "ngp_hash_fwd_f32": ("hash_fwd_f32", "hbm", 12 + 1024 + 128, "n_arg"),       # occupancy-update encodes (exact n = arg 3)
     "ngp_mlp_fwd_ex": ("mlp_fwd", "mfma", 18816, "sample"),
     "ngp_mlp_bwd_ex": ("mlp_bwd", "mfma", 37632, "sample"),
     "ngp_hash_bwd_f32_ex": ("hash_bwd_f32", "hbm", 12 + 128 + 1024 + 1024, "sample"),
-    "ngp_mlp_bwd_live_ex": ("mlp_bwd", "mfma", 37632, "live"),
     "ngp_mlp_bwd_live": ("mlp_bwd", "mfma", 37632, "live"),                        # backward kernels run on the live-sample list
     "ngp_hash_bwd_f32_live": ("hash_bwd_f32", "hbm", 12 + 128 + 1024 + 1024, "live"),
     "ngp_hash_bwd_f32_sliced": ("hash_bwd_f32", "hbm", 12 + 128 + 1024 + 1024, "live"),   # LDS-sliced form (prep + main launch)
     "ngp_hash_bwd_sliced_main": ("hash_bwd_f32", "hbm", 12 + 128 + 1024 + 1024, "live"),  # ... its main launch (what the trainer issues)
-    "ngp_hash_bwd_sliced_main_marched": ("hash_bwd_f32", "hbm", 12 + 128 + 1024 + 1024, "live"),   # ... prepass folded into the forward
     "ngp_hash_bwd_sliced_prep": ("hash_bwd_prep", "hbm", 12 + 12 + 16 * 8, "live"),        # ... its prepass (in line, before the MLP backward)
     "ngp_hash_bwd_f16_live": ("hash_bwd_f16", "hbm", 12 + 128 + 512 + 512, "live"),
     "ngp_hash_bwd_sliced_main_f16": ("hash_bwd_f16", "hbm", 12 + 128 + 512 + 512, "live"),    # half2 encoder, LDS-sliced form
@@ -668,7 +665,7 @@ def _measure(args, ctx, brief):
             adam_bytes = 48.0 * n4 + 80.0 * touched4 + (8.0 * touched4 if (args.half or args.table == "bf16") else 0.0)
             # critical-path gaps on the sampled steps (each includes the two event packets in between): prepass end -> MLP backward
             # start, MLP backward end -> scatter-add start
-            ev_b = warm_events.get("ngp_mlp_bwd_live_ex", []); ev_m = warm_events.get("ngp_hash_bwd_sliced_main", [])
+            ev_b = warm_events.get("ngp_mlp_bwd_live", []); ev_m = warm_events.get("ngp_hash_bwd_sliced_main", [])
             ev_p = warm_events.get("ngp_hash_bwd_sliced_prep", [])
             if ev_b and len(ev_b) == len(ev_m) == len(ev_p):
                 gaps["mlp_bwd_end_to_scatter_start_us"] = float(np.mean([b[1].elapsed_time(m[0]) for b, m in zip(ev_b, ev_m)])) * 1e3
@@ -696,7 +693,7 @@ def _measure(args, ctx, brief):
                     else:
                         # _ex launches: device-side count (the marched samples of the step) unless n_dev is NULL
                         # (occupancy-update encodes: exact n = arg 3)
-                        n_dev = a[4] if name in ("ngp_hash_fwd_f32_ex", "ngp_hash_fwd_f32_emit", "ngp_hash_fwd_bf16_ex", "ngp_hash_fwd_f16_ex", "ngp_mlp_fwd_ex") else None
+                        n_dev = a[4] if name in ("ngp_hash_fwd_f32_ex", "ngp_hash_fwd_bf16_ex", "ngp_hash_fwd_f16_ex", "ngp_mlp_fwd_ex") else None
                         units = float(a[3]) if (n_dev is not None and getattr(n_dev, "value", 1) is None) else float(marched)
                     if unit == "param":
                         work = adam_bytes

@@ -190,7 +190,7 @@ int ngp_composite_train_fused_live(const float* sigmas, const void* rgbs, int rg
                                    const float* loss_scale, float T_threshold, int n_rays, int32_t* vr_per_ray,
                                    float* opacity, float* depth, float* rgb, float* ws, float* d_sigmas, void* d_rgbs,
                                    float* sq_err, int32_t* live_idx, int32_t* live_total, int32_t* live_zero,
-                                   unsigned long long* live_words /*nullable*/, void* stream);
+                                   void* stream);
 
 /* Live-sample list for the backward pass: the first vr_per_ray[r] samples of ray r (those in front of the early-termination
  * point, volume_train.py:31-47) are the only ones with a non-zero gradient.  live_idx[j] = sample index of the j-th live
@@ -201,10 +201,6 @@ int ngp_live_compact(const int32_t* rays_a, const int32_t* vr_per_ray /*[n], by 
 int ngp_mlp_bwd_live(const float* enc, const float* dirs, const uint16_t* wpack, const float* dsigmas, const uint16_t* drgbs,
                      int n_max, const int32_t* n_dev, const int32_t* live_idx, int enc_pairs, float* d_enc, float* dW,
                      int32_t* found_inf, void* stream);
-/* d_enc_by_sample = 1 (needs live_idx): the gradient row of list position p goes to row live_idx[p] of d_enc instead of row p */
-int ngp_mlp_bwd_live_ex(const float* enc, const float* dirs, const uint16_t* wpack, const float* dsigmas, const uint16_t* drgbs,
-                        int n_max, const int32_t* n_dev, const int32_t* live_idx, int enc_pairs, int d_enc_by_sample, float* d_enc,
-                        float* dW, int32_t* found_inf, void* stream);
 int ngp_hash_bwd_f32_live(const float* xyzs, const float* dout, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev,
                           const int32_t* live_idx, int normalize, float lo, float hi, int enc_pairs, float* dtable,
                           int32_t* found_inf, void* stream);
@@ -234,22 +230,6 @@ int ngp_hash_bwd_sliced_main(const float* dout, const ngp_hash_levels* lv, int n
 int ngp_hash_bwd_sliced_main_f16(const float* dout, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev, int enc_pairs,
                                  uint16_t* dtable_f16, int32_t* found_inf, const void* workspace, long long workspace_bytes,
                                  void* stream);
-/* The same scatter-add WITHOUT the prepass launch ("marched-sample form", what FusedTrainer issues for the fp32 table):
- *   ngp_hash_fwd_f32_emit            the forward gather of ngp_hash_fwd_f32_ex (16 levels x 2 features, pair-major output, bit-identical
- *                                    encodings) that also leaves in `workspace` what the prepass computes -- compact positions, hit
- *                                    words per (level, slice) -- over ALL n_dev[0] samples of the buffers, and clears one LIVE bit per
- *                                    sample (64-bit words at byte offset ngp_hash_bwd_sliced_live_offset() of the workspace);
- *   ngp_composite_train_fused_live   sets the bits of the samples that carry a gradient (live_words argument);
- *   ngp_mlp_bwd_live_ex              d_enc_by_sample = 1: the gradient row of list position p is written at row live_idx[p];
- *   ngp_hash_bwd_sliced_main_marched the owners scan hit & live words; dout rows are indexed by sample.  n_dev = the sample count
- *                                    the forward ran with.  Same sums as the prepass form (f64 accumulation, one rounding). */
-long long ngp_hash_bwd_sliced_live_offset(const ngp_hash_levels* lv, int n_max);
-int ngp_hash_fwd_f32_emit(const float* xyzs, const float* table, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev,
-                          int normalize, float lo, float hi, float* out_pairs, void* workspace, long long workspace_bytes,
-                          void* stream);
-int ngp_hash_bwd_sliced_main_marched(const float* dout, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev, int enc_pairs,
-                                     float* dtable, int32_t* found_inf, const void* workspace, long long workspace_bytes,
-                                     void* stream);
 /* host-side introspection of the task plan (no GPU): tasks[k] = level | slice << 4 | replica << 10; XCD x owns
  * tasks[xoff[x] .. xoff[x] + xlen[x]); returns the number of tasks or -2 when the level table cannot be expressed */
 int ngp_hash_bwd_sliced_plan(const ngp_hash_levels* lv, uint16_t* tasks, int max_tasks, uint16_t* xoff /*[8]*/, uint16_t* xlen /*[8]*/,

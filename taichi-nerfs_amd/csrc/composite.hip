@@ -179,8 +179,7 @@ __global__ void __launch_bounds__(LIVE ? 1024 : 256) composite_train_fused_kerne
     const int32_t* __restrict__ rays_a, const float* __restrict__ target, float bg, const float* __restrict__ loss_scale, float thr,
     int n_rays, int32_t* __restrict__ vr_per_ray, float* __restrict__ opacity, float* __restrict__ depth, float* __restrict__ rgb,
     float* __restrict__ ws, float* __restrict__ d_sigmas, void* __restrict__ d_rgbs, float* __restrict__ sq_err,
-    int32_t* __restrict__ live_idx, int32_t* __restrict__ live_total, int32_t* __restrict__ live_zero,
-    unsigned long long* __restrict__ live_words /*nullable: bit s = sample s is live (pre-zeroed; ngp_hash_fwd_f32_emit)*/) {
+    int32_t* __restrict__ live_idx, int32_t* __restrict__ live_total, int32_t* __restrict__ live_zero) {
     const int n_raw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (!LIVE && n_raw >= n_rays) return;
     const bool has_ray = n_raw < n_rays;                       // LIVE: every wave reaches the block barriers at the end
@@ -207,15 +206,6 @@ __global__ void __launch_bounds__(LIVE ? 1024 : 256) composite_train_fused_kerne
         const bool live = valid && (deadm == 0 || lane < __builtin_ctzll(deadm));
         const float w = live ? a * Ts : 0.0f;
         if (valid) ws[s] = w;
-        if (LIVE && live_words) {                               // this chunk's live lanes -> bits [start + base, + 64) of the mask
-            const unsigned long long m = __ballot(live);
-            if (lane == 0 && m) {
-                const size_t s0 = (size_t)start + base;
-                const int sh = (int)(s0 & 63);
-                atomicOr(&live_words[s0 >> 6], m << sh);
-                if (sh && (m >> (64 - sh))) atomicOr(&live_words[(s0 >> 6) + 1], m >> (64 - sh));
-            }
-        }
         r0 += w * c[0]; r1 += w * c[1]; r2 += w * c[2]; dep += w * tm; op += w; cnt += live ? 1 : 0;
         T = deadm ? 0.0f : T * __shfl(incl, NGP_WAVE - 1, NGP_WAVE);    // a dead sample in this chunk ends the ray for good
     }
@@ -372,29 +362,29 @@ int ngp_composite_train_fused_live(const float* sigmas, const void* rgbs, int rg
                                    const int32_t* rays_a, const float* target, float bg, const float* loss_scale, float T_threshold,
                                    int n_rays, int32_t* vr_per_ray, float* opacity, float* depth, float* rgb, float* ws,
                                    float* d_sigmas, void* d_rgbs, float* sq_err, int32_t* live_idx, int32_t* live_total,
-                                   int32_t* live_zero, unsigned long long* live_words, void* stream) {
+                                   int32_t* live_zero, void* stream) {
     if (n_rays <= 0) return 0;
     if (!live_idx) {
         dim3 grid((n_rays + 3) / 4), block(256);
         if (rgbs_is_half)
             hipLaunchKernelGGL((composite_train_fused_kernel<true, false>), grid, block, 0, (hipStream_t)stream, sigmas, rgbs, deltas, ts,
                                rays_a, target, bg, loss_scale, T_threshold, n_rays, vr_per_ray, opacity, depth, rgb, ws, d_sigmas, d_rgbs,
-                               sq_err, nullptr, nullptr, nullptr, nullptr);
+                               sq_err, nullptr, nullptr, nullptr);
         else
             hipLaunchKernelGGL((composite_train_fused_kernel<false, false>), grid, block, 0, (hipStream_t)stream, sigmas, rgbs, deltas, ts,
                                rays_a, target, bg, loss_scale, T_threshold, n_rays, vr_per_ray, opacity, depth, rgb, ws, d_sigmas, d_rgbs,
-                               sq_err, nullptr, nullptr, nullptr, nullptr);
+                               sq_err, nullptr, nullptr, nullptr);
     } else {
         if (!live_total) return -1;
         dim3 grid((n_rays + 15) / 16), block(1024);
         if (rgbs_is_half)
             hipLaunchKernelGGL((composite_train_fused_kernel<true, true>), grid, block, 0, (hipStream_t)stream, sigmas, rgbs, deltas, ts,
                                rays_a, target, bg, loss_scale, T_threshold, n_rays, vr_per_ray, opacity, depth, rgb, ws, d_sigmas, d_rgbs,
-                               sq_err, live_idx, live_total, live_zero, live_words);
+                               sq_err, live_idx, live_total, live_zero);
         else
             hipLaunchKernelGGL((composite_train_fused_kernel<false, true>), grid, block, 0, (hipStream_t)stream, sigmas, rgbs, deltas, ts,
                                rays_a, target, bg, loss_scale, T_threshold, n_rays, vr_per_ray, opacity, depth, rgb, ws, d_sigmas, d_rgbs,
-                               sq_err, live_idx, live_total, live_zero, live_words);
+                               sq_err, live_idx, live_total, live_zero);
     }
     NGP_LAUNCH_CHECK();
     return 0;
@@ -405,7 +395,7 @@ int ngp_composite_train_fused(const float* sigmas, const void* rgbs, int rgbs_is
                               int n_rays, int32_t* vr_per_ray, float* opacity, float* depth, float* rgb, float* ws,
                               float* d_sigmas, void* d_rgbs, float* sq_err, void* stream) {
     return ngp_composite_train_fused_live(sigmas, rgbs, rgbs_is_half, deltas, ts, rays_a, target, bg, loss_scale, T_threshold, n_rays,
-                                          vr_per_ray, opacity, depth, rgb, ws, d_sigmas, d_rgbs, sq_err, nullptr, nullptr, nullptr, nullptr, stream);
+                                          vr_per_ray, opacity, depth, rgb, ws, d_sigmas, d_rgbs, sq_err, nullptr, nullptr, nullptr, stream);
 }
 
 int ngp_composite_test(const float* sigmas, const void* rgbs, int rgbs_is_half, const float* deltas, const float* ts,

@@ -228,107 +228,6 @@ __global__ void __launch_bounds__(256) hash_bwd_prep_kernel(const float* __restr
     }
 }
 
-// ---- the prepass as a by-product of the FORWARD gather (round 3) --------------------------------------------------------------
-// The forward encoder (hash_grid.hip, hash_fwd_f32_xcd_kernel: block b gathers level pair (b % 8, 15 - b % 8) for 128 consecutive
-// samples, lanes (2s, 2s + 1) = the two levels of sample s) already holds every sample's cell coordinates per level while it waits
-// on the L2.  This variant also emits what hash_bwd_prep_kernel computes -- the per-(level, slice) hit words and the compact
-// normalised positions -- over ALL marched samples, tile t = samples [64 t, 64 t + 64), and clears one LIVE word per tile; the
-// trainer's composite kernel then sets a bit per live sample (ngp_composite_train_fused_live) and the owners of the main launch
-// scan hit & live.  The 40-50 us prepass launch between compositing and the MLP backward disappears from the step.
-// Same gather arithmetic and output as hash_fwd_f32_xcd_kernel<0> with the pair-major layout (bit-identical encodings).
-// Block barrier that orders LDS traffic only: __syncthreads() also drains the wave's outstanding GLOBAL loads (its fence is a
-// s_waitcnt vmcnt(0)), which here would make every wave wait for its eight gathers before the hit words are even started.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-__global__ void __launch_bounds__(256) hash_fwd_emit_kernel(const float* __restrict__ xyzs, const float* __restrict__ table,
-                                                            ngp_hash_levels lv, int n, const int32_t* __restrict__ n_dev, XyzNorm nm,
-                                                            float* __restrict__ out, size_t wstride, uint32_t single_slice_levels,
-                                                            float* __restrict__ xyzc, unsigned long long* __restrict__ bitmap,
-                                                            unsigned long long* __restrict__ live_words, uint32_t* __restrict__ ctr) {
-    __shared__ LevelLDS L;
-    __shared__ unsigned long long words[2][2][2][BW_MAX_SLICES];          // [buffer][tile of the block][which level][slice]
-    load_levels(lv, L);
-    const size_t plane = (size_t)n;
-    if (n_dev) n = min(n, *n_dev);
-    if (blockIdx.x == 0 && threadIdx.x < 16) ctr[threadIdx.x] = 0u;       // the main launch's queue heads
-    const int tid = threadIdx.x;
-    const int pair = blockIdx.x & 7, which = tid & 1;
-    const int level = which ? 15 - pair : pair;
-    const int bfhl = lv.begin_fast_hash_level;
-    // this lane's level is fixed for the whole launch
-    const uint32_t res = L.res[level], size = L.size[level], mode = L.mode[level];
-    const bool dense = level < bfhl, dense0 = dense && mode == 0u;
-    const SliceMap SM = slice_map(size, res, dense);
-    const bool need_bits = !((single_slice_levels >> level) & 1u);
-    const bool fast_hash = !dense && mode == 1u && res < (1u << BW_SLICE_LOG2);
-    // the (tile, level, slice) word this thread stores after the ORs
-    const int st_tile = tid >> 7, st_which = (tid >> 6) & 1, st_slice = tid & 63;
-    const int st_level = st_which ? 15 - pair : pair;
-    const bool st_on = !((single_slice_levels >> st_level) & 1u) &&
-                       st_slice < (int)slice_map(L.size[st_level], L.res[st_level], st_level < bfhl).ns;
-    unsigned long long* st_row = bitmap + ((size_t)st_level * BW_MAX_SLICES + st_slice) * wstride;
-    const int tiles = gridDim.x >> 3;
-    int buf = 0;
-    for (int base = (blockIdx.x >> 3) * 128; base < n; base += tiles * 128) {
-        const int i = base + (tid >> 1);
-        const bool valid = i < n;
-        words[buf][st_tile][st_which][st_slice] = 0ull;
-        float x = 0.f, y = 0.f, z = 0.f;
-        if (valid) { x = norm01(nm, xyzs[3 * (size_t)i]); y = norm01(nm, xyzs[3 * (size_t)i + 1]); z = norm01(nm, xyzs[3 * (size_t)i + 2]); }
-        Corners c;
-        corners<false>(L, level, bfhl, x, y, z, c);
-        float2 v[8];
-#pragma unroll
-        for (int ci = 0; ci < 8; ++ci) v[ci] = valid ? *reinterpret_cast<const float2*>(table + (size_t)c.idx[ci] * 2) : make_float2(0.f, 0.f);
-        if (pair == 0) {
-            if (valid && which == 0) { xyzc[3 * (size_t)i] = x; xyzc[3 * (size_t)i + 1] = y; xyzc[3 * (size_t)i + 2] = z; }
-            if (tid < 2 && base + 64 * tid < n) live_words[(base >> 6) + tid] = 0ull;
-        }
-        lds_barrier();
-        if (valid && need_bits) {
-            unsigned long long* W = words[buf][tid >> 7][which];
-            const unsigned long long bit = 1ull << ((tid >> 1) & 63);
-            const float scale = L.scale[level];
-            const uint32_t cx = f2u_sat(floorf(x * scale + 0.5f)), cy = f2u_sat(floorf(y * scale + 0.5f)),
-                           cz = f2u_sat(floorf(z * scale + 0.5f));
-            if (fast_hash) {
-                // xor hash, power-of-two table: x only flips bits below the slice bits -> one slice per (y, z) combination
-                const uint32_t b0 = cy * 2654435761u, b1 = b0 + 2654435761u, c0 = cz * 805459861u, c1 = c0 + 805459861u;
-                const uint32_t msk = size - 1u;
-                atomicOr(&W[((b0 ^ c0) & msk) >> BW_SLICE_LOG2], bit);
-                atomicOr(&W[((b1 ^ c0) & msk) >> BW_SLICE_LOG2], bit);
-                atomicOr(&W[((b0 ^ c1) & msk) >> BW_SLICE_LOG2], bit);
-                atomicOr(&W[((b1 ^ c1) & msk) >> BW_SLICE_LOG2], bit);
-            } else {
-                // few distinct slices per sample (dense levels: 1-2): OR each distinct one once
-                const uint32_t res2 = res * res, cbase = cx + cy * res + cz * res2;
-                unsigned long long mask = 0ull;                                  // slices of this sample (ns <= 64)
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    uint32_t loc;
-                    const uint32_t h = dense0 ? dense0_index(cbase, res, res2, size, k)
-                                              : level_index(dense, mode, size, res, cx + (k & 1), cy + ((k >> 1) & 1), cz + (k >> 2));
-                    mask |= 1ull << slice_of(SM, h, loc);
-                }
-                while (mask) {
-                    const int sl = __builtin_ctzll(mask);
-                    mask &= mask - 1ull;
-                    atomicOr(&W[sl], bit);
-                }
-            }
-        }
-        lds_barrier();
-        if (st_on && base + 64 * st_tile < n) st_row[(base >> 6) + st_tile] = words[buf][st_tile][st_which][st_slice];
-        if (valid) {
-            float a0 = 0.0f, a1 = 0.0f;
-#pragma unroll
-            for (int ci = 0; ci < 8; ++ci) { a0 += c.w[ci] * v[ci].x; a1 += c.w[ci] * v[ci].y; }    // same order as the generic kernel
-            *reinterpret_cast<float2*>(out + ((size_t)pair * plane + i) * 4 + which * 2) = make_float2(a0, a1);
-        }
-        buf ^= 1;
-    }
-}
-
 // ---- main kernel -------------------------------------------------------------------------------------------------------
 struct LevelParams {
     float scale;
@@ -530,9 +429,7 @@ __device__ __forceinline__ void accumulate_batch(const LevelParams P, const uint
 template <int KIND>
 __device__ __forceinline__ void bwd_task(const LevelParams P, const int level, const uint32_t sl, const bool single, const int n,
                                          const int rep, const int nrep, const float* __restrict__ xyzc,
-                                         const unsigned long long* __restrict__ brow,
-                                         const unsigned long long* __restrict__ lw /*nullable: one live bit per sample*/,
-                                         const float* __restrict__ dout,
+                                         const unsigned long long* __restrict__ brow, const float* __restrict__ dout,
                                          const size_t plane, const int enc_pairs, const int nl, double* __restrict__ slice,
                                          uint32_t* __restrict__ q, uint32_t* __restrict__ next_sc, int32_t* __restrict__ found_inf) {
     constexpr bool HALF = (KIND & KIND_HALF) != 0;
@@ -550,10 +447,7 @@ __device__ __forceinline__ void bwd_task(const LevelParams P, const int level, c
     if (single) {
         for (int w0 = lo_w + 2 * wave; w0 < hi_w; w0 += 2 * BW_WAVES) {
             const int i0 = w0 * 64 + lane, i1 = i0 + 64;
-            const bool more = w0 + 1 < hi_w;
-            const unsigned long long l0 = lw ? lw[w0] : ~0ull, l1 = (lw && more) ? lw[w0 + 1] : ~0ull;
-            const Batch nxt = load_batch(level, i0, i0 < n && ((l0 >> lane) & 1ull), i1, more && i1 < n && ((l1 >> lane) & 1ull), xyzc, dout,
-                                         plane, enc_pairs, nl, found_inf, P.diag, HALF);
+            const Batch nxt = load_batch(level, i0, i0 < n, i1, (w0 + 1 < hi_w) && i1 < n, xyzc, dout, plane, enc_pairs, nl, found_inf, P.diag, HALF);
             accumulate_batch<KIND>(P, sl, true, pend, slice, found_inf);
             pend = nxt;
         }
@@ -571,8 +465,7 @@ __device__ __forceinline__ void bwd_task(const LevelParams P, const int level, c
     const int n_sc = (hi_w - lo_w + SCW - 1) / SCW;
     auto load_words = [&](int c) -> unsigned long long {
         const int w = lo_w + c * SCW + lane;
-        if (!(c < n_sc && lane < SCW && w < hi_w)) return 0ull;
-        return lw ? (brow[w] & lw[w]) : brow[w];
+        return (c < n_sc && lane < SCW && w < hi_w) ? brow[w] : 0ull;
     };
     auto grab = [&]() -> int {
         int c = 0;
@@ -715,8 +608,7 @@ __device__ __forceinline__ uint32_t claim_task(const BwdPlan& plan, uint32_t* __
 
 template <bool HALF>
 __global__ void __launch_bounds__(BW_THREADS) hash_bwd_lds_kernel(const float* __restrict__ xyzc,
-                                                                  const unsigned long long* __restrict__ bitmap,
-                                                                  const unsigned long long* __restrict__ live_words, size_t wstride,
+                                                                  const unsigned long long* __restrict__ bitmap, size_t wstride,
                                                                   const float* __restrict__ dout, ngp_hash_levels lv, int n,
                                                                   const int32_t* __restrict__ n_dev, int enc_pairs, BwdPlan plan,
                                                                   void* __restrict__ dtable /* f32 pairs; HALF: f16 pairs */,
@@ -770,10 +662,10 @@ __global__ void __launch_bounds__(BW_THREADS) hash_bwd_lds_kernel(const float* _
     if (dbg) t_init = wall_clock64();
     uint32_t* q = queues + (tid >> 6) * BW_Q;
     const unsigned long long* brow = bitmap + ((size_t)level * BW_MAX_SLICES + sl) * wstride;
-    if (merge && P.dense && P.mode == 0u) bwd_task<KIND_MERGE0 | (HALF ? KIND_HALF : 0)>(P, level, sl, single, n, rep, nrep, xyzc, brow, live_words, dout, plane, enc_pairs, lv.n_levels, slice, q, &next_sc, found_inf);
-    else if (merge) bwd_task<KIND_MERGE | (HALF ? KIND_HALF : 0)>(P, level, sl, single, n, rep, nrep, xyzc, brow, live_words, dout, plane, enc_pairs, lv.n_levels, slice, q, &next_sc, found_inf);
-    else if (hashed) bwd_task<KIND_HASHED | (HALF ? KIND_HALF : 0)>(P, level, sl, single, n, rep, nrep, xyzc, brow, live_words, dout, plane, enc_pairs, lv.n_levels, slice, q, &next_sc, found_inf);
-    else bwd_task<KIND_GENERIC | (HALF ? KIND_HALF : 0)>(P, level, sl, single, n, rep, nrep, xyzc, brow, live_words, dout, plane, enc_pairs, lv.n_levels, slice, q, &next_sc, found_inf);
+    if (merge && P.dense && P.mode == 0u) bwd_task<KIND_MERGE0 | (HALF ? KIND_HALF : 0)>(P, level, sl, single, n, rep, nrep, xyzc, brow, dout, plane, enc_pairs, lv.n_levels, slice, q, &next_sc, found_inf);
+    else if (merge) bwd_task<KIND_MERGE | (HALF ? KIND_HALF : 0)>(P, level, sl, single, n, rep, nrep, xyzc, brow, dout, plane, enc_pairs, lv.n_levels, slice, q, &next_sc, found_inf);
+    else if (hashed) bwd_task<KIND_HASHED | (HALF ? KIND_HALF : 0)>(P, level, sl, single, n, rep, nrep, xyzc, brow, dout, plane, enc_pairs, lv.n_levels, slice, q, &next_sc, found_inf);
+    else bwd_task<KIND_GENERIC | (HALF ? KIND_HALF : 0)>(P, level, sl, single, n, rep, nrep, xyzc, brow, dout, plane, enc_pairs, lv.n_levels, slice, q, &next_sc, found_inf);
     unsigned long long t_wave = 0;
     if (dbg) t_wave = wall_clock64();
     __syncthreads();
@@ -1005,10 +897,10 @@ static const BwdPlan* get_plan(const ngp_hash_levels& lv, uint32_t& single_mask)
     return c.ok ? &c.plan : nullptr;
 }
 
-// ---- workspace: compact positions | one hit bit per (level, slice, sample) | queue heads | one live bit per sample
+// ---- workspace: compact positions | one hit bit per (level, slice, sample) | queue heads
 struct WsLayout {
     size_t ms, words;                          // capacity in samples (a multiple of 512) and in 64-sample bitmap words
-    size_t off_bitmap, off_ctr, off_live, total;         // bytes
+    size_t off_bitmap, off_ctr, total;         // bytes
 };
 static WsLayout ws_layout(const ngp_hash_levels& lv, int n_max) {
     WsLayout w;
@@ -1016,8 +908,7 @@ static WsLayout ws_layout(const ngp_hash_levels& lv, int n_max) {
     w.words = w.ms / 64;
     w.off_bitmap = w.ms * 3 * sizeof(float);
     w.off_ctr = w.off_bitmap + (size_t)lv.n_levels * BW_MAX_SLICES * w.words * sizeof(unsigned long long);
-    w.off_live = w.off_ctr + BW_CTR_BYTES;                  // one live bit per sample (the *_marched form only)
-    w.total = w.off_live + w.words * sizeof(unsigned long long);
+    w.total = w.off_ctr + BW_CTR_BYTES;
     return w;
 }
 
@@ -1081,7 +972,7 @@ int ngp_hash_bwd_sliced_prep(const float* xyzs, const ngp_hash_levels* lv, int n
     return 0;
 }
 
-static int sliced_main(bool half, bool marched, const float* dout, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev, int enc_pairs,
+static int sliced_main(bool half, const float* dout, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev, int enc_pairs,
                        void* dtable, int32_t* found_inf, const void* workspace, long long workspace_bytes, void* stream) {
     if (n_max <= 0) return 0;
     if (enc_pairs && !(lv->n_features == 2 && lv->n_levels == 16)) return -1;
@@ -1095,20 +986,19 @@ static int sliced_main(bool half, bool marched, const float* dout, const ngp_has
     const float* xyzc = reinterpret_cast<const float*>(base);
     const unsigned long long* bitmap = reinterpret_cast<const unsigned long long*>(base + W.off_bitmap);
     uint32_t* ctr = reinterpret_cast<uint32_t*>(const_cast<char*>(base) + W.off_ctr);
-    const unsigned long long* live = marched ? reinterpret_cast<const unsigned long long*>(base + W.off_live) : nullptr;
     if (half)
-        hipLaunchKernelGGL(hash_bwd_lds_kernel<true>, dim3(plan->n_blocks), dim3(BW_THREADS), 0, (hipStream_t)stream, xyzc, bitmap, live,
-                           W.words, dout, *lv, n_max, n_dev, enc_pairs, *plan, dtable, found_inf, ctr, g_bwd_debug);
+        hipLaunchKernelGGL(hash_bwd_lds_kernel<true>, dim3(plan->n_blocks), dim3(BW_THREADS), 0, (hipStream_t)stream, xyzc, bitmap, W.words,
+                           dout, *lv, n_max, n_dev, enc_pairs, *plan, dtable, found_inf, ctr, g_bwd_debug);
     else
-        hipLaunchKernelGGL(hash_bwd_lds_kernel<false>, dim3(plan->n_blocks), dim3(BW_THREADS), 0, (hipStream_t)stream, xyzc, bitmap, live,
-                           W.words, dout, *lv, n_max, n_dev, enc_pairs, *plan, dtable, found_inf, ctr, g_bwd_debug);
+        hipLaunchKernelGGL(hash_bwd_lds_kernel<false>, dim3(plan->n_blocks), dim3(BW_THREADS), 0, (hipStream_t)stream, xyzc, bitmap, W.words,
+                           dout, *lv, n_max, n_dev, enc_pairs, *plan, dtable, found_inf, ctr, g_bwd_debug);
     NGP_LAUNCH_CHECK();
     return 0;
 }
 
 int ngp_hash_bwd_sliced_main(const float* dout, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev, int enc_pairs, float* dtable,
                              int32_t* found_inf, const void* workspace, long long workspace_bytes, void* stream) {
-    return sliced_main(false, false, dout, lv, n_max, n_dev, enc_pairs, dtable, found_inf, workspace, workspace_bytes, stream);
+    return sliced_main(false, dout, lv, n_max, n_dev, enc_pairs, dtable, found_inf, workspace, workspace_bytes, stream);
 }
 
 // the half2 encoder's backward (hash_encoder_half.py:163-213) on the same prepass: fp16 gradient table [entries][2], the
@@ -1116,39 +1006,7 @@ int ngp_hash_bwd_sliced_main(const float* dout, const ngp_hash_levels* lv, int n
 int ngp_hash_bwd_sliced_main_f16(const float* dout, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev, int enc_pairs,
                                  uint16_t* dtable_f16, int32_t* found_inf, const void* workspace, long long workspace_bytes,
                                  void* stream) {
-    return sliced_main(true, false, dout, lv, n_max, n_dev, enc_pairs, dtable_f16, found_inf, workspace, workspace_bytes, stream);
-}
-
-// ---- the marched-sample form: prepass folded into the forward gather, live mask from the composite kernel -------------------------
-// byte offset of the live words (one bit per sample of the buffers, tile t = bits of samples [64 t, 64 t + 64)) inside the workspace
-long long ngp_hash_bwd_sliced_live_offset(const ngp_hash_levels* lv, int n_max) {
-    if (!lv || n_max <= 0) return -1;
-    return (long long)ws_layout(*lv, n_max).off_live;
-}
-
-int ngp_hash_fwd_f32_emit(const float* xyzs, const float* table, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev,
-                          int normalize, float lo, float hi, float* out_pairs, void* workspace, long long workspace_bytes, void* stream) {
-    if (n_max <= 0) return 0;
-    if (!(lv->n_features == 2 && lv->n_levels == 16)) return -1;
-    if (!workspace || workspace_bytes < ngp_hash_bwd_sliced_workspace(lv, n_max)) return -1;
-    uint32_t single_mask;
-    const BwdPlan* plan = get_plan(*lv, single_mask);
-    if (!plan) return -2;
-    const WsLayout W = ws_layout(*lv, n_max);
-    char* base = reinterpret_cast<char*>(workspace);
-    int tiles = (n_max + 127) / 128;
-    if (tiles > 512) tiles = 512;
-    const XyzNorm nm = {normalize, lo, hi};
-    hipLaunchKernelGGL(hash_fwd_emit_kernel, dim3(8 * tiles), dim3(256), 0, (hipStream_t)stream, xyzs, table, *lv, n_max, n_dev, nm, out_pairs,
-                       W.words, single_mask, reinterpret_cast<float*>(base), reinterpret_cast<unsigned long long*>(base + W.off_bitmap),
-                       reinterpret_cast<unsigned long long*>(base + W.off_live), reinterpret_cast<uint32_t*>(base + W.off_ctr));
-    NGP_LAUNCH_CHECK();
-    return 0;
-}
-
-int ngp_hash_bwd_sliced_main_marched(const float* dout, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev, int enc_pairs,
-                                     float* dtable, int32_t* found_inf, const void* workspace, long long workspace_bytes, void* stream) {
-    return sliced_main(false, true, dout, lv, n_max, n_dev, enc_pairs, dtable, found_inf, workspace, workspace_bytes, stream);
+    return sliced_main(true, dout, lv, n_max, n_dev, enc_pairs, dtable_f16, found_inf, workspace, workspace_bytes, stream);
 }
 
 int ngp_hash_bwd_f32_sliced(const float* xyzs, const float* dout, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev,

@@ -1,7 +1,6 @@
 // hash_common.h -- level table in LDS + position normalisation shared by hash_grid.hip and hash_bwd_lds.hip.
 #pragma once
 #include "ngp_device.h"
-#include <hip/hip_fp16.h>
 
 namespace ngp {
 
@@ -41,46 +40,5 @@ struct XyzNorm {            // optional fused (x - lo) / (hi - lo) of reference 
 };
 __device__ __forceinline__ float norm01(const XyzNorm& nm, float v) { return nm.enabled ? (v - nm.lo) / (nm.hi - nm.lo) : v; }
 
-
-struct Corners {
-    uint32_t idx[8];
-    float w[8];
-};
-
-// hash_encoder.py:100-137; HALF_CELL applies hash_encoder_half.py:133 (cell cast to f16 before the subtract)
-template <bool HALF_CELL>
-__device__ __forceinline__ void corners(const LevelLDS& L, int level, int bfhl, float x, float y, float z, Corners& c) {
-    const float scale = L.scale[level];
-    const uint32_t res = L.res[level], size = L.size[level], mode = L.mode[level];
-    float pos[3] = {x * scale + 0.5f, y * scale + 0.5f, z * scale + 0.5f};
-    uint32_t cell[3];
-    float fr[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        cell[k] = f2u_sat(floorf(pos[k]));
-        float cf = (float)cell[k];
-        if (HALF_CELL) cf = __half2float(__float2half_rn(cf));
-        fr[k] = pos[k] - cf;
-    }
-    const bool dense = level < bfhl;
-    const uint32_t res2 = res * res;
-#pragma unroll
-    for (int ci = 0; ci < 8; ++ci) {
-        float w = 1.0f;
-        uint32_t g[3];
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            if ((ci & (1 << d)) == 0) { g[d] = cell[d]; w *= 1.0f - fr[d]; }
-            else { g[d] = cell[d] + 1u; w *= fr[d]; }
-        }
-        uint32_t h = dense ? (g[0] + g[1] * res + g[2] * res2)                     // under_hash :53-60
-                           : (g[0] ^ (g[1] * 2654435761u) ^ (g[2] * 805459861u));  // fast_hash :43-51
-        if (mode == 1u) h &= (size - 1u);
-        else if (mode == 0u) { if (h >= size) { h -= size; if (h >= size) h %= size; } }
-        else h = h % size;
-        c.idx[ci] = L.offset[level] + h;
-        c.w[ci] = w;
-    }
-}
 
 }  // namespace ngp

@@ -435,7 +435,6 @@ __global__ void __launch_bounds__(768) mlp_bwd_kernel(const float* __restrict__ 
                                                        const half_t* __restrict__ wpack, const float* __restrict__ dsigmas,
                                                        const half_t* __restrict__ drgbs, int S,
                                                        const int32_t* __restrict__ n_dev, const int32_t* __restrict__ idx, int pairs,
-                                                       int denc_by_sample /* d_enc row = sample index idx[p], not list position p */,
                                                        float* __restrict__ d_enc,
                                                        float* __restrict__ dW /*[N_W], pre-zeroed or accumulating*/,
                                                        int32_t* __restrict__ found_inf) {
@@ -468,11 +467,9 @@ __global__ void __launch_bounds__(768) mlp_bwd_kernel(const float* __restrict__ 
     const int lofs = lrow + 4 * (g ^ (n >> 2));
 
     BwdIn in;
-    int src_cur = bwd_src((blockIdx.x * BG + grp) * 32 + col, S, idx);
-    bwd_load(in, enc, dirs, dsigmas, drgbs, src_cur, g, pairs, plane);
+    bwd_load(in, enc, dirs, dsigmas, drgbs, bwd_src((blockIdx.x * BG + grp) * 32 + col, S, idx), g, pairs, plane);
     for (int round = blockIdx.x; round < n_round; round += gridDim.x) {
         const int smp = (round * BG + grp) * 32 + col;
-        const int row = denc_by_sample ? src_cur : smp;
         // The next round's list entry is requested now and its inputs once this round's data path has consumed `in` (below):
         // the dependent idx -> enc load chain then runs underneath the three dW phases instead of in front of the next round
         // (74.5 -> 72.5 us at 400 k live samples, +10 VGPRs; with the uncompacted list of rounds 1-2 it measured no gain)
@@ -527,7 +524,7 @@ __global__ void __launch_bounds__(768) mlp_bwd_kernel(const float* __restrict__ 
                 d = NGP_MFMA(wfrag(wl, B_W1T + 2 * mt + 1, lane), b11, d);
                 bad_denc |= !(isfinite(d[0]) && isfinite(d[1]) && isfinite(d[2]) && isfinite(d[3]));
                 if (smp < S) {       // D rows 4g..4g+3 of tile mt = natural features 16mt+4g.. or, pair layout, plane 4mt+g
-                    float* dp = pairs ? d_enc + ((size_t)(4 * mt + g) * plane + row) * 4 : d_enc + (size_t)row * 32 + 16 * mt + 4 * g;
+                    float* dp = pairs ? d_enc + ((size_t)(4 * mt + g) * plane + smp) * 4 : d_enc + (size_t)smp * 32 + 16 * mt + 4 * g;
                     *reinterpret_cast<float4*>(dp) = make_float4(d[0], d[1], d[2], d[3]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -536,7 +533,6 @@ __global__ void __launch_bounds__(768) mlp_bwd_kernel(const float* __restrict__ 
 
         MLP_T(2);
         bwd_load(in, enc, dirs, dsigmas, drgbs, src_next, g, pairs, plane);
-        src_cur = src_next;
         // ---- weight gradients: every wave publishes its dZ / X rows, then accumulates ITS dW tiles over all BG group images ----
         // phase A: layer 5 (dZ5 [16] x a4 [64]) and layer 4 (dZ4 [64] x a3 [64])
         img_store(img, A_DZ5, lofs, dz5);
@@ -725,23 +721,17 @@ int ngp_mlp_fwd(const float* enc, const float* dirs, const uint16_t* wpack, int 
     return ngp_mlp_fwd_ex(enc, dirs, wpack, n, nullptr, 0, sigmas, rgbs, stream);
 }
 
-int ngp_mlp_bwd_live_ex(const float* enc, const float* dirs, const uint16_t* wpack, const float* dsigmas, const uint16_t* drgbs,
-                        int n_max, const int32_t* n_dev, const int32_t* live_idx, int enc_pairs, int d_enc_by_sample, float* d_enc,
-                        float* dW, int32_t* found_inf, void* stream) {
+int ngp_mlp_bwd_live(const float* enc, const float* dirs, const uint16_t* wpack, const float* dsigmas, const uint16_t* drgbs,
+                     int n_max, const int32_t* n_dev, const int32_t* live_idx, int enc_pairs, float* d_enc, float* dW,
+                     int32_t* found_inf, void* stream) {
     if (n_max <= 0) return 0;
     int blocks = ((n_max + 31) / 32 + BG - 1) / BG;
     if (blocks > 256) blocks = 256;                       // one 12-wave block per CU: 3 waves per SIMD
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(mlp_bwd_kernel, dim3(blocks), dim3(64 * BW), 0, (hipStream_t)stream, enc, dirs, (const half_t*)wpack, dsigmas,
-                       (const half_t*)drgbs, n_max, n_dev, live_idx, enc_pairs, (d_enc_by_sample && live_idx) ? 1 : 0, d_enc, dW, found_inf);
+                       (const half_t*)drgbs, n_max, n_dev, live_idx, enc_pairs, d_enc, dW, found_inf);
     NGP_LAUNCH_CHECK();
     return 0;
-}
-
-int ngp_mlp_bwd_live(const float* enc, const float* dirs, const uint16_t* wpack, const float* dsigmas, const uint16_t* drgbs,
-                     int n_max, const int32_t* n_dev, const int32_t* live_idx, int enc_pairs, float* d_enc, float* dW,
-                     int32_t* found_inf, void* stream) {
-    return ngp_mlp_bwd_live_ex(enc, dirs, wpack, dsigmas, drgbs, n_max, n_dev, live_idx, enc_pairs, 0, d_enc, dW, found_inf, stream);
 }
 
 int ngp_mlp_bwd_ex(const float* enc, const float* dirs, const uint16_t* wpack, const float* dsigmas, const uint16_t* drgbs,

@@ -96,7 +96,6 @@ SIGNATURES = {
     "ngp_check_finite_f16": [_P, ctypes.c_longlong, _P, _P],
     "ngp_live_compact": [_P, _P, _I, _P, _P, _P, _P],
     "ngp_mlp_bwd_live": [_P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P],
-    "ngp_mlp_bwd_live_ex": [_P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _P, _P, _P, _P],
     "ngp_hash_bwd_f32_live": [_P, _P, _LV, _I, _P, _P, _I, _F, _F, _I, _P, _P, _P],
     "ngp_hash_bwd_f16_live": [_P, _P, _LV, _I, _P, _P, _I, _F, _F, _I, _P, _P, _P],
     "ngp_hash_bwd_sliced_workspace": [_LV, _I],
@@ -105,16 +104,13 @@ SIGNATURES = {
     "ngp_hash_bwd_sliced_prep": [_P, _LV, _I, _P, _P, _I, _F, _F, _P, ctypes.c_longlong, _P],
     "ngp_hash_bwd_sliced_main": [_P, _LV, _I, _P, _I, _P, _P, _P, ctypes.c_longlong, _P],
     "ngp_hash_bwd_sliced_main_f16": [_P, _LV, _I, _P, _I, _P, _P, _P, ctypes.c_longlong, _P],
-    "ngp_hash_bwd_sliced_main_marched": [_P, _LV, _I, _P, _I, _P, _P, _P, ctypes.c_longlong, _P],
-    "ngp_hash_fwd_f32_emit": [_P, _P, _LV, _I, _P, _I, _F, _F, _P, _P, ctypes.c_longlong, _P],
-    "ngp_hash_bwd_sliced_live_offset": [_LV, _I],
     "ngp_hash_bwd_f32_sliced": [_P, _P, _LV, _I, _P, _P, _I, _F, _F, _I, _P, _P, _P, ctypes.c_longlong, _P],
     "ngp_sh16_fwd": [_P, _I, _P, _P],
     "ngp_sh16_bwd": [_P, _P, _I, _P, _P],
     "ngp_composite_train_fwd": [_P, _P, _I, _P, _P, _P, _F, _I, _P, _P, _P, _P, _P, _P],
     "ngp_composite_train_bwd": [_P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _F, _I, _P, _P, _P],
     "ngp_composite_train_fused": [_P, _P, _I, _P, _P, _P, _P, _F, _P, _F, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
-    "ngp_composite_train_fused_live": [_P, _P, _I, _P, _P, _P, _P, _F, _P, _F, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "ngp_composite_train_fused_live": [_P, _P, _I, _P, _P, _P, _P, _F, _P, _F, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "ngp_composite_test": [_P, _P, _I, _P, _P, _P, _P, _F, _I, _P, _P, _P, _P],
     "ngp_mlp_wpack_halfs": [],
     "ngp_mlp_pack": [_P, _P, _P, _P, _P, _I, _P, _P],
@@ -147,7 +143,7 @@ SIGNATURES = {
     "ngp_packbits": [_P, _F, _I, _P, _P],
 }
 
-_LONGLONG_RESULT = {"ngp_hash_bwd_sliced_workspace", "ngp_hash_bwd_sliced_live_offset"}       # byte counts; every other entry point returns an int status
+_LONGLONG_RESULT = {"ngp_hash_bwd_sliced_workspace"}       # byte counts; every other entry point returns an int status
 _lib = None
 
 

@@ -59,7 +59,6 @@ class FusedTrainer:
         # backward over the samples in front of each ray's early-termination point only (NGP_LIVE_BACKWARD=0: over all of them)
         self.live_backward = os.environ.get("NGP_LIVE_BACKWARD", "1") != "0"
         self.march_fused = os.environ.get("NGP_MARCH_FUSED", "1") != "0"
-        self.marched_form = os.environ.get("NGP_BWD_MARCHED", "1") != "0"      # 0: the prepass launch (ngp_hash_bwd_sliced_prep)
         # table gradient (fp32, or fp16 for the half2 encoder): "sliced" = LDS-owned table slices, no global float atomics
         # (csrc/hash_bwd_lds.hip; the default whenever the level table fits: F = 2, levels of <= 2^19 entries), "atomic" = round
         # 1's float-atomic / packed-f16-atomic kernels
@@ -337,24 +336,7 @@ class FusedTrainer:
         sq_err = torch.empty(n, **f32)
         found = ctypes.c_void_p(si.data_ptr() + 4 * _SI_FOUND_INF)
         P = self.enc_pairs
-        # "marched-sample form" of the LDS-sliced scatter-add (fp32 table, MSE-only loss): the forward gather leaves the prepass
-        # results (hit words, compact positions) for ALL marched samples, the composite kernel marks the live ones, the MLP
-        # backward writes its gradient rows by sample -- no prepass launch between compositing and the MLP backward
-        marched_form = (self.marched_form and self.hash_bwd == "sliced" and not self.half and self.table_bf16 is None and P == 1
-                        and self.live_backward and self.distortion_loss_w == 0)
-        ws = live_words = None
-        if marched_form:
-            ws = A.sliced_ws(cfg.levels)
-            rc = L.ngp_hash_fwd_f32_emit(_ptr(M.xyzs), _ptr(self.table), ctypes.byref(cfg.levels), A.cap, _ptr(total), 1, cfg.lo, cfg.hi,
-                                         _ptr(A.enc), _ptr(ws), ws.numel(), st)
-            if rc == -2:
-                self.hash_bwd, marched_form = "atomic", False           # level table not expressible as <= 64 LDS slices per level
-            else:
-                check(rc, "ngp_hash_fwd_f32_emit")
-                live_words = ctypes.c_void_p(ws.data_ptr() + L.ngp_hash_bwd_sliced_live_offset(ctypes.byref(cfg.levels), A.cap))
-        if marched_form:
-            pass
-        elif self.half:
+        if self.half:
             check(L.ngp_hash_fwd_f16_ex(_ptr(M.xyzs), _ptr(self.table_f16), ctypes.byref(cfg.levels), A.cap, _ptr(total), 1, cfg.lo,
                                         cfg.hi, P, _ptr(A.enc), st), "ngp_hash_fwd_f16_ex")
         elif self.table_bf16 is not None:
@@ -383,8 +365,7 @@ class FusedTrainer:
                                                    _ptr(target), self.bg, _ptr(sf), cfg.T_threshold, n, _ptr(vr_per_ray), _ptr(opacity),
                                                    _ptr(depth), _ptr(rgb), _ptr(A.ws), _ptr(A.d_sigmas), _ptr(A.d_rgbs), _ptr(sq_err),
                                                    _ptr(A.live_idx if fused_live else None), _ptr(live_total if fused_live else None),
-                                                   _ptr(live_next if fused_live else None), live_words if fused_live else _ptr(None), st),
-                  "ngp_composite_train_fused_live")
+                                                   _ptr(live_next if fused_live else None), st), "ngp_composite_train_fused_live")
         live_idx = A.live_idx
         if self.live_backward and not fused_live:                 # (distortion-loss path: its composite is the operator chain)
             check(L.ngp_live_compact(_ptr(rays_a), _ptr(vr_per_ray), n, _ptr(A.live_off(n)), _ptr(live_idx), _ptr(live_total), st),
@@ -399,7 +380,7 @@ class FusedTrainer:
         # a second stream underneath the MLP backward, but the two share the VALU (87 us overlapped vs 43 alone) and the
         # cross-stream join cost 23 us between the prepass's end and the scatter-add's start: in line it is 17 us per step faster
         sliced = self.hash_bwd == "sliced"          # (half2 encoder: same prepass, main pass with its fp16 arithmetic + fp16 table)
-        if sliced and not marched_form:
+        if sliced:
             ws = A.sliced_ws(cfg.levels)
             rc = L.ngp_hash_bwd_sliced_prep(_ptr(M.xyzs), ctypes.byref(cfg.levels), A.cap, _ptr(cnt), _ptr(live_idx), 1, cfg.lo, cfg.hi,
                                             _ptr(ws), ws.numel(), st)
@@ -407,15 +388,11 @@ class FusedTrainer:
                 self.hash_bwd, sliced = "atomic", False                  # level table not expressible as <= 64 LDS slices per level
             else:
                 check(rc, "ngp_hash_bwd_sliced_prep")
-        check(L.ngp_mlp_bwd_live_ex(_ptr(A.enc), _ptr(M.dirs), _ptr(self.wpack), _ptr(A.d_sigmas), _ptr(A.d_rgbs), A.cap, _ptr(cnt),
-                                    _ptr(live_idx), P, 1 if marched_form else 0, _ptr(A.d_enc), _ptr(self.mlp_grad), found, st),
-              "ngp_mlp_bwd_live_ex")
+        check(L.ngp_mlp_bwd_live(_ptr(A.enc), _ptr(M.dirs), _ptr(self.wpack), _ptr(A.d_sigmas), _ptr(A.d_rgbs), A.cap, _ptr(cnt),
+                                 _ptr(live_idx), P, _ptr(A.d_enc), _ptr(self.mlp_grad), found, st), "ngp_mlp_bwd_live")
         if hook is not None and self._prefetch_at <= 3:
             hook(); hook = None                                             # position 3: under the scatter-add and the optimizer
-        if marched_form:
-            check(L.ngp_hash_bwd_sliced_main_marched(_ptr(A.d_enc), ctypes.byref(cfg.levels), A.cap, _ptr(total), P, _ptr(self.table_grad),
-                                                     found, _ptr(ws), ws.numel(), st), "ngp_hash_bwd_sliced_main_marched")
-        elif self.half and sliced:
+        if self.half and sliced:
             check(L.ngp_hash_bwd_sliced_main_f16(_ptr(A.d_enc), ctypes.byref(cfg.levels), A.cap, _ptr(cnt), P, _ptr(self.table_grad), found,
                                                  _ptr(ws), ws.numel(), st), "ngp_hash_bwd_sliced_main_f16")
         elif self.half:

@@ -300,40 +300,6 @@ def test_live_backward_equals_full_backward(hip_lib, lego_bitfield):
     assert int(tot) == n_live and np.array_equal(lst[:n_live].cpu().numpy(), want_ray_order)
 
 
-def test_marched_form_equals_prepass_form(hip_lib, lego_bitfield):
-    """The scatter-add without its prepass launch (hit words + compact positions emitted by the forward gather over all marched
-    samples, live bits from the composite kernel, gradient rows by sample) == the prepass form over the compacted live list:
-    same f64 sums per table entry, so the gradients agree to the last rounding; the forward encodings are bit-identical."""
-    from ngp_hip.trainer import FusedTrainer
-    from ngp_hip.fused import TrainArena
-    m, o, d, target = _make(lego_bitfield, n=4096)
-    tr = FusedTrainer(m, init_scale=2.0**10)
-    for _ in range(10):                                          # a state in which a good part of the rays terminates early
-        st = tr.compute_gradients(o, d, target)
-        if int(st["vr_per_ray"].sum()) < 0.7 * int(st["rm_samples"][0]):
-            break
-        with torch.no_grad():
-            m.xyz_encoder.output_layer.weight.mul_(3.0)
-        tr.repack()
-    outs, encs = [], []
-    for marched in (True, False):
-        tr.marched_form = marched
-        tr.march_fused = False                                  # ray-order packing: the two runs see the same sample indices
-        torch.manual_seed(78)
-        outs.append(tr.compute_gradients(o, d, target))
-        S = int(outs[-1]["rm_samples"][0])
-        A = TrainArena.get(o.device, o.shape[0], 1024)
-        encs.append(A.enc.view(8, -1, 4)[:, :S].clone())
-    a, b = outs
-    assert 0 < int(a["vr_per_ray"].sum()) < int(a["rm_samples"][0])
-    assert torch.equal(a["rays_a"], b["rays_a"]) and torch.equal(a["rgb"], b["rgb"]) and torch.equal(encs[0], encs[1])
-    ga, gb = a["table_grad"], b["table_grad"]
-    assert gb.abs().max() > 0 and torch.equal(ga != 0, gb != 0)
-    assert ((ga - gb).abs().max() / gb.abs().max()).item() < 1e-6
-    assert (ga != gb).float().mean().item() < 1e-3              # (the rounding of an f64 sum taken in another order, rarely)
-    assert ((a["mlp_grad"] - b["mlp_grad"]).norm() / b["mlp_grad"].norm()).item() < 1e-5
-
-
 @pytest.mark.parametrize("kind", ["f32", "bf16", "half"])
 def test_checkpoint_roundtrip_through_trainer(hip_lib, lego_bitfield, kind):
     """state_dict out of a trained FusedTrainer model -> fresh model + trainer (load_state_dict + repack) renders the same image;
