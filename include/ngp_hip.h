@@ -269,6 +269,14 @@ int ngp_mlp_bwd_ex(const float* enc, const float* dirs, const uint16_t* wpack, c
                    const uint16_t* drgbs, int n_max, const int32_t* n_dev, int enc_pairs, float* d_enc, float* dW,
                    int32_t* found_inf, void* stream);
 
+/* Stream plumbing for a caller that runs the march of the NEXT batch on a second stream (FusedTrainer): events that order two
+ * streams of THIS device without the system-scope cache write-back + invalidate a default HIP event performs when it is recorded
+ * (hipEventDisableTiming | hipEventDisableSystemFence).  Not for host-visible results. */
+int ngp_event_create(void** event);
+int ngp_event_record(void* event, void* stream);
+int ngp_stream_wait_event(void* stream, void* event);
+int ngp_event_destroy(void* event);
+
 /* ---- f-2  device-resident optimisation-step epilogue (reference train.py:193-201: mse_loss, GradScaler,
  * Adam(eps=1e-15), CosineAnnealingLR, zero_grad) -- see csrc/optim.hip.
  * state_f[8] f32: [0] loss scale, [1] 1/scale of this step, [2] lr, [3] 1-beta1^t, [4] sqrt(1-beta2^t), [5] last loss

@@ -99,6 +99,23 @@ using namespace ngp;
 
 extern "C" {
 
+// ---- stream plumbing: device-scope events ---------------------------------------------------------------------------------------
+// The prefetched march lives on a side stream; the two streams meet through events.  An event created without
+// hipEventDisableSystemFence makes the queue write back and invalidate its caches to SYSTEM scope when it is recorded -- the step
+// paid 7 + 9 us for its two meeting points.  Both sides are kernels on this device: a device-scope event is all they need.
+int ngp_event_create(void** event) {
+    if (!event) return -1;
+    hipEvent_t e;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) return -1;
+    *event = (void*)e;
+    return 0;
+}
+int ngp_event_record(void* event, void* stream) { return hipEventRecord((hipEvent_t)event, (hipStream_t)stream) == hipSuccess ? 0 : -1; }
+int ngp_stream_wait_event(void* stream, void* event) {
+    return hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0) == hipSuccess ? 0 : -1;
+}
+int ngp_event_destroy(void* event) { return hipEventDestroy((hipEvent_t)event) == hipSuccess ? 0 : -1; }
+
 int ngp_train_prologue(float* state_f, int32_t* state_i, float lr0, float eta_min, int t_max, float beta1, float beta2,
                        float growth, float backoff, int growth_interval, void* stream) {
     hipLaunchKernelGGL(train_prologue_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state_f, state_i, lr0, eta_min, t_max,

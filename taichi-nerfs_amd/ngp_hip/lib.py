@@ -119,6 +119,10 @@ SIGNATURES = {
     "ngp_mlp_fwd_ex": [_P, _P, _P, _I, _P, _I, _P, _P, _P],
     "ngp_mlp_bwd_ex": [_P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P],
     "ngp_mse_loss_grad": [_P, _P, _P, _F, _I, _P, _P, _P, _P],
+    "ngp_event_create": [ctypes.POINTER(ctypes.c_void_p)],
+    "ngp_event_record": [_P, _P],
+    "ngp_stream_wait_event": [_P, _P],
+    "ngp_event_destroy": [_P],
     "ngp_train_prologue": [_P, _P, _F, _F, _I, _F, _F, _F, _F, _I, _P],
     "ngp_adam_step": [_P, _P, _P, _P, ctypes.c_longlong, _P, _P, _F, _F, _F, _P],
     "ngp_adam_step_bf16": [_P, _P, _P, _P, ctypes.c_longlong, _P, _P, _F, _F, _F, _P, _P],

@@ -142,6 +142,7 @@ class FusedTrainer:
         self._sets = {}
         self._cur = 0
         self._side = torch.cuda.Stream(device=dev)
+        self._ev_start = self._DevEvent(self.L)              # main stream -> side stream: the prefetch may start
         self.prefetch_hits = 0                # steps that consumed a march prefetched by the previous step() call
         # where in the step the next batch's march is put on the side stream: 0 = at the start, 1 = after the hash gather
         # (default: with the backward running on the live samples only, the ~115 us march chain has to start this early to be
@@ -192,6 +193,27 @@ class FusedTrainer:
         check(self.L.ngp_mlp_pack(*[_ptr(w) for w in ws], self.enc_pairs, _ptr(self.wpack), _stream()), "ngp_mlp_pack")
 
     # ------------------------------------------------------------------------------------------------ one step
+    class _DevEvent:
+        """Device-scope HIP event (ngp_event_*: no timing, no system-scope fence): orders two streams of this device."""
+
+        def __init__(self, L):
+            self.L = L
+            h = ctypes.c_void_p()
+            check(L.ngp_event_create(ctypes.byref(h)), "ngp_event_create")
+            self.h = h
+
+        def record(self, stream):
+            check(self.L.ngp_event_record(self.h, ctypes.c_void_p(stream.cuda_stream)), "ngp_event_record")
+
+        def wait(self, stream):
+            check(self.L.ngp_stream_wait_event(ctypes.c_void_p(stream.cuda_stream), self.h), "ngp_stream_wait_event")
+
+        def __del__(self):
+            try:
+                self.L.ngp_event_destroy(self.h)
+            except Exception:
+                pass
+
     class _MarchSet:
         """Outputs of one batch's march.  Two sets alternate so the NEXT batch can be marched on a side stream while
         the current batch's encode / MLP / backward kernels (which read xyzs, dirs, deltas, ts) are still running."""
@@ -231,6 +253,8 @@ class FusedTrainer:
         sets = self._sets.get(key)
         if sets is None:
             sets = self._sets[key] = [self._MarchSet(self.dev, n, self.max_samples) for _ in range(2)]
+            for m_ in sets:
+                m_.ev_ready = self._DevEvent(self.L)           # recorded on the side stream behind a prefetched march
             sets[0].index, sets[1].index = 0, 1
         return sets
 
@@ -280,7 +304,7 @@ class FusedTrainer:
         if M.ready is not None:
             # whatever the side stream did to this set has to be finished before the main stream reads OR rewrites it (a stale
             # prefetch for other rays would otherwise race with the re-march below on M.stage / counts / xyzs)
-            torch.cuda.current_stream().wait_event(M.ready)
+            M.ready.wait(torch.cuda.current_stream())
         if not hit:
             self._march(M, rays_o, rays_d, cfg, A, noise=noise)
         M.ready, M.src, M.held = None, None, None
@@ -294,14 +318,14 @@ class FusedTrainer:
             nxt = sets[1 - self._cur]
 
             def hook():
-                start = torch.cuda.Event()
-                start.record()                                              # everything that still reads `nxt` is before this
+                start = self._ev_start
+                start.record(torch.cuda.current_stream())                   # everything that still reads `nxt` is before this
                 with torch.cuda.stream(self._side):
-                    self._side.wait_event(start)
+                    start.wait(self._side)
                     if nxt.ready is not None:
-                        self._side.wait_event(nxt.ready)                    # an unconsumed earlier prefetch into the same set
+                        nxt.ready.wait(self._side)                          # an unconsumed earlier prefetch into the same set
                     self._march(nxt, prefetch[0], prefetch[1], cfg, A)
-                    nxt.ready = torch.cuda.Event()
+                    nxt.ready = nxt.ev_ready
                     nxt.ready.record(self._side)
                 nxt.src = None if src_next is None else (src_next[0], src_next[1], src_next[0]._version, src_next[1]._version)
                 nxt.held = prefetch          # (possibly temporaries of step()): alive until the set is consumed or re-marched
