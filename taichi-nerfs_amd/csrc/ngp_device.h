@@ -170,16 +170,18 @@ __device__ __forceinline__ void adam_table_pass(float4* __restrict__ p, void* __
         } else {
             gi = g32[i];
         }
+        // the gradient slot is cleared for the next step -- only where it holds something: most float4 groups of the fine levels
+        // receive no gradient in a given step, and a store of zeros over zeros is 16 bytes of HBM write traffic per group
+        const bool g_any = !(gi.x == 0.f && gi.y == 0.f && gi.z == 0.f && gi.w == 0.f);
         if (skip) {
-            if constexpr (GRAD16) g16[i] = make_uint2(0u, 0u); else g32[i] = zero;
+            if (g_any) { if constexpr (GRAD16) g16[i] = make_uint2(0u, 0u); else g32[i] = zero; }
             continue;
         }
         float4 mi = m[i], vi = v[i];
         // an entry that never received a gradient (g = m = v = 0) is a fixed point of Adam: m' = v' = 0 and the update is
         // lr * 0 / (0 + eps) = 0 exactly -- skip its parameter read and all four writes (hashed levels of a sparse scene
         // leave a large part of the table untouched for the whole run)
-        if (gi.x == 0.f && gi.y == 0.f && gi.z == 0.f && gi.w == 0.f && mi.x == 0.f && mi.y == 0.f && mi.z == 0.f && mi.w == 0.f &&
-            vi.x == 0.f && vi.y == 0.f && vi.z == 0.f && vi.w == 0.f)
+        if (!g_any && mi.x == 0.f && mi.y == 0.f && mi.z == 0.f && mi.w == 0.f && vi.x == 0.f && vi.y == 0.f && vi.z == 0.f && vi.w == 0.f)
             continue;
         float4 pi = p[i];
 #define NGP_ADAM1(c)                                                          \
@@ -193,7 +195,7 @@ __device__ __forceinline__ void adam_table_pass(float4* __restrict__ p, void* __
         NGP_ADAM1(x) NGP_ADAM1(y) NGP_ADAM1(z) NGP_ADAM1(w)
 #undef NGP_ADAM1
         p[i] = pi; m[i] = mi; v[i] = vi;
-        if constexpr (GRAD16) g16[i] = make_uint2(0u, 0u); else g32[i] = zero;
+        if (g_any) { if constexpr (GRAD16) g16[i] = make_uint2(0u, 0u); else g32[i] = zero; }
         if constexpr (SHADOW == 1)
             shadow[i] = make_uint2(f32_to_bf16_bits(pi.x) | (f32_to_bf16_bits(pi.y) << 16),
                                    f32_to_bf16_bits(pi.z) | (f32_to_bf16_bits(pi.w) << 16));
