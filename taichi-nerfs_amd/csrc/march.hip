@@ -302,6 +302,12 @@ __global__ void __launch_bounds__(64) march_count_kernel(const float* __restrict
     if (r < n_rays && threadIdx.x % G == 0) counts[r] = n;
 }
 
+#ifdef NGP_MARCH_DIAG
+// timing builds only (profiles/microbench/march_waves.py): per wave of the one-launch march, 100 MHz stamps (start, march done,
+// block done) and the sample count of its first ray
+__device__ unsigned long long ngp_march_dbg[4 * 8192];
+#endif
+
 // ---- the whole training march in ONE launch: count, allocate, expand -------------------------------------------------------
 // A 16-wave block marches 16 * 64 / G rays, takes its output range with one atomic add on a device counter (block-local
 // prefix inside it) and expands its rays' staged (t, dt) pairs into xyzs / dirs / deltas / ts itself.  The samples of a ray are
@@ -325,8 +331,17 @@ __global__ void __launch_bounds__(1024) march_fused_kernel(const float* __restri
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, grp = lane / G, sub = lane % G;
     const int first = blockIdx.x * RPB + wv * GROUPS, r = first + grp;
     float o[3], d[3];
+#ifdef NGP_MARCH_DIAG
+    const unsigned long long t_w0 = wall_clock64();
+#endif
     const int n = march_rays_of_wave<CONST_DT, G, CASC1>(rays_o, rays_d, hits_t, bits, noise, p, max_samples, n_rays, coarse_s, use_coarse,
                                                          stage, chain[wv], first, o, d);
+#ifdef NGP_MARCH_DIAG
+    if (lane == 0 && blockIdx.x * 16 + wv < 8192) {
+        unsigned long long* q = ngp_march_dbg + 4 * (blockIdx.x * 16 + wv);
+        q[0] = t_w0; q[1] = wall_clock64(); q[3] = (unsigned long long)n;
+    }
+#endif
     const bool has_ray = r < n_rays;
     if (sub == 0) s_off[wv * GROUPS + grp] = has_ray ? n : 0;
     __threadfence_block();                                  // the staging rows are read back by other lanes below
@@ -359,6 +374,9 @@ __global__ void __launch_bounds__(1024) march_fused_kernel(const float* __restri
     // Last block out publishes the total and clears the counters.  No device-scope fence: on gfx950 that is an L2 write-back per
     // block (measured: the kernel 4x slower); nothing but the two counters travels between blocks, both are device-scope atomics
     // on one cache line, and every block's allocation precedes its own "finished" increment in program order.
+#ifdef NGP_MARCH_DIAG
+    if (lane == 0 && blockIdx.x * 16 + wv < 8192) ngp_march_dbg[4 * (blockIdx.x * 16 + wv) + 2] = wall_clock64();
+#endif
     if (threadIdx.x == 0) {
         if (atomicAdd(&ctr[1], 1) == (int)gridDim.x - 1) {
             total[0] = atomicExch(&ctr[0], 0);
@@ -620,6 +638,12 @@ int ngp_march_train_fused(const float* rays_o, const float* rays_d, const float*
     NGP_LAUNCH_CHECK();
     return 0;
 }
+
+#ifdef NGP_MARCH_DIAG
+int ngp_march_debug_read(unsigned long long* host, int n_words) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(ngp_march_dbg), sizeof(unsigned long long) * (size_t)n_words) == hipSuccess ? 0 : -1;
+}
+#endif
 
 int ngp_march_train_scan(const int32_t* counts, int n_rays, int32_t* rays_a, int32_t* total, void* stream) {
     hipLaunchKernelGGL(march_scan_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, counts, n_rays, rays_a, total);
