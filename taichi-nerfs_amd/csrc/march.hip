@@ -5,12 +5,17 @@
 // Design (not a translation of the Taichi launch shape):
 //   The reference marches every ray twice in one kernel and packs samples with two global atomics per ray.
 //   Here the orbit t_{k+1} = t_k + calc_dt(t_k) is recognised as independent of occupancy (occupied cells and
-//   the skip loop both advance by calc_dt), so the count kernel probes a batch of consecutive orbit points
-//   speculatively -- 16 lanes per ray, one orbit point each, all bitfield loads independent -- and then
-//   resolves the reference's "examined / skipped" logic over the batch in order.  Emitted (t, dt)
-//   pairs go to a per-ray staging row; a deterministic prefix sum replaces the atomics (rays_a in ray order);
-//   the expansion into xyzs/dirs/deltas/ts is a coalesced wave-per-ray kernel.  Samples are bit-identical to
-//   the reference's serial march (checked against the oracle).
+//   the skip loop both advance by calc_dt), so a batch of consecutive orbit points is probed speculatively --
+//   32 lanes per ray, one orbit point each, all bitfield loads independent -- and the reference's "examined /
+//   skipped / emitted" logic is then resolved over the batch in parallel (march_batches: prefix popcounts, a rank
+//   search per skip, pointer doubling over the chain of examined points).  Emitted (t, dt) pairs go to a per-ray
+//   staging row.  Two packings of the result:
+//     * march_fused_kernel (what the trainer and the fused render launch): ONE launch; a 16-wave block takes its output
+//       range with one atomic add and expands its own rays -- the rays follow each other in block-completion order,
+//       as in the reference, whose order is that of its atomic adds (ray_march.py:76-80);
+//     * march_count / march_scan / march_write (the operator chain): a prefix sum over the per-ray counts, rays_a in
+//       ray order -- what a serial execution of the reference produces.
+//   Per ray the samples are bit-identical to the reference's serial march either way (checked against the oracle).
 #include "ngp_device.h"
 #include <stdlib.h>
 
