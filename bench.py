@@ -729,6 +729,11 @@ def _measure(args, ctx, brief):
                         os.path.join(ROOT, "profiles", "r03_pmc.json"))
         pmc_name = "profiles/" + os.path.basename(pmc_path)
         traffic_src = None
+        if "march_count" in rooflines and use_trainer and args.prefetch and not args.graph:
+            rooflines["march_count"]["note"] = (
+                "launched on the side stream under the scatter-add's tail and the optimizer pass: the event-to-event time includes waiting "
+                "for the scatter-add's workgroups to retire (their 128-VGPR waves fill the register files) and the slowdown of running "
+                "beside the optimizer; alone the launch takes ~45-55 us (rocprofv3 / profiles/microbench/march_waves.py)")
         if "hash_bwd_f32" in rooflines and use_trainer and trainer.hash_bwd == "sliced":
             rooflines["hash_bwd_f32"]["note"] = (
                 "bytes = SURVEY 8(d)'s algorithmic figure for the reference's autodiff scatter (2188 B per live sample: position, "
