@@ -48,6 +48,7 @@ TRAINER_KERNELS = {
     "ngp_mlp_bwd_ex": ("mlp_bwd", "mfma", 37632, "sample"),
     "ngp_hash_bwd_f32_ex": ("hash_bwd_f32", "hbm", 12 + 128 + 1024 + 1024, "sample"),
     "ngp_mlp_bwd_live": ("mlp_bwd", "mfma", 37632, "live"),                        # backward kernels run on the live-sample list
+    "ngp_mlp_bwd_live_parts": ("mlp_bwd", "mfma", 37632, "live"),                  # ... weight gradients as per-block slabs (the trainer)
     "ngp_hash_bwd_f32_live": ("hash_bwd_f32", "hbm", 12 + 128 + 1024 + 1024, "live"),
     "ngp_hash_bwd_f32_sliced": ("hash_bwd_f32", "hbm", 12 + 128 + 1024 + 1024, "live"),   # LDS-sliced form (prep + main launch)
     "ngp_hash_bwd_sliced_main": ("hash_bwd_f32", "hbm", 12 + 128 + 1024 + 1024, "live"),  # ... its main launch (what the trainer issues)
@@ -665,7 +666,7 @@ def _measure(args, ctx, brief):
             adam_bytes = 48.0 * n4 + 80.0 * touched4 + (8.0 * touched4 if (args.half or args.table == "bf16") else 0.0)
             # critical-path gaps on the sampled steps (each includes the two event packets in between): prepass end -> MLP backward
             # start, MLP backward end -> scatter-add start
-            ev_b = warm_events.get("ngp_mlp_bwd_live", []); ev_m = warm_events.get("ngp_hash_bwd_sliced_main", [])
+            ev_b = warm_events.get("ngp_mlp_bwd_live_parts", []) or warm_events.get("ngp_mlp_bwd_live", []); ev_m = warm_events.get("ngp_hash_bwd_sliced_main", [])
             ev_p = warm_events.get("ngp_hash_bwd_sliced_prep", [])
             if ev_b and len(ev_b) == len(ev_m) == len(ev_p):
                 gaps["mlp_bwd_end_to_scatter_start_us"] = float(np.mean([b[1].elapsed_time(m[0]) for b, m in zip(ev_b, ev_m)])) * 1e3

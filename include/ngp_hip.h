@@ -201,6 +201,16 @@ int ngp_live_compact(const int32_t* rays_a, const int32_t* vr_per_ray /*[n], by 
 int ngp_mlp_bwd_live(const float* enc, const float* dirs, const uint16_t* wpack, const float* dsigmas, const uint16_t* drgbs,
                      int n_max, const int32_t* n_dev, const int32_t* live_idx, int enc_pairs, float* d_enc, float* dW,
                      int32_t* found_inf, void* stream);
+/* The same backward with the weight gradients left as PER-BLOCK SLABS instead of float atomics on dW: block b of the launch
+ * writes its sums of all 9408 weights to dW_parts[b * 9408 ...] with plain stores (256 blocks x 9408 same-address atomics were
+ * 13 us of a 72 us launch).  dW_parts: ngp_mlp_dw_parts_max() * 9408 floats, no initialisation needed.  Returns the number of
+ * slabs written (>= 1; 0 for n_max <= 0; < 0 on error).  ngp_mlp_dw_reduce ADDS the slabs to dW [9408] -- or the trainer's
+ * ngp_train_prologue_reduce does, in the launch it needs anyway. */
+int ngp_mlp_dw_parts_max(void);
+int ngp_mlp_bwd_live_parts(const float* enc, const float* dirs, const uint16_t* wpack, const float* dsigmas,
+                           const uint16_t* drgbs, int n_max, const int32_t* n_dev, const int32_t* live_idx, int enc_pairs,
+                           float* d_enc, float* dW_parts, int32_t* found_inf, void* stream);
+int ngp_mlp_dw_reduce(const float* dW_parts, int n_parts, float* dW, void* stream);
 int ngp_hash_bwd_f32_live(const float* xyzs, const float* dout, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev,
                           const int32_t* live_idx, int normalize, float lo, float hi, int enc_pairs, float* dtable,
                           int32_t* found_inf, void* stream);
@@ -286,6 +296,10 @@ int ngp_mse_loss_grad(const float* rgb, const float* opacity, const float* targe
                       float* state_f, float* g_rgb, float* g_opacity, void* stream);
 int ngp_train_prologue(float* state_f, int32_t* state_i, float lr0, float eta_min, int t_max, float beta1,
                        float beta2, float growth, float backoff, int growth_interval, void* stream);
+/* The prologue and, in the same launch, ngp_mlp_dw_reduce(dW_parts, n_parts, dW). */
+int ngp_train_prologue_reduce(float* state_f, int32_t* state_i, float lr0, float eta_min, int t_max, float beta1,
+                              float beta2, float growth, float backoff, int growth_interval, const float* dW_parts,
+                              int n_parts, float* dW, void* stream);
 /* p, g, m, v: n floats each (n % 4 == 0, 16-byte aligned); g is unscaled on the fly and zero-filled. */
 int ngp_adam_step(float* p, float* g, float* m, float* v, long long n, const float* state_f,
                   const int32_t* state_i, float beta1, float beta2, float eps, void* stream);

@@ -59,6 +59,20 @@ def main():
         return L.ngp_mlp_bwd_live(_ptr(A.enc), _ptr(M.dirs), _ptr(tr.wpack), _ptr(A.d_sigmas), _ptr(A.d_rgbs), A.cap, _ptr(tr._live_total),
                                   _ptr(A.live_idx), P, _ptr(d_enc), _ptr(dW), _ptr(None), st)
 
+    def bwd_no_dw():                  # dW = NULL: the same launch without the end-of-kernel weight-gradient flush (2.6 M atomics)
+        return L.ngp_mlp_bwd_live(_ptr(A.enc), _ptr(M.dirs), _ptr(tr.wpack), _ptr(A.d_sigmas), _ptr(A.d_rgbs), A.cap, _ptr(tr._live_total),
+                                  _ptr(A.live_idx), P, _ptr(d_enc), _ptr(None), _ptr(None), st)
+
+    parts = torch.empty(L.ngp_mlp_dw_parts_max() * 9408, device=dev)
+
+    def bwd_parts():                  # per-block slabs instead of atomics (what the trainer launches; the sum rides in its prologue)
+        rc = L.ngp_mlp_bwd_live_parts(_ptr(A.enc), _ptr(M.dirs), _ptr(tr.wpack), _ptr(A.d_sigmas), _ptr(A.d_rgbs), A.cap,
+                                      _ptr(tr._live_total), _ptr(A.live_idx), P, _ptr(d_enc), _ptr(parts), _ptr(None), st)
+        return 0 if rc > 0 else -1
+
+    def reduce_():
+        return L.ngp_mlp_dw_reduce(_ptr(parts), 256, _ptr(dW), st)
+
     def fwd():
         return L.ngp_mlp_fwd_ex(_ptr(A.enc), _ptr(M.dirs), _ptr(tr.wpack), A.cap, _ptr(M.total), P, _ptr(sig), _ptr(rgb), st)
 
@@ -87,6 +101,9 @@ def main():
             e1 = float((d_enc - ref_denc).abs().max() / ref_denc.abs().max())
             e2 = float((dW - ref_dW).abs().max() / ref_dW.abs().max())
             mb, _ = timeit(bwd, args.reps)
+            mb0, _ = timeit(bwd_no_dw, args.reps)
+            mbp, _ = timeit(bwd_parts, args.reps)
+            mred, _ = timeit(reduce_, args.reps)
             mf, _ = timeit(fwd, args.reps)
             if hasattr(L, "ngp_mlp_debug_read") and rnd == 0:        # -DNGP_MLP_DIAG build: where a round's cycles go (block 0)
                 import numpy as np
@@ -94,13 +111,19 @@ def main():
                 L.ngp_mlp_debug_read(buf.ctypes.data_as(ctypes.c_void_p), 1)
                 bwd(); torch.cuda.synchronize()
                 L.ngp_mlp_debug_read(buf.ctypes.data_as(ctypes.c_void_p), 1)
+                if os.environ.get("NGP_MLP_BWD", "reg")[0] != "l":           # register form: absolute stamps per wave of blocks 0..3
+                    print("   register form, ticks since kernel entry per wave (blocks 0-3 x 4 waves): after weights | loop end | reduced | exit")
+                    for w_, row in enumerate(buf.reshape(16, 8)):
+                        print("     wave %2d: %8d %8d %8d %8d" % (w_, row[0], row[1], row[2], row[3]))
+                    print("round %d %-40s: mlp_bwd %.1f us" % (rnd, v, mb))
+                    continue
                 seg = ["wait inputs", "forward", "dX chain", "phase A", "phase B", "phase C"]
                 b = buf.reshape(16, 8)[:12, :6].astype(np.float64)
                 print("   cycles per launch in block 0, mean over waves 0-7 / 8-11 (s_memtime ticks):")
                 for k, name in enumerate(seg):
                     print("     %-12s %9.0f %9.0f" % (name, b[:8, k].mean(), b[8:, k].mean()))
                 print("     total        %9.0f %9.0f" % (b[:8].sum(1).mean(), b[8:].sum(1).mean()))
-            print("round %d %-40s: mlp_bwd %.1f us  mlp_fwd %.1f us   d_enc err %.1e  dW err %.1e" % (rnd, v, mb, mf, e1, e2))
+            print("round %d %-40s: mlp_bwd %.1f us (%.1f without the dW flush, %.1f with slabs + %.1f stand-alone reduce)  mlp_fwd %.1f us   d_enc err %.1e  dW err %.1e" % (rnd, v, mb, mb0, mbp, mred, mf, e1, e2))
 
 
 if __name__ == "__main__":

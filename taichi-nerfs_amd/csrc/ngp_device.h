@@ -135,6 +135,36 @@ __device__ __forceinline__ int wave_scan_add_i(int v, int lane) {
 
 // ---- optimizer state layout (include/ngp_hip.h) and the dense Adam pass shared by optim.hip and mlp.hip ----------------
 enum { SF_LOSS_SCALE = 0, SF_INV_SCALE = 1, SF_LR = 2, SF_BC1 = 3, SF_BC2_SQRT = 4, SF_LOSS = 5, SF_LOSS_ACC = 6 };
+// ---- cross-block sum of the MLP backward's per-block weight-gradient slabs (csrc/mlp.hip: the kernels leave one [NGP_MLP_NW]
+// slab of plain stores per block instead of 2.6 M same-address float atomics, 13 us of a 72 us launch).  A 1024-thread block sums
+// 64 weights: thread (w = tid & 63, q = tid >> 6) takes every 16th slab -- at most 16 loads, all in flight at once: the pass is
+// latency-, not bandwidth-bound (10 MB) --, the sixteen partial sums meet in LDS.  Used by the stand-alone reduction
+// (ngp_mlp_dw_reduce) and by the trainer's prologue launch, which has to exist anyway.
+constexpr int NGP_MLP_NW = 9408;                       // W1 | W2 | W3 | W4 | W5
+constexpr int NGP_MLP_REDUCE_BLOCKS = (NGP_MLP_NW + 63) / 64;
+constexpr int NGP_MLP_REDUCE_THREADS = 1024;
+__device__ __forceinline__ void mlp_dw_reduce_block(const float* __restrict__ parts, int n_parts, float* __restrict__ dW, int block) {
+    __shared__ float partial[15][64];
+    const int lane = threadIdx.x & 63, w = block * 64 + lane, q = threadIdx.x >> 6;
+    float v[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int p = q + 16 * k;
+        v[k] = (w < NGP_MLP_NW && p < n_parts) ? parts[(size_t)p * NGP_MLP_NW + w] : 0.0f;
+    }
+    float s = 0.0f;
+    for (int p = q + 256; p < n_parts; p += 16) s += (w < NGP_MLP_NW) ? parts[(size_t)p * NGP_MLP_NW + w] : 0.0f;   // (n_parts > 256)
+#pragma unroll
+    for (int k = 0; k < 16; k += 4) s += (v[k] + v[k + 1]) + (v[k + 2] + v[k + 3]);
+    if (q) partial[q - 1][lane] = s;
+    __syncthreads();
+    if (q == 0 && w < NGP_MLP_NW) {
+#pragma unroll
+        for (int k = 0; k < 15; ++k) s += partial[k][lane];
+        dW[w] += s;
+    }
+}
+
 enum { SI_ITER = 0, SI_OPT_STEP = 1, SI_GROWTH = 2, SI_FOUND_INF = 3, SI_SKIP = 4, SI_SKIPPED_TOTAL = 5 };
 
 // round-to-nearest-even f32 -> bf16 (what torch's .bfloat16() does); NaN stays NaN

@@ -15,9 +15,8 @@
 namespace ngp {
 
 
-__global__ void train_prologue_kernel(float* __restrict__ sf, int32_t* __restrict__ si, float lr0, float eta_min, int t_max,
-                                      float beta1, float beta2, float growth, float backoff, int growth_interval) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__device__ __forceinline__ void train_prologue_thread(float* __restrict__ sf, int32_t* __restrict__ si, float lr0, float eta_min, int t_max,
+                                                      float beta1, float beta2, float growth, float backoff, int growth_interval) {
     const int iter = si[SI_ITER];
     const int found = si[SI_FOUND_INF];
     const float scale = sf[SF_LOSS_SCALE];
@@ -41,6 +40,26 @@ __global__ void train_prologue_kernel(float* __restrict__ sf, int32_t* __restric
     }
     si[SI_FOUND_INF] = 0;
     si[SI_ITER] = iter + 1;
+}
+
+__global__ void train_prologue_kernel(float* __restrict__ sf, int32_t* __restrict__ si, float lr0, float eta_min, int t_max,
+                                      float beta1, float beta2, float growth, float backoff, int growth_interval) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    train_prologue_thread(sf, si, lr0, eta_min, t_max, beta1, beta2, growth, backoff, growth_interval);
+}
+
+// The same launch also finishes the MLP backward: blocks 0..146 add up the per-block weight-gradient slabs (ngp_device.h); the
+// scalar bookkeeping rides in one extra block.  The launch exists anyway and is latency-, not work-bound (5 us for one thread).
+__global__ void __launch_bounds__(NGP_MLP_REDUCE_THREADS) train_prologue_reduce_kernel(float* __restrict__ sf, int32_t* __restrict__ si, float lr0,
+                                                                    float eta_min, int t_max, float beta1, float beta2, float growth,
+                                                                    float backoff, int growth_interval,
+                                                                    const float* __restrict__ parts, int n_parts,
+                                                                    float* __restrict__ dW) {
+    if (blockIdx.x == NGP_MLP_REDUCE_BLOCKS) {
+        if (threadIdx.x == 0) train_prologue_thread(sf, si, lr0, eta_min, t_max, beta1, beta2, growth, backoff, growth_interval);
+        return;
+    }
+    mlp_dw_reduce_block(parts, n_parts, dW, blockIdx.x);
 }
 
 // the dense Adam pass itself (adam_table_pass) lives in ngp_device.h: the fused "table + MLP + repack" kernel of mlp.hip runs the
@@ -120,6 +139,16 @@ int ngp_train_prologue(float* state_f, int32_t* state_i, float lr0, float eta_mi
                        float growth, float backoff, int growth_interval, void* stream) {
     hipLaunchKernelGGL(train_prologue_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state_f, state_i, lr0, eta_min, t_max,
                        beta1, beta2, growth, backoff, growth_interval);
+    NGP_LAUNCH_CHECK();
+    return 0;
+}
+
+int ngp_train_prologue_reduce(float* state_f, int32_t* state_i, float lr0, float eta_min, int t_max, float beta1, float beta2,
+                              float growth, float backoff, int growth_interval, const float* dW_parts, int n_parts, float* dW,
+                              void* stream) {
+    if (n_parts <= 0 || !dW_parts || !dW) return -1;
+    hipLaunchKernelGGL(train_prologue_reduce_kernel, dim3(NGP_MLP_REDUCE_BLOCKS + 1), dim3(NGP_MLP_REDUCE_THREADS), 0, (hipStream_t)stream, state_f, state_i,
+                       lr0, eta_min, t_max, beta1, beta2, growth, backoff, growth_interval, dW_parts, n_parts, dW);
     NGP_LAUNCH_CHECK();
     return 0;
 }

@@ -17,7 +17,10 @@ INCLUDE = os.path.join(os.path.dirname(PKG_ROOT), "include")
 LIB_PATH = os.path.join(CSRC, "libngp_hip.so")
 SOURCES = ["march.hip", "hash_grid.hip", "hash_bwd_lds.hip", "composite.hip", "sh_grid.hip", "mlp.hip", "optim.hip", "distortion.hip", "occupancy.hip", "rays.hip"]
 HEADERS = ["ngp_device.h", "hash_common.h"]
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+# -amdgpu-mfma-vgpr-form: builtin MFMAs keep their results in arch VGPRs even in a kernel that also pins accumulators to AGPRs through
+# inline asm (csrc/mlp.hip, mlp_bwd_reg_kernel); without it every MFMA result of that kernel is written to ONE AGPR quad and read
+# back with v_accvgpr_read (the data path serialises).  No other kernel's code changes with the flag.
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-mllvm", "-amdgpu-mfma-vgpr-form"]
 
 NGP_MAX_LEVELS = 16
 
@@ -96,6 +99,9 @@ SIGNATURES = {
     "ngp_check_finite_f16": [_P, ctypes.c_longlong, _P, _P],
     "ngp_live_compact": [_P, _P, _I, _P, _P, _P, _P],
     "ngp_mlp_bwd_live": [_P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P],
+    "ngp_mlp_dw_parts_max": [],
+    "ngp_mlp_bwd_live_parts": [_P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P],
+    "ngp_mlp_dw_reduce": [_P, _I, _P, _P],
     "ngp_hash_bwd_f32_live": [_P, _P, _LV, _I, _P, _P, _I, _F, _F, _I, _P, _P, _P],
     "ngp_hash_bwd_f16_live": [_P, _P, _LV, _I, _P, _P, _I, _F, _F, _I, _P, _P, _P],
     "ngp_hash_bwd_sliced_workspace": [_LV, _I],
@@ -124,6 +130,7 @@ SIGNATURES = {
     "ngp_stream_wait_event": [_P, _P],
     "ngp_event_destroy": [_P],
     "ngp_train_prologue": [_P, _P, _F, _F, _I, _F, _F, _F, _F, _I, _P],
+    "ngp_train_prologue_reduce": [_P, _P, _F, _F, _I, _F, _F, _F, _F, _I, _P, _I, _P, _P],
     "ngp_adam_step": [_P, _P, _P, _P, ctypes.c_longlong, _P, _P, _F, _F, _F, _P],
     "ngp_adam_step_bf16": [_P, _P, _P, _P, ctypes.c_longlong, _P, _P, _F, _F, _F, _P, _P],
     "ngp_cast_f32_bf16": [_P, _P, ctypes.c_longlong, _P],

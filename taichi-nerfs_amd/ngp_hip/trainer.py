@@ -128,6 +128,9 @@ class FusedTrainer:
                 self._comm_shard = torch.empty(self.shard_len, device=dev, dtype=grad_comm_dtype)
             else:
                 self._comm = torch.empty_like(self.grad_flat, dtype=grad_comm_dtype)
+        # per-block slabs of the MLP backward's weight gradients (ngp_mlp_bwd_live_parts), summed by the prologue launch
+        self.mlp_parts = torch.empty(self.L.ngp_mlp_dw_parts_max() * MLP_N_WEIGHTS, **f32)
+        self._dw_atomic = os.environ.get("NGP_MLP_DW", "") == "atomic"
         self.table_m, self.table_v = torch.zeros(self.nt_pad, **f32), torch.zeros(self.nt_pad, **f32)
         self.mlp_m, self.mlp_v = torch.zeros(MLP_N_WEIGHTS, **f32), torch.zeros(MLP_N_WEIGHTS, **f32)
         self.state_f = torch.zeros(8, **f32)
@@ -412,8 +415,21 @@ class FusedTrainer:
                 self.hash_bwd, sliced = "atomic", False                  # level table not expressible as <= 64 LDS slices per level
             else:
                 check(rc, "ngp_hash_bwd_sliced_prep")
-        check(L.ngp_mlp_bwd_live(_ptr(A.enc), _ptr(M.dirs), _ptr(self.wpack), _ptr(A.d_sigmas), _ptr(A.d_rgbs), A.cap, _ptr(cnt),
-                                 _ptr(live_idx), P, _ptr(A.d_enc), _ptr(self.mlp_grad), found, st), "ngp_mlp_bwd_live")
+        # weight gradients leave the launch as per-block slabs (plain stores) instead of 256 x 9408 same-address float atomics (13 us
+        # of the launch); the slabs are added up by the prologue launch below, or -- when the gradient is needed before that (an
+        # exchange between ranks, compute_gradients) -- by a launch of its own right here
+        if self._dw_atomic:                                   # NGP_MLP_DW=atomic: round 3's flush, for A/B runs
+            check(L.ngp_mlp_bwd_live(_ptr(A.enc), _ptr(M.dirs), _ptr(self.wpack), _ptr(A.d_sigmas), _ptr(A.d_rgbs), A.cap, _ptr(cnt),
+                                     _ptr(live_idx), P, _ptr(A.d_enc), _ptr(self.mlp_grad), found, st), "ngp_mlp_bwd_live")
+            n_parts = 0
+        else:
+            n_parts = L.ngp_mlp_bwd_live_parts(_ptr(A.enc), _ptr(M.dirs), _ptr(self.wpack), _ptr(A.d_sigmas), _ptr(A.d_rgbs), A.cap,
+                                               _ptr(cnt), _ptr(live_idx), P, _ptr(A.d_enc), _ptr(self.mlp_parts), found, st)
+            if n_parts <= 0:
+                check(n_parts or -1, "ngp_mlp_bwd_live_parts")
+        reduce_in_prologue = self.world == 1 and not self._grads_only and n_parts > 0
+        if n_parts > 0 and not reduce_in_prologue:
+            check(L.ngp_mlp_dw_reduce(_ptr(self.mlp_parts), n_parts, _ptr(self.mlp_grad), st), "ngp_mlp_dw_reduce")
         if hook is not None and self._prefetch_at <= 3:
             hook(); hook = None                                             # position 3: under the scatter-add and the optimizer
         if self.half and sliced:
@@ -441,8 +457,13 @@ class FusedTrainer:
         if self._grads_only:
             return {"rm_samples": total, "vr_per_ray": vr_per_ray, "rgb": rgb, "opacity": opacity, "depth": depth, "rays_a": rays_a,
                     "deltas": M.deltas, "ts": M.ts, "sq_err": sq_err}
-        check(L.ngp_train_prologue(_ptr(sf), _ptr(si), self.lr0, self.eta_min, self.t_max, self.beta1,
-                                   self.beta2, self.growth, self.backoff, self.growth_interval, st), "ngp_train_prologue")
+        if reduce_in_prologue:
+            check(L.ngp_train_prologue_reduce(_ptr(sf), _ptr(si), self.lr0, self.eta_min, self.t_max, self.beta1, self.beta2,
+                                              self.growth, self.backoff, self.growth_interval, _ptr(self.mlp_parts), n_parts,
+                                              _ptr(self.mlp_grad), st), "ngp_train_prologue_reduce")
+        else:
+            check(L.ngp_train_prologue(_ptr(sf), _ptr(si), self.lr0, self.eta_min, self.t_max, self.beta1,
+                                       self.beta2, self.growth, self.backoff, self.growth_interval, st), "ngp_train_prologue")
         # Adam on the table (+ its bf16 copy) and on the MLP weights + the fp16 fragment repack the next step needs: one launch
         kind = 2 if self.half else (1 if self.table_bf16 is not None else 0)
         if sharded:

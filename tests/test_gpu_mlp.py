@@ -173,3 +173,42 @@ def test_pair_major_layout_equals_natural_layout(hip_lib):
     check(L.ngp_hash_bwd_f32_ex(_ptr(x), _ptr(_to_pairs(de_nat, n)), ctypes.byref(lv), n, _ptr(None), 0, 0.0, 1.0, 1, _ptr(gt_p),
                                 _ptr(None), _stream()), "hash bwd")
     torch.testing.assert_close(gt_p, gt_nat, rtol=1e-4, atol=1e-5 * gt_nat.abs().max().item())
+
+
+@pytest.mark.parametrize("form", ["lds", "reg"])
+@pytest.mark.parametrize("n", [1, 47, 20000])
+def test_backward_forms_and_slab_reduction(hip_lib, monkeypatch, form, n):
+    """Both backward kernels (the LDS-image form, the default, and round 4's register-resident form, NGP_MLP_BWD=reg) and both
+    ways the weight gradients leave them -- float atomics on dW, or per-block slabs + ngp_mlp_dw_reduce (what the trainer
+    uses) -- give the same d_enc bit for bit and the same dW up to the summation order; a live list in reverse order too."""
+    import ctypes
+    from ngp_hip import lib, ops
+    from ngp_hip.ops import _ptr, _stream
+    L = lib.load()
+    m = _model()
+    enc, dirs = _inputs(n, seed=5)
+    g = torch.Generator(device="cpu").manual_seed(11)
+    g_sig = (torch.randn(n, generator=g) * 64).cuda()
+    g_rgb = (torch.randn(n, 3, generator=g) * 64).half().cuda()
+    wpack = ops.mlp_pack(m._mlp_weights())
+    monkeypatch.setenv("NGP_MLP_BWD", "lds")
+    de_ref, dw_ref = ops.mlp_bwd(enc, dirs, wpack, g_sig, g_rgb)
+    monkeypatch.setenv("NGP_MLP_BWD", form)
+    de, dw = ops.mlp_bwd(enc, dirs, wpack, g_sig, g_rgb)
+    assert torch.equal(de, de_ref)
+    scale = dw_ref.abs().max().item() + 1e-30
+    assert (dw - dw_ref).abs().max().item() <= 2e-6 * scale
+    # slabs + reduction, over a reversed live list
+    idx = torch.arange(n - 1, -1, -1, device="cuda", dtype=torch.int32)
+    n_dev = torch.tensor([n], device="cuda", dtype=torch.int32)
+    parts = torch.full((L.ngp_mlp_dw_parts_max() * 9408,), float("nan"), device="cuda")
+    d_enc = torch.empty(n, 32, device="cuda")
+    found = torch.zeros(1, device="cuda", dtype=torch.int32)
+    n_parts = L.ngp_mlp_bwd_live_parts(_ptr(enc), _ptr(dirs), _ptr(wpack), _ptr(g_sig), _ptr(g_rgb), n, _ptr(n_dev), _ptr(idx), 0,
+                                       _ptr(d_enc), _ptr(parts), _ptr(found), _stream())
+    assert 1 <= n_parts <= L.ngp_mlp_dw_parts_max()
+    dw2 = torch.zeros(9408, device="cuda")
+    lib.check(L.ngp_mlp_dw_reduce(_ptr(parts), n_parts, _ptr(dw2), _stream()), "ngp_mlp_dw_reduce")
+    assert int(found[0]) == 0
+    assert torch.equal(d_enc.flip(0), de_ref)                       # position j of the list = sample n-1-j
+    assert torch.isfinite(dw2).all() and (dw2 - dw_ref).abs().max().item() <= 2e-6 * scale
