@@ -306,51 +306,74 @@ __device__ __forceinline__ void tile_forward_regs(const half8* __restrict__ wl, 
     tile_forward_frags<COLOR>([&](int id) -> const half8& { return wl[id * 64 + lane]; }, g, e0, e1, dx, dy, dz, t);
 }
 
-__device__ __forceinline__ void load_wpack(const half_t* __restrict__ wpack, half8* __restrict__ wl, int n_frags) {
+// the packed weight image -> LDS.  All of a thread's 16-byte pieces are requested before the first one is stored (the plain loop
+// waited for every load before issuing the next: 5 serial L2 round trips at the head of each of the forward's 768 blocks)
+template <int THREADS, int N_FRAGS>
+__device__ __forceinline__ void load_wpack(const half_t* __restrict__ wpack, half8* __restrict__ wl) {
     const uint4* src = reinterpret_cast<const uint4*>(wpack);
     uint4* dst = reinterpret_cast<uint4*>(wl);
-    for (int k = threadIdx.x; k < n_frags * 64; k += blockDim.x) dst[k] = src[k];
+    constexpr int PER = (N_FRAGS * 64 + THREADS - 1) / THREADS;
+    uint4 v[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int k = threadIdx.x + i * THREADS;
+        v[i] = src[k < N_FRAGS * 64 ? k : 0];
+    }
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int k = threadIdx.x + i * THREADS;
+        if (k < N_FRAGS * 64) dst[k] = v[i];
+    }
     __syncthreads();
 }
 
 // ---- forward kernel: persistent waves, 32 samples (two 16-sample tiles) per trip; the next trip's inputs are requested
-//      before this trip's math (the loads are the only long-latency operations of a trip) ----------------------------------
+//      before this trip's math (the loads are the only long-latency operations of a trip).  Round 4: the request is branch-free
+//      (a lane past the end reads sample 0; zeros are SELECTED where the values are consumed, one trip later) -- with the loads
+//      inside `if (smp < S)` the compiler merged them with the defaults at the end of that block and waited for them right there
+//      (s_waitcnt vmcnt(2) three instructions behind the "prefetch"): 22 -> ... us at 400 k samples.  PAIRS is a template
+//      parameter so that the uniform branch on the encoding layout does not split the request into blocks either. ------------
 struct FwdIn { float4 e0, e1; float dx, dy, dz; };
-template <bool COLOR>
-__device__ __forceinline__ void fwd_load(FwdIn& in, const float* __restrict__ enc, const float* __restrict__ dirs, int smp, int S,
-                                         int g, int pairs, size_t plane) {
-    in.e0 = in.e1 = make_float4(0.f, 0.f, 0.f, 0.f);
-    in.dx = 0.f; in.dy = 0.f; in.dz = 1.f;
-    if (smp < S) {
-        const float *ep0, *ep1;
-        enc_ptrs(enc, pairs, plane, smp, g, ep0, ep1);
-        in.e0 = *reinterpret_cast<const float4*>(ep0);
-        in.e1 = *reinterpret_cast<const float4*>(ep1);
-        if (COLOR) { in.dx = dirs[3 * (size_t)smp]; in.dy = dirs[3 * (size_t)smp + 1]; in.dz = dirs[3 * (size_t)smp + 2]; }
-    }
+template <bool COLOR, bool PAIRS>
+__device__ __forceinline__ void fwd_request(FwdIn& raw, const float* __restrict__ enc, const float* __restrict__ dirs, int smp, int S,
+                                            int g, size_t plane) {
+    const size_t s0 = smp < S ? (size_t)smp : 0;
+    const float *ep0, *ep1;
+    enc_ptrs(enc, PAIRS ? 1 : 0, plane, (int)s0, g, ep0, ep1);
+    raw.e0 = *reinterpret_cast<const float4*>(ep0);
+    raw.e1 = *reinterpret_cast<const float4*>(ep1);
+    if (COLOR) { raw.dx = dirs[3 * s0]; raw.dy = dirs[3 * s0 + 1]; raw.dz = dirs[3 * s0 + 2]; }
+    else { raw.dx = 0.f; raw.dy = 0.f; raw.dz = 1.f; }
+}
+__device__ __forceinline__ FwdIn fwd_take(const FwdIn& raw, bool ok) {
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    FwdIn in;
+    in.e0 = ok ? raw.e0 : z4; in.e1 = ok ? raw.e1 : z4;
+    in.dx = ok ? raw.dx : 0.f; in.dy = ok ? raw.dy : 0.f; in.dz = ok ? raw.dz : 1.f;
+    return in;
 }
 
-template <bool COLOR>
+template <bool COLOR, bool PAIRS>
 __global__ void __launch_bounds__(256) mlp_fwd_kernel(const float* __restrict__ enc, const float* __restrict__ dirs,
                                                       const half_t* __restrict__ wpack, int S,
-                                                      const int32_t* __restrict__ n_dev, int pairs, float* __restrict__ sigmas,
+                                                      const int32_t* __restrict__ n_dev, float* __restrict__ sigmas,
                                                       half_t* __restrict__ rgbs) {
     __shared__ half8 wl[N_FWD_FRAGS * 64];
     const size_t plane = (size_t)S;
     if (n_dev) S = min(S, *n_dev);
-    load_wpack(wpack, wl, COLOR ? N_FWD_FRAGS : F_W3);
+    load_wpack<256, COLOR ? N_FWD_FRAGS : F_W3>(wpack, wl);
     const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
     const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), n_waves = gridDim.x * (blockDim.x >> 6);
     const int n_iter = (S + 31) >> 5;
     FwdIn nxt[2];
 #pragma unroll
-    for (int tt = 0; tt < 2; ++tt) fwd_load<COLOR>(nxt[tt], enc, dirs, wave * 32 + 16 * tt + n, S, g, pairs, plane);
+    for (int tt = 0; tt < 2; ++tt) fwd_request<COLOR, PAIRS>(nxt[tt], enc, dirs, wave * 32 + 16 * tt + n, S, g, plane);
     for (int it = wave; it < n_iter; it += n_waves) {
-        const FwdIn cur[2] = {nxt[0], nxt[1]};
-        if (it + n_waves < n_iter) {
+        FwdIn cur[2];
 #pragma unroll
-            for (int tt = 0; tt < 2; ++tt) fwd_load<COLOR>(nxt[tt], enc, dirs, (it + n_waves) * 32 + 16 * tt + n, S, g, pairs, plane);
-        }
+        for (int tt = 0; tt < 2; ++tt) cur[tt] = fwd_take(nxt[tt], it * 32 + 16 * tt + n < S);
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) fwd_request<COLOR, PAIRS>(nxt[tt], enc, dirs, (it + n_waves) * 32 + 16 * tt + n, S, g, plane);
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
             const int smp = it * 32 + 16 * tt + n;
@@ -500,7 +523,7 @@ __global__ void __launch_bounds__(768) mlp_bwd_kernel(const float* __restrict__ 
     const size_t plane = (size_t)S;
     if (n_dev) S = min(S, *n_dev);
     half8* wl = reinterpret_cast<half8*>(smem);
-    load_wpack(wpack, wl, N_ALL_FRAGS);
+    load_wpack<64 * BW, N_ALL_FRAGS>(wpack, wl);
     const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
     const int grp = wv >> 1, par = wv & 1;
     half_t* Iall = reinterpret_cast<half_t*>(smem + N_ALL_FRAGS * 64 * 16);
@@ -1148,12 +1171,12 @@ static inline int mlp_grid(int S) {
 int ngp_mlp_fwd_ex(const float* enc, const float* dirs, const uint16_t* wpack, int n_max, const int32_t* n_dev, int enc_pairs,
                    float* sigmas, uint16_t* rgbs, void* stream) {
     if (n_max <= 0) return 0;
-    if (dirs && rgbs)
-        hipLaunchKernelGGL(mlp_fwd_kernel<true>, dim3(mlp_grid(n_max)), dim3(256), 0, (hipStream_t)stream, enc, dirs,
-                           (const half_t*)wpack, n_max, n_dev, enc_pairs, sigmas, (half_t*)rgbs);
-    else
-        hipLaunchKernelGGL(mlp_fwd_kernel<false>, dim3(mlp_grid(n_max)), dim3(256), 0, (hipStream_t)stream, enc,
-                           (const float*)nullptr, (const half_t*)wpack, n_max, n_dev, enc_pairs, sigmas, (half_t*)nullptr);
+#define NGP_FWD(C, P, D, R)                                                                                          \
+    hipLaunchKernelGGL((mlp_fwd_kernel<C, P>), dim3(mlp_grid(n_max)), dim3(256), 0, (hipStream_t)stream, enc, (const float*)(D), \
+                       (const half_t*)wpack, n_max, n_dev, sigmas, (half_t*)(R))
+    if (dirs && rgbs) { if (enc_pairs) NGP_FWD(true, true, dirs, rgbs); else NGP_FWD(true, false, dirs, rgbs); }
+    else { if (enc_pairs) NGP_FWD(false, true, nullptr, nullptr); else NGP_FWD(false, false, nullptr, nullptr); }
+#undef NGP_FWD
     NGP_LAUNCH_CHECK();
     return 0;
 }
