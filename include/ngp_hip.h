@@ -300,6 +300,11 @@ int ngp_train_prologue(float* state_f, int32_t* state_i, float lr0, float eta_mi
 int ngp_train_prologue_reduce(float* state_f, int32_t* state_i, float lr0, float eta_min, int t_max, float beta1,
                               float beta2, float growth, float backoff, int growth_interval, const float* dW_parts,
                               int n_parts, float* dW, void* stream);
+/* Prologue for an optimizer driven by torch.cuda.amp.GradScaler (train.py:143-149,198-201 with apex.optimizers.FusedAdam =
+ * compat/apex): grad_scale / found_inf are the scaler's device tensors (NULL: scale 1 / never skip), lr the host-side scheduler's
+ * value; fills state_f[1..4] and state_i[1,4] for ngp_adam_step; the bias-correction step count advances on non-skipped steps. */
+int ngp_adam_amp_prologue(float* state_f, int32_t* state_i, const float* grad_scale, const float* found_inf, float lr,
+                          float beta1, float beta2, void* stream);
 /* p, g, m, v: n floats each (n % 4 == 0, 16-byte aligned); g is unscaled on the fly and zero-filled. */
 int ngp_adam_step(float* p, float* g, float* m, float* v, long long n, const float* state_f,
                   const int32_t* state_i, float beta1, float beta2, float eps, void* stream);

@@ -1,0 +1,72 @@
+"""apex.optimizers.FusedAdam as the reference's train.py:143-149 constructs it (`FusedAdam(model.parameters(), lr=..., eps=1e-15)`),
+on top of the C ABI's one-pass Adam (`ngp_adam_step`, csrc/optim.hip: unscale + moments + update in a single sweep over p/g/m/v;
+parameter groups never touched by a step are skipped as exact fixed points).
+
+What the unchanged driver gains over its torch.optim.Adam fall-back: torch's GradScaler.step() makes a separate unscale pass over
+every gradient and then READS THE INF FLAG BACK to the host before it may call step() -- one host sync per iteration.  This class
+declares `_step_supports_amp_scaling`: the scaler hands it `grad_scale` / `found_inf` as device tensors, the unscale happens inside
+the Adam sweep and a skipped step is skipped on the device (`ngp_adam_amp_prologue`).  Same arithmetic as
+torch.optim.Adam(eps=1e-15) (tests/test_gpu_apex_adam.py holds it to a 50-step torch loop incl. an overflow step).
+Scope: Adam without weight decay / amsgrad on contiguous fp32 CUDA tensors whose size is a multiple of 4 (every parameter of the
+reference's models); anything else raises."""
+import ctypes
+
+import torch
+
+from ngp_hip import lib as _lib
+from ngp_hip.ops import _ptr, _stream
+
+
+class FusedAdam(torch.optim.Optimizer):
+    _step_supports_amp_scaling = True
+
+    def __init__(self, params, lr=1e-3, bias_correction=True, betas=(0.9, 0.999), eps=1e-8, adam_w_mode=True, weight_decay=0.0,
+                 amsgrad=False, set_grad_none=True):
+        if amsgrad:
+            raise RuntimeError("FusedAdam does not support the AMSGrad variant.")          # (apex's own message)
+        if weight_decay != 0.0:
+            raise NotImplementedError("compat FusedAdam: weight_decay != 0 is not implemented (the reference uses 0)")
+        if not bias_correction:
+            raise NotImplementedError("compat FusedAdam: bias_correction=False is not implemented")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.set_grad_none = set_grad_none
+        self._L = _lib.load()
+        self._sf = self._si = None
+
+    def zero_grad(self, set_to_none=None):
+        return super().zero_grad(self.set_grad_none if set_to_none is None else set_to_none)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        L = self._L
+        scale, found = getattr(self, "grad_scale", None), getattr(self, "found_inf", None)
+        for gi, group in enumerate(self.param_groups):
+            ps = [p for p in group["params"] if p.grad is not None]
+            if not ps:
+                continue
+            dev = ps[0].device
+            if self._sf is None:
+                self._sf = [torch.zeros(8, device=dev, dtype=torch.float32) for _ in self.param_groups]
+                self._si = [torch.zeros(8, device=dev, dtype=torch.int32) for _ in self.param_groups]
+            sf, si = self._sf[gi], self._si[gi]
+            b1, b2 = group["betas"]
+            if scale is not None and (scale.dtype != torch.float32 or found.dtype != torch.float32):
+                raise TypeError("grad_scale / found_inf must be float32 device tensors (torch.cuda.amp.GradScaler's are)")
+            _lib.check(L.ngp_adam_amp_prologue(_ptr(sf), _ptr(si), _ptr(scale), _ptr(found), float(group["lr"]), float(b1), float(b2),
+                                               _stream()), "ngp_adam_amp_prologue")
+            for p in ps:
+                g = p.grad
+                if (not p.is_cuda or p.dtype != torch.float32 or g.dtype != torch.float32 or not p.is_contiguous() or not g.is_contiguous()
+                        or p.numel() % 4 or p.data_ptr() % 16 or g.data_ptr() % 16):
+                    raise NotImplementedError("compat FusedAdam: parameters and gradients must be contiguous, 16-byte aligned fp32 "
+                                              "CUDA tensors with a multiple of 4 elements (got {} {})".format(tuple(p.shape), p.dtype))
+                st = self.state[p]
+                if not st:
+                    st["exp_avg"], st["exp_avg_sq"] = torch.zeros_like(p), torch.zeros_like(p)
+                _lib.check(L.ngp_adam_step(_ptr(p), _ptr(g), _ptr(st["exp_avg"]), _ptr(st["exp_avg_sq"]), ctypes.c_longlong(p.numel()),
+                                           _ptr(sf), _ptr(si), float(b1), float(b2), float(group["eps"]), _stream()), "ngp_adam_step")
+        return loss

@@ -48,6 +48,26 @@ __global__ void train_prologue_kernel(float* __restrict__ sf, int32_t* __restric
     train_prologue_thread(sf, si, lr0, eta_min, t_max, beta1, beta2, growth, backoff, growth_interval);
 }
 
+// Prologue of an optimizer step driven by torch.cuda.amp.GradScaler (compat/apex FusedAdam under the reference's unchanged
+// train.py:143-149,198-201): the scale and the inf flag are the scaler's own device tensors, the learning rate comes from
+// torch's scheduler on the host; the step counter of the bias corrections advances only when the step is not skipped.
+__global__ void adam_amp_prologue_kernel(float* __restrict__ sf, int32_t* __restrict__ si, const float* __restrict__ grad_scale,
+                                         const float* __restrict__ found_inf, float lr, float beta1, float beta2) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const bool skip = found_inf && *found_inf != 0.0f;
+    sf[SF_INV_SCALE] = grad_scale ? 1.0f / *grad_scale : 1.0f;
+    sf[SF_LR] = lr;
+    si[SI_SKIP] = skip ? 1 : 0;
+    if (!skip) {
+        const int step = si[SI_OPT_STEP] + 1;
+        si[SI_OPT_STEP] = step;
+        sf[SF_BC1] = 1.0f - powf(beta1, (float)step);
+        sf[SF_BC2_SQRT] = sqrtf(1.0f - powf(beta2, (float)step));
+    } else {
+        si[SI_SKIPPED_TOTAL] += 1;
+    }
+}
+
 // The same launch also finishes the MLP backward: blocks 0..146 add up the per-block weight-gradient slabs (ngp_device.h); the
 // scalar bookkeeping rides in one extra block.  The launch exists anyway and is latency-, not work-bound (5 us for one thread).
 __global__ void __launch_bounds__(NGP_MLP_REDUCE_THREADS) train_prologue_reduce_kernel(float* __restrict__ sf, int32_t* __restrict__ si, float lr0,
@@ -139,6 +159,14 @@ int ngp_train_prologue(float* state_f, int32_t* state_i, float lr0, float eta_mi
                        float growth, float backoff, int growth_interval, void* stream) {
     hipLaunchKernelGGL(train_prologue_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state_f, state_i, lr0, eta_min, t_max,
                        beta1, beta2, growth, backoff, growth_interval);
+    NGP_LAUNCH_CHECK();
+    return 0;
+}
+
+int ngp_adam_amp_prologue(float* state_f, int32_t* state_i, const float* grad_scale, const float* found_inf, float lr, float beta1,
+                          float beta2, void* stream) {
+    hipLaunchKernelGGL(adam_amp_prologue_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state_f, state_i, grad_scale, found_inf, lr,
+                       beta1, beta2);
     NGP_LAUNCH_CHECK();
     return 0;
 }

