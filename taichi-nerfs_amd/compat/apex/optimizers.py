@@ -14,7 +14,7 @@ import ctypes
 import torch
 
 from ngp_hip import lib as _lib
-from ngp_hip.ops import _ptr, _stream
+from ngp_hip.ops import _ptr, _stream, _touched
 
 
 class FusedAdam(torch.optim.Optimizer):
@@ -69,4 +69,5 @@ class FusedAdam(torch.optim.Optimizer):
                     st["exp_avg"], st["exp_avg_sq"] = torch.zeros_like(p), torch.zeros_like(p)
                 _lib.check(L.ngp_adam_step(_ptr(p), _ptr(g), _ptr(st["exp_avg"]), _ptr(st["exp_avg_sq"]), ctypes.c_longlong(p.numel()),
                                            _ptr(sf), _ptr(si), float(b1), float(b2), float(group["eps"]), _stream()), "ngp_adam_step")
+                _touched(p, g)       # written through raw pointers: version-keyed caches (the encoders' 16-bit table copies) must see it
         return loss

@@ -120,9 +120,9 @@ class NGP(nn.Module):
                 self.rgb_net.hidden_layers[0].weight, self.rgb_net.hidden_layers[1].weight, self.rgb_net.output_layer.weight)
 
     def fused_train_ok(self, rays):
-        """Whole-render fusion (ngp_hip/fused.py): fp32 hash table + default MLPs + autocast(fp16) numerics."""
-        return (self._fused_ok(rays) and torch.is_grad_enabled() and not self.half_opt
-                and os.environ.get("NGP_FUSED_RENDER", "1") != "0")
+        """Whole-render fusion (ngp_hip/fused.py): fp32 (or bf16-copy) hash table or the half2 encoder + default MLPs +
+        autocast(fp16) numerics."""
+        return (self._fused_ok(rays) and torch.is_grad_enabled() and os.environ.get("NGP_FUSED_RENDER", "1") != "0")
 
     def _fused_ok(self, x):
         """Fused path = the fp16-autocast numerics of the reference's training/eval loops (train.py:177,250)."""

@@ -110,7 +110,10 @@ class FusedTrainRender(torch.autograd.Function):
                                       _ptr(A.stage), _ptr(A.march_ctr), _ptr(rays_a), _ptr(total), _ptr(A.xyzs), _ptr(A.dirs),
                                       _ptr(A.deltas), _ptr(A.ts), st), "ngp_march_train_fused")
         P = cfg.enc_pairs
-        if cfg.table_bf16 is not None:
+        if cfg.table_f16 is not None:            # the half2 encoder (NGP(half_opt=True), hash_encoder_half.py:218-368): f16 table, f16 arithmetic
+            check(L.ngp_hash_fwd_f16_ex(_ptr(A.xyzs), _ptr(cfg.table_f16), ctypes.byref(cfg.levels), A.cap, _ptr(total), 1, cfg.lo,
+                                        cfg.hi, P, _ptr(A.enc), st), "ngp_hash_fwd_f16_ex")
+        elif cfg.table_bf16 is not None:
             check(L.ngp_hash_fwd_bf16_ex(_ptr(A.xyzs), _ptr(cfg.table_bf16), ctypes.byref(cfg.levels), A.cap, _ptr(total), 1, cfg.lo,
                                          cfg.hi, P, _ptr(A.enc), st), "ngp_hash_fwd_bf16_ex")
         else:
@@ -127,7 +130,7 @@ class FusedTrainRender(torch.autograd.Function):
                                         cfg.T_threshold, n, _ptr(vr_per_ray), _ptr(opacity), _ptr(depth), _ptr(rgb), _ptr(A.ws),
                                         st), "ngp_composite_train_fwd")
         A.generation += 1
-        ctx.cfg, ctx.arena, ctx.table_numel, ctx.generation = cfg, A, table.numel(), A.generation
+        ctx.cfg, ctx.arena, ctx.table_numel, ctx.table_shape, ctx.generation = cfg, A, table.numel(), table.shape, A.generation
         ctx.save_for_backward(rays_a, total, opacity, depth, rgb, vr_per_ray)
         ctx.set_materialize_grads(False)
         rm = total[0]
@@ -162,7 +165,6 @@ class FusedTrainRender(torch.autograd.Function):
               "ngp_composite_train_bwd")
         dW = torch.zeros(MLP_N_WEIGHTS, device=dev, dtype=torch.float32)
         P = cfg.enc_pairs
-        dtable = torch.zeros(ctx.table_numel, device=dev, dtype=torch.float32)
         # backward over the LIVE samples only (the first vr_per_ray[r] of ray r: everything behind the early-termination point has
         # exact-zero gradients), compacted into an index list; the scatter-add in its LDS-sliced form (no global float atomics)
         # when the level table fits it -- the same kernels FusedTrainer runs
@@ -171,6 +173,23 @@ class FusedTrainRender(torch.autograd.Function):
               "ngp_live_compact")
         check(L.ngp_mlp_bwd_live(_ptr(A.enc), _ptr(A.dirs), _ptr(A.wpack), _ptr(A.d_sigmas), _ptr(A.d_rgbs), A.cap, _ptr(live_total),
                                  _ptr(A.live_idx), P, _ptr(A.d_enc), _ptr(dW), _ptr(None), st), "ngp_mlp_bwd_live")
+        if cfg.table_f16 is not None:
+            # half2 encoder: the scatter-add with the encoder's fp16 arithmetic into an fp16 gradient table (the reference's
+            # hash_grad, hash_encoder_half.py:300-306,350-352), handed to autograd widened to the fp32 parameter's dtype
+            grad_h = torch.zeros(ctx.table_numel, device=dev, dtype=torch.float16)
+            ws = A.sliced_ws(cfg.levels)
+            rc = L.ngp_hash_bwd_sliced_prep(_ptr(A.xyzs), ctypes.byref(cfg.levels), A.cap, _ptr(live_total), _ptr(A.live_idx), 1, cfg.lo,
+                                            cfg.hi, _ptr(ws), ws.numel(), st)
+            if rc == -2 or os.environ.get("NGP_HASH_BWD", "sliced") == "atomic":
+                check(L.ngp_hash_bwd_f16_live(_ptr(A.xyzs), _ptr(A.d_enc), ctypes.byref(cfg.levels), A.cap, _ptr(live_total),
+                                              _ptr(A.live_idx), 1, cfg.lo, cfg.hi, P, _ptr(grad_h), _ptr(None), st), "ngp_hash_bwd_f16_live")
+            else:
+                check(rc, "ngp_hash_bwd_sliced_prep")
+                check(L.ngp_hash_bwd_sliced_main_f16(_ptr(A.d_enc), ctypes.byref(cfg.levels), A.cap, _ptr(live_total), P, _ptr(grad_h),
+                                                     _ptr(None), _ptr(ws), ws.numel(), st), "ngp_hash_bwd_sliced_main_f16")
+            grads = [g.view(shape) for g, shape in zip(dW.split(MLP_SPLITS), MLP_SHAPES)]
+            return (None, None, None, grad_h.float().view(ctx.table_shape), *grads, None)
+        dtable = torch.zeros(ctx.table_numel, device=dev, dtype=torch.float32)
         rc = -2
         if os.environ.get("NGP_HASH_BWD", "sliced") != "atomic":
             ws = A.sliced_ws(cfg.levels)
@@ -182,7 +201,7 @@ class FusedTrainRender(torch.autograd.Function):
         else:
             check(rc, "ngp_hash_bwd_f32_sliced")
         grads = [g.view(shape) for g, shape in zip(dW.split(MLP_SPLITS), MLP_SHAPES)]
-        return (None, None, None, dtable, *grads, None)
+        return (None, None, None, dtable.view(ctx.table_shape), *grads, None)
 
 
 class RenderConfig:
@@ -204,3 +223,5 @@ class RenderConfig:
         self.enc_pairs = 1 if (self.levels.n_levels == 16 and self.levels.n_features == 2) else 0
         enc = model.pos_encoder
         self.table_bf16 = enc.table_bf16() if getattr(enc, "table_dtype", torch.float32) == torch.bfloat16 else None
+        # half2 encoder: the fp16 copy of the fp32 master the kernels gather from (re-cast when the parameter changed, :367)
+        self.table_f16 = enc.table_f16() if getattr(model, "half_opt", False) else None

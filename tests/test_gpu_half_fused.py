@@ -177,3 +177,52 @@ def test_trainer_half_matches_torch_loop(hip_lib, lego_bitfield):
     tr.update_density_grid(0.01 * 1024 / 3**0.5, warmup=True)
     torch.cuda.synchronize()
     assert torch.isfinite(m_b.density_grid).all() and (m_b.density_grid > 0).any()
+
+
+def test_render_fused_half_matches_operator_path(hip_lib, lego_bitfield):
+    """`render(NGP(half_opt=True))` -- what the reference's unchanged `train.py --half_opt` calls (README.md:39-42: its fastest
+    mode) -- through the fused render (the half2 encoder's kernels inside one autograd node, round 4) against the operator chain
+    (modules/hash_encoder_half.py): same samples, radiance within fp16 tolerance, table gradient with the same support."""
+    import os
+    import torch.nn.functional as F
+    from conftest import ray_order
+    from modules.networks import NGP
+    from modules.rendering import render
+    from ngp_hip import synthetic
+    torch.manual_seed(0)
+    m = NGP(scale=0.5, max_res=1024, half_opt=True).cuda()
+    m.density_bitfield.copy_(torch.from_numpy(lego_bitfield).cuda())
+    with torch.no_grad():
+        m.pos_encoder.hash_table.uniform_(-0.15, 0.15)          # (the reference's 1e-4 init gives no signal to compare)
+    o, d = synthetic.lego_rays(4096, seed=3)
+    o, d = torch.from_numpy(o).cuda(), torch.from_numpy(d).cuda()
+    target = torch.rand(4096, 3, device="cuda")
+
+    def run(fused):
+        for p in m.parameters():
+            p.grad = None
+        torch.manual_seed(123)
+        os.environ["NGP_FUSED_RENDER"] = "1" if fused else "0"
+        try:
+            with torch.autocast("cuda", dtype=torch.float16):
+                assert m.fused_train_ok(o) == fused
+                res = render(m, o, d, exp_step_factor=0.0)
+                loss = F.mse_loss(res["rgb"], target)
+            (loss * 256.0).backward()
+        finally:
+            os.environ["NGP_FUSED_RENDER"] = "1"
+        return res, [p.grad.clone().float() for p in [m.pos_encoder.hash_table, *m._mlp_weights()]]
+
+    r_f, g_f = run(True)
+    r_o, g_o = run(False)
+    assert torch.equal(r_f["rays_a"][:, [0, 2]], r_o["rays_a"][:, [0, 2]]) and int(r_f["rm_samples"]) == int(r_o["rm_samples"]) > 0
+    pf, po = [torch.from_numpy(ray_order(r["rays_a"])).cuda() for r in (r_f, r_o)]
+    assert torch.equal(r_f["ts"][pf], r_o["ts"][po])
+    torch.testing.assert_close(r_f["rgb"], r_o["rgb"], rtol=0, atol=4e-3)
+    torch.testing.assert_close(r_f["opacity"], r_o["opacity"], rtol=0, atol=4e-3)
+    assert g_f[0].shape == m.pos_encoder.hash_table.shape and torch.isfinite(g_f[0]).all()
+    nz_f, nz_o = g_f[0] != 0, g_o[0] != 0
+    assert (nz_f != nz_o).float().mean().item() < 2e-3
+    for k in range(6):
+        rel = ((g_f[k] - g_o[k]).norm() / g_o[k].norm().clamp_min(1e-30)).item()
+        assert rel < 3e-2, (k, rel)
