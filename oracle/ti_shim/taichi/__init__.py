@@ -13,8 +13,10 @@ Taichi's typing rules emulated by numpy scalars:
   * every parallel-for runs serially in index order, so atomics are deterministic (ray order);
   * separate multiply and add (no FMA contraction) -- Taichi's fast_math may contract; the restatement and the
     HIP kernels are defined against the strict evaluation.
-It is NOT the Taichi runtime: autodiff (`kernel.grad`) is not emulated (backward parity uses closed forms checked
-against torch autograd instead), and nothing here is optimised -- golden cases are a few hundred rays/points.
+It is NOT the Taichi runtime, and nothing here is optimised -- golden cases are a few hundred rays/points.
+Round 4: `kernel.grad(...)` is emulated by a reverse-mode tape over the same forward source (taichi/_autodiff.py): tensor
+arguments that require grad become taped arrays, output seeds are read from / input adjoints accumulated into their `.grad`,
+as Taichi's torch interop does (oracle/gen_golden_autodiff.py makes the backward fixtures with it).
 """
 import ast
 import inspect
@@ -23,6 +25,8 @@ import textwrap
 import types as _pytypes
 
 import numpy as np
+
+from ._autodiff import AD as _AD, ADArray as _ADArray, Tape as _Tape, ad_max as _ad_max, ad_min as _ad_min
 
 np.seterr(all="ignore")
 
@@ -80,6 +84,8 @@ class Vector:
         return self.a[i]
 
     def __setitem__(self, i, v):
+        if isinstance(v, _AD) and self.a.dtype != object:
+            self.a = self.a.astype(object)            # a taped scalar (kernel.grad emulation): element-wise Python arithmetic
         self.a[i] = v
 
     def __len__(self):
@@ -229,10 +235,14 @@ def _minmax(fn, a, b):
 
 
 def min(a, b):  # noqa: A001
+    if isinstance(a, _AD) or isinstance(b, _AD):
+        return _ad_min(a, b)
     return _minmax(np.fmin if (_is_float(a) or _is_float(b)) else np.minimum, a, b)
 
 
 def max(a, b):  # noqa: A001
+    if isinstance(a, _AD) or isinstance(b, _AD):
+        return _ad_max(a, b)
     return _minmax(np.fmax if (_is_float(a) or _is_float(b)) else np.maximum, a, b)
 
 
@@ -246,7 +256,7 @@ def _unary(fn, x):
     return np.float32(fn(np.float32(x)))
 
 
-def exp(x): return _unary(np.exp, x)
+def exp(x): return x.exp() if isinstance(x, _AD) else _unary(np.exp, x)
 def log(x): return _unary(np.log, x)
 def sqrt(x): return _unary(np.sqrt, x)
 def floor(x): return _unary(np.floor, x)
@@ -422,8 +432,38 @@ class _Kernel:
                 conv.append(val)
         return self._compiled(*conv)
 
-    def grad(self, *a, **k):
-        raise NotImplementedError("Taichi autodiff is not emulated by ti_shim")
+    def grad(self, *args, **kwargs):
+        """`kernel.grad(...)`: the forward source once more under a reverse-mode tape (taichi/_autodiff.py).  Tensor arguments
+        with requires_grad are taped; seeds come from / adjoints go to their `.grad`, like Taichi's torch interop."""
+        if self._compiled is None:
+            self._build()
+        bound = self.sig.bind(*args, **kwargs)
+        tape = _Tape()
+        conv, taped = [], []
+        for name, val in bound.arguments.items():
+            ann = self.sig.parameters[name].annotation
+            if isinstance(ann, _NdAnn):
+                if getattr(val, "requires_grad", False) and val.dtype.is_floating_point:
+                    if ann.is_vec:
+                        raise NotImplementedError("taped vector-typed ndarrays")
+                    w = _ADArray(tape, val)
+                    conv.append(w); taped.append(w)
+                else:
+                    arr = val.detach().numpy() if hasattr(val, "detach") else np.asarray(val)
+                    conv.append(_VecArray(arr) if ann.is_vec else arr)
+            elif ann in (float, np.float32):
+                conv.append(np.float32(val))
+            elif ann in (int, np.int32):
+                conv.append(int(val))
+            else:
+                conv.append(val)
+        self._compiled(*conv)
+        seeds = {}
+        for w in taped:
+            w.seeds(seeds)
+        adj = tape.backward(seeds)
+        for w in taped:
+            w.collect(adj)
 
 
 def kernel(fn):
