@@ -360,10 +360,17 @@ def comm_fields(trainer, ctx, args):
         ver = ".".join(str(x) for x in torch.cuda.nccl.version())
     except Exception:
         ver = None
-    return {"comm_ms": comm_ms, "exposed_comm_ms": comm_ms,
+    overlap = trainer is not None and getattr(trainer, "_groups", None) is not None
+    stub_ms = getattr(_Probe, "stub_ms", None)
+    return {"comm_ms": comm_ms,
+            "exposed_comm_ms": None if (stub_ms is None or ctx.get("ms_per_step") is None) else ctx["ms_per_step"] - stub_ms,
+            "ms_per_step_comm_stubbed": stub_ms,
+            "comm_overlap": {"enabled": overlap, "level_groups": os.environ.get("NGP_COMM_GROUPS", "8,0") if overlap else None},
             "comm_breakdown_ms": {k: float(np.mean(v)) for k, v in per.items()},
-            "comm_note": "per step, HIP events on the step's stream around each collective (sampled steps); the collectives are issued in "
-                         "line after the scatter-add, so all of it is exposed -- what runs underneath is the next batch's march",
+            "comm_note": "comm_ms = per step, HIP events on the step's stream around each collective (sampled steps) -- in line: the "
+                         "transfer; with NGP_COMM_OVERLAP=1: what the step's stream WAITS for the collective issued earlier.  "
+                         "exposed_comm_ms = ms_per_step minus the same K steps re-run with every collective replaced by its local "
+                         "part (ms_per_step_comm_stubbed): measured, not assumed",
             "comm_bytes_per_rank_per_step": None if trainer is None else trainer.comm_bytes_per_step(),
             "rccl_version": ver, "rccl_ranks": ctx["world"], "backend": ctx["backend"],
             "rccl_env": {k: v for k, v in sorted(os.environ.items()) if k.startswith(("NCCL_", "RCCL_", "HSA_ENABLE_IPC"))}}
@@ -640,6 +647,28 @@ def _measure(args, ctx, brief):
         fence()
         elapsed_np = time.perf_counter() - t0
 
+    # ---- N > 1, after the timed region (untimed): the same K steps with every collective replaced by its local part (FusedTrainer
+    # `_comm_stub`): ms_per_step minus this is the communication the step really waits for (round 3 reported comm_ms as exposed)
+    elapsed_stub = None
+    if use_trainer and world > 1 and not args.graph and not brief:
+        i0 = base + args.warmup + args.steps
+        i0 += (-i0) % 16
+        i0 += (base + args.warmup) % 16
+        trainer.finish_comm()
+        trainer._comm_stub = True
+        step(i0 - 1, prefetch=args.prefetch, log=False)
+        fence()
+        t0 = time.perf_counter()
+        for i in range(i0, i0 + args.steps):
+            step(i, prefetch=args.prefetch, log=False)
+        fence()
+        elapsed_stub = time.perf_counter() - t0
+        trainer._comm_stub = False
+        tt = torch.tensor([elapsed_stub], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed_stub = float(tt.item())
+    _Probe.stub_ms = None if elapsed_stub is None else elapsed_stub / args.steps * 1e3
+
     if use_trainer:
         n_st = (k_timed + STAT_EVERY - 1) // STAT_EVERY
         state["rm"] = stat_log[:n_st].sum(dtype=torch.int64) * k_timed // max(n_st, 1)
@@ -811,7 +840,7 @@ def _measure(args, ctx, brief):
             "kernels": ks, "critical_path_gaps": gaps, "roofline": roof, "rooflines": rooflines,
         }
         if world > 1:
-            out.update(comm_fields(trainer if use_trainer else None, ctx, args))
+            out.update(comm_fields(trainer if use_trainer else None, dict(ctx, ms_per_step=out.get("ms_per_step")), args))
         if not args.no_cpu_baseline and world == 1 and not garden:     # the CPU leg restates the C2 workload only
             if scene:
                 out["cpu_baseline"] = cpu_baseline(model.density_bitfield.cpu().numpy(), args.cpu_seconds,

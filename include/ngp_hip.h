@@ -235,6 +235,13 @@ int ngp_hash_bwd_sliced_prep(const float* xyzs, const ngp_hash_levels* lv, int n
 int ngp_hash_bwd_sliced_main(const float* dout, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev, int enc_pairs,
                              float* dtable, int32_t* found_inf, const void* workspace, long long workspace_bytes,
                              void* stream);
+/* ngp_hash_bwd_sliced_main restricted to the levels in `level_mask` (bit l = level l), optionally on at most max_blocks persistent
+ * workgroups (0 = as many as CUs): a caller that exchanges the gradient between ranks launches the fine levels first and sends
+ * their part of dtable while the coarse levels are still being accumulated.  Launches over disjoint masks add up to the full
+ * scatter-add; they share the prepass's workspace and must run one after the other on one stream. */
+int ngp_hash_bwd_sliced_main_levels(const float* dout, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev, int enc_pairs,
+                                    float* dtable, int32_t* found_inf, const void* workspace, long long workspace_bytes,
+                                    unsigned int level_mask, int max_blocks, void* stream);
 /* the half2 encoder's backward (hash_encoder_half.py:163-213) over the same prepass: dtable_f16 = fp16 pairs [entries][2]; the
  * encoder's fp16 arithmetic per contribution (cell cast to f16, w * g rounded to f16), the owner's f64 sum rounded to fp16 once */
 int ngp_hash_bwd_sliced_main_f16(const float* dout, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev, int enc_pairs,

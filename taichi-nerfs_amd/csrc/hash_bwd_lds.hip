@@ -883,14 +883,18 @@ struct PlanCache {
     BwdPlan plan;
     uint32_t single_mask = 0u;
 };
-static const BwdPlan* get_plan(const ngp_hash_levels& lv, uint32_t& single_mask) {
-    static thread_local PlanCache cache[2];                      // two tables alternate in a process that trains and evaluates
-    static thread_local int victim = 0;
-    const Knobs& K = knobs();
+// level_mask / max_blocks: ngp_hash_bwd_sliced_main_levels -- the scatter-add of a level group in a launch of its own, on fewer
+// than 256 workgroups when something else (a collective) has to find free CUs beside it
+static const BwdPlan* get_plan(const ngp_hash_levels& lv, uint32_t& single_mask, uint32_t level_mask = 0xffffffffu, int max_blocks = 0) {
+    static thread_local PlanCache cache[6];                      // two tables alternate in a process that trains and evaluates,
+    static thread_local int victim = 0;                          // each possibly split into a few level groups
+    Knobs K = knobs();
+    K.level_mask &= level_mask;
+    if (max_blocks > 0 && (K.blocks <= 0 || max_blocks < K.blocks)) K.blocks = max_blocks;
     for (PlanCache& c : cache)
         if (c.valid && memcmp(&c.key, &lv, sizeof(lv)) == 0 && c.knobs == K) { single_mask = c.single_mask; return c.ok ? &c.plan : nullptr; }
     PlanCache& c = cache[victim];
-    victim ^= 1;
+    victim = (victim + 1) % 6;
     c.valid = true; c.key = lv; c.knobs = K;
     c.ok = build_plan_uncached(lv, c.plan, c.single_mask, K);
     single_mask = c.single_mask;
@@ -973,12 +977,13 @@ int ngp_hash_bwd_sliced_prep(const float* xyzs, const ngp_hash_levels* lv, int n
 }
 
 static int sliced_main(bool half, const float* dout, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev, int enc_pairs,
-                       void* dtable, int32_t* found_inf, const void* workspace, long long workspace_bytes, void* stream) {
+                       void* dtable, int32_t* found_inf, const void* workspace, long long workspace_bytes, void* stream,
+                       uint32_t level_mask = 0xffffffffu, int max_blocks = 0) {
     if (n_max <= 0) return 0;
     if (enc_pairs && !(lv->n_features == 2 && lv->n_levels == 16)) return -1;
     if (!workspace || workspace_bytes < ngp_hash_bwd_sliced_workspace(lv, n_max)) return -1;
     uint32_t single_mask;
-    const BwdPlan* plan = get_plan(*lv, single_mask);
+    const BwdPlan* plan = get_plan(*lv, single_mask, level_mask, max_blocks);
     if (!plan) return -2;
     if (plan->n_blocks <= 0) return 0;
     const WsLayout W = ws_layout(*lv, n_max);
@@ -999,6 +1004,16 @@ static int sliced_main(bool half, const float* dout, const ngp_hash_levels* lv, 
 int ngp_hash_bwd_sliced_main(const float* dout, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev, int enc_pairs, float* dtable,
                              int32_t* found_inf, const void* workspace, long long workspace_bytes, void* stream) {
     return sliced_main(false, dout, lv, n_max, n_dev, enc_pairs, dtable, found_inf, workspace, workspace_bytes, stream);
+}
+
+// The scatter-add of the levels in `level_mask` only (same prepass, same workspace; the other levels' part of dtable is not
+// touched): FusedTrainer's overlapped gradient exchange issues the fine levels first and sends their gradient while the coarse
+// levels are still being accumulated.  max_blocks > 0 caps the persistent workgroups (a collective needs CUs to run on).
+int ngp_hash_bwd_sliced_main_levels(const float* dout, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev, int enc_pairs,
+                                    float* dtable, int32_t* found_inf, const void* workspace, long long workspace_bytes,
+                                    unsigned int level_mask, int max_blocks, void* stream) {
+    return sliced_main(false, dout, lv, n_max, n_dev, enc_pairs, dtable, found_inf, workspace, workspace_bytes, stream, level_mask,
+                       max_blocks);
 }
 
 // the half2 encoder's backward (hash_encoder_half.py:163-213) on the same prepass: fp16 gradient table [entries][2], the

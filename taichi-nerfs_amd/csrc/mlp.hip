@@ -161,7 +161,7 @@ __global__ void __launch_bounds__(1024) adam_all_kernel(float4* __restrict__ tp,
                                                         float* __restrict__ v, const float* __restrict__ sf,
                                                         const int32_t* __restrict__ si, float beta1, float beta2, float eps,
                                                         int pairs, half_t* __restrict__ wpack) {
-    if (blockIdx.x == 0) adam_mlp_pack_block(p, g, m, v, sf, si, beta1, beta2, eps, pairs, wpack);
+    if (blockIdx.x == 0) { if (p) adam_mlp_pack_block(p, g, m, v, sf, si, beta1, beta2, eps, pairs, wpack); }     // (mlp == NULL: table range only)
     else adam_table_pass<SHADOW, GRAD16>(tp, tg, tm, tv, n4, sf, si, beta1, beta2, eps, shadow, (long)blockIdx.x - 1, (long)gridDim.x - 1);
 }
 

@@ -180,6 +180,17 @@ class FusedTrainer:
             enc._f16, enc._f16_ver = self.copy16_store[:nt].view(enc.hash_table.shape), None
             self.table_f16 = enc.table_f16().view(-1)
         self._master_stale = False            # sharded + 16-bit copy: the fp32 master of the other ranks' shards is gathered lazily
+        # NGP_COMM_OVERLAP=1 (sharded exchange, fp32 gradient, LDS-sliced scatter-add): the scatter-add is issued as one launch per
+        # LEVEL GROUP (NGP_COMM_GROUPS = first level of each group in launch order, default "8,0": levels 8-15, then 0-7) and a
+        # group's reduce-scatter travels while the next group is still being accumulated; every rank owns the rank-th 1/world of
+        # EACH group.  Default off until a multi-GPU run has decided.  NGP_COMM_STUB=1 replaces every collective
+        # by its local part (bench.py: the step without communication, i.e. what of comm_ms is exposed).
+        self._comm_stub = os.environ.get("NGP_COMM_STUB", "0") == "1"
+        self._pending_comm = []
+        self._groups = None
+        if (self.shard and os.environ.get("NGP_COMM_OVERLAP", "0") == "1" and not self.half and self.hash_bwd == "sliced"
+                and lvs.n_features == 2):
+            self._groups = self._make_groups(lvs, os.environ.get("NGP_COMM_GROUPS", "8,0"))
         self.repack()
 
     def repack(self):
@@ -297,6 +308,7 @@ class FusedTrainer:
                                       _ptr(M.xyzs), _ptr(M.dirs), _ptr(M.deltas), _ptr(M.ts), st), "ngp_march_train_write")
 
     def _launch(self, rays_o, rays_d, target, prefetch=None, src=None, src_next=None, noise=None):
+        self.finish_comm()                   # (overlapped exchange: the previous step's all-gathers, before the table is read)
         n = rays_o.shape[0]
         cfg = RenderConfig(self.model, self.exp_step_factor, self.T_threshold, self.max_samples)
         A = TrainArena.get(self.dev, n, self.max_samples)
@@ -432,6 +444,10 @@ class FusedTrainer:
             check(L.ngp_mlp_dw_reduce(_ptr(self.mlp_parts), n_parts, _ptr(self.mlp_grad), st), "ngp_mlp_dw_reduce")
         if hook is not None and self._prefetch_at <= 3:
             hook(); hook = None                                             # position 3: under the scatter-add and the optimizer
+        if self._groups is not None and sliced and not self._grads_only:
+            self._tail_overlapped(A, cfg, cnt, P, ws, found, st, hook, None)
+            return {"rm_samples": total, "vr_per_ray": vr_per_ray, "rgb": rgb, "opacity": opacity, "depth": depth, "rays_a": rays_a,
+                    "deltas": M.deltas, "ts": M.ts, "sq_err": sq_err}
         if self.half and sliced:
             check(L.ngp_hash_bwd_sliced_main_f16(_ptr(A.d_enc), ctypes.byref(cfg.levels), A.cap, _ptr(cnt), P, _ptr(self.table_grad), found,
                                                  _ptr(ws), ws.numel(), st), "ngp_hash_bwd_sliced_main_f16")
@@ -522,6 +538,176 @@ class FusedTrainer:
     def _nccl(self):
         return dist.get_backend(self.group) == "nccl"
 
+    # ---- overlapped exchange: one launch + one reduce-scatter / Adam / all-gather per level group -------------------------
+    class _Group:
+        pass
+
+    def _make_groups(self, lvs, spec):
+        """Level groups of the overlapped exchange.  Group k = levels [l0_k, l0_{k-1}) (the first one ends at the last level and
+        also takes the padding behind the table), flat float range [a, b) of the table storage; rank r owns the r-th chunk of
+        c = ceil((b - a) / (4 world)) * 4 floats of EACH group.  A group whose length is not a multiple of 4 * world (the coarse
+        levels' sizes are multiples of 16 floats only) is exchanged through padded staging buffers."""
+        starts = [int(x) for x in spec.split(",") if x.strip() != ""]
+        nl = int(lvs.n_levels)
+        if not starts or starts[-1] != 0 or any(a <= b for a, b in zip(starts, starts[1:])) or starts[0] >= nl:
+            raise ValueError("NGP_COMM_GROUPS must be strictly descending first levels ending in 0, e.g. '12,8,0' (got %r)" % spec)
+        F = int(lvs.n_features)
+        groups, hi_level = [], nl
+        for k, l0 in enumerate(starts):
+            g = self._Group()
+            g.index, g.l0, g.l1 = k, l0, hi_level
+            g.mask = sum(1 << l for l in range(l0, hi_level))
+            g.a = F * int(lvs.offset[l0])
+            g.b = self.nt_pad if k == 0 else F * int(lvs.offset[hi_level])
+            n = g.b - g.a
+            g.c = (n + 4 * self.world - 1) // (4 * self.world) * 4
+            g.aligned = g.c * self.world == n
+            g.lo = g.a + self.rank * g.c
+            g.hi = max(g.lo, min(g.lo + g.c, g.b))
+            g.shard = torch.zeros(g.c, device=self.dev, dtype=torch.float32)
+            g.stage = {}
+            g.comm = g.comm_shard = None
+            if self._comm is not None:
+                g.comm = torch.empty(g.c * self.world, device=self.dev, dtype=self._comm.dtype)
+                g.comm_shard = torch.empty(g.c, device=self.dev, dtype=self._comm.dtype)
+            groups.append(g)
+            hi_level = l0
+        if groups[0].hi <= groups[0].lo:
+            raise ValueError("the first level group leaves rank %d without a chunk" % self.rank)
+        return groups
+
+    def _stage(self, g, dtype):
+        buf = g.stage.get(dtype)
+        if buf is None:
+            buf = g.stage[dtype] = torch.zeros(g.c * self.world, device=self.dev, dtype=dtype)
+        return buf
+
+    def _timed_wait(self, name, fn):
+        """Overlapped exchange: what the step's stream WAITS for a collective that was issued earlier (sampled steps only)."""
+        return self._timed(name, fn)
+
+    def _rs_async(self, g):
+        """Start the reduce-scatter (cross-rank average) of group g's part of the table gradient; returns finish()."""
+        src = self.table_grad_store
+        n = g.b - g.a
+        inp = src[g.a:g.b]
+        if not g.aligned:
+            st_ = self._stage(g, torch.float32)
+            st_[:n].copy_(inp)
+            inp = st_
+        out = g.shard
+        if g.comm is not None:
+            g.comm.copy_(inp)
+            inp, out = g.comm, g.comm_shard
+        if self._comm_stub:
+            work, post = None, (lambda: out.copy_(inp[self.rank * g.c:(self.rank + 1) * g.c]))
+        elif self._nccl():
+            work, post = dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.AVG, group=self.group, async_op=True), None
+        else:                                      # gloo (functional tests): no AVG, no CUDA reduce-scatter
+            work = dist.all_reduce(inp, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            post = lambda: out.copy_(inp[self.rank * g.c:(self.rank + 1) * g.c]).div_(self.world)
+
+        def finish():
+            def wait():
+                if work is not None:
+                    work.wait()
+            self._timed_wait("wait_reduce_scatter_group%d" % g.index, wait)
+            if post is not None:
+                post()
+            if out is not g.shard:
+                g.shard.copy_(out)
+            src[g.a:g.b].zero_()                   # the local accumulator of this group, for the next step
+        return finish
+
+    def _ag_async(self, g, store):
+        """Start the all-gather of group g's part of `store` (every rank holds its own chunk); returns finish()."""
+        n = g.b - g.a
+        if self._comm_stub:
+            return lambda: None
+        if g.aligned:
+            mine = store[g.lo:g.lo + g.c]
+            if self._nccl():
+                work = dist.all_gather_into_tensor(store[g.a:g.b], mine, group=self.group, async_op=True)
+            else:
+                work = dist.all_gather([store[g.a + r * g.c:g.a + (r + 1) * g.c] for r in range(self.world)], mine.clone(),
+                                       group=self.group, async_op=True)
+            post = None
+        else:
+            st_ = self._stage(g, store.dtype)
+            mine = st_[self.rank * g.c:(self.rank + 1) * g.c]
+            mine[:g.hi - g.lo].copy_(store[g.lo:g.hi])
+            if self._nccl():
+                work = dist.all_gather_into_tensor(st_, mine, group=self.group, async_op=True)
+            else:
+                work = dist.all_gather([st_[r * g.c:(r + 1) * g.c] for r in range(self.world)], mine.clone(), group=self.group,
+                                       async_op=True)
+            post = lambda: store[g.a:g.b].copy_(st_[:n])
+
+        def finish():
+            self._timed_wait("wait_all_gather_group%d" % g.index, work.wait)
+            if post is not None:
+                post()
+        return finish
+
+    def finish_comm(self):
+        """Overlapped exchange: make the step's stream wait for the all-gathers of the previous step (before anything reads the
+        table: the next forward, an occupancy update, a checkpoint)."""
+        pend, self._pending_comm = self._pending_comm, []
+        for fin in pend:
+            fin()
+
+    def _gather_groups(self, store):
+        """state_dict() / sync_master() of the overlapped layout: all-gather a full-size buffer group by group (synchronous)."""
+        for g in self._groups:
+            self._ag_async(g, store)()
+
+    def _tail_overlapped(self, A, cfg, cnt, P, ws, found, st, hook, reduce_parts):
+        """Scatter-add, gradient exchange and optimizer of one step with the exchange overlapped (see __init__)."""
+        L, sf, si = self.L, self.state_f, self.state_i
+        max_blocks = int(os.environ.get("NGP_COMM_SCATTER_BLOCKS", "240"))     # leave CUs for RCCL's workgroups beside the later launches
+        fins = []
+        for k, g in enumerate(self._groups):
+            check(L.ngp_hash_bwd_sliced_main_levels(_ptr(A.d_enc), ctypes.byref(cfg.levels), A.cap, _ptr(cnt), P, _ptr(self.table_grad),
+                                                    found, _ptr(ws), ws.numel(), g.mask, 0 if k == 0 else max_blocks, st),
+                  "ngp_hash_bwd_sliced_main_levels")
+            fins.append(self._rs_async(g))
+        if hook is not None:
+            hook()                                                          # the next batch's march: under the exchange
+        # [MLP gradient | inf flag]: every rank has to take the same skip / step decision; behind the last reduce-scatter
+        flag_i = si[_SI_FOUND_INF:_SI_FOUND_INF + 1]
+        self._flag_f.copy_(flag_i)
+        small_work = None
+        if not self._comm_stub:
+            if self._nccl():
+                small_work = dist.all_reduce(self.small_bucket, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
+            else:
+                small_work = dist.all_reduce(self.small_bucket, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        def wait_small():
+            if small_work is not None:
+                small_work.wait()
+        self._timed_wait("wait_all_reduce_mlp_grad_and_flag", wait_small)
+        if small_work is not None and not self._nccl():
+            self.small_bucket.div_(self.world)
+        flag_i.copy_(self._flag_f != 0)
+        self._flag_f.zero_()
+        check(L.ngp_train_prologue(_ptr(sf), _ptr(si), self.lr0, self.eta_min, self.t_max, self.beta1, self.beta2, self.growth,
+                                   self.backoff, self.growth_interval, st), "ngp_train_prologue")
+        kind = 1 if self.table_bf16 is not None else 0
+        back = self.copy16_store if self.copy16_store is not None else self.table_store
+        for k, (g, fin) in enumerate(zip(self._groups, fins)):
+            fin()                                                           # this group's averaged gradient chunk has arrived
+            n_own = g.hi - g.lo
+            if n_own > 0:
+                sl = slice(g.lo, g.hi)
+                c16 = self.copy16_store[sl] if self.copy16_store is not None else None
+                mlp = (self.mlp_flat, self.mlp_grad, self.mlp_m, self.mlp_v) if k == 0 else (None, None, None, None)
+                check(L.ngp_adam_all_ex(_ptr(self.table_store[sl]), _ptr(g.shard), 0, _ptr(self.table_m[sl]), _ptr(self.table_v[sl]),
+                                        n_own, _ptr(c16), kind, _ptr(mlp[0]), _ptr(mlp[1]), _ptr(mlp[2]), _ptr(mlp[3]), _ptr(sf),
+                                        _ptr(si), self.beta1, self.beta2, self.eps, P, _ptr(self.wpack), st), "ngp_adam_all_ex")
+            self._pending_comm.append(self._ag_async(g, back))
+        if self.copy16_store is not None:
+            self._master_stale = True
+
     def _exchange_sharded(self, found, st):
         """(1) reduce-scatter of the padded table gradient: this rank receives the cross-rank AVERAGE of shard `rank` (MSE is a
         mean over the local ray shard); the local accumulator is cleared for the next step.  (2) one small all-reduce of
@@ -540,6 +726,8 @@ class FusedTrainer:
         flag_i = self.state_i[_SI_FOUND_INF:_SI_FOUND_INF + 1]
         self._flag_f.copy_(flag_i)
         def small():
+            if self._comm_stub:
+                return
             if self._nccl():
                 dist.all_reduce(self.small_bucket, op=dist.ReduceOp.AVG, group=self.group)
             else:
@@ -580,18 +768,26 @@ class FusedTrainer:
 
     def _reduce_scatter(self, out, inp):
         from .dist import reduce_scatter_avg
+        if self._comm_stub:
+            return out.copy_(inp[self.rank * out.numel():(self.rank + 1) * out.numel()])
         self._timed("reduce_scatter_table_grad", lambda: reduce_scatter_avg(out, inp, self.rank, self.world, self.group))
 
     def _all_gather(self, store, sl):
         from .dist import all_gather_shards
+        if self._comm_stub:
+            return store
         self._timed("all_gather_table", lambda: all_gather_shards(store, self.rank, self.shard_len, self.world, self.group))
 
     def sync_master(self):
         """Sharded optimizer with a 16-bit table copy: only the copy is exchanged every step; gather the fp32 master table of
         all shards (for a checkpoint / model.state_dict()).  No-op otherwise."""
+        self.finish_comm()
         if self.shard and self._master_stale:
-            lo = self.rank * self.shard_len
-            self._all_gather(self.table_store, slice(lo, lo + self.shard_len))
+            if self._groups is not None:
+                self._gather_groups(self.table_store)
+            else:
+                lo = self.rank * self.shard_len
+                self._all_gather(self.table_store, slice(lo, lo + self.shard_len))
             self._master_stale = False
 
     def _all_reduce(self):
@@ -611,6 +807,8 @@ class FusedTrainer:
             buf = self._comm
             buf.copy_(self.grad_flat)                           # loss-scaled gradients: bf16 keeps the fp32 exponent range
         def flat():
+            if self._comm_stub:
+                return
             if dist.get_backend(self.group) == "nccl":
                 dist.all_reduce(buf, op=dist.ReduceOp.AVG, group=self.group)
             else:
@@ -675,6 +873,7 @@ class FusedTrainer:
         """Occupancy-grid maintenance (train.py:178-182).  With world_size > 1 rank 0's freshly updated grid + bitfield are
         broadcast (8.4 MB + 262 KB per cascade, once per 16 steps): the update samples random cells, and replicas that march
         different bitfields stop being replicas."""
+        self.finish_comm()
         with torch.autocast(device_type="cuda", dtype=torch.float16):
             self.model.update_density_grid(density_threshold, warmup=warmup, **kw)
         if self.world > 1 and self.sync_occupancy:
@@ -694,7 +893,10 @@ class FusedTrainer:
         the other shards is brought up to date (sync_master).  The moments are saved WITHOUT the world-dependent padding
         ([:nt]): a checkpoint loads into any world size."""
         self.sync_master()
-        if self.shard:
+        if self.shard and self._groups is not None:
+            self._gather_groups(self.table_m)
+            self._gather_groups(self.table_v)
+        elif self.shard:
             lo = self.rank * self.shard_len
             sl = slice(lo, lo + self.shard_len)
             self._all_gather(self.table_m, sl)

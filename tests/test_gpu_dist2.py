@@ -19,8 +19,10 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, kind, shard_opt, bits_np, out_dir):
+def _worker(rank, world, port, kind, shard_opt, bits_np, out_dir, overlap=None):
     try:
+        if overlap:                          # round 4: the exchange overlapped with the scatter-add, one launch per level group
+            os.environ["NGP_COMM_OVERLAP"], os.environ["NGP_COMM_GROUPS"] = "1", overlap
         for p in (ROOT, os.path.join(ROOT, "taichi-nerfs_amd")):
             if p not in sys.path:
                 sys.path.insert(0, p)
@@ -33,7 +35,7 @@ def _worker(rank, world, port, kind, shard_opt, bits_np, out_dir):
         from ngp_hip.dist import shard_rays
         from ngp_hip.trainer import FusedTrainer
         dev = torch.device("cuda", 0)
-        n = 2048
+        n = 2048 if world == 2 else 2049         # (equal ray shards: the exchange averages)
 
         def make():
             torch.manual_seed(0)
@@ -51,6 +53,9 @@ def _worker(rank, world, port, kind, shard_opt, bits_np, out_dir):
         scale0 = 2.0**10 if kind == "half" else 2.0**15
         tr = FusedTrainer(make(), world_size=world, init_scale=scale0, shard_optimizer=shard_opt)
         assert tr.shard == bool(shard_opt) and tr.rank == rank
+        assert (tr._groups is not None) == bool(overlap)
+        if overlap and world == 3:               # 4 * world = 12 does not divide the groups' lengths: padded staging buffers
+            assert not all(g.aligned for g in tr._groups)
 
         # (1) exchanged gradients == single-rank full-batch gradients
         out = tr.compute_gradients(o[a:b], d[a:b], target[a:b], noise=noise[a:b].contiguous())
@@ -59,9 +64,9 @@ def _worker(rank, world, port, kind, shard_opt, bits_np, out_dir):
 
         def rel(x, y):
             return float((x - y).norm() / y.norm())
-        tol = 2e-2 if kind == "half" else 1e-5
+        tol = 2e-2 if kind == "half" else (1e-5 if world == 2 else 2e-4)    # (3 ranks: 1 / (3 n) and the mean of three are not exact in f32)
         assert rel(out["table_grad"], ref["table_grad"]) < tol, rel(out["table_grad"], ref["table_grad"])
-        assert rel(out["mlp_grad"], ref["mlp_grad"]) < (1e-3 if kind == "half" else 1e-5), rel(out["mlp_grad"], ref["mlp_grad"])
+        assert rel(out["mlp_grad"], ref["mlp_grad"]) < (1e-3 if kind == "half" else tol), rel(out["mlp_grad"], ref["mlp_grad"])
 
         # (2) inf on rank 1 only -> both ranks skip
         before = tr.table.clone()
@@ -95,7 +100,7 @@ def _worker(rank, world, port, kind, shard_opt, bits_np, out_dir):
             mine = t.detach().cpu().contiguous()
             both = [torch.empty_like(mine) for _ in range(world)]
             dist.all_gather(both, mine)
-            assert torch.equal(both[0], both[1]), "replicas differ in %s" % name
+            assert all(torch.equal(both[0], x) for x in both[1:]), "replicas differ in %s" % name
         if tr.copy16_store is not None:                           # the 16-bit copy is the cast of the (synced) master
             want = tr.table.half() if kind == "half" else tr.table.bfloat16()
             assert torch.equal(want.view(torch.int16), tr.copy16_store[:tr.nt].view(torch.int16))
@@ -107,10 +112,16 @@ def _worker(rank, world, port, kind, shard_opt, bits_np, out_dir):
         half_nt = tr.nt // 2
         for k in ("table_m", "table_v"):
             assert float(sd[k][:half_nt].abs().max()) > 0 and float(sd[k][half_nt:].abs().max()) > 0, "moments of one shard missing in " + k
+            if tr._groups is not None:                              # every rank's chunk of every level group arrived
+                for g_ in tr._groups:
+                    for r_ in range(world):
+                        lo_, hi_ = g_.a + r_ * g_.c, min(g_.a + (r_ + 1) * g_.c, g_.b, tr.nt)
+                        if hi_ - lo_ > 4096 and g_.l0 >= 8:       # (fine levels: every chunk sees gradients in 5 steps)
+                            assert float(sd[k][lo_:hi_].abs().max()) > 0, (k, g_.index, r_)
             mine = sd[k].cpu().contiguous()
             both = [torch.empty_like(mine) for _ in range(world)]
             dist.all_gather(both, mine)
-            assert torch.equal(both[0], both[1]), "rank checkpoints differ in " + k
+            assert all(torch.equal(both[0], x) for x in both[1:]), "rank checkpoints differ in " + k
         objs = [(sd, model_sd) if rank == 0 else None]
         dist.broadcast_object_list(objs, src=0)                    # everybody resumes from rank 0's files
         sd0, model_sd0 = objs[0]
@@ -143,12 +154,14 @@ def _worker(rank, world, port, kind, shard_opt, bits_np, out_dir):
         raise
 
 
-@pytest.mark.parametrize("kind,shard_opt", [("f32", True), ("f32", False), ("half", True), ("half", False), ("bf16", True)])
-def test_two_ranks_on_one_gpu(hip_lib, lego_bitfield, tmp_path, kind, shard_opt):
+@pytest.mark.parametrize("kind,shard_opt,overlap,world", [("f32", True, None, 2), ("f32", False, None, 2), ("half", True, None, 2),
+                                                          ("half", False, None, 2), ("bf16", True, None, 2),
+                                                          ("f32", True, "12,8,0", 2), ("bf16", True, "8,0", 2), ("f32", True, "8,0", 3)])
+def test_two_ranks_on_one_gpu(hip_lib, lego_bitfield, tmp_path, kind, shard_opt, overlap, world):
     import torch.multiprocessing as mp
-    port = 29600 + (os.getpid() + hash((kind, shard_opt))) % 300
+    port = 29600 + (os.getpid() + hash((kind, shard_opt, overlap, world))) % 300
     ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, kind, shard_opt, lego_bitfield, str(tmp_path))) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, kind, shard_opt, lego_bitfield, str(tmp_path), overlap)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -157,7 +170,7 @@ def test_two_ranks_on_one_gpu(hip_lib, lego_bitfield, tmp_path, kind, shard_opt)
     msg = "\n".join(open(os.path.join(tmp_path, f)).read() for f in fails)
     assert not fails, msg
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
-    assert sorted(os.listdir(tmp_path)) == ["ok_0", "ok_1"]
+    assert sorted(os.listdir(tmp_path)) == ["ok_%d" % r for r in range(world)]
 
 
 def _comm_worker(rank, world, port, out_dir):
