@@ -315,7 +315,7 @@ def _is_headline(args):
 OTHER_CONFIGS = [
     ("C2-bf16-table", "BASELINE config 2 as worded: bf16 storage copy of the fp32 master table", ["--table", "bf16"]),
     ("C5-half2", "BASELINE config 5: half2 encoder (hash_encoder_half semantics) + fp16 MFMA MLP", ["--half"]),
-    ("C3-garden", "BASELINE config 3 shape: scale 16, 6 cascades, max_res 4096, 65 536 rays, distortion loss (synthetic occupancy, random targets)", ["--scene", "garden"]),
+    ("C3-garden", "BASELINE config 3 shape: scale 16, 6 cascades, max_res 4096, 65 536 rays, distortion loss; analytic unbounded scene, model conditioned 512 steps", ["--scene", "garden", "--condition", "512"]),
     ("C2-65536-rays", "the per-GPU batch of BASELINE config 4's global batch on one GPU", ["--rays", "65536", "--pool", "8", "--condition", "512"]),
     ("C2-init-random50", "initialisation regime of SURVEY 8(d): seeded 50 % occupancy, random targets, ~250 samples per ray", ["--regime", "random50"]),
 ]
@@ -408,9 +408,7 @@ def _measure(args, ctx, brief):
     if args.half and args.table != "f32":
         raise SystemExit("--half already selects the fp16 table")
     garden = args.scene == "garden"
-    if garden and args.regime == "scene":
-        args.regime = "lego"                     # there is no analytic Garden scene: C3 keeps the synthetic-occupancy diagnostic state
-    scene = args.regime == "scene"
+    scene = args.regime == "scene"               # (round 4: Garden has an analytic scene too, synthetic.garden_field: C3 is conditioned like C2)
     if scene and args.condition % 16 != 0:
         raise SystemExit("--condition must be a multiple of 16 (the occupancy-update cadence)")
     if args.rays is None:
@@ -423,8 +421,10 @@ def _measure(args, ctx, brief):
                     table_dtype=torch.bfloat16 if args.table == "bf16" else None).to(dev)
     golden = os.path.join(ROOT, "tests", "golden", "lego_density_bitfield.npz")
     bits = bits_np = None
-    if garden:
+    if garden and not scene:
         bits_np = synthetic.ball_slab_bitfield(model.cascades, 16.0, seed=23)
+    elif scene:
+        pass                                     # the model's own occupancy grid
     elif args.regime == "lego":
         bits_np = np.load(golden)["density_bitfield"]
     elif args.regime == "random50":
@@ -450,12 +450,14 @@ def _measure(args, ctx, brief):
 
     # a pool of synthetic batches resident in HBM before the timed region (rank-dependent shards of one stream of seeds);
     # scene regime: every ray's target colour is the analytic scene's radiance along it, rendered here once
-    n_pool = args.pool if scene else 8
+    n_pool = (min(args.pool, 8) if garden else args.pool) if scene else 8       # (Garden: 65 536 rays per batch)
     pool = []
     for b in range(n_pool):
         o, d = (synthetic.garden_rays if garden else synthetic.lego_rays)(args.rays, seed=1000 + 97 * b + rank)
         o, d = torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev)
-        if scene:
+        if scene and garden:
+            tgt = synthetic.garden_render_gt(o, d, scale=16.0).contiguous()
+        elif scene:
             tgt = synthetic.procedural_render_gt(o, d).contiguous()
         else:
             g = torch.Generator(device="cpu").manual_seed(b * 131 + rank)
@@ -792,16 +794,22 @@ def _measure(args, ctx, brief):
                     "live_over_marched": vr / max(rm, 1),
                     "occupied_fraction": float((torch.cat([(model.density_bitfield >> b) & 1 for b in range(8)]) > 0).float().mean())}
         if scene:
-            workload.update({"targets": "analytic Lego-shape scene (ngp_hip/synthetic.py), dense-integration radiance per ray, white background",
+            workload.update({"targets": ("analytic Garden-shape unbounded scene (ngp_hip/synthetic.py: object on a table, ground to 0.85 x scale, "
+                                         "boxes at radii 1.5-10), exponentially spaced integration per ray, black background") if garden else
+                                        "analytic Lego-shape scene (ngp_hip/synthetic.py), dense-integration radiance per ray, white background",
                              "conditioning_steps": args.condition, "conditioning_seconds": t_cond, "pool_batches": n_pool,
                              "occupancy": "the model's own grid (update every 16 steps; all-cell warm-up for steps < 256)"})
             if use_trainer:
                 workload["loss_at_end"] = trainer.last_loss()
         if garden:
             text = ("360_v2 Garden shape (BASELINE C3): %d rays/GPU/step, scale 16, 6 cascades 128^3, hash grid L=16 F=2 "
-                    "T=2^19 max_res=4096 (%s table), exp_step_factor 1/256, synthetic ball+slab+far-cells occupancy, random target colours, "
-                    "MSE + 1e-3 distortion loss, full train step (fwd+bwd+GradScaler+Adam, grid update every 16 steps)"
-                    % (args.rays, "f16" if args.half else args.table))
+                    "T=2^19 max_res=4096 (%s table), exp_step_factor 1/256, %s, "
+                    "MSE + 1e-3 distortion loss, full train step (fwd+bwd+GradScaler+Adam, grid update every 16 steps); "
+                    "%.1f marched / %.1f composited samples per ray"
+                    % (args.rays, "f16" if args.half else args.table,
+                       ("analytic-scene targets, model conditioned for %d steps, marching its own occupancy grid" % args.condition) if scene
+                       else "synthetic ball+slab+far-cells occupancy, random target colours (diagnostic state)",
+                       rm / total_rays * world, vr / total_rays * world))
         else:
             text = ("Synthetic-NeRF Lego shape (BASELINE C2%s): %d rays/GPU/step, scale 0.5, 1 cascade 128^3, hash grid L=16 F=2 T=2^19 "
                     "max_res=1024 (%s table), %s, full train step (fwd+bwd+GradScaler+Adam, grid update every 16 steps); "

@@ -54,6 +54,36 @@ def cameras(n, radius, seed):
     return c2w
 
 
+def garden_cameras(n, seed):
+    """n camera-to-world matrices in NORMALISED (= model) coordinates for the Garden-shape scene: a ring of radius 1.0-1.3 at heights
+    0.15-0.6 around the object on the table, looking at it (the 360_v2 capture pattern)."""
+    g = torch.Generator().manual_seed(seed)
+    phi = 2 * math.pi * (torch.arange(n) + torch.rand(n, generator=g)) / n
+    rad = 1.0 + 0.3 * torch.rand(n, generator=g)
+    pos = torch.stack([rad * torch.cos(phi), rad * torch.sin(phi), 0.15 + 0.45 * torch.rand(n, generator=g)], -1)
+    fwd = F.normalize(torch.tensor([0.0, 0.0, -0.1]) + 0.05 * torch.randn(n, 3, generator=g) - pos, dim=-1)
+    up = torch.tensor([0.0, 0.0, 1.0]).expand_as(fwd)
+    right = F.normalize(torch.cross(fwd, up, dim=-1), dim=-1)
+    down = torch.cross(fwd, right, dim=-1)
+    c2w = torch.eye(4).repeat(n, 1, 1)
+    c2w[:, :3, :3] = torch.stack([right, down, fwd], -1)
+    c2w[:, :3, 3] = pos
+    return c2w[torch.randperm(n, generator=g)]                   # (train / test views interleaved around the ring)
+
+
+def render_views_garden(c2w, wh, focal, device, model_scale, n_samples=768):
+    """[n, wh*wh, 3] radiance of the analytic Garden-shape scene (synthetic.garden_field) inside [-model_scale, model_scale]^3,
+    black background (what rendering.py composites onto for exp_step_factor > 0)."""
+    from ngp_hip.synthetic import garden_render_gt
+    ys, xs = torch.meshgrid(torch.arange(wh, device=device), torch.arange(wh, device=device), indexing="ij")
+    dirs = torch.stack([(xs - wh / 2 + 0.5) / focal, (ys - wh / 2 + 0.5) / focal, torch.ones_like(xs, dtype=torch.float32)], -1).reshape(-1, 3)
+    out = []
+    for p in c2w.to(device):
+        d = dirs @ p[:3, :3].T
+        out.append(garden_render_gt(p[:3, 3].expand_as(d).contiguous(), d.contiguous(), scale=model_scale, n_samples=n_samples).cpu())
+    return torch.stack(out)
+
+
 def render_views(c2w, wh, focal, device, n_samples=512):
     """[n, wh*wh, 3] float32 radiance of the analytic scene, white background.  Only the rays that meet the scene's bounding
     box are integrated (inside that box, n_samples midpoint samples); everything else is background."""
@@ -74,8 +104,10 @@ def render_views(c2w, wh, focal, device, n_samples=512):
     return torch.stack(out)
 
 
-def write_scene(out, wh=800, n_train=100, n_val=0, n_test=10, radius=1.39, seed=23, device=None, n_samples=512):
-    """Returns a small dict describing what was written."""
+def write_scene(out, wh=800, n_train=100, n_val=0, n_test=10, radius=1.39, seed=23, device=None, n_samples=512, scene="lego",
+                model_scale=8.0):
+    """Returns a small dict describing what was written.  scene="garden": the analytic unbounded scene (object in the unit box the
+    bbox file names, ground and far boxes out to +-model_scale: train it with `--scale <model_scale>`, like 360_v2 Garden)."""
     from PIL import Image
     device = device or ("cuda" if torch.cuda.is_available() else "cpu")
     os.makedirs(os.path.join(out, "rgb"), exist_ok=True)
@@ -87,9 +119,9 @@ def write_scene(out, wh=800, n_train=100, n_val=0, n_test=10, radius=1.39, seed=
     with open(os.path.join(out, "bbox.txt"), "w") as f:
         f.write("%.6f %.6f %.6f %.6f %.6f %.6f 0.4\n" % ((-BBOX_HALF,) * 3 + (BBOX_HALF,) * 3))
     n = n_train + n_val + n_test
-    c2w = cameras(n, radius, seed)
+    c2w = garden_cameras(n, seed) if scene == "garden" else cameras(n, radius, seed)
     t0 = time.time()
-    imgs = render_views(c2w, wh, focal, device, n_samples)
+    imgs = render_views_garden(c2w, wh, focal, device, model_scale) if scene == "garden" else render_views(c2w, wh, focal, device, n_samples)
     t_render = time.time() - t0
     t0 = time.time()
     for k in range(n):
@@ -103,7 +135,8 @@ def write_scene(out, wh=800, n_train=100, n_val=0, n_test=10, radius=1.39, seed=
         Image.fromarray(rgba, "RGBA").save(os.path.join(out, "rgb", name + ".png"), compress_level=1)
     return {"out": out, "image_wh": wh, "downsample_to_pass": wh / 800.0, "n_train": n_train, "n_val": n_val, "n_test": n_test,
             "gt_render_seconds": t_render, "png_write_seconds": time.time() - t0, "device": str(device),
-            "scene": "procedural Lego-shape (ngp_hip/synthetic.py) -- NOT Synthetic-NeRF Lego"}
+            "scene": ("procedural Garden-shape unbounded scene, model scale %g (ngp_hip/synthetic.py) -- NOT 360_v2 Garden" % model_scale)
+                     if scene == "garden" else "procedural Lego-shape (ngp_hip/synthetic.py) -- NOT Synthetic-NeRF Lego"}
 
 
 def main():
@@ -114,9 +147,12 @@ def main():
     ap.add_argument("--n_val", type=int, default=0)
     ap.add_argument("--n_test", type=int, default=10)
     ap.add_argument("--seed", type=int, default=23)
+    ap.add_argument("--scene", default="lego", choices=["lego", "garden"])
+    ap.add_argument("--model_scale", type=float, default=8.0, help="--scene garden: the --scale train.py will be given")
     args = ap.parse_args()
     import json
-    print(json.dumps(write_scene(args.out, args.wh, args.n_train, args.n_val, args.n_test, seed=args.seed)))
+    print(json.dumps(write_scene(args.out, args.wh, args.n_train, args.n_val, args.n_test, seed=args.seed, scene=args.scene,
+                                 model_scale=args.model_scale)))
 
 
 if __name__ == "__main__":

@@ -76,26 +76,35 @@ def main():
     ap.add_argument("--n_test", type=int, default=10)
     ap.add_argument("--max_steps", type=int, default=20000)
     ap.add_argument("--batch_size", type=int, default=8192)
+    ap.add_argument("--scene", default="lego", choices=["lego", "garden"],
+                    help="garden: the analytic unbounded scene + the recipe of scripts/train_360_v2_garden.sh:5-11 (--scale 8 --batch_size 4096 "
+                         "--downsample 0.25) through the NSVF loader (there is no colmap capture here)")
+    ap.add_argument("--scale", type=float, default=None, help="train.py --scale (default: 0.5 for lego, 8 for garden)")
     ap.add_argument("--extra", default="", help="extra train.py arguments, e.g. '--distortion_loss_w 1e-3' or '--half_opt'")
     ap.add_argument("--env", default="", help="extra environment, e.g. 'NGP_FUSED_RENDER=0'")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--log", default=None, help="write train.py's own stdout (its step / evaluation lines) to this file, verbatim")
     ap.add_argument("--keep", action="store_true", help="keep the scratch work directory")
     args = ap.parse_args()
 
     work = tempfile.mkdtemp(prefix="ngp_ref_train_")
     lease = os.path.join(work, "lease")
     source, shas = make_lease(args.ref, lease)
-    data = args.data or os.path.join(tempfile.gettempdir(), "ngp_nsvf_%d_%d_%d" % (args.wh, args.n_train, args.n_test),
-                                     "Synthetic_NSVF_procedural", "Lego")
+    garden = args.scene == "garden"
+    scale = args.scale if args.scale is not None else (8.0 if garden else 0.5)
+    data = args.data or os.path.join(tempfile.gettempdir(), "ngp_nsvf_%s_%d_%d_%d" % (args.scene, args.wh, args.n_train, args.n_test),
+                                     "Synthetic_NSVF_procedural" + ("_garden" if garden else ""), "Lego")
     scene = None
     if not os.path.exists(os.path.join(data, "bbox.txt")):
         sys.path.insert(0, os.path.join(ROOT, "scripts"))
         import make_nsvf_scene
-        scene = make_nsvf_scene.write_scene(data, wh=args.wh, n_train=args.n_train, n_test=args.n_test)
+        scene = make_nsvf_scene.write_scene(data, wh=args.wh, n_train=args.n_train, n_test=args.n_test, scene=args.scene, model_scale=scale)
     cmd = [sys.executable, os.path.join(lease, "train.py"), "--root_dir", data, "--exp_name", "Lego", "--batch_size", str(args.batch_size),
            "--lr", "1e-2", "--gpu", "0", "--max_steps", str(args.max_steps)]
     if args.wh != 800:
         cmd += ["--downsample", repr(args.wh / 800.0)]
+    if scale != 0.5:
+        cmd += ["--scale", repr(scale)]
     cmd += args.extra.split()
     env = dict(os.environ)
     env["PYTHONPATH"] = os.pathsep.join([os.path.join(ROOT, "taichi-nerfs_amd"), os.path.join(ROOT, "taichi-nerfs_amd", "compat")])
@@ -106,6 +115,10 @@ def main():
     p = subprocess.run(cmd, cwd=work, env=env, capture_output=True, text=True)
     wall = time.time() - t0
     log = p.stdout
+    if args.log:
+        os.makedirs(os.path.dirname(os.path.abspath(args.log)), exist_ok=True)
+        with open(args.log, "w") as f:
+            f.write("$ " + " ".join(cmd).replace(lease, "<lease>") + "\n" + log)
     sys.stderr.write(p.stderr[-4000:])
     if p.returncode != 0:
         sys.stdout.write(log[-4000:])
@@ -117,7 +130,8 @@ def main():
     last = steps[-1] if steps else None
     out = {
         "what": "the reference's unchanged train.py (+ opt.py, gui.py, datasets/) run against this repo's modules package",
-        "scene": "procedural Lego-shape scene in NSVF Synthetic layout (scripts/make_nsvf_scene.py) -- NOT Synthetic-NeRF Lego",
+        "scene": ("procedural Garden-shape unbounded scene in NSVF Synthetic layout (scripts/make_nsvf_scene.py --scene garden) -- NOT 360_v2 Garden"
+                  if garden else "procedural Lego-shape scene in NSVF Synthetic layout (scripts/make_nsvf_scene.py) -- NOT Synthetic-NeRF Lego"),
         "command": " ".join(cmd).replace(lease, "<lease>"), "pythonpath": "taichi-nerfs_amd:taichi-nerfs_amd/compat", "extra_env": args.env,
         "driver_source": source, "driver_sha256": shas, "driver_sha256_matches_reference_snapshot": True,
         "train_py_diff_vs_reference": "empty (sha256 equal)",

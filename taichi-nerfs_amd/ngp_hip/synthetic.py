@@ -5,6 +5,9 @@
                reference hands to render() for Lego (un-normalised directions, one origin per ray).
 `garden_rays`: N rays from cameras on a ring inside a scale-16 unbounded scene (360_v2 Garden shape).
 `random_bitfield` / `ball_slab_bitfield`: seeded occupancy bitfields for the initialisation / Garden regimes.
+`garden_field` / `garden_render_gt`: an analytic UNBOUNDED scene of the 360_v2 Garden shape (object on a table in the unit box,
+               ground out to 0.85 * scale, boxes at radii 1.5 .. 10) and its renderer (exponentially spaced samples, black
+               background) -- the scene-consistent targets of bench.py --scene garden and of the Garden recipe run.
 `procedural_field` / `procedural_render_gt`: an analytic "Lego-shape" scene (base plate, tower, studs inside
                [-0.35, 0.35]^3, white background) and its dense-integration renderer -- the scene-consistent target
                colours bench.py and examples/train_procedural.py train against.
@@ -54,6 +57,77 @@ def procedural_render_gt(rays_o, rays_d, n_samples=768, chunk=16384, scale=0.5):
             T = torch.cumprod(torch.cat([torch.ones_like(alpha[:, :1]), 1 - alpha[:, :-1]], 1), 1)
             w = alpha * T * hit[:, None]
             out.append((w[..., None] * rgb).sum(1) + (1 - w.sum(1, keepdim=True)))       # white background
+    return torch.cat(out)
+
+
+# ---- analytic unbounded scene (Garden shape): everything in MODEL coordinates, z up, the cameras ring at radius ~1 ---------
+GARDEN_SIGMA = 80.0
+
+
+def _garden_far_boxes(scale):
+    boxes = []
+    for k in range(10):
+        r = 1.5 * 1.6 ** (k % 5) * (1.0 if k < 5 else 1.27)
+        if r > 0.8 * scale:
+            continue
+        ang = 2 * np.pi * (k / 10.0) + 0.3
+        h = 0.18 * r
+        col = (0.25 + 0.7 * ((k * 37) % 10) / 10.0, 0.25 + 0.7 * ((k * 53) % 10) / 10.0, 0.25 + 0.7 * ((k * 71) % 10) / 10.0)
+        boxes.append(((r * np.cos(ang), r * np.sin(ang), -0.65 + h), (h, h, h), col))
+    return boxes
+
+
+def garden_field(x, scale=16.0):
+    """x: [...,3] torch tensor (model coordinates) -> (sigma [...], rgb [...,3]).  A striped ball on a table inside the unit box,
+    a ground slab (z in [-0.75, -0.65]) with a polar checker out to 0.85 * scale, ten boxes growing with their distance."""
+    import torch
+    X, Y, Z = x[..., 0], x[..., 1], x[..., 2]
+    sigma = torch.zeros(x.shape[:-1], device=x.device)
+    rgb = torch.zeros(x.shape, device=x.device)
+
+    def put(inside, col):
+        nonlocal sigma, rgb
+        sigma = torch.where(inside, torch.full_like(sigma, GARDEN_SIGMA), sigma)
+        rgb = torch.where(inside[..., None], col, rgb)
+    rxy = torch.sqrt(X * X + Y * Y).clamp_min(1e-6)
+    ground = (Z > -0.75) & (Z < -0.65) & (rxy < 0.85 * scale)
+    check = torch.sign(torch.sin(8.0 * torch.atan2(Y, X)) * torch.sin(5.0 * torch.log(rxy + 0.05)))
+    g_col = torch.stack([0.35 + 0.15 * check, 0.5 + 0.2 * check, 0.3 + 0.1 * check], -1)
+    put(ground, g_col)
+    table = (X.abs() < 0.45) & (Y.abs() < 0.45) & ((Z + 0.4).abs() < 0.05)
+    put(table, torch.stack([0.55 + 0.1 * torch.sin(30.0 * X), 0.35 + 0.05 * torch.sin(30.0 * X), 0.2 + 0.0 * X], -1))
+    for leg in ((0.38, 0.38), (-0.38, 0.38), (0.38, -0.38), (-0.38, -0.38)):
+        put(((X - leg[0]).abs() < 0.04) & ((Y - leg[1]).abs() < 0.04) & (Z > -0.65) & (Z < -0.45),
+            torch.tensor([0.3, 0.2, 0.1], device=x.device).expand(x.shape))
+    ball = (X * X + Y * Y + (Z + 0.05) ** 2) < 0.3 ** 2
+    stripe = 0.5 + 0.5 * torch.sin(25.0 * Z + 8.0 * torch.atan2(Y, X))
+    put(ball, torch.stack([0.9 * stripe + 0.05, 0.2 + 0.6 * (1 - stripe), 0.15 + 0.0 * X], -1))
+    for c, h, col in _garden_far_boxes(scale):
+        inside = ((x - torch.tensor(c, device=x.device, dtype=x.dtype)).abs() < torch.tensor(h, device=x.device, dtype=x.dtype)).all(-1)
+        shade = 0.7 + 0.3 * torch.sin(6.0 * (X + Y + Z) / h[0])
+        put(inside, torch.tensor(col, device=x.device) * shade[..., None])
+    return sigma, rgb
+
+
+def garden_render_gt(rays_o, rays_d, scale=16.0, n_samples=1024, chunk=8192, near=0.02):
+    """Radiance of the analytic Garden-shape scene along rays [N,3] whose origins lie inside [-scale, scale]^3: midpoint rule over
+    n_samples EXPONENTIALLY spaced points between `near` and the exit of the box (the march's own spacing grows with t, train.py:54),
+    black background (rendering.py:219-226 for exp_step_factor > 0) -> [N,3] float32."""
+    import torch
+    out = []
+    with torch.no_grad():
+        for i in range(0, rays_o.shape[0], chunk):
+            o, d = rays_o[i:i + chunk].float(), rays_d[i:i + chunk].float()
+            inv = 1.0 / d
+            far = torch.maximum((-scale - o) * inv, (scale - o) * inv).amin(-1).clamp_min(2 * near)
+            ratio = torch.log(far / near)
+            u = (torch.arange(n_samples, device=o.device) + 0.5) / n_samples
+            ts = near * torch.exp(u[None, :] * ratio[:, None])
+            dt = ts * (ratio / n_samples)[:, None] * d.norm(dim=-1, keepdim=True)
+            sigma, rgb = garden_field(o[:, None] + ts[..., None] * d[:, None], scale)
+            alpha = 1 - torch.exp(-sigma * dt)
+            T = torch.cumprod(torch.cat([torch.ones_like(alpha[:, :1]), 1 - alpha[:, :-1]], 1), 1)
+            out.append(((alpha * T)[..., None] * rgb).sum(1))
     return torch.cat(out)
 
 
