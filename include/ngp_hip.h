@@ -88,6 +88,19 @@ int ngp_march_train_fused(const float* rays_o, const float* rays_d, const float*
                           int grid_size, float scale, float exp_step_factor, int max_samples, int n_rays,
                           float* stage, int32_t* ctr, int32_t* rays_a, int32_t* total, float* xyzs, float* dirs,
                           float* deltas, float* ts, void* stream);
+/* ngp_march_train_fused writes start + k for every emitted sample: xyzs / dirs / deltas / ts must have n_rays * max_samples rows.
+ * With smaller arrays use this form: samples at or beyond `capacity` rows are dropped, total[0] still counts them. */
+int ngp_march_train_fused_cap(const float* rays_o, const float* rays_d, const float* hits_t, const uint8_t* density_bitfield,
+                              const uint32_t* coarse, const float* noise, int cascades, int grid_size, float scale,
+                              float exp_step_factor, int max_samples, int n_rays, long long capacity, float* stage, int32_t* ctr,
+                              int32_t* rays_a, int32_t* total, float* xyzs, float* dirs, float* deltas, float* ts, void* stream);
+/* The same with the jitter drawn in the kernel: ray r gets rng_uniform(seed, r) (splitmix64 -> 24-bit uniform in [0, 1); the
+ * reference draws torch.rand_like, ray_march.py:138).  ngp_rng_uniform writes those values out (tests / callers wanting a tensor). */
+int ngp_march_train_fused_rng(const float* rays_o, const float* rays_d, const float* hits_t, const uint8_t* density_bitfield,
+                              const uint32_t* coarse, unsigned long long seed, int cascades, int grid_size, float scale,
+                              float exp_step_factor, int max_samples, int n_rays, float* stage, int32_t* ctr, int32_t* rays_a,
+                              int32_t* total, float* xyzs, float* dirs, float* deltas, float* ts, void* stream);
+int ngp_rng_uniform(unsigned long long seed, int n, float* out, void* stream);
 int ngp_march_train_scan(const int32_t* counts, int n_rays, int32_t* rays_a /*[n,3]*/,
                          int32_t* total /*[1]*/, void* stream);
 int ngp_march_train_write(const float* rays_o, const float* rays_d, const int32_t* rays_a,

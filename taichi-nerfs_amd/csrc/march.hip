@@ -27,7 +27,10 @@ struct MarchParams {
     float grid_size_f, grid_size_inv, grid_max;   // G, 1/G, G-1
     float scale, esf, dt_min, dt_max;
     float scale_inv, mb0, mb0_inv;                // 1/scale; mip_bound of cascade 0 = min(2^-1, scale) and its reciprocal
-};
+    unsigned long long rng_seed;                  // rng != 0: the jitter of ray r is rng_uniform(rng_seed, r) instead of noise[r]
+    int rng;
+    long long capacity;                           // one-launch march: rows of the output arrays (samples at or beyond it are dropped,
+};                                                // `total` still counts them); 0 = the caller guarantees n_rays * max_samples rows
 
 __host__ inline MarchParams make_march_params(int cascades, int grid_size, float scale, float esf) {
     MarchParams p;
@@ -37,6 +40,7 @@ __host__ inline MarchParams make_march_params(int cascades, int grid_size, float
     p.grid_size_f = (float)grid_size;
     p.grid_size_inv = 1.0f / (float)grid_size;
     p.grid_max = (float)grid_size - 1.0f;
+    p.rng_seed = 0ull; p.rng = 0; p.capacity = 0;
     p.scale = scale;
     p.esf = esf;
     p.dt_min = (float)(1.7320508075688772 / 1024);                       // utils.py:15
@@ -174,7 +178,7 @@ __device__ __forceinline__ int march_rays_of_wave(const float* __restrict__ rays
     float t1 = h.x;
     const float t2 = h.y;
     const float dt_c = calc_dt(0.0f, p.esf, p.dt_min, p.dt_max);                    // the step when exp_step_factor == 0
-    if (t1 >= 0.0f) t1 += calc_dt(t1, p.esf, p.dt_min, p.dt_max) * noise[rr];      // ray_march.py:39-41
+    if (t1 >= 0.0f) t1 += calc_dt(t1, p.esf, p.dt_min, p.dt_max) * (p.rng ? rng_uniform(p.rng_seed, (unsigned int)rr) : noise[rr]);      // ray_march.py:39-41
     float t = t1;                                    // group-uniform: first orbit point of the current batch
     int n = 0;                                       // group-uniform: samples emitted so far
     float t_target = -INFINITY;                      // group-uniform: orbit points below this are skipped
@@ -367,6 +371,7 @@ __global__ void __launch_bounds__(1024) march_fused_kernel(const float* __restri
         for (int k = sub; k < n; k += G) {
             const float2 s = row[k];
             const size_t g = (size_t)start + k;
+            if (p.capacity > 0 && (long long)g >= p.capacity) break;                 // (never write past the caller's arrays)
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
                 xyzs[3 * g + a] = o[a] + s.x * d[a];                               // ray_march.py:88
@@ -623,13 +628,14 @@ int ngp_march_train_count_ex(const float* rays_o, const float* rays_d, const flo
     return 0;
 }
 
-int ngp_march_train_fused(const float* rays_o, const float* rays_d, const float* hits_t, const uint8_t* density_bitfield,
-                          const uint32_t* coarse, const float* noise, int cascades, int grid_size, float scale, float exp_step_factor,
-                          int max_samples, int n_rays, float* stage, int32_t* ctr, int32_t* rays_a, int32_t* total, float* xyzs,
-                          float* dirs, float* deltas, float* ts, void* stream) {
+static int march_train_fused(const float* rays_o, const float* rays_d, const float* hits_t, const uint8_t* density_bitfield,
+                             const uint32_t* coarse, const float* noise, bool rng, unsigned long long seed, int cascades, int grid_size,
+                             float scale, float exp_step_factor, int max_samples, int n_rays, float* stage, int32_t* ctr, int32_t* rays_a,
+                             int32_t* total, float* xyzs, float* dirs, float* deltas, float* ts, void* stream, long long capacity = 0) {
     if (n_rays <= 0) return 0;
-    if (!ctr || !rays_a || !total) return -1;
+    if (!ctr || !rays_a || !total || (!rng && !noise) || capacity < 0) return -1;
     MarchParams p = make_march_params(cascades, grid_size, scale, exp_step_factor);
+    p.rng = rng ? 1 : 0; p.rng_seed = seed; p.capacity = capacity;
     hipStream_t s = (hipStream_t)stream;
     constexpr int RPB = 16 * (64 / MARCH_GROUP);
 #define NGP_LAUNCH_MARCH(CD, C1)                                                                                                   \
@@ -640,6 +646,48 @@ int ngp_march_train_fused(const float* rays_o, const float* rays_d, const float*
     if (cd && c1) NGP_LAUNCH_MARCH(true, true); else if (cd) NGP_LAUNCH_MARCH(true, false);
     else if (c1) NGP_LAUNCH_MARCH(false, true); else NGP_LAUNCH_MARCH(false, false);
 #undef NGP_LAUNCH_MARCH
+    NGP_LAUNCH_CHECK();
+    return 0;
+}
+
+int ngp_march_train_fused(const float* rays_o, const float* rays_d, const float* hits_t, const uint8_t* density_bitfield,
+                          const uint32_t* coarse, const float* noise, int cascades, int grid_size, float scale, float exp_step_factor,
+                          int max_samples, int n_rays, float* stage, int32_t* ctr, int32_t* rays_a, int32_t* total, float* xyzs,
+                          float* dirs, float* deltas, float* ts, void* stream) {
+    return march_train_fused(rays_o, rays_d, hits_t, density_bitfield, coarse, noise, false, 0ull, cascades, grid_size, scale,
+                             exp_step_factor, max_samples, n_rays, stage, ctr, rays_a, total, xyzs, dirs, deltas, ts, stream);
+}
+
+// ... with output arrays of only `capacity` rows: samples that would land at or beyond it are dropped (never written); total[0]
+// still holds the full count, so the caller sees total > capacity
+int ngp_march_train_fused_cap(const float* rays_o, const float* rays_d, const float* hits_t, const uint8_t* density_bitfield,
+                              const uint32_t* coarse, const float* noise, int cascades, int grid_size, float scale,
+                              float exp_step_factor, int max_samples, int n_rays, long long capacity, float* stage, int32_t* ctr,
+                              int32_t* rays_a, int32_t* total, float* xyzs, float* dirs, float* deltas, float* ts, void* stream) {
+    return march_train_fused(rays_o, rays_d, hits_t, density_bitfield, coarse, noise, false, 0ull, cascades, grid_size, scale,
+                             exp_step_factor, max_samples, n_rays, stage, ctr, rays_a, total, xyzs, dirs, deltas, ts, stream, capacity);
+}
+
+// The same march with the per-ray jitter drawn IN the kernel: rng_uniform(seed, ray) (ngp_device.h) -- no noise tensor and no
+// generator launch in front of it (FusedTrainer's prefetched march: torch's uniform_ kernel used to sit on the side stream for
+// 130-170 us waiting for a free CU under the scatter-add).
+int ngp_march_train_fused_rng(const float* rays_o, const float* rays_d, const float* hits_t, const uint8_t* density_bitfield,
+                              const uint32_t* coarse, unsigned long long seed, int cascades, int grid_size, float scale,
+                              float exp_step_factor, int max_samples, int n_rays, float* stage, int32_t* ctr, int32_t* rays_a,
+                              int32_t* total, float* xyzs, float* dirs, float* deltas, float* ts, void* stream) {
+    return march_train_fused(rays_o, rays_d, hits_t, density_bitfield, coarse, nullptr, true, seed, cascades, grid_size, scale,
+                             exp_step_factor, max_samples, n_rays, stage, ctr, rays_a, total, xyzs, dirs, deltas, ts, stream);
+}
+
+__global__ void rng_uniform_kernel(unsigned long long seed, int n, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = rng_uniform(seed, (unsigned int)i);
+}
+
+// out[i] = rng_uniform(seed, i): the jitter ngp_march_train_fused_rng(seed) gives ray i (tests; callers that want it as a tensor)
+int ngp_rng_uniform(unsigned long long seed, int n, float* out, void* stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(rng_uniform_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, seed, n, out);
     NGP_LAUNCH_CHECK();
     return 0;
 }

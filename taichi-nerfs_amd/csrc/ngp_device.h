@@ -135,6 +135,18 @@ __device__ __forceinline__ int wave_scan_add_i(int v, int lane) {
 
 // ---- optimizer state layout (include/ngp_hip.h) and the dense Adam pass shared by optim.hip and mlp.hip ----------------
 enum { SF_LOSS_SCALE = 0, SF_INV_SCALE = 1, SF_LR = 2, SF_BC1 = 3, SF_BC2_SQRT = 4, SF_LOSS = 5, SF_LOSS_ACC = 6 };
+// Counter-based uniform in [0, 1) with float32's 24-bit resolution (what torch.rand gives): splitmix64 of (seed, index).  The march
+// jitter of ray r in the step with seed s is rng_uniform(s, r): no noise tensor, no generator launch on the stream (reference:
+// torch.rand_like, ray_march.py:138 -- any i.i.d. uniform does; tests/test_gpu_parity.py holds the distribution and the
+// equivalence with an explicit noise vector of the same values).
+__host__ __device__ __forceinline__ float rng_uniform(unsigned long long seed, unsigned int index) {
+    unsigned long long z = seed + ((unsigned long long)index + 1ull) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (float)(unsigned int)(z >> 40) * (1.0f / 16777216.0f);
+}
+
 // ---- cross-block sum of the MLP backward's per-block weight-gradient slabs (csrc/mlp.hip: the kernels leave one [NGP_MLP_NW]
 // slab of plain stores per block instead of 2.6 M same-address float atomics, 13 us of a 72 us launch).  A 1024-thread block sums
 // 64 weights: thread (w = tid & 63, q = tid >> 6) takes every 16th slab -- at most 16 loads, all in flight at once: the pass is

@@ -116,12 +116,18 @@ def march_train(rays_o, rays_d, hits_t, density_bitfield, noise, cascades, scale
 
 
 def march_train_fused(rays_o, rays_d, hits_t, density_bitfield, noise, cascades, scale, exp_step_factor, grid_size, max_samples,
-                      capacity=None):
+                      capacity=None, seed=None):
     """ngp_march_train_fused: the same samples per ray as march_train() in ONE launch, the rays packed in block-completion order
-    (rays_a[r] = (r, start, count)); outputs are sized for `capacity` samples (default n * max_samples), the first `total` valid.
-    hits_t may be None (slab test inline)."""
+    (rays_a[r] = (r, start, count)); outputs are sized for `capacity` samples (default n * max_samples), the first `total` valid --
+    with a smaller capacity the kernel drops what does not fit (compare the returned total with it).  hits_t may be None (slab
+    test inline).  noise=None + seed: the jitter is drawn in the kernel, ray r gets rng_uniform(seed, r)."""
     _dev(rays_o, torch.float32, "rays_o"); _dev(rays_d, torch.float32, "rays_d")
-    _dev(density_bitfield, torch.uint8, "density_bitfield"); _dev(noise, torch.float32, "noise")
+    _dev(density_bitfield, torch.uint8, "density_bitfield")
+    if noise is None:
+        if seed is None:
+            raise ValueError("march_train_fused needs a noise vector or a seed")
+    else:
+        _dev(noise, torch.float32, "noise")
     n = rays_o.shape[0]
     dev = rays_o.device
     L = _lib()
@@ -133,11 +139,26 @@ def march_train_fused(rays_o, rays_d, hits_t, density_bitfield, noise, cascades,
     xyzs, dirs = torch.empty(cap, 3, device=dev, dtype=torch.float32), torch.empty(cap, 3, device=dev, dtype=torch.float32)
     deltas, ts = torch.empty(cap, device=dev, dtype=torch.float32), torch.empty(cap, device=dev, dtype=torch.float32)
     coarse = coarse_bitfield(density_bitfield, cascades, grid_size)
-    check(L.ngp_march_train_fused(_ptr(rays_o), _ptr(rays_d), _ptr(hits_t), _ptr(density_bitfield), _ptr(coarse), _ptr(noise),
-                                  int(cascades), int(grid_size), float(scale), float(exp_step_factor), int(max_samples), n,
-                                  _ptr(stage), _ptr(ctr), _ptr(rays_a), _ptr(total), _ptr(xyzs), _ptr(dirs), _ptr(deltas), _ptr(ts),
-                                  _stream()), "ngp_march_train_fused")
+    if noise is None:
+        if cap < n * int(max_samples):
+            raise ValueError("the seeded form writes into arrays of n * max_samples rows")
+        check(L.ngp_march_train_fused_rng(_ptr(rays_o), _ptr(rays_d), _ptr(hits_t), _ptr(density_bitfield), _ptr(coarse), int(seed),
+                                          int(cascades), int(grid_size), float(scale), float(exp_step_factor), int(max_samples), n,
+                                          _ptr(stage), _ptr(ctr), _ptr(rays_a), _ptr(total), _ptr(xyzs), _ptr(dirs), _ptr(deltas), _ptr(ts),
+                                          _stream()), "ngp_march_train_fused_rng")
+    else:
+        check(L.ngp_march_train_fused_cap(_ptr(rays_o), _ptr(rays_d), _ptr(hits_t), _ptr(density_bitfield), _ptr(coarse), _ptr(noise),
+                                          int(cascades), int(grid_size), float(scale), float(exp_step_factor), int(max_samples), n, cap,
+                                          _ptr(stage), _ptr(ctr), _ptr(rays_a), _ptr(total), _ptr(xyzs), _ptr(dirs), _ptr(deltas), _ptr(ts),
+                                          _stream()), "ngp_march_train_fused_cap")
     return rays_a, xyzs, dirs, deltas, ts, total[0], ctr
+
+
+def rng_uniform(seed, n, device="cuda"):
+    """[n] float32: rng_uniform(seed, i) -- the jitter ngp_march_train_fused_rng(seed) gives ray i."""
+    out = torch.empty(n, device=device, dtype=torch.float32)
+    check(_lib().ngp_rng_uniform(int(seed), int(n), _ptr(out), _stream()), "ngp_rng_uniform")
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------- a-3

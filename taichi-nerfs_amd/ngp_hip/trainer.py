@@ -288,10 +288,20 @@ class FusedTrainer:
     def _march(self, M, rays_o, rays_d, cfg, A, coarse=None, noise=None):
         """ray-AABB + count/scan/write into march set M on the CURRENT stream."""
         L, st, n = self.L, _stream(), rays_o.shape[0]
-        if noise is None:
-            noise = torch.rand(n, device=self.dev, dtype=torch.float32)                     # ray_march.py:138
         if coarse is None:
             coarse = self._coarse_bits(cfg, A)
+        if noise is None and self.march_fused:
+            # the per-ray jitter (torch.rand_like, ray_march.py:138) is drawn inside the march kernel from a counter-based
+            # generator keyed by (seed, ray); the seed comes from torch's CPU generator, so torch.manual_seed() still fixes the
+            # jitter sequence -- and no uniform_ kernel sits on the (side) stream in front of the march
+            seed = int(torch.randint(0, 2**62, (), dtype=torch.int64))
+            check(L.ngp_march_train_fused_rng(_ptr(rays_o), _ptr(rays_d), _ptr(None), _ptr(cfg.bitfield), _ptr(coarse), seed,
+                                              cfg.cascades, cfg.grid_size, cfg.scale, cfg.exp_step_factor, cfg.max_samples, n,
+                                              _ptr(M.stage), _ptr(M.ctr), _ptr(M.rays_a), _ptr(M.total), _ptr(M.xyzs), _ptr(M.dirs),
+                                              _ptr(M.deltas), _ptr(M.ts), st), "ngp_march_train_fused_rng")
+            return
+        if noise is None:
+            noise = torch.rand(n, device=self.dev, dtype=torch.float32)                     # ray_march.py:138
         if self.march_fused:
             # one launch: count, block-wise allocation of the output ranges (rays in block-completion order, like the reference's
             # atomic packing), expansion.  NGP_MARCH_FUSED=0: the count / scan / write chain (rays packed in ray order)

@@ -544,3 +544,57 @@ def test_full_size_properties(hip_lib, lego_bitfield):
     ops.hash_bwd_f32(x01, g, lv, dt)
     lhs = (e1.double() * g.double()).sum().item(); rhs = (t1.double() * dt.double()).sum().item()
     assert abs(lhs - rhs) <= 1e-4 * max(abs(lhs), 1.0)
+
+
+def test_march_in_kernel_jitter(oracle, lego_batch):
+    """Round 4: the trainer's march draws its per-ray jitter in the kernel (ngp_march_train_fused_rng: splitmix64 of (seed, ray) ->
+    24-bit uniform) instead of reading a torch.rand tensor (ray_march.py:138 draws torch.rand_like -- any i.i.d. uniform in [0, 1)
+    is the same algorithm).  (a) the values are uniform: moments, a Kolmogorov-Smirnov bound, no repeats across seeds / rays;
+    (b) the march with seed s == the march given the explicit vector rng_uniform(s, .) == the oracle on that vector, bit for bit."""
+    o, d, _, bits = lego_batch
+    n = 4096
+    u = ops.rng_uniform(1234567, 1 << 20).cpu().numpy().astype(np.float64)
+    assert u.min() >= 0.0 and u.max() < 1.0
+    assert abs(u.mean() - 0.5) < 2e-3 and abs(u.var() - 1.0 / 12.0) < 1e-3
+    ks = np.abs(np.sort(u) - (np.arange(u.size) + 0.5) / u.size).max()
+    assert ks < 2.0 / np.sqrt(u.size)                                      # ~1.95 / sqrt(n) is the 0.1 % point
+    assert abs(np.corrcoef(u[:-1], u[1:])[0, 1]) < 5e-3                    # neighbouring rays are uncorrelated ...
+    u2 = ops.rng_uniform(1234568, 1 << 20).cpu().numpy().astype(np.float64)
+    assert abs(np.corrcoef(u, u2)[0, 1]) < 5e-3                            # ... and so are consecutive seeds
+    seed = 987654321
+    noise = ops.rng_uniform(seed, n)
+    g_rng = ops.march_train_fused(dev(o[:n]), dev(d[:n]), None, dev(bits), None, 1, 0.5, 0.0, 128, 1024, seed=seed)
+    g_vec = ops.march_train_fused(dev(o[:n]), dev(d[:n]), None, dev(bits), noise, 1, 0.5, 0.0, 128, 1024)
+    hits = oracle.ray_aabb(o[:n], d[:n], 0.5)
+    ref = oracle.march_train(o[:n], d[:n], hits, bits, noise.cpu().numpy(), 1, 0.5, 0.0, 128, 1024)
+    _check_fused_march(ref, g_rng, n)
+    _check_fused_march(ref, g_vec, n)
+
+
+def test_march_fused_capacity_is_respected(oracle, lego_batch):
+    """output arrays smaller than the data-dependent total must not be overrun -- what does not fit is dropped, the
+    total still reports everything (the caller compares)."""
+    o, d, noise, bits = lego_batch
+    n = 2048
+    hits = oracle.ray_aabb(o[:n], d[:n], 0.5)
+    ref = oracle.march_train(o[:n], d[:n], hits, bits, noise[:n], 1, 0.5, 0.0, 128, 1024)
+    total = ref[5]
+    cap = total // 2
+    guard = 4096
+    from ngp_hip.ops import _lib, _ptr, _stream, MarchArena, coarse_bitfield, check
+    import torch
+    dv = torch.device("cuda")
+    xyzs = torch.full((cap + guard, 3), -7.0, device=dv); dirs = torch.full((cap + guard, 3), -7.0, device=dv)
+    deltas = torch.full((cap + guard,), -7.0, device=dv); ts = torch.full((cap + guard,), -7.0, device=dv)
+    rays_a = torch.empty(n, 3, device=dv, dtype=torch.int32); tot = torch.zeros(1, device=dv, dtype=torch.int32)
+    ctr = torch.zeros(2, device=dv, dtype=torch.int32)
+    stage = MarchArena.get(dv, n, 1024)
+    o_d, d_d, bits_d, noise_d = dev(o[:n]), dev(d[:n]), dev(bits), dev(noise[:n])      # (named: they must outlive the launch)
+    coarse = coarse_bitfield(bits_d, 1, 128)
+    check(_lib().ngp_march_train_fused_cap(_ptr(o_d), _ptr(d_d), _ptr(None), _ptr(bits_d), _ptr(coarse), _ptr(noise_d), 1, 128, 0.5, 0.0,
+                                           1024, n, cap, _ptr(stage), _ptr(ctr), _ptr(rays_a), _ptr(tot), _ptr(xyzs), _ptr(dirs),
+                                           _ptr(deltas), _ptr(ts), _stream()), "cap")
+    assert int(tot[0]) == total > cap
+    for t in (xyzs, dirs, deltas, ts):
+        assert bool((t[cap:] == -7.0).all())                                # nothing beyond the capacity was touched
+    assert bool((ts[:cap] != -7.0).all())                                   # everything below it was written
