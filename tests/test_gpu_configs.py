@@ -65,7 +65,7 @@ def test_garden_trainer_with_distortion_loss_gradients(hip_lib):
     _, _, g_ref0 = _step(m, o, d, target, False, 0.0)
     tr = FusedTrainer(m, exp_step_factor=1 / 256, distortion_loss_w=w, init_scale=256.0)
     torch.manual_seed(7)
-    out = tr.compute_gradients(o, d, target)
+    out = tr.compute_gradients(o, d, target, noise=torch.rand(o.shape[0], device="cuda"))     # the jitter _step()'s render() drew
     assert int(out["found_inf"]) == 0
     got = [out["table_grad"] * 256.0] + [g.reshape(-1) * 256.0 for g in torch.split(out["mlp_grad"], [2048, 1024, 2048, 4096, 192])]
     for k, (a, b, b0) in enumerate(zip(got, g_ref, g_ref0)):

@@ -99,7 +99,8 @@ def _model(kind, state):
 
 def _noise_for(n, seed):
     torch.manual_seed(seed)
-    noise = torch.rand(n, device="cuda").cpu().numpy()          # the first draw after the seed is the march jitter
+    noise = torch.rand(n, device="cuda").cpu().numpy()          # render(): the first draw after the seed is the march jitter; the
+    # trainer draws its jitter in the march kernel (round 4) and is handed this vector explicitly
     torch.manual_seed(seed)
     return noise
 
@@ -115,7 +116,7 @@ def test_trainer_forward_matches_oracle_on_content(oracle, conditioned, kind):
     o, d = synthetic.lego_rays(n, seed=41)
     target = torch.rand(n, 3, device="cuda")
     noise = _noise_for(n, 77)
-    out = tr.compute_gradients(torch.from_numpy(o).cuda(), torch.from_numpy(d).cuda(), target)
+    out = tr.compute_gradients(torch.from_numpy(o).cuda(), torch.from_numpy(d).cuda(), target, noise=torch.from_numpy(noise).cuda())
     table = m.pos_encoder.hash_table.detach().float().view(-1).cpu().numpy()
     ref = _oracle_forward(oracle, [w.detach().cpu().numpy() for w in m._mlp_weights()], table, o, d, conditioned["bits"], noise,
                           0.5, 1, 0.0, 1.0, 1024, kind)
@@ -198,7 +199,7 @@ def test_c3_garden_shape_matches_oracle(oracle, hip_lib):
     tr.repack()
     target = torch.rand(n, 3, device="cuda")
     noise = _noise_for(n, 79)                                               # (after every other draw: the march jitter comes next)
-    out = tr.compute_gradients(torch.from_numpy(o).cuda(), torch.from_numpy(d).cuda(), target)
+    out = tr.compute_gradients(torch.from_numpy(o).cuda(), torch.from_numpy(d).cuda(), target, noise=torch.from_numpy(noise).cuda())
     table = m.pos_encoder.hash_table.detach().float().view(-1).cpu().numpy()
     ref = _oracle_forward(oracle, [w.detach().cpu().numpy() for w in m._mlp_weights()], table, o, d, bits, noise, 16.0, 6, 1.0 / 256, 0.0, 4096)
     rm = int(out["rm_samples"][0])
@@ -255,7 +256,7 @@ def test_end_to_end_gradients_vs_fp32_cpu_chain(oracle, conditioned):
     m1 = _model("f32", state)
     tr = FusedTrainer(m1, init_scale=2.0**15)
     noise = _noise_for(n, 80)
-    out = tr.compute_gradients(to, td, target)
+    out = tr.compute_gradients(to, td, target, noise=torch.from_numpy(noise).cuda())
     g_table = out["table_grad"].cpu().numpy()
     g_mlp = np.split(out["mlp_grad"].cpu().numpy(), np.cumsum([2048, 1024, 2048, 4096])[:4])
     assert int(out["found_inf"]) == 0

@@ -156,7 +156,7 @@ def test_trainer_half_matches_torch_loop(hip_lib, lego_bitfield):
     losses_b = []
     for i in range(steps):
         torch.manual_seed(100 + i)
-        tr.step(o, d, target)
+        tr.step(o, d, target, noise=torch.rand(o.shape[0], device="cuda"))            # the jitter render() drew for this seed
         losses_b.append(tr.last_loss())
     torch.cuda.synchronize()
     np.testing.assert_allclose(losses_b, losses_a, rtol=3e-2, atol=3e-3)

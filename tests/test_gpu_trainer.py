@@ -50,7 +50,7 @@ def test_trainer_matches_torch_loop(hip_lib, lego_bitfield):
     losses_b = []
     for i in range(steps):
         torch.manual_seed(100 + i)
-        st = tr.step(o, d, target)
+        st = tr.step(o, d, target, noise=torch.rand(o.shape[0], device="cuda"))       # the jitter render() drew for this seed
         losses_b.append(tr.last_loss())
     assert tr.counters()["iter"] == steps
     # both loops skip the same (early, overflowing) steps or none; compare the trajectories
@@ -364,7 +364,7 @@ def test_coarse_table_follows_grid_update(hip_lib, lego_bitfield):
     tr.update_density_grid(0.01 * 1024 / 3**0.5, warmup=True)    # writes the bitfield through ngp_occ_pack (raw pointer)
     assert int(m.density_bitfield.count_nonzero()) > 0
     torch.manual_seed(77)
-    st = tr.step(o, d, target)
+    st = tr.step(o, d, target, noise=torch.rand(2048, device="cuda"))   # (the trainer draws its own jitter in the march kernel otherwise)
     torch.manual_seed(77)                                        # same jitter noise: first draw after the seed
     hits = ray_aabb_intersection(o, d, 0.5)
     rays_a, _x, _d, _dl, _ts, total = raymarching_train(o, d, hits, m.density_bitfield, 1, 0.5, 0.0, 128, 1024)
