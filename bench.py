@@ -757,8 +757,8 @@ def _measure(args, ctx, brief):
         # which records the workload state it was taken in); it is attached only if that state matches this run within 15 %
         # (two runs of the same command end their conditioning 5-12 % apart in live samples per step: float-atomic order in the
         # MLP weight gradients), otherwise traffic stays null -- a counter value from another state says nothing about this one
-        pmc_path = next((q for q in (os.path.join(ROOT, "profiles", f) for f in ("r03_pmc.json", "r02_pmc.json")) if os.path.exists(q)),
-                        os.path.join(ROOT, "profiles", "r03_pmc.json"))
+        pmc_path = next((q for q in (os.path.join(ROOT, "profiles", f) for f in ("r04_pmc.json", "r03_pmc.json", "r02_pmc.json")) if os.path.exists(q)),
+                        os.path.join(ROOT, "profiles", "r04_pmc.json"))
         pmc_name = "profiles/" + os.path.basename(pmc_path)
         traffic_src = None
         if "march_count" in rooflines and use_trainer and args.prefetch and not args.graph:
@@ -790,6 +790,14 @@ def _measure(args, ctx, brief):
                     ]
         dom = max(eligible, key=lambda k: ks[k]["avg_ms"], default=None)     # (one launch of each per step: the per-launch average ranks them)
         roof = rooflines.get(dom)
+        # the reference's ONE backward op (hash_encoder.py:269) is TWO launches here -- the prepass (hit bitmaps +
+        # compact positions, in line before the MLP backward) and the main launch.  The same algorithmic bytes over the SUM of the
+        # two durations (the prepass from the warm-up steps' events, the main launch from the timed region)
+        if roof is not None and dom == "hash_bwd_f32" and "hash_bwd_prep" in ks and use_trainer and trainer.hash_bwd == "sliced":
+            both_ms = roof["avg_launch_ms"] + ks["hash_bwd_prep"]["avg_ms"]
+            ach2 = roof["work_per_unit"] * roof["avg_units_per_launch"] / (both_ms * 1e-3) / 1e9
+            roof["with_prepass"] = {"avg_ms_main_plus_prep": both_ms, "achieved": float(ach2), "frac": float(ach2 / HBM_PEAK_GBS),
+                                    "note": "the reference's one backward op = prepass + main launch here; same algorithmic bytes over both"}
         workload = {"regime": args.regime, "rm_samples_per_ray": rm / total_rays * world, "vr_samples_per_ray": vr / total_rays * world,
                     "live_over_marched": vr / max(rm, 1),
                     "occupied_fraction": float((torch.cat([(model.density_bitfield >> b) & 1 for b in range(8)]) > 0).float().mean())}

@@ -136,6 +136,9 @@ __device__ __forceinline__ const float* grad_ptr(const float* dout, int level, s
 // samples.  Levels of many slices: each lane ORs its corners' bits into a 64-word LDS table (one word per slice; random
 // slices, few same-word collisions), lane s then stores word s.  Levels of <= 8 slices (where every lane would hit the same
 // few words and the LDS atomics serialise): one wave ballot per slice.
+// (Round 4, measured and not kept: FOUR tiles per wave trip with lane s storing the four words of slice s as one 32-byte piece --
+// 6.4 M scattered 8-byte stores become 1.6 M -- is correct and SLOWER, 65 vs 50 us at 433 k samples: the launch then has 1700
+// working waves instead of 6800, and a trip is a serial chain over 16 levels.  The prepass is latency-, not store-bound.)
 __global__ void __launch_bounds__(256) hash_bwd_prep_kernel(const float* __restrict__ xyzs, const int32_t* __restrict__ idx,
                                                             ngp_hash_levels lv, int n, const int32_t* __restrict__ n_dev, XyzNorm nm,
                                                             size_t wstride, uint32_t single_slice_levels, float* __restrict__ xyzc,

@@ -383,7 +383,11 @@ __global__ void __launch_bounds__(1024) march_fused_kernel(const float* __restri
     }
     // Last block out publishes the total and clears the counters.  No device-scope fence: on gfx950 that is an L2 write-back per
     // block (measured: the kernel 4x slower); nothing but the two counters travels between blocks, both are device-scope atomics
-    // on one cache line, and every block's allocation precedes its own "finished" increment in program order.
+    // on one cache line, and every block's allocation precedes its own "finished" increment in program order.  (the two
+    // atomics are issued by different lanes.  The allocation is a RETURNING atomic whose value wave 0 broadcasts before the block
+    // barrier above, i.e. it has completed at the L2 before any lane passes that barrier; the "finished" increment is issued after
+    // it, and both are executed by the L2 in arrival order.  A release / acquire pair at agent scope would say the same to the
+    // memory model at the price of the write-back measured above; tests assert total == sum of the per-ray counts on every case.)
 #ifdef NGP_MARCH_DIAG
     if (lane == 0 && blockIdx.x * 16 + wv < 8192) ngp_march_dbg[4 * (blockIdx.x * 16 + wv) + 2] = wall_clock64();
 #endif

@@ -63,6 +63,31 @@ class TrainResults(dict):
     def __len__(self):
         return len(self.keys())
 
+    # the rest of the mapping protocol sees the lazily materialised keys too: dict's own pop / setdefault / copy
+    # bypass __missing__
+    def pop(self, key, *default):
+        if key in self:
+            value = self[key]
+            dict.pop(self, key, None)
+            self._padded.pop(key, None)
+            return value
+        if default:
+            return default[0]
+        raise KeyError(key)
+
+    def setdefault(self, key, default=None):
+        if key in self:
+            return self[key]
+        self[key] = default
+        return default
+
+    def copy(self):
+        """A plain dict with every key materialised (what `dict(results)` gives)."""
+        return {k: self[k] for k in self.keys()}
+
+    def __reduce__(self):
+        return (dict, (self.copy(),))                  # pickling / deepcopy: the reference's plain dictionary
+
 
 def _background(exp_step_factor, device):
     # synthetic scenes (exp_step_factor == 0) are composited over white, real scenes over black

@@ -140,6 +140,7 @@ class FusedTrainer:
         # to be 0 at launch) and clears the other one for the next step -- no memset launch on the step's critical path
         self._live_pair = torch.zeros(2, device=dev, dtype=torch.int32)    # (parity = which of the two march sets the step shades)
         self._graph = None
+        self._launch_incomplete = False       # a _launch() that raised between flipping the march-set parity and issuing the step
         self._grads_only = False
         self.stats = {}
         self._sets = {}
@@ -356,9 +357,17 @@ class FusedTrainer:
                 nxt.held = prefetch          # (possibly temporaries of step()): alive until the set is consumed or re-marched
             if self._prefetch_at == 0 or self._graph is not None:
                 hook(); hook = None
+        # The fused live list relies on the counter of this step's parity being 0 at launch (the composite kernel of the PREVIOUS
+        # step cleared it).  A step that raised after the flip below never ran that kernel: if the last launch did not complete,
+        # clear both counters on the stream before going on (stale counts would be added to, silently).
+        if self._launch_incomplete:
+            self._live_pair.zero_()
+        self._launch_incomplete = True
         cur, self._cur = self._cur, 1 - self._cur
         if self._graph is None:
-            return self._shade(M, n, target, cfg, A, hook)
+            stats = self._shade(M, n, target, cfg, A, hook)
+            self._launch_incomplete = False
+            return stats
         # hipGraph mode: the shading / backward / optimizer chain of march set `cur` is one graph launch
         if n != self._graph_n:
             raise ValueError("graph mode was captured for %d rays per step" % self._graph_n)
@@ -371,6 +380,7 @@ class FusedTrainer:
             self._graph[cur] = (g, stats)
         g, stats = self._graph[cur]
         g.replay()
+        self._launch_incomplete = False
         return stats
 
     def _shade(self, M, n, target, cfg, A, hook=None):

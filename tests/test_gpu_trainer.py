@@ -440,3 +440,56 @@ def test_trainer_state_dict_resumes_exactly(hip_lib, lego_bitfield):
     # same kernels, same inputs; only the float-atomic order of the scatter-add differs between the two runs
     ta, tb = m_a.pos_encoder.hash_table.detach(), m_b.pos_encoder.hash_table.detach()
     assert ((ta - tb).norm() / ta.norm()).item() < 1e-4
+
+
+def test_step_after_a_failed_launch_does_not_inherit_live_counts(hip_lib, lego_bitfield):
+    """a _launch() that raises after the march-set parity flip leaves the NEXT step of that parity with a non-zero
+    live counter (the composite kernel that clears it never ran) -- the trainer now clears the counters when the previous launch
+    did not complete.  Provoked by a failing entry point in the middle of the step."""
+    from ngp_hip.trainer import FusedTrainer
+    m, o, d, target = _make(lego_bitfield, n=2048)
+    tr = FusedTrainer(m)
+    tr.step(o, d, target)
+    tr.step(o, d, target)
+    ref_live = int(tr._live_total[0])
+
+    class Boom(Exception):
+        pass
+
+    class Flaky:
+        def __init__(self, L):
+            self._L, self.fail = L, False
+
+        def __getattr__(self, name):
+            fn = getattr(self._L, name)
+            if name == "ngp_mlp_fwd_ex" and self.fail:
+                def boom(*a):
+                    raise Boom()
+                return boom
+            return fn
+    tr.L = Flaky(tr.L)
+    tr._live_pair.fill_(12345)                                   # what stale counters would look like
+    tr.L.fail = True
+    with pytest.raises(Boom):
+        tr.step(o, d, target)
+    tr.L.fail = False
+    tr.step(o, d, target)
+    assert abs(int(tr._live_total[0]) - ref_live) < 0.2 * ref_live + 64           # a fresh count, not 12345 + count
+    assert tr.counters()["skipped"] == 0
+
+
+def test_train_results_mapping_protocol(hip_lib, lego_bitfield):
+    """pop / setdefault / copy / dict() of the fused render's result see the lazily materialised per-sample keys."""
+    import copy as _copy
+    from modules.rendering import render
+    m, o, d, _ = _make(lego_bitfield, n=1024)
+    with torch.autocast("cuda", dtype=torch.float16):
+        res = render(m, o, d, exp_step_factor=0.0)
+    S = int(res["rm_samples"])
+    plain = res.copy()
+    assert type(plain) is dict and plain["ws"].shape[0] == S and set(plain) == set(res.keys())
+    assert dict(res)["ts"].shape[0] == S
+    assert res.setdefault("deltas", None).shape[0] == S and res.setdefault("extra", 3) == 3
+    ws = res.pop("ws")
+    assert ws.shape[0] == S and "ws" not in res and res.pop("ws", "gone") == "gone"
+    assert type(_copy.deepcopy({k: v.detach() if torch.is_tensor(v) else v for k, v in res.copy().items()})) is dict
