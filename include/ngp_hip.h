@@ -306,6 +306,10 @@ int ngp_event_create(void** event);
 int ngp_event_record(void* event, void* stream);
 int ngp_stream_wait_event(void* stream, void* event);
 int ngp_event_destroy(void* event);
+/* A non-blocking stream of the lowest priority the device offers (for the prefetched march: it should take only the CUs the step's
+ * own kernels leave free); *least / *greatest (nullable) = hipDeviceGetStreamPriorityRange. */
+int ngp_stream_create_low_priority(void** stream, int* least, int* greatest);
+int ngp_stream_destroy(void* stream);
 
 /* ---- f-2  device-resident optimisation-step epilogue (reference train.py:193-201: mse_loss, GradScaler,
  * Adam(eps=1e-15), CosineAnnealingLR, zero_grad) -- see csrc/optim.hip.

@@ -155,6 +155,22 @@ int ngp_stream_wait_event(void* stream, void* event) {
 }
 int ngp_event_destroy(void* event) { return hipEventDestroy((hipEvent_t)event) == hipSuccess ? 0 : -1; }
 
+// A non-blocking stream of the LOWEST priority the device offers, for work that should only take the CUs the step's own kernels
+// leave free (FusedTrainer's prefetched march: launched at equal priority it is dispatched in front of the scatter-add's persistent
+// workgroups and runs beside them for the whole launch).  *lo / *hi (nullable) return the priority range.
+int ngp_stream_create_low_priority(void** stream, int* lo, int* hi) {
+    if (!stream) return -1;
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return -1;
+    hipStream_t s;
+    if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, least) != hipSuccess) return -1;
+    *stream = (void*)s;
+    if (lo) *lo = least;
+    if (hi) *hi = greatest;
+    return 0;
+}
+int ngp_stream_destroy(void* stream) { return hipStreamDestroy((hipStream_t)stream) == hipSuccess ? 0 : -1; }
+
 int ngp_train_prologue(float* state_f, int32_t* state_i, float lr0, float eta_min, int t_max, float beta1, float beta2,
                        float growth, float backoff, int growth_interval, void* stream) {
     hipLaunchKernelGGL(train_prologue_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state_f, state_i, lr0, eta_min, t_max,

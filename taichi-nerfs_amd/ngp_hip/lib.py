@@ -133,6 +133,8 @@ SIGNATURES = {
     "ngp_event_record": [_P, _P],
     "ngp_stream_wait_event": [_P, _P],
     "ngp_event_destroy": [_P],
+    "ngp_stream_create_low_priority": [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)],
+    "ngp_stream_destroy": [_P],
     "ngp_train_prologue": [_P, _P, _F, _F, _I, _F, _F, _F, _F, _I, _P],
     "ngp_train_prologue_reduce": [_P, _P, _F, _F, _I, _F, _F, _F, _F, _I, _P, _I, _P, _P],
     "ngp_adam_amp_prologue": [_P, _P, _P, _P, _F, _F, _F, _P],

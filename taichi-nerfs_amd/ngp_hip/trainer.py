@@ -146,6 +146,18 @@ class FusedTrainer:
         self._sets = {}
         self._cur = 0
         self._side = torch.cuda.Stream(device=dev)
+        # The side stream runs at the device's LOWEST priority (NGP_SIDE_PRIORITY=default: torch's): since the march draws its jitter
+        # itself (no torch uniform_ kernel in front of it any more) it is ready the moment the scatter-add is launched, and at equal
+        # priority its blocks were dispatched in front of the scatter-add's persistent workgroups and ran beside them for the whole
+        # launch (scatter-add 190 -> 210 us, march 235 us: profiles/r04_rocprofv3_timed_region_equal_priority.txt); at low priority
+        # it takes the CUs the scatter-add's workgroups leave as they retire (A/B on one box, 2 x 200 steps each: 0.882-0.894 vs
+        # 0.911-0.923 us per 1000 live samples)
+        self._side_prio = None
+        if os.environ.get("NGP_SIDE_PRIORITY", "low") == "low":
+            h, lo, hi = ctypes.c_void_p(), ctypes.c_int(), ctypes.c_int()
+            check(self.L.ngp_stream_create_low_priority(ctypes.byref(h), ctypes.byref(lo), ctypes.byref(hi)), "ngp_stream_create_low_priority")
+            self._side = torch.cuda.ExternalStream(h.value, device=dev)
+            self._side_prio = (lo.value, hi.value)
         self._ev_start = self._DevEvent(self.L)              # main stream -> side stream: the prefetch may start
         self.prefetch_hits = 0                # steps that consumed a march prefetched by the previous step() call
         # where in the step the next batch's march is put on the side stream: 0 = at the start, 1 = after the hash gather
