@@ -59,6 +59,7 @@ class FusedTrainer:
         # backward over the samples in front of each ray's early-termination point only (NGP_LIVE_BACKWARD=0: over all of them)
         self.live_backward = os.environ.get("NGP_LIVE_BACKWARD", "1") != "0"
         self.march_fused = os.environ.get("NGP_MARCH_FUSED", "1") != "0"
+        self._march_rng = os.environ.get("NGP_MARCH_RNG", "kernel") != "torch"     # torch: a torch.rand vector per march (rounds 1-3)
         # table gradient (fp32, or fp16 for the half2 encoder): "sliced" = LDS-owned table slices, no global float atomics
         # (csrc/hash_bwd_lds.hip; the default whenever the level table fits: F = 2, levels of <= 2^19 entries), "atomic" = round
         # 1's float-atomic / packed-f16-atomic kernels
@@ -303,7 +304,7 @@ class FusedTrainer:
         L, st, n = self.L, _stream(), rays_o.shape[0]
         if coarse is None:
             coarse = self._coarse_bits(cfg, A)
-        if noise is None and self.march_fused:
+        if noise is None and self.march_fused and self._march_rng:
             # the per-ray jitter (torch.rand_like, ray_march.py:138) is drawn inside the march kernel from a counter-based
             # generator keyed by (seed, ray); the seed comes from torch's CPU generator, so torch.manual_seed() still fixes the
             # jitter sequence -- and no uniform_ kernel sits on the (side) stream in front of the march
