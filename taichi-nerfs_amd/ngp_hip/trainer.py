@@ -571,116 +571,28 @@ class FusedTrainer:
     def _nccl(self):
         return dist.get_backend(self.group) == "nccl"
 
-    # ---- overlapped exchange: one launch + one reduce-scatter / Adam / all-gather per level group -------------------------
-    class _Group:
-        pass
-
+    # ---- overlapped exchange: one launch + one reduce-scatter / Adam / all-gather per level group (ngp_hip/dist.py) ------------
     def _make_groups(self, lvs, spec):
-        """Level groups of the overlapped exchange.  Group k = levels [l0_k, l0_{k-1}) (the first one ends at the last level and
-        also takes the padding behind the table), flat float range [a, b) of the table storage; rank r owns the r-th chunk of
-        c = ceil((b - a) / (4 world)) * 4 floats of EACH group.  A group whose length is not a multiple of 4 * world (the coarse
-        levels' sizes are multiples of 16 floats only) is exchanged through padded staging buffers."""
-        starts = [int(x) for x in spec.split(",") if x.strip() != ""]
-        nl = int(lvs.n_levels)
-        if not starts or starts[-1] != 0 or any(a <= b for a, b in zip(starts, starts[1:])) or starts[0] >= nl:
-            raise ValueError("NGP_COMM_GROUPS must be strictly descending first levels ending in 0, e.g. '12,8,0' (got %r)" % spec)
-        F = int(lvs.n_features)
-        groups, hi_level = [], nl
-        for k, l0 in enumerate(starts):
-            g = self._Group()
-            g.index, g.l0, g.l1 = k, l0, hi_level
-            g.mask = sum(1 << l for l in range(l0, hi_level))
-            g.a = F * int(lvs.offset[l0])
-            g.b = self.nt_pad if k == 0 else F * int(lvs.offset[hi_level])
-            n = g.b - g.a
-            g.c = (n + 4 * self.world - 1) // (4 * self.world) * 4
-            g.aligned = g.c * self.world == n
-            g.lo = g.a + self.rank * g.c
-            g.hi = max(g.lo, min(g.lo + g.c, g.b))
-            g.shard = torch.zeros(g.c, device=self.dev, dtype=torch.float32)
-            g.stage = {}
-            g.comm = g.comm_shard = None
-            if self._comm is not None:
-                g.comm = torch.empty(g.c * self.world, device=self.dev, dtype=self._comm.dtype)
-                g.comm_shard = torch.empty(g.c, device=self.dev, dtype=self._comm.dtype)
-            groups.append(g)
-            hi_level = l0
+        from .dist import GroupedExchange, make_level_groups
+        groups = make_level_groups([int(lvs.offset[l]) for l in range(int(lvs.n_levels))], int(lvs.n_features), self.nt_pad,
+                                   self.world, self.rank, spec)
         if groups[0].hi <= groups[0].lo:
             raise ValueError("the first level group leaves rank %d without a chunk" % self.rank)
+        self._gx = GroupedExchange(groups, self.rank, self.world, self.dev, group=self.group,
+                                   comm_dtype=self._comm.dtype if self._comm is not None else None, timed=self._timed)
         return groups
 
-    def _stage(self, g, dtype):
-        buf = g.stage.get(dtype)
-        if buf is None:
-            buf = g.stage[dtype] = torch.zeros(g.c * self.world, device=self.dev, dtype=dtype)
-        return buf
+    def _rs_async(self, g):
+        self._gx.stub = self._comm_stub
+        return self._gx.rs_async(g, self.table_grad_store)
+
+    def _ag_async(self, g, store):
+        self._gx.stub = self._comm_stub
+        return self._gx.ag_async(g, store)
 
     def _timed_wait(self, name, fn):
         """Overlapped exchange: what the step's stream WAITS for a collective that was issued earlier (sampled steps only)."""
         return self._timed(name, fn)
-
-    def _rs_async(self, g):
-        """Start the reduce-scatter (cross-rank average) of group g's part of the table gradient; returns finish()."""
-        src = self.table_grad_store
-        n = g.b - g.a
-        inp = src[g.a:g.b]
-        if not g.aligned:
-            st_ = self._stage(g, torch.float32)
-            st_[:n].copy_(inp)
-            inp = st_
-        out = g.shard
-        if g.comm is not None:
-            g.comm.copy_(inp)
-            inp, out = g.comm, g.comm_shard
-        if self._comm_stub:
-            work, post = None, (lambda: out.copy_(inp[self.rank * g.c:(self.rank + 1) * g.c]))
-        elif self._nccl():
-            work, post = dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.AVG, group=self.group, async_op=True), None
-        else:                                      # gloo (functional tests): no AVG, no CUDA reduce-scatter
-            work = dist.all_reduce(inp, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-            post = lambda: out.copy_(inp[self.rank * g.c:(self.rank + 1) * g.c]).div_(self.world)
-
-        def finish():
-            def wait():
-                if work is not None:
-                    work.wait()
-            self._timed_wait("wait_reduce_scatter_group%d" % g.index, wait)
-            if post is not None:
-                post()
-            if out is not g.shard:
-                g.shard.copy_(out)
-            src[g.a:g.b].zero_()                   # the local accumulator of this group, for the next step
-        return finish
-
-    def _ag_async(self, g, store):
-        """Start the all-gather of group g's part of `store` (every rank holds its own chunk); returns finish()."""
-        n = g.b - g.a
-        if self._comm_stub:
-            return lambda: None
-        if g.aligned:
-            mine = store[g.lo:g.lo + g.c]
-            if self._nccl():
-                work = dist.all_gather_into_tensor(store[g.a:g.b], mine, group=self.group, async_op=True)
-            else:
-                work = dist.all_gather([store[g.a + r * g.c:g.a + (r + 1) * g.c] for r in range(self.world)], mine.clone(),
-                                       group=self.group, async_op=True)
-            post = None
-        else:
-            st_ = self._stage(g, store.dtype)
-            mine = st_[self.rank * g.c:(self.rank + 1) * g.c]
-            mine[:g.hi - g.lo].copy_(store[g.lo:g.hi])
-            if self._nccl():
-                work = dist.all_gather_into_tensor(st_, mine, group=self.group, async_op=True)
-            else:
-                work = dist.all_gather([st_[r * g.c:(r + 1) * g.c] for r in range(self.world)], mine.clone(), group=self.group,
-                                       async_op=True)
-            post = lambda: store[g.a:g.b].copy_(st_[:n])
-
-        def finish():
-            self._timed_wait("wait_all_gather_group%d" % g.index, work.wait)
-            if post is not None:
-                post()
-        return finish
 
     def finish_comm(self):
         """Overlapped exchange: make the step's stream wait for the all-gathers of the previous step (before anything reads the
