@@ -52,6 +52,7 @@ TRAINER_KERNELS = {
     "ngp_hash_bwd_f32_live": ("hash_bwd_f32", "hbm", 12 + 128 + 1024 + 1024, "live"),
     "ngp_hash_bwd_f32_sliced": ("hash_bwd_f32", "hbm", 12 + 128 + 1024 + 1024, "live"),   # LDS-sliced form (prep + main launch)
     "ngp_hash_bwd_sliced_main": ("hash_bwd_f32", "hbm", 12 + 128 + 1024 + 1024, "live"),  # ... its main launch (what the trainer issues)
+    "ngp_hash_bwd_sliced_main_slabs": ("hash_bwd_f32", "hbm", 12 + 128 + 1024 + 1024, "live"),  # ... + the sum of the MLP backward's slabs at its head (round 4)
     "ngp_hash_bwd_sliced_prep": ("hash_bwd_prep", "hbm", 12 + 12 + 16 * 8, "live"),        # ... its prepass (in line, before the MLP backward)
     "ngp_hash_bwd_f16_live": ("hash_bwd_f16", "hbm", 12 + 128 + 512 + 512, "live"),
     "ngp_hash_bwd_sliced_main_f16": ("hash_bwd_f16", "hbm", 12 + 128 + 512 + 512, "live"),    # half2 encoder, LDS-sliced form
@@ -697,7 +698,7 @@ def _measure(args, ctx, brief):
             adam_bytes = 48.0 * n4 + 80.0 * touched4 + (8.0 * touched4 if (args.half or args.table == "bf16") else 0.0)
             # critical-path gaps on the sampled steps (each includes the two event packets in between): prepass end -> MLP backward
             # start, MLP backward end -> scatter-add start
-            ev_b = warm_events.get("ngp_mlp_bwd_live_parts", []) or warm_events.get("ngp_mlp_bwd_live", []); ev_m = warm_events.get("ngp_hash_bwd_sliced_main", [])
+            ev_b = warm_events.get("ngp_mlp_bwd_live_parts", []) or warm_events.get("ngp_mlp_bwd_live", []); ev_m = warm_events.get("ngp_hash_bwd_sliced_main_slabs", []) or warm_events.get("ngp_hash_bwd_sliced_main", [])
             ev_p = warm_events.get("ngp_hash_bwd_sliced_prep", [])
             if ev_b and len(ev_b) == len(ev_m) == len(ev_p):
                 gaps["mlp_bwd_end_to_scatter_start_us"] = float(np.mean([b[1].elapsed_time(m[0]) for b, m in zip(ev_b, ev_m)])) * 1e3

@@ -248,6 +248,12 @@ int ngp_hash_bwd_sliced_prep(const float* xyzs, const ngp_hash_levels* lv, int n
 int ngp_hash_bwd_sliced_main(const float* dout, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev, int enc_pairs,
                              float* dtable, int32_t* found_inf, const void* workspace, long long workspace_bytes,
                              void* stream);
+/* ngp_hash_bwd_sliced_main / _main_f16 (table_is_f16) whose first workgroups ALSO finish the MLP backward: dW[9408] += the sum of
+ * the n_parts weight-gradient slabs ngp_mlp_bwd_live_parts left (= ngp_mlp_dw_reduce, without a launch of its own: in a 200 us
+ * launch of persistent workgroups the ~2 us are invisible; the trainer's single-GPU step). */
+int ngp_hash_bwd_sliced_main_slabs(const float* dout, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev, int enc_pairs,
+                                   void* dtable, int table_is_f16, int32_t* found_inf, const void* workspace,
+                                   long long workspace_bytes, const float* mlp_dw_parts, int n_parts, float* mlp_dw, void* stream);
 /* ngp_hash_bwd_sliced_main restricted to the levels in `level_mask` (bit l = level l), optionally on at most max_blocks persistent
  * workgroups (0 = as many as CUs): a caller that exchanges the gradient between ranks launches the fine levels first and sends
  * their part of dtable while the coarse levels are still being accumulated.  Launches over disjoint masks add up to the full

@@ -609,6 +609,12 @@ __device__ __forceinline__ uint32_t claim_task(const BwdPlan& plan, uint32_t* __
     return 0xffffffffu;
 }
 
+struct MlpSlabs {                     // optional extra work of the main launch: sum n_parts weight-gradient slabs into dW (NULL: none)
+    const float* parts;
+    int n_parts;
+    float* dW;
+};
+
 template <bool HALF>
 __global__ void __launch_bounds__(BW_THREADS) hash_bwd_lds_kernel(const float* __restrict__ xyzc,
                                                                   const unsigned long long* __restrict__ bitmap, size_t wstride,
@@ -616,11 +622,21 @@ __global__ void __launch_bounds__(BW_THREADS) hash_bwd_lds_kernel(const float* _
                                                                   const int32_t* __restrict__ n_dev, int enc_pairs, BwdPlan plan,
                                                                   void* __restrict__ dtable /* f32 pairs; HALF: f16 pairs */,
                                                                   int32_t* __restrict__ found_inf, uint32_t* __restrict__ ctr,
-                                                                  unsigned long long* __restrict__ dbg) {
+                                                                  unsigned long long* __restrict__ dbg, MlpSlabs mlp) {
     __shared__ double slice[2 * BW_SLICE_ENTRIES];
     __shared__ uint32_t queues[BW_WAVES * BW_Q];
     __shared__ uint32_t next_sc;
     __shared__ uint32_t s_claim;
+    // Epilogue of the PREVIOUS kernel riding at the head of this one (FusedTrainer, one GPU): the MLP backward left its weight
+    // gradients as per-block slabs; the first 147 of the persistent workgroups add them up (ngp_device.h: 64 weights each, 16
+    // loads in flight per thread, ~2 us) before they take their first task.  As its own launch -- or inside the prologue launch
+    // that follows this kernel -- the sum cost 6-8 us of the step; here it is hidden in a 200 us launch whose queues rebalance.
+    if (mlp.parts) {
+        for (int b = blockIdx.x; b < NGP_MLP_REDUCE_BLOCKS; b += gridDim.x) {
+            mlp_dw_reduce_block(mlp.parts, mlp.n_parts, mlp.dW, b);
+            __syncthreads();
+        }
+    }
     const size_t plane = (size_t)n;
     if (n_dev) n = min(n, *n_dev);
     if (n <= 0) return;
@@ -981,7 +997,7 @@ int ngp_hash_bwd_sliced_prep(const float* xyzs, const ngp_hash_levels* lv, int n
 
 static int sliced_main(bool half, const float* dout, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev, int enc_pairs,
                        void* dtable, int32_t* found_inf, const void* workspace, long long workspace_bytes, void* stream,
-                       uint32_t level_mask = 0xffffffffu, int max_blocks = 0) {
+                       uint32_t level_mask = 0xffffffffu, int max_blocks = 0, MlpSlabs mlp = MlpSlabs{nullptr, 0, nullptr}) {
     if (n_max <= 0) return 0;
     if (enc_pairs && !(lv->n_features == 2 && lv->n_levels == 16)) return -1;
     if (!workspace || workspace_bytes < ngp_hash_bwd_sliced_workspace(lv, n_max)) return -1;
@@ -996,10 +1012,10 @@ static int sliced_main(bool half, const float* dout, const ngp_hash_levels* lv, 
     uint32_t* ctr = reinterpret_cast<uint32_t*>(const_cast<char*>(base) + W.off_ctr);
     if (half)
         hipLaunchKernelGGL(hash_bwd_lds_kernel<true>, dim3(plan->n_blocks), dim3(BW_THREADS), 0, (hipStream_t)stream, xyzc, bitmap, W.words,
-                           dout, *lv, n_max, n_dev, enc_pairs, *plan, dtable, found_inf, ctr, g_bwd_debug);
+                           dout, *lv, n_max, n_dev, enc_pairs, *plan, dtable, found_inf, ctr, g_bwd_debug, mlp);
     else
         hipLaunchKernelGGL(hash_bwd_lds_kernel<false>, dim3(plan->n_blocks), dim3(BW_THREADS), 0, (hipStream_t)stream, xyzc, bitmap, W.words,
-                           dout, *lv, n_max, n_dev, enc_pairs, *plan, dtable, found_inf, ctr, g_bwd_debug);
+                           dout, *lv, n_max, n_dev, enc_pairs, *plan, dtable, found_inf, ctr, g_bwd_debug, mlp);
     NGP_LAUNCH_CHECK();
     return 0;
 }
@@ -1007,6 +1023,16 @@ static int sliced_main(bool half, const float* dout, const ngp_hash_levels* lv, 
 int ngp_hash_bwd_sliced_main(const float* dout, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev, int enc_pairs, float* dtable,
                              int32_t* found_inf, const void* workspace, long long workspace_bytes, void* stream) {
     return sliced_main(false, dout, lv, n_max, n_dev, enc_pairs, dtable, found_inf, workspace, workspace_bytes, stream);
+}
+
+// ngp_hash_bwd_sliced_main (half = 0) / _main_f16 (half = 1) with the sum of the MLP backward's weight-gradient slabs
+// (ngp_mlp_bwd_live_parts -> ngp_mlp_dw_reduce) done by the head of the same launch: dW[9408] += sum over n_parts slabs.
+int ngp_hash_bwd_sliced_main_slabs(const float* dout, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev, int enc_pairs,
+                                   void* dtable, int table_is_f16, int32_t* found_inf, const void* workspace, long long workspace_bytes,
+                                   const float* mlp_dw_parts, int n_parts, float* mlp_dw, void* stream) {
+    if (!mlp_dw_parts || !mlp_dw || n_parts <= 0) return -1;
+    return sliced_main(table_is_f16 != 0, dout, lv, n_max, n_dev, enc_pairs, dtable, found_inf, workspace, workspace_bytes, stream,
+                       0xffffffffu, 0, MlpSlabs{mlp_dw_parts, n_parts, mlp_dw});
 }
 
 // The scatter-add of the levels in `level_mask` only (same prepass, same workspace; the other levels' part of dtable is not

@@ -112,6 +112,7 @@ SIGNATURES = {
     "ngp_hash_bwd_sliced_plan": [_LV, _P, _I, _P, _P, _P, _P, _P],
     "ngp_hash_bwd_sliced_prep": [_P, _LV, _I, _P, _P, _I, _F, _F, _P, ctypes.c_longlong, _P],
     "ngp_hash_bwd_sliced_main": [_P, _LV, _I, _P, _I, _P, _P, _P, ctypes.c_longlong, _P],
+    "ngp_hash_bwd_sliced_main_slabs": [_P, _LV, _I, _P, _I, _P, _I, _P, _P, ctypes.c_longlong, _P, _I, _P, _P],
     "ngp_hash_bwd_sliced_main_levels": [_P, _LV, _I, _P, _I, _P, _P, _P, ctypes.c_longlong, ctypes.c_uint32, _I, _P],
     "ngp_hash_bwd_sliced_main_f16": [_P, _LV, _I, _P, _I, _P, _P, _P, ctypes.c_longlong, _P],
     "ngp_hash_bwd_f32_sliced": [_P, _P, _LV, _I, _P, _P, _I, _F, _F, _I, _P, _P, _P, ctypes.c_longlong, _P],

@@ -472,8 +472,13 @@ class FusedTrainer:
                                                _ptr(cnt), _ptr(live_idx), P, _ptr(A.d_enc), _ptr(self.mlp_parts), found, st)
             if n_parts <= 0:
                 check(n_parts or -1, "ngp_mlp_bwd_live_parts")
-        reduce_in_prologue = self.world == 1 and not self._grads_only and n_parts > 0
-        if n_parts > 0 and not reduce_in_prologue:
+        # ... summed by the head of the scatter-add launch (its first 147 persistent workgroups, ~2 us hidden in 200) on one GPU with
+        # the LDS-sliced scatter-add; by the prologue launch when the scatter-add is another kernel; by a launch of its own when the
+        # gradient is needed earlier (an exchange between ranks, compute_gradients)
+        single = self.world == 1 and not self._grads_only and n_parts > 0
+        reduce_in_scatter = single and sliced and not self.half and os.environ.get("NGP_MLP_DW_REDUCE", "scatter") == "scatter"
+        reduce_in_prologue = single and not reduce_in_scatter
+        if n_parts > 0 and not single:
             check(L.ngp_mlp_dw_reduce(_ptr(self.mlp_parts), n_parts, _ptr(self.mlp_grad), st), "ngp_mlp_dw_reduce")
         if hook is not None and self._prefetch_at <= 3:
             hook(); hook = None                                             # position 3: under the scatter-add and the optimizer
@@ -481,7 +486,11 @@ class FusedTrainer:
             self._tail_overlapped(A, cfg, cnt, P, ws, found, st, hook, None)
             return {"rm_samples": total, "vr_per_ray": vr_per_ray, "rgb": rgb, "opacity": opacity, "depth": depth, "rays_a": rays_a,
                     "deltas": M.deltas, "ts": M.ts, "sq_err": sq_err}
-        if self.half and sliced:
+        if reduce_in_scatter:
+            check(L.ngp_hash_bwd_sliced_main_slabs(_ptr(A.d_enc), ctypes.byref(cfg.levels), A.cap, _ptr(cnt), P, _ptr(self.table_grad),
+                                                   0, found, _ptr(ws), ws.numel(), _ptr(self.mlp_parts), n_parts,
+                                                   _ptr(self.mlp_grad), st), "ngp_hash_bwd_sliced_main_slabs")
+        elif self.half and sliced:
             check(L.ngp_hash_bwd_sliced_main_f16(_ptr(A.d_enc), ctypes.byref(cfg.levels), A.cap, _ptr(cnt), P, _ptr(self.table_grad), found,
                                                  _ptr(ws), ws.numel(), st), "ngp_hash_bwd_sliced_main_f16")
         elif self.half:

@@ -493,3 +493,26 @@ def test_train_results_mapping_protocol(hip_lib, lego_bitfield):
     ws = res.pop("ws")
     assert ws.shape[0] == S and "ws" not in res and res.pop("ws", "gone") == "gone"
     assert type(_copy.deepcopy({k: v.detach() if torch.is_tensor(v) else v for k, v in res.copy().items()})) is dict
+
+
+def test_mlp_slab_sum_in_scatter_launch_equals_other_paths(hip_lib, lego_bitfield, monkeypatch):
+    """Round 4: the MLP backward's per-block weight-gradient slabs are summed by the head of the scatter-add launch
+    (ngp_hash_bwd_sliced_main_slabs), by the prologue launch (NGP_MLP_DW_REDUCE=prologue), or not used at all (NGP_MLP_DW=atomic:
+    round 3's float atomics): three trainers from the same model and jitter take the same first steps."""
+    from ngp_hip.trainer import FusedTrainer
+    outs = []
+    for env in ({"NGP_MLP_DW_REDUCE": "scatter"}, {"NGP_MLP_DW_REDUCE": "prologue"}, {"NGP_MLP_DW": "atomic"}):
+        for k in ("NGP_MLP_DW_REDUCE", "NGP_MLP_DW"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        m, o, d, target = _make(lego_bitfield, n=2048)
+        tr = FusedTrainer(m, init_scale=2.0**12)
+        g = torch.Generator(device="cuda").manual_seed(9)
+        for _ in range(3):
+            tr.step(o, d, target, noise=torch.rand(2048, device="cuda", generator=g))
+        assert tr.counters()["skipped"] == 0
+        outs.append((tr.mlp_flat.clone(), tr.table.clone(), tr.mlp_m.clone()))
+    for a, b in ((outs[0], outs[1]), (outs[0], outs[2])):
+        for x, y in zip(a, b):
+            assert ((x - y).norm() / y.norm()).item() < 2e-4            # (summation order of the weight gradients; fp16 MLP)
