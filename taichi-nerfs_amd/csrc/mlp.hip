@@ -361,13 +361,13 @@ __global__ void __launch_bounds__(256) mlp_fwd_kernel(const float* __restrict__ 
     __shared__ half8 wl[N_FWD_FRAGS * 64];
     const size_t plane = (size_t)S;
     if (n_dev) S = min(S, *n_dev);
-    load_wpack<256, COLOR ? N_FWD_FRAGS : F_W3>(wpack, wl);
     const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
     const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), n_waves = gridDim.x * (blockDim.x >> 6);
     const int n_iter = (S + 31) >> 5;
     FwdIn nxt[2];
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt) fwd_request<COLOR, PAIRS>(nxt[tt], enc, dirs, wave * 32 + 16 * tt + n, S, g, plane);
+    load_wpack<256, COLOR ? N_FWD_FRAGS : F_W3>(wpack, wl);          // (behind the first trip's input request: both in flight together)
     for (int it = wave; it < n_iter; it += n_waves) {
         FwdIn cur[2];
 #pragma unroll
@@ -523,7 +523,6 @@ __global__ void __launch_bounds__(768) mlp_bwd_kernel(const float* __restrict__ 
     const size_t plane = (size_t)S;
     if (n_dev) S = min(S, *n_dev);
     half8* wl = reinterpret_cast<half8*>(smem);
-    load_wpack<64 * BW, N_ALL_FRAGS>(wpack, wl);
     const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
     const int grp = wv >> 1, par = wv & 1;
     half_t* Iall = reinterpret_cast<half_t*>(smem + N_ALL_FRAGS * 64 * 16);
@@ -549,6 +548,7 @@ __global__ void __launch_bounds__(768) mlp_bwd_kernel(const float* __restrict__ 
 
     BwdRaw raw;
     bwd_request(raw, enc, dirs, dsigmas, drgbs, bwd_src((blockIdx.x * BG + grp) * 32 + col, S, idx), g, pairs, plane);
+    load_wpack<64 * BW, N_ALL_FRAGS>(wpack, wl);                     // (behind the first round's input request: both in flight together)
     for (int round = blockIdx.x; round < n_round; round += gridDim.x) {
         BwdIn in;
         bwd_take(in, raw, g);

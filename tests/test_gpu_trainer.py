@@ -160,12 +160,18 @@ def test_trainer_allreduce_path_on_rccl_world1(hip_lib, lego_bitfield):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kind", ["f32", "bf16"])
-def test_sharded_optimizer_on_rccl_world1(hip_lib, lego_bitfield, kind):
+@pytest.mark.parametrize("kind", ["f32", "bf16", "f32-overlap"])
+def test_sharded_optimizer_on_rccl_world1(hip_lib, lego_bitfield, kind, monkeypatch):
     """reduce-scatter -> Adam on the own shard -> all-gather (the N > 1 default) on the real `nccl` backend with a 1-rank group:
     the shard is the whole table, so three steps must land where the plain single-GPU trainer lands (same kernels; only the
-    float-atomic flush order of the replicated coarse levels differs run to run)."""
+    float-atomic flush order of the replicated coarse levels differs run to run).  "f32-overlap": the same with the exchange
+    split by level group and issued async under the scatter-add (NGP_COMM_OVERLAP=1), i.e. RCCL's async reduce-scatter /
+    all-gather on the group staging buffers."""
     import os
+    overlap = kind == "f32-overlap"
+    if overlap:
+        monkeypatch.setenv("NGP_COMM_OVERLAP", "1")
+        monkeypatch.setenv("NGP_COMM_GROUPS", "12,8,0")
     import socket
     import torch.distributed as dist
     from modules.networks import NGP
@@ -186,8 +192,10 @@ def test_sharded_optimizer_on_rccl_world1(hip_lib, lego_bitfield, kind):
         o, d = [torch.from_numpy(a).cuda() for a in synthetic.lego_rays(2048, seed=9)]
         target = torch.rand(2048, 3, device="cuda")
         tr_a = FusedTrainer(make(), world_size=1, shard_optimizer=True, init_scale=2.0**15)
+        monkeypatch.delenv("NGP_COMM_OVERLAP", raising=False)
         tr_b = FusedTrainer(make(), world_size=1, init_scale=2.0**15)
         assert tr_a.shard and not tr_b.shard and tr_a.shard_len == tr_a.nt_pad
+        assert (tr_a._groups is not None) == overlap and tr_b._groups is None
         for i in range(3):
             noise = torch.rand(2048, device="cuda")
             tr_a.step(o, d, target, noise=noise); tr_b.step(o, d, target, noise=noise)
