@@ -3,7 +3,10 @@ The switch (NGP_HASH_FWD_PAIR) is read once per process, so each variant runs in
 marched through the committed Lego occupancy (8192 rays x 4 batches ~ 400 k+ samples, sample order = the march's packing), a
 seeded table.  Prints the median launch time (HIP events) per variant and whether the outputs are bit-identical.
 
-    python profiles/microbench/hash_fwd_pair.py"""
+    python profiles/microbench/hash_fwd_pair.py
+
+Result: profiles/r04_hash_fwd_pair_experiment.txt (paired loads were slower; the PAIR variant and its switch were removed again, so
+at HEAD both subprocesses time the same kernel -- the harness is kept for the next idea about this gather)."""
 import hashlib
 import json
 import os
