@@ -60,7 +60,7 @@ def main():
     res = {}
     for rep in range(2):
         for v in ("0", "1"):
-            env = dict(os.environ, NGP_HASH_FWD_PAIR=v)
+            env = dict(os.environ, NGP_HASH_FWD_V1=v)
             o = subprocess.run([sys.executable, os.path.abspath(__file__), "--child"], env=env, capture_output=True, text=True)
             line = [l for l in o.stdout.splitlines() if l.startswith("RESULT ")]
             if not line:

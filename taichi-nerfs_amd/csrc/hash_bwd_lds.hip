@@ -114,16 +114,39 @@ __device__ __forceinline__ uint32_t entry_of(const SliceMap M, uint32_t sl, uint
     if (!M.interleaved) return sl * (uint32_t)BW_SLICE_ENTRIES + local;
     return (((local >> M.bshift) * M.ns + sl) << M.bshift) | (local & ((1u << M.bshift) - 1u));
 }
-__device__ __forceinline__ SliceMap slice_map(uint32_t size, uint32_t res, bool dense) {
+__host__ __device__ __forceinline__ SliceMap slice_map(uint32_t size, uint32_t res, bool dense) {
     SliceMap M;
     M.ns = (size + BW_SLICE_ENTRIES - 1) >> BW_SLICE_LOG2;
     // interleave only where there are many slices (and therefore few sample-range replicas to even out the load): a sample of
     // a dense level touches the z and z + 1 planes, so with blocks of about one z-plane it still falls into 1-2 slices
     M.interleaved = dense && M.ns >= 8;
-    const uint32_t plane = res * res;
-    M.bshift = min((uint32_t)BW_SLICE_LOG2, (uint32_t)(31 - __clz((int)max(plane, 128u))));
+    const uint32_t plane = res * res, pl = plane > 128u ? plane : 128u, lg = 31u - (uint32_t)__builtin_clz(pl);
+    M.bshift = lg < (uint32_t)BW_SLICE_LOG2 ? lg : (uint32_t)BW_SLICE_LOG2;
     M.magic = M.ns > 1 ? (uint32_t)((0x100000000ull + M.ns - 1) / M.ns) : 0u;
     return M;
+}
+
+// The prepass's per-level constants, made once on the host and handed over by value (kernel arguments are read with scalar loads:
+// everything here lands in SGPRs).  Round 1-3 the kernel rebuilt them per level per 64-sample tile from the level table in LDS;
+// slice_map's 64-bit division alone was ~110 dependent scalar instructions of every level trip (70 % of the launch's 13 M SALU
+// instructions, profiles/r04_pmc.json).
+struct PrepLevel {
+    float scale;
+    uint32_t res, size, mode;        // mode as load_levels derives it: 0 dense (conditional subtract), 1 hashed pow2 (mask), 2 real modulo
+    SliceMap map;
+};
+struct PrepLevels { PrepLevel l[NGP_MAX_LEVELS]; };
+static PrepLevels make_prep_levels(const ngp_hash_levels& lv) {
+    PrepLevels P = {};
+    for (int t = 0; t < lv.n_levels && t < NGP_MAX_LEVELS; ++t) {
+        PrepLevel& q = P.l[t];
+        q.scale = lv.scale[t]; q.res = lv.resolution[t]; q.size = lv.map_size[t];
+        const bool dense = t < lv.begin_fast_hash_level;
+        if (dense) { const uint64_t r = q.res; q.mode = ((uint64_t)q.size >= r * r * r && r >= 2) ? 0u : 2u; }
+        else q.mode = (q.size != 0 && (q.size & (q.size - 1)) == 0) ? 1u : 2u;
+        q.map = slice_map(q.size, q.res, dense);
+    }
+    return P;
 }
 
 __device__ __forceinline__ const float* grad_ptr(const float* dout, int level, size_t i, size_t plane, int enc_pairs, int nl) {
@@ -140,16 +163,14 @@ __device__ __forceinline__ const float* grad_ptr(const float* dout, int level, s
 // 6.4 M scattered 8-byte stores become 1.6 M -- is correct and SLOWER, 65 vs 50 us at 433 k samples: the launch then has 1700
 // working waves instead of 6800, and a trip is a serial chain over 16 levels.  The prepass is latency-, not store-bound.)
 __global__ void __launch_bounds__(256) hash_bwd_prep_kernel(const float* __restrict__ xyzs, const int32_t* __restrict__ idx,
-                                                            ngp_hash_levels lv, int n, const int32_t* __restrict__ n_dev, XyzNorm nm,
-                                                            size_t wstride, uint32_t single_slice_levels, float* __restrict__ xyzc,
-                                                            unsigned long long* __restrict__ bitmap, uint32_t* __restrict__ ctr) {
-    __shared__ LevelLDS L;
+                                                            PrepLevels pl, int nl, int bfhl, int n, const int32_t* __restrict__ n_dev,
+                                                            XyzNorm nm, size_t wstride, uint32_t single_slice_levels,
+                                                            float* __restrict__ xyzc, unsigned long long* __restrict__ bitmap,
+                                                            uint32_t* __restrict__ ctr) {
     __shared__ unsigned long long words[4][BW_MAX_SLICES];
     if (blockIdx.x == 0 && threadIdx.x < 16) ctr[threadIdx.x] = 0u;       // the main kernel's queue heads (it also resets them itself)
-    load_levels(lv, L);
     if (n_dev) n = min(n, *n_dev);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nl = lv.n_levels, bfhl = lv.begin_fast_hash_level;
     const int n_tiles = (n + 63) >> 6;
     for (int tile = blockIdx.x * 4 + wave; tile < n_tiles; tile += gridDim.x * 4) {
         const int i = tile * 64 + lane;
@@ -157,17 +178,19 @@ __global__ void __launch_bounds__(256) hash_bwd_prep_kernel(const float* __restr
         float x = 0.f, y = 0.f, z = 0.f;
         if (valid) {
             const size_t src = idx ? (size_t)idx[i] : (size_t)i;
-            x = norm01(nm, xyzs[3 * src]); y = norm01(nm, xyzs[3 * src + 1]); z = norm01(nm, xyzs[3 * src + 2]);
+            const float rx = xyzs[3 * src], ry = xyzs[3 * src + 1], rz = xyzs[3 * src + 2];   // one request, then norm01's branches
+            x = norm01(nm, rx); y = norm01(nm, ry); z = norm01(nm, rz);
             xyzc[3 * (size_t)i] = x; xyzc[3 * (size_t)i + 1] = y; xyzc[3 * (size_t)i + 2] = z;
         }
         for (int level = 0; level < nl; ++level) {
             if ((single_slice_levels >> level) & 1u) continue;             // every sample is a hit there: no bitmap needed
-            const float scale = L.scale[level];
-            const uint32_t res = L.res[level], size = L.size[level], mode = L.mode[level];
+            const PrepLevel& P = pl.l[level];
+            const float scale = P.scale;
+            const uint32_t res = P.res, size = P.size, mode = P.mode;
             const uint32_t cx = f2u_sat(floorf(x * scale + 0.5f)), cy = f2u_sat(floorf(y * scale + 0.5f)),
                            cz = f2u_sat(floorf(z * scale + 0.5f));
             const bool dense = level < bfhl;
-            const SliceMap SM = slice_map(size, res, dense);
+            const SliceMap SM = P.map;
             const int ns = (int)SM.ns;
             unsigned long long* row = bitmap + ((size_t)level * BW_MAX_SLICES) * wstride + tile;
             const bool dense0 = dense && mode == 0u;
@@ -989,8 +1012,8 @@ int ngp_hash_bwd_sliced_prep(const float* xyzs, const ngp_hash_levels* lv, int n
     unsigned long long* bitmap = reinterpret_cast<unsigned long long*>(base + W.off_bitmap);
     uint32_t* ctr = reinterpret_cast<uint32_t*>(base + W.off_ctr);
     const XyzNorm nm = {normalize, lo, hi};
-    hipLaunchKernelGGL(hash_bwd_prep_kernel, dim3(BW_PREP_BLOCKS), dim3(256), 0, (hipStream_t)stream, xyzs, live_idx, *lv, n_max, n_dev, nm,
-                       W.words, single_mask, xyzc, bitmap, ctr);
+    hipLaunchKernelGGL(hash_bwd_prep_kernel, dim3(BW_PREP_BLOCKS), dim3(256), 0, (hipStream_t)stream, xyzs, live_idx, make_prep_levels(*lv),
+                       lv->n_levels, lv->begin_fast_hash_level, n_max, n_dev, nm, W.words, single_mask, xyzc, bitmap, ctr);
     NGP_LAUNCH_CHECK();
     return 0;
 }

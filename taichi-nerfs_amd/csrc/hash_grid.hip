@@ -61,6 +61,50 @@ __device__ __forceinline__ void corners(const LevelLDS& L, int level, int bfhl, 
     }
 }
 
+// The same corners for ONE level whose constants the caller holds in registers, without a branch: both index forms are one
+// three-operand instruction per corner (v_add3 / v_xor3) behind per-axis terms ((c + 1) * k = c * k + k mod 2^32), and `% size` is
+// `& (size - 1)` on a power-of-two hashed level or one conditional subtract (min(h, h - size), unsigned) on a dense one -- exactly
+// `corners` above; a lane whose level needs the real modulo (mode 2, or a dense index >= 2 * size) reports it in the return
+// value and the caller redoes that lane's eight indices with `%` under ONE rarely taken branch.  Straight-line code keeps the
+// eight gathers of an iteration -- and the next iteration's position request -- in one basic block.
+struct LevelRegs {
+    float scale;
+    uint32_t res, size, mode, offset;
+    bool dense;
+};
+template <bool HALF_CELL>
+__device__ __forceinline__ bool corners_flat(const LevelRegs& lr, float x, float y, float z, Corners& c, uint32_t h_raw[8]) {
+    float pos[3] = {x * lr.scale + 0.5f, y * lr.scale + 0.5f, z * lr.scale + 0.5f};
+    uint32_t cell[3];
+    float fr[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        cell[k] = f2u_sat(floorf(pos[k]));
+        float cf = (float)cell[k];
+        if (HALF_CELL) cf = __half2float(__float2half_rn(cf));
+        fr[k] = pos[k] - cf;
+    }
+    const uint32_t ky = lr.dense ? lr.res : 2654435761u, kz = lr.dense ? lr.res * lr.res : 805459861u;
+    const uint32_t ax[2] = {cell[0], cell[0] + 1u};
+    const uint32_t ay[2] = {cell[1] * ky, cell[1] * ky + ky};
+    const uint32_t az[2] = {cell[2] * kz, cell[2] * kz + kz};
+    uint32_t worst = 0u;
+#pragma unroll
+    for (int ci = 0; ci < 8; ++ci) {
+        float w = 1.0f;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) w *= (ci & (1 << d)) ? fr[d] : 1.0f - fr[d];
+        const uint32_t gx = ax[ci & 1], gy = ay[(ci >> 1) & 1], gz = az[(ci >> 2) & 1];
+        const uint32_t h = lr.dense ? gx + gy + gz : gx ^ gy ^ gz;                 // under_hash :53-60 / fast_hash :43-51
+        h_raw[ci] = h;
+        const uint32_t r = lr.mode == 1u ? (h & (lr.size - 1u)) : min(h, h - lr.size);
+        worst = max(worst, r);
+        c.idx[ci] = lr.offset + r;
+        c.w[ci] = w;
+    }
+    return lr.mode != 1u && worst >= lr.size;
+}
+
 // BF16 = true: the table is stored as bf16 pairs (uint32 per entry, F = 2 only); bf16 -> f32 is exact, the interpolation and
 // the output stay f32, so the result equals the f32 kernel run on the bf16-rounded table, bit for bit.
 __device__ __forceinline__ float2 bf16x2_to_f32(uint32_t u) {
@@ -124,7 +168,12 @@ __global__ void __launch_bounds__(256) hash_fwd_f32_kernel(const float* __restri
 // MODE 0: f32 table.  MODE 1: bf16 storage copy, f32 arithmetic.  MODE 2: the half2 encoder's arithmetic (hash_encoder_half.py:
 // 112-161: f16 table, cell cast to f16 before the subtract, every w * table term rounded to f16, f16 accumulation) with the
 // result widened to f32 (exact) so the consumers of the fused path stay the same.
-template <int MODE>
+// Round 4: the loop body is one basic block.  The position of the NEXT iteration is requested (index clamped, so the request is
+// unconditional) before this iteration's index arithmetic, the level's constants live in registers, and the corners come from
+// corners_flat: an iteration used to be four dependent memory round trips (x, y, z each behind a branch of norm01, then the
+// gathers) and ~60 scalar branches; it is now the gathers' round trip alone.  V1 = the round-1..3 loop (NGP_HASH_FWD_V1=1), kept
+// for the A/B in profiles/r04_hash_fwd_loop_experiment.txt.
+template <int MODE, bool V1 = false>
 __global__ void __launch_bounds__(256) hash_fwd_f32_xcd_kernel(const float* __restrict__ xyzs, const float* __restrict__ table,
                                                                ngp_hash_levels lv, int n, const int32_t* __restrict__ n_dev,
                                                                XyzNorm nm, int enc_pairs, float* __restrict__ out) {
@@ -132,21 +181,19 @@ __global__ void __launch_bounds__(256) hash_fwd_f32_xcd_kernel(const float* __re
     load_levels(lv, L);
     const size_t plane = (size_t)n;                       // pair-major plane stride = buffer capacity
     if (n_dev) n = min(n, *n_dev);
+    if (n <= 0) return;
     const int pair = blockIdx.x & 7, which = threadIdx.x & 1;
     const int level = which ? 15 - pair : pair;
     const int tiles = gridDim.x >> 3;
-    for (int i = (blockIdx.x >> 3) * 128 + (threadIdx.x >> 1); i < n; i += tiles * 128) {
-        const float x = norm01(nm, xyzs[3 * (size_t)i]), y = norm01(nm, xyzs[3 * (size_t)i + 1]),
-                    z = norm01(nm, xyzs[3 * (size_t)i + 2]);
-        Corners c;
-        corners<MODE == 2>(L, level, lv.begin_fast_hash_level, x, y, z, c);
-        float2 v[8];
+    auto gather = [&](const Corners& c, float2 v[8]) {
 #pragma unroll
         for (int ci = 0; ci < 8; ++ci) {
             if constexpr (MODE == 1) v[ci] = bf16x2_to_f32(reinterpret_cast<const uint32_t*>(table)[c.idx[ci]]);
             else if constexpr (MODE == 2) v[ci] = __half22float2(reinterpret_cast<const __half2*>(table)[c.idx[ci]]);
             else v[ci] = *reinterpret_cast<const float2*>(table + (size_t)c.idx[ci] * 2);
         }
+    };
+    auto blend = [&](const Corners& c, const float2 v[8]) {
         float a0 = 0.0f, a1 = 0.0f;
         if constexpr (MODE == 2) {
             __half2 acc = __floats2half2_rn(0.0f, 0.0f);
@@ -158,8 +205,57 @@ __global__ void __launch_bounds__(256) hash_fwd_f32_xcd_kernel(const float* __re
 #pragma unroll
             for (int ci = 0; ci < 8; ++ci) { a0 += c.w[ci] * v[ci].x; a1 += c.w[ci] * v[ci].y; }   // same order as the generic kernel
         }
-        float* o = enc_pairs ? out + ((size_t)pair * plane + i) * 4 + which * 2 : out + (size_t)i * 32 + level * 2;
-        *reinterpret_cast<float2*>(o) = make_float2(a0, a1);
+        return make_float2(a0, a1);
+    };
+    auto out_at = [&](int i) { return reinterpret_cast<float2*>(enc_pairs ? out + ((size_t)pair * plane + i) * 4 + which * 2 : out + (size_t)i * 32 + level * 2); };
+    if constexpr (V1) {
+        for (int i = (blockIdx.x >> 3) * 128 + (threadIdx.x >> 1); i < n; i += tiles * 128) {
+            const float x = norm01(nm, xyzs[3 * (size_t)i]), y = norm01(nm, xyzs[3 * (size_t)i + 1]),
+                        z = norm01(nm, xyzs[3 * (size_t)i + 2]);
+            Corners c;
+            corners<MODE == 2>(L, level, lv.begin_fast_hash_level, x, y, z, c);
+            float2 v[8];
+            gather(c, v);
+            *out_at(i) = blend(c, v);
+        }
+    } else {
+        const LevelRegs lr = {L.scale[level], L.res[level], L.size[level], L.mode[level], L.offset[level], level < lv.begin_fast_hash_level};
+        const int stride = tiles * 128;
+        int i = (blockIdx.x >> 3) * 128 + (threadIdx.x >> 1);
+        const float den = nm.hi - nm.lo;
+        float2* o_prev = nullptr;
+        float2 r_prev = make_float2(0.0f, 0.0f);
+        float p[3];
+        {
+            const float* q = xyzs + 3 * (size_t)min(i, n - 1);
+            p[0] = q[0]; p[1] = q[1]; p[2] = q[2];
+        }
+        for (; i < n; i += stride) {
+            float xyz[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float d = (p[k] - nm.lo) / den;                 // norm01: the reference's two f32 ops (networks.py:144)
+                xyz[k] = nm.enabled ? d : p[k];
+            }
+            {
+                const float* q = xyzs + 3 * (size_t)min(i + stride, n - 1);
+                p[0] = q[0]; p[1] = q[1]; p[2] = q[2];
+            }
+            Corners c;
+            uint32_t h_raw[8];
+            if (corners_flat<MODE == 2>(lr, xyz[0], xyz[1], xyz[2], c, h_raw)) {
+#pragma unroll
+                for (int ci = 0; ci < 8; ++ci) c.idx[ci] = lr.offset + h_raw[ci] % lr.size;
+            }
+            float2 v[8];
+            gather(c, v);
+            // the PREVIOUS iteration's result is written here, underneath this iteration's gathers: gfx950 counts loads and stores
+            // in one counter, so a store issued last in the loop body is what the next iteration's first wait would sit on
+            if (o_prev) *o_prev = r_prev;
+            r_prev = blend(c, v);
+            o_prev = out_at(i);
+        }
+        if (o_prev) *o_prev = r_prev;
     }
 }
 
@@ -466,7 +562,9 @@ int ngp_hash_fwd_f32_ex(const float* xyzs, const float* table, const ngp_hash_le
     if (lv->n_features == 2 && lv->n_levels == 16 && (n_max >= 4096 || enc_pairs)) {
         int tiles = (n_max + 127) / 128;
         if (tiles > 512) tiles = 512;                       // 4096 blocks, tile-stride beyond
-        hipLaunchKernelGGL(hash_fwd_f32_xcd_kernel<0>, dim3(8 * tiles), dim3(256), 0, s, xyzs, table, *lv, n_max, n_dev, nm, enc_pairs, out);
+        static const bool v1 = [] { const char* e = getenv("NGP_HASH_FWD_V1"); return e && e[0] == '1'; }();
+        if (v1) hipLaunchKernelGGL((hash_fwd_f32_xcd_kernel<0, true>), dim3(8 * tiles), dim3(256), 0, s, xyzs, table, *lv, n_max, n_dev, nm, enc_pairs, out);
+        else hipLaunchKernelGGL((hash_fwd_f32_xcd_kernel<0, false>), dim3(8 * tiles), dim3(256), 0, s, xyzs, table, *lv, n_max, n_dev, nm, enc_pairs, out);
         NGP_LAUNCH_CHECK();
         return 0;
     }

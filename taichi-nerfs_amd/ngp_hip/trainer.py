@@ -475,7 +475,7 @@ class FusedTrainer:
         # ... summed by the head of the scatter-add launch (its first 147 persistent workgroups, ~2 us hidden in 200) on one GPU with
         # the LDS-sliced scatter-add; by the prologue launch when the scatter-add is another kernel; by a launch of its own when the
         # gradient is needed earlier (an exchange between ranks, compute_gradients)
-        single = self.world == 1 and not self._grads_only and n_parts > 0
+        single = self.world == 1 and not self._grads_only and n_parts > 0 and self._groups is None   # (overlapped tail: no slab hand-over)
         reduce_in_scatter = single and sliced and not self.half and os.environ.get("NGP_MLP_DW_REDUCE", "scatter") == "scatter"
         reduce_in_prologue = single and not reduce_in_scatter
         if n_parts > 0 and not single:
