@@ -162,16 +162,27 @@ __device__ __forceinline__ const float* grad_ptr(const float* dout, int level, s
 // (Round 4, measured and not kept: FOUR tiles per wave trip with lane s storing the four words of slice s as one 32-byte piece --
 // 6.4 M scattered 8-byte stores become 1.6 M -- is correct and SLOWER, 65 vs 50 us at 433 k samples: the launch then has 1700
 // working waves instead of 6800, and a trip is a serial chain over 16 levels.  The prepass is latency-, not store-bound.)
+// Levels are dealt to the ballot form (<= 8 slices) or the LDS form (> 8) by their slice count, which grows with the level: lds_begin
+// is the first LDS-form level (the host checks that the split is a prefix / suffix).  The LDS-form levels are done BATCH at a time:
+// all their ORs, one fence, then every level's row is read, stored and cleared.  BATCH = 1 is rounds 2-3's order and the default:
+// measured at 750 k samples (profiles/r04_hash_fwd_loop_experiment.txt) BATCH 1 / 3 / 6 / 12 = 59.2 / 59.7 / 63.2 / 66.7 us -- the
+// per-level chain (clear, fence, ORs, fence, read, store) is NOT what the launch waits for; its LDS atomics and its 8-byte
+// scattered row stores are (larger batches only cost occupancy: 24 KB of LDS per workgroup at 12).
+template <int BATCH>
 __global__ void __launch_bounds__(256) hash_bwd_prep_kernel(const float* __restrict__ xyzs, const int32_t* __restrict__ idx,
-                                                            PrepLevels pl, int nl, int bfhl, int n, const int32_t* __restrict__ n_dev,
-                                                            XyzNorm nm, size_t wstride, uint32_t single_slice_levels,
-                                                            float* __restrict__ xyzc, unsigned long long* __restrict__ bitmap,
-                                                            uint32_t* __restrict__ ctr) {
-    __shared__ unsigned long long words[4][BW_MAX_SLICES];
+                                                            PrepLevels pl, int nl, int bfhl, int lds_begin, int n,
+                                                            const int32_t* __restrict__ n_dev, XyzNorm nm, size_t wstride,
+                                                            uint32_t single_slice_levels, float* __restrict__ xyzc,
+                                                            unsigned long long* __restrict__ bitmap, uint32_t* __restrict__ ctr) {
+    __shared__ unsigned long long words[4][BATCH][BW_MAX_SLICES];
     if (blockIdx.x == 0 && threadIdx.x < 16) ctr[threadIdx.x] = 0u;       // the main kernel's queue heads (it also resets them itself)
     if (n_dev) n = min(n, *n_dev);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n_tiles = (n + 63) >> 6;
+#pragma unroll
+    for (int k = 0; k < BATCH; ++k) words[wave][k][lane] = 0ull;         // (a wave only ever touches its own rows)
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     for (int tile = blockIdx.x * 4 + wave; tile < n_tiles; tile += gridDim.x * 4) {
         const int i = tile * 64 + lane;
         const bool valid = i < n;
@@ -182,73 +193,85 @@ __global__ void __launch_bounds__(256) hash_bwd_prep_kernel(const float* __restr
             x = norm01(nm, rx); y = norm01(nm, ry); z = norm01(nm, rz);
             xyzc[3 * (size_t)i] = x; xyzc[3 * (size_t)i + 1] = y; xyzc[3 * (size_t)i + 2] = z;
         }
-        for (int level = 0; level < nl; ++level) {
+        // ---- levels of <= 8 slices: one wave ballot per slice
+        for (int level = 0; level < lds_begin; ++level) {
             if ((single_slice_levels >> level) & 1u) continue;             // every sample is a hit there: no bitmap needed
             const PrepLevel& P = pl.l[level];
-            const float scale = P.scale;
             const uint32_t res = P.res, size = P.size, mode = P.mode;
-            const uint32_t cx = f2u_sat(floorf(x * scale + 0.5f)), cy = f2u_sat(floorf(y * scale + 0.5f)),
-                           cz = f2u_sat(floorf(z * scale + 0.5f));
+            const uint32_t cx = f2u_sat(floorf(x * P.scale + 0.5f)), cy = f2u_sat(floorf(y * P.scale + 0.5f)),
+                           cz = f2u_sat(floorf(z * P.scale + 0.5f));
             const bool dense = level < bfhl;
             const SliceMap SM = P.map;
-            const int ns = (int)SM.ns;
             unsigned long long* row = bitmap + ((size_t)level * BW_MAX_SLICES) * wstride + tile;
-            const bool dense0 = dense && mode == 0u;
             const uint32_t res2 = res * res, base = cx + cy * res + cz * res2;
-            if (ns <= 8) {
-                uint32_t m = 0u;
-                if (valid) {
-                    if (dense0) {
-#pragma unroll
-                        for (int c = 0; c < 8; ++c) { uint32_t loc; m |= 1u << slice_of(SM, dense0_index(base, res, res2, size, c), loc); }
-                    } else {
-#pragma unroll
-                        for (int c = 0; c < 8; ++c) {
-                            uint32_t loc;
-                            m |= 1u << slice_of(SM, level_index(dense, mode, size, res, cx + (c & 1), cy + ((c >> 1) & 1), cz + (c >> 2)), loc);
-                        }
-                    }
-                }
-                for (int s = 0; s < ns; ++s) {
-                    const unsigned long long w = __ballot((m >> s) & 1u);
-                    if (lane == 0) row[(size_t)s * wstride] = w;
-                }
-                continue;
-            }
-            words[wave][lane] = 0ull;
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+            uint32_t m = 0u;
             if (valid) {
-                if (!dense && mode == 1u && res < (1u << BW_SLICE_LOG2)) {
-                    // xor hash, power-of-two table: x only flips bits below the slice bits -> one slice per (y, z) combination
-                    const uint32_t b0 = cy * 2654435761u, b1 = b0 + 2654435761u, c0 = cz * 805459861u, c1 = c0 + 805459861u;
-                    const uint32_t msk = size - 1u;
-                    atomicOr(&words[wave][((b0 ^ c0) & msk) >> BW_SLICE_LOG2], 1ull << lane);         // ds_or_b64
-                    atomicOr(&words[wave][((b1 ^ c0) & msk) >> BW_SLICE_LOG2], 1ull << lane);
-                    atomicOr(&words[wave][((b0 ^ c1) & msk) >> BW_SLICE_LOG2], 1ull << lane);
-                    atomicOr(&words[wave][((b1 ^ c1) & msk) >> BW_SLICE_LOG2], 1ull << lane);
-                } else if (dense0) {
-                    // the x pair is adjacent and stays inside one interleaving block except at a block edge: 4 ORs, + the edge cases
+                if (dense && mode == 0u) {
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        uint32_t loc;
-                        const uint32_t s0 = slice_of(SM, dense0_index(base, res, res2, size, 2 * k), loc);
-                        const uint32_t s1 = slice_of(SM, dense0_index(base, res, res2, size, 2 * k + 1), loc);
-                        atomicOr(&words[wave][s0], 1ull << lane);
-                        if (s1 != s0) atomicOr(&words[wave][s1], 1ull << lane);
-                    }
+                    for (int c = 0; c < 8; ++c) { uint32_t loc; m |= 1u << slice_of(SM, dense0_index(base, res, res2, size, c), loc); }
                 } else {
 #pragma unroll
                     for (int c = 0; c < 8; ++c) {
                         uint32_t loc;
-                        const uint32_t h = level_index(dense, mode, size, res, cx + (c & 1), cy + ((c >> 1) & 1), cz + (c >> 2));
-                        atomicOr(&words[wave][slice_of(SM, h, loc)], 1ull << lane);
+                        m |= 1u << slice_of(SM, level_index(dense, mode, size, res, cx + (c & 1), cy + ((c >> 1) & 1), cz + (c >> 2)), loc);
+                    }
+                }
+            }
+            for (int s = 0; s < (int)SM.ns; ++s) {
+                const unsigned long long w = __ballot((m >> s) & 1u);
+                if (lane == 0) row[(size_t)s * wstride] = w;
+            }
+        }
+        // ---- levels of many slices: each lane ORs its corners' bits into the level's 64-word LDS table
+        for (int lb = lds_begin; lb < nl; lb += BATCH) {
+            const int le = min(lb + BATCH, nl);
+            if (valid) {
+                for (int level = lb; level < le; ++level) {
+                    const PrepLevel& P = pl.l[level];
+                    const uint32_t res = P.res, size = P.size, mode = P.mode;
+                    const uint32_t cx = f2u_sat(floorf(x * P.scale + 0.5f)), cy = f2u_sat(floorf(y * P.scale + 0.5f)),
+                                   cz = f2u_sat(floorf(z * P.scale + 0.5f));
+                    const bool dense = level < bfhl;
+                    const SliceMap SM = P.map;
+                    unsigned long long* wd = words[wave][level - lb];
+                    if (!dense && mode == 1u && res < (1u << BW_SLICE_LOG2)) {
+                        // xor hash, power-of-two table: x only flips bits below the slice bits -> one slice per (y, z) combination
+                        const uint32_t b0 = cy * 2654435761u, b1 = b0 + 2654435761u, c0 = cz * 805459861u, c1 = c0 + 805459861u;
+                        const uint32_t msk = size - 1u;
+                        atomicOr(&wd[((b0 ^ c0) & msk) >> BW_SLICE_LOG2], 1ull << lane);         // ds_or_b64
+                        atomicOr(&wd[((b1 ^ c0) & msk) >> BW_SLICE_LOG2], 1ull << lane);
+                        atomicOr(&wd[((b0 ^ c1) & msk) >> BW_SLICE_LOG2], 1ull << lane);
+                        atomicOr(&wd[((b1 ^ c1) & msk) >> BW_SLICE_LOG2], 1ull << lane);
+                    } else if (dense && mode == 0u) {
+                        // the x pair is adjacent and stays inside one interleaving block except at a block edge: 4 ORs, + the edge cases
+                        const uint32_t res2 = res * res, base = cx + cy * res + cz * res2;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            uint32_t loc;
+                            const uint32_t s0 = slice_of(SM, dense0_index(base, res, res2, size, 2 * k), loc);
+                            const uint32_t s1 = slice_of(SM, dense0_index(base, res, res2, size, 2 * k + 1), loc);
+                            atomicOr(&wd[s0], 1ull << lane);
+                            if (s1 != s0) atomicOr(&wd[s1], 1ull << lane);
+                        }
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) {
+                            uint32_t loc;
+                            const uint32_t h = level_index(dense, mode, size, res, cx + (c & 1), cy + ((c >> 1) & 1), cz + (c >> 2));
+                            atomicOr(&wd[slice_of(SM, h, loc)], 1ull << lane);
+                        }
                     }
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            if (lane < ns) row[(size_t)lane * wstride] = words[wave][lane];
+            for (int level = lb; level < le; ++level) {
+                const unsigned long long w = words[wave][level - lb][lane];
+                words[wave][level - lb][lane] = 0ull;                              // clean for the next batch / tile
+                if (lane < (int)pl.l[level].map.ns)
+                    bitmap[((size_t)level * BW_MAX_SLICES + lane) * wstride + tile] = w;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
     }
@@ -1012,8 +1035,16 @@ int ngp_hash_bwd_sliced_prep(const float* xyzs, const ngp_hash_levels* lv, int n
     unsigned long long* bitmap = reinterpret_cast<unsigned long long*>(base + W.off_bitmap);
     uint32_t* ctr = reinterpret_cast<uint32_t*>(base + W.off_ctr);
     const XyzNorm nm = {normalize, lo, hi};
-    hipLaunchKernelGGL(hash_bwd_prep_kernel, dim3(BW_PREP_BLOCKS), dim3(256), 0, (hipStream_t)stream, xyzs, live_idx, make_prep_levels(*lv),
-                       lv->n_levels, lv->begin_fast_hash_level, n_max, n_dev, nm, W.words, single_mask, xyzc, bitmap, ctr);
+    const PrepLevels pl = make_prep_levels(*lv);
+    int lds_begin = 0;                                                    // ballot form below, LDS form from here on
+    while (lds_begin < lv->n_levels && pl.l[lds_begin].map.ns <= 8u) ++lds_begin;
+    for (int l = lds_begin; l < lv->n_levels; ++l)
+        if (pl.l[l].map.ns <= 8u) return -2;                              // (sizes grow with the level in every table ngp_hash_levels_init makes)
+    static const int batch = [] { const char* e = getenv("NGP_PREP_BATCH"); return e ? atoi(e) : 1; }();
+#define NGP_PREP(B) hipLaunchKernelGGL(hash_bwd_prep_kernel<B>, dim3(BW_PREP_BLOCKS), dim3(256), 0, (hipStream_t)stream, xyzs, live_idx, pl, \
+                                       lv->n_levels, lv->begin_fast_hash_level, lds_begin, n_max, n_dev, nm, W.words, single_mask, xyzc, bitmap, ctr)
+    if (batch == 3) NGP_PREP(3); else if (batch == 6) NGP_PREP(6); else if (batch == 12) NGP_PREP(12); else NGP_PREP(1);
+#undef NGP_PREP
     NGP_LAUNCH_CHECK();
     return 0;
 }

@@ -64,13 +64,21 @@ __device__ __forceinline__ void corners(const LevelLDS& L, int level, int bfhl, 
 // The same corners for ONE level whose constants the caller holds in registers, without a branch: both index forms are one
 // three-operand instruction per corner (v_add3 / v_xor3) behind per-axis terms ((c + 1) * k = c * k + k mod 2^32), and `% size` is
 // `& (size - 1)` on a power-of-two hashed level or one conditional subtract (min(h, h - size), unsigned) on a dense one -- exactly
-// `corners` above; a lane whose level needs the real modulo (mode 2, or a dense index >= 2 * size) reports it in the return
-// value and the caller redoes that lane's eight indices with `%` under ONE rarely taken branch.  Straight-line code keeps the
+// `corners` above, but with c.idx RELATIVE to the level's first entry (the caller folds the offset into its base pointer); a lane
+// whose level needs the real modulo (mode 2, or a dense index >= 2 * size) reports it in the return value and the caller redoes
+// that lane's eight indices with `%` under ONE rarely taken branch.  Straight-line code keeps the
 // eight gathers of an iteration -- and the next iteration's position request -- in one basic block.
 struct LevelRegs {
     float scale;
     uint32_t res, size, mode, offset;
     bool dense;
+    // one form for both cheap cases: r = min(h & mask, (h & mask) - wrap), unsigned.  Power-of-two hashed level: mask = size - 1 and
+    // wrap = 2^31 (never taken: h & mask < 2^31).  Dense level: mask = all ones, wrap = size (the conditional subtract).
+    uint32_t mask, wrap;
+    __device__ __forceinline__ void derive() {
+        mask = mode == 1u ? size - 1u : 0xffffffffu;
+        wrap = mode == 1u ? 0x80000000u : size;
+    }
 };
 template <bool HALF_CELL>
 __device__ __forceinline__ bool corners_flat(const LevelRegs& lr, float x, float y, float z, Corners& c, uint32_t h_raw[8]) {
@@ -97,9 +105,9 @@ __device__ __forceinline__ bool corners_flat(const LevelRegs& lr, float x, float
         const uint32_t gx = ax[ci & 1], gy = ay[(ci >> 1) & 1], gz = az[(ci >> 2) & 1];
         const uint32_t h = lr.dense ? gx + gy + gz : gx ^ gy ^ gz;                 // under_hash :53-60 / fast_hash :43-51
         h_raw[ci] = h;
-        const uint32_t r = lr.mode == 1u ? (h & (lr.size - 1u)) : min(h, h - lr.size);
+        const uint32_t hm = h & lr.mask, r = min(hm, hm - lr.wrap);
         worst = max(worst, r);
-        c.idx[ci] = lr.offset + r;
+        c.idx[ci] = r;                                                             // relative to the level's first entry
         c.w[ci] = w;
     }
     return lr.mode != 1u && worst >= lr.size;
@@ -185,12 +193,22 @@ __global__ void __launch_bounds__(256) hash_fwd_f32_xcd_kernel(const float* __re
     const int pair = blockIdx.x & 7, which = threadIdx.x & 1;
     const int level = which ? 15 - pair : pair;
     const int tiles = gridDim.x >> 3;
-    auto gather = [&](const Corners& c, float2 v[8]) {
+    // V1: c.idx = entry in the table (64-bit address per corner).  Otherwise c.idx = entry in the level and `off` = the level's
+    // first BYTE: a 32-bit byte offset on the uniform table pointer (global_load ... v_off, s[base]) -- one VGPR per corner
+    // instead of two; the host entry point takes this form only for tables below 4 GB.
+    auto gather = [&](uint32_t off, const Corners& c, float2 v[8]) {
+        const char* tb = reinterpret_cast<const char*>(table);
 #pragma unroll
         for (int ci = 0; ci < 8; ++ci) {
-            if constexpr (MODE == 1) v[ci] = bf16x2_to_f32(reinterpret_cast<const uint32_t*>(table)[c.idx[ci]]);
-            else if constexpr (MODE == 2) v[ci] = __half22float2(reinterpret_cast<const __half2*>(table)[c.idx[ci]]);
-            else v[ci] = *reinterpret_cast<const float2*>(table + (size_t)c.idx[ci] * 2);
+            if constexpr (V1) {
+                if constexpr (MODE == 1) v[ci] = bf16x2_to_f32(reinterpret_cast<const uint32_t*>(table)[c.idx[ci]]);
+                else if constexpr (MODE == 2) v[ci] = __half22float2(reinterpret_cast<const __half2*>(table)[c.idx[ci]]);
+                else v[ci] = *reinterpret_cast<const float2*>(table + (size_t)c.idx[ci] * 2);
+            } else {
+                if constexpr (MODE == 1) v[ci] = bf16x2_to_f32(*reinterpret_cast<const uint32_t*>(tb + (c.idx[ci] * 4u + off)));
+                else if constexpr (MODE == 2) v[ci] = __half22float2(*reinterpret_cast<const __half2*>(tb + (c.idx[ci] * 4u + off)));
+                else v[ci] = *reinterpret_cast<const float2*>(tb + (c.idx[ci] * 8u + off));
+            }
         }
     };
     auto blend = [&](const Corners& c, const float2 v[8]) {
@@ -215,14 +233,23 @@ __global__ void __launch_bounds__(256) hash_fwd_f32_xcd_kernel(const float* __re
             Corners c;
             corners<MODE == 2>(L, level, lv.begin_fast_hash_level, x, y, z, c);
             float2 v[8];
-            gather(c, v);
+            gather(0u, c, v);
             *out_at(i) = blend(c, v);
         }
     } else {
-        const LevelRegs lr = {L.scale[level], L.res[level], L.size[level], L.mode[level], L.offset[level], level < lv.begin_fast_hash_level};
+        LevelRegs lr = {L.scale[level], L.res[level], L.size[level], L.mode[level], L.offset[level], level < lv.begin_fast_hash_level};
+        lr.derive();
+        const uint32_t level_off = lr.offset * (MODE == 0 ? 8u : 4u);
         const int stride = tiles * 128;
         int i = (blockIdx.x >> 3) * 128 + (threadIdx.x >> 1);
-        const float den = nm.hi - nm.lo;
+        // norm01 = (v - lo) / (hi - lo), the reference's two f32 ops (networks.py:144).  Where hi - lo is a power of two (every scale
+        // the reference ships: 0.5, 1, 2, ... 16), x / 2^k and x * 2^-k are the same correctly rounded value: one multiply
+        // instead of the ~10-instruction IEEE division, three times per sample and level.
+        // No normalisation is the same multiply with lo = 0 and 2^-k = 1 (v - 0 and v * 1 are exact).
+        const float den = nm.enabled ? nm.hi - nm.lo : 1.0f, lo = nm.enabled ? nm.lo : 0.0f;
+        const uint32_t den_bits = __float_as_uint(den);
+        const bool den_pow2 = (den_bits & 0x807fffffu) == 0u && den_bits >= 0x20000000u && den_bits <= 0x5f800000u;   // 2^-63 .. 2^64
+        const float inv_den = den_pow2 ? 1.0f / den : 0.0f;
         float2* o_prev = nullptr;
         float2 r_prev = make_float2(0.0f, 0.0f);
         float p[3];
@@ -232,10 +259,12 @@ __global__ void __launch_bounds__(256) hash_fwd_f32_xcd_kernel(const float* __re
         }
         for (; i < n; i += stride) {
             float xyz[3];
+            if (den_pow2) {
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const float d = (p[k] - nm.lo) / den;                 // norm01: the reference's two f32 ops (networks.py:144)
-                xyz[k] = nm.enabled ? d : p[k];
+                for (int k = 0; k < 3; ++k) xyz[k] = (p[k] - lo) * inv_den;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) xyz[k] = (p[k] - lo) / den;
             }
             {
                 const float* q = xyzs + 3 * (size_t)min(i + stride, n - 1);
@@ -245,10 +274,10 @@ __global__ void __launch_bounds__(256) hash_fwd_f32_xcd_kernel(const float* __re
             uint32_t h_raw[8];
             if (corners_flat<MODE == 2>(lr, xyz[0], xyz[1], xyz[2], c, h_raw)) {
 #pragma unroll
-                for (int ci = 0; ci < 8; ++ci) c.idx[ci] = lr.offset + h_raw[ci] % lr.size;
+                for (int ci = 0; ci < 8; ++ci) c.idx[ci] = h_raw[ci] % lr.size;
             }
             float2 v[8];
-            gather(c, v);
+            gather(level_off, c, v);
             // the PREVIOUS iteration's result is written here, underneath this iteration's gathers: gfx950 counts loads and stores
             // in one counter, so a store issued last in the loop body is what the next iteration's first wait would sit on
             if (o_prev) *o_prev = r_prev;
@@ -537,6 +566,13 @@ __global__ void __launch_bounds__(256) check_finite_f16_kernel(const uint4* __re
     if (__any(bad) && (threadIdx.x & 63) == 0) *found_inf = 1;
 }
 
+// The round-4 loop of hash_fwd_f32_xcd_kernel addresses the table with 32-bit byte offsets: tables of 4 GB and more (and
+// NGP_HASH_FWD_V1=1, for A/B timing) take the round-1..3 loop.
+inline bool xcd_v1(const ngp_hash_levels& lv, unsigned entry_bytes) {
+    static const bool forced = [] { const char* e = getenv("NGP_HASH_FWD_V1"); return e && e[0] == '1'; }();
+    return forced || (unsigned long long)(unsigned)lv.total_entries * entry_bytes >= 0xffffff00ull;
+}
+
 inline int grid_for(long long work, int block) {
     long long b = (work + block - 1) / block;
     const long long cap = 256LL * 16;      // 256 CUs x 16 blocks, grid-stride beyond that
@@ -562,8 +598,7 @@ int ngp_hash_fwd_f32_ex(const float* xyzs, const float* table, const ngp_hash_le
     if (lv->n_features == 2 && lv->n_levels == 16 && (n_max >= 4096 || enc_pairs)) {
         int tiles = (n_max + 127) / 128;
         if (tiles > 512) tiles = 512;                       // 4096 blocks, tile-stride beyond
-        static const bool v1 = [] { const char* e = getenv("NGP_HASH_FWD_V1"); return e && e[0] == '1'; }();
-        if (v1) hipLaunchKernelGGL((hash_fwd_f32_xcd_kernel<0, true>), dim3(8 * tiles), dim3(256), 0, s, xyzs, table, *lv, n_max, n_dev, nm, enc_pairs, out);
+        if (xcd_v1(*lv, 8)) hipLaunchKernelGGL((hash_fwd_f32_xcd_kernel<0, true>), dim3(8 * tiles), dim3(256), 0, s, xyzs, table, *lv, n_max, n_dev, nm, enc_pairs, out);
         else hipLaunchKernelGGL((hash_fwd_f32_xcd_kernel<0, false>), dim3(8 * tiles), dim3(256), 0, s, xyzs, table, *lv, n_max, n_dev, nm, enc_pairs, out);
         NGP_LAUNCH_CHECK();
         return 0;
@@ -590,7 +625,8 @@ int ngp_hash_fwd_bf16_ex(const float* xyzs, const uint16_t* table, const ngp_has
     if (lv->n_levels == 16 && (n_max >= 4096 || enc_pairs)) {
         int tiles = (n_max + 127) / 128;
         if (tiles > 512) tiles = 512;
-        hipLaunchKernelGGL(hash_fwd_f32_xcd_kernel<1>, dim3(8 * tiles), dim3(256), 0, s, xyzs, t, *lv, n_max, n_dev, nm, enc_pairs, out);
+        if (xcd_v1(*lv, 4)) hipLaunchKernelGGL((hash_fwd_f32_xcd_kernel<1, true>), dim3(8 * tiles), dim3(256), 0, s, xyzs, t, *lv, n_max, n_dev, nm, enc_pairs, out);
+        else hipLaunchKernelGGL((hash_fwd_f32_xcd_kernel<1, false>), dim3(8 * tiles), dim3(256), 0, s, xyzs, t, *lv, n_max, n_dev, nm, enc_pairs, out);
     } else {
         const int grid = grid_for((long long)n_max * lv->n_levels, 256);
         hipLaunchKernelGGL((hash_fwd_f32_kernel<2, true>), dim3(grid), dim3(256), 0, s, xyzs, t, *lv, n_max, n_dev, nm, out);
@@ -665,8 +701,12 @@ int ngp_hash_fwd_f16_ex(const float* xyzs, const uint16_t* table, const ngp_hash
     int tiles = (n_max + 127) / 128;
     if (tiles > 512) tiles = 512;
     const XyzNorm nm = {normalize, lo, hi};
-    hipLaunchKernelGGL(hash_fwd_f32_xcd_kernel<2>, dim3(8 * tiles), dim3(256), 0, (hipStream_t)stream, xyzs,
-                       reinterpret_cast<const float*>(table), *lv, n_max, n_dev, nm, enc_pairs, out);
+    if (xcd_v1(*lv, 4))
+        hipLaunchKernelGGL((hash_fwd_f32_xcd_kernel<2, true>), dim3(8 * tiles), dim3(256), 0, (hipStream_t)stream, xyzs,
+                           reinterpret_cast<const float*>(table), *lv, n_max, n_dev, nm, enc_pairs, out);
+    else
+        hipLaunchKernelGGL((hash_fwd_f32_xcd_kernel<2, false>), dim3(8 * tiles), dim3(256), 0, (hipStream_t)stream, xyzs,
+                           reinterpret_cast<const float*>(table), *lv, n_max, n_dev, nm, enc_pairs, out);
     NGP_LAUNCH_CHECK();
     return 0;
 }
