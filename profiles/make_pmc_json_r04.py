@@ -10,9 +10,9 @@ import json
 import os
 import sys
 
-KEYS = {"hash_fwd_f32_xcd_kernel<0>": "hash_fwd_f32", "hash_bwd_lds_kernel<false>": "hash_bwd_f32", "hash_bwd_prep_kernel": "hash_bwd_prep",
+KEYS = {"hash_fwd_f32_xcd_kernel<0": "hash_fwd_f32", "hash_bwd_lds_kernel<false>": "hash_bwd_f32", "hash_bwd_prep_kernel": "hash_bwd_prep",
         "mlp_fwd_kernelILb1": "mlp_fwd", "mlp_bwd_kernel": "mlp_bwd", "adam_all_kernel": "adam", "march_count_kernel": "march_count", "march_fused_kernel": "march_count",
-        "composite_train_fused_kernel": "composite_fused", "train_prologue_reduce_kernel": "prologue_reduce", "march_write_kernel": "march_write", "live_scan_kernel": "live_scan"}
+        "composite_train_fused_kernel": "composite_fused", "train_prologue_reduce_kernel": "prologue_reduce", "train_prologue_kernel": "prologue", "march_write_kernel": "march_write", "live_scan_kernel": "live_scan"}
 PASSES = ("fetch", "write", "sq1", "sq2", "sq3", "tcp", "tcc")
 
 
