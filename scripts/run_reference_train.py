@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--out", default=None)
     ap.add_argument("--log", default=None, help="write train.py's own stdout (its step / evaluation lines) to this file, verbatim")
     ap.add_argument("--keep", action="store_true", help="keep the scratch work directory")
+    ap.add_argument("--cprofile", default=None, help="run train.py under cProfile and write the top of the table (by own time) here")
     args = ap.parse_args()
 
     work = tempfile.mkdtemp(prefix="ngp_ref_train_")
@@ -99,7 +100,8 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "scripts"))
         import make_nsvf_scene
         scene = make_nsvf_scene.write_scene(data, wh=args.wh, n_train=args.n_train, n_test=args.n_test, scene=args.scene, model_scale=scale)
-    cmd = [sys.executable, os.path.join(lease, "train.py"), "--root_dir", data, "--exp_name", "Lego", "--batch_size", str(args.batch_size),
+    prof = os.path.join(work, "train.prof")
+    cmd = [sys.executable] + (["-m", "cProfile", "-o", prof] if args.cprofile else []) + [os.path.join(lease, "train.py"), "--root_dir", data, "--exp_name", "Lego", "--batch_size", str(args.batch_size),
            "--lr", "1e-2", "--gpu", "0", "--max_steps", str(args.max_steps)]
     if args.wh != 800:
         cmd += ["--downsample", repr(args.wh / 800.0)]
@@ -120,6 +122,15 @@ def main():
         with open(args.log, "w") as f:
             f.write("$ " + " ".join(cmd).replace(lease, "<lease>") + "\n" + log)
     sys.stderr.write(p.stderr[-4000:])
+    if args.cprofile and os.path.exists(prof):
+        import io
+        import pstats
+        buf = io.StringIO()
+        st = pstats.Stats(prof, stream=buf)
+        st.sort_stats("tottime").print_stats(45)
+        st.sort_stats("cumulative").print_stats(45)
+        with open(args.cprofile, "w") as f:
+            f.write(buf.getvalue().replace(lease, "<lease>").replace(ROOT, "<repo>"))
     if p.returncode != 0:
         sys.stdout.write(log[-4000:])
         raise SystemExit("train.py exited with %d" % p.returncode)
