@@ -218,6 +218,54 @@ def test_hash_fwd_f32(oracle, hip_lib, max_res, features, levels):
     assert bits_equal(ref, got)
 
 
+@pytest.mark.parametrize("max_params", [3 * 2**17, 2**19 - 8, 100000])
+def test_hash_fwd_f32_real_modulo_levels(oracle, hip_lib, max_params):
+    """Tables whose hashed levels are NOT a power of two entries (index = hash % size, hash_encoder.py:71; no shipped config has
+    one): the round-4 gather loop takes the `%` under its one rarely taken branch (hash_grid.hip corners_flat), per lane -- the
+    dense levels of the same launch keep the conditional subtract.  Bit-exact against the oracle, natural and pair-major layout."""
+    lv = ops.make_levels(max_params, 16, 16, 1024, 2)
+    assert bytes(lv) == bytes(oracle.make_levels(max_params, 16, 16, 1024, 2))
+    sizes = [int(v) for v in np.ctypeslib.as_array(lv.map_size)[:16]]
+    assert any(v & (v - 1) for v in sizes[int(lv.begin_fast_hash_level):])       # at least one hashed level needs the real modulo
+    rng = np.random.default_rng(4)
+    n = 20000
+    x = rng.random((n, 3), dtype=np.float32)
+    x[:6] = [[0, 0, 0], [1, 1, 1], [0.5, 0.5, 0.5], [1, 0, 0], [0.25, 0.75, 1.0], [0.999999, 1e-7, 0.5]]
+    table = rng.random(lv.total_entries * 2, dtype=np.float32)
+    ref = oracle.hash_fwd_f32(x, table, lv)
+    assert bits_equal(ref, ops.hash_fwd_f32(dev(x), dev(table), lv).cpu().numpy())
+    L = ops._lib()
+    xd, td = dev(x), dev(table)
+    pm = torch.empty(8 * n * 4, device="cuda")
+    assert L.ngp_hash_fwd_f32_ex(ops._ptr(xd), ops._ptr(td), ctypes.byref(lv), n, ops._ptr(None), 0, 0.0, 1.0, 1, ops._ptr(pm),
+                                 ops._stream()) == 0
+    got = pm.view(8, n, 2, 2).cpu().numpy()                # [pair][sample][level p | level 15 - p][feature]
+    nat = ref.reshape(n, 16, 2)
+    for pr in range(8):
+        assert bits_equal(got[pr, :, 0], nat[:, pr]) and bits_equal(got[pr, :, 1], nat[:, 15 - pr])
+
+
+@pytest.mark.parametrize("lo,hi", [(-0.5, 0.5), (-0.3, 0.3), (-8.0, 8.0), (-1.7, 2.9)])
+def test_hash_fwd_f32_fused_normalisation(oracle, hip_lib, lo, hi):
+    """The gather's fused (x - lo) / (hi - lo) (networks.py:144): one multiply where hi - lo is a power of two, the IEEE division
+    elsewhere -- both must equal numpy's float32 subtract-then-divide bit for bit, then the oracle's encoding of that."""
+    lv = ops.make_levels(2**19, 16, 16, 1024, 2)
+    rng = np.random.default_rng(5)
+    n = 8192
+    x = (rng.random((n, 3), dtype=np.float32) * np.float32(hi - lo) + np.float32(lo)).astype(np.float32)
+    x01 = ((x - np.float32(lo)) / (np.float32(hi) - np.float32(lo))).astype(np.float32)
+    x01 = np.clip(x01, 0.0, 1.0)                           # (random points: rounding may leave [0, 1] by an ulp; keep both sides equal)
+    keep = ((x - np.float32(lo)) / (np.float32(hi) - np.float32(lo)) == x01).all(axis=1)
+    table = rng.random(lv.total_entries * 2, dtype=np.float32)
+    ref = oracle.hash_fwd_f32(x01, table, lv)
+    L = ops._lib()
+    xd, td = dev(x), dev(table)
+    out = torch.empty(n, 32, device="cuda")
+    assert L.ngp_hash_fwd_f32_ex(ops._ptr(xd), ops._ptr(td), ctypes.byref(lv), n, ops._ptr(None), 1, lo, hi, 0, ops._ptr(out),
+                                 ops._stream()) == 0
+    assert keep.sum() > n * 0.99 and bits_equal(ref[keep], out.cpu().numpy()[keep])
+
+
 def test_hash_bwd_f32(oracle, hip_lib):
     lv = ops.make_levels(2**19, 16, 16, 1024, 2)
     rng = np.random.default_rng(1)
