@@ -573,6 +573,12 @@ inline bool xcd_v1(const ngp_hash_levels& lv, unsigned entry_bytes) {
     return forced || (unsigned long long)(unsigned)lv.total_entries * entry_bytes >= 0xffffff00ull;
 }
 
+// tiles of 128 samples per level pair in one launch of hash_fwd_f32_xcd_kernel (8 workgroups per tile); NGP_HASH_FWD_TILES for A/B runs
+inline int xcd_tiles_cap() {
+    static const int cap = [] { const char* e = getenv("NGP_HASH_FWD_TILES"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 512; }();
+    return cap;
+}
+
 inline int grid_for(long long work, int block) {
     long long b = (work + block - 1) / block;
     const long long cap = 256LL * 16;      // 256 CUs x 16 blocks, grid-stride beyond that
@@ -597,7 +603,7 @@ int ngp_hash_fwd_f32_ex(const float* xyzs, const float* table, const ngp_hash_le
     if (enc_pairs && !(lv->n_features == 2 && lv->n_levels == 16)) return -1;
     if (lv->n_features == 2 && lv->n_levels == 16 && (n_max >= 4096 || enc_pairs)) {
         int tiles = (n_max + 127) / 128;
-        if (tiles > 512) tiles = 512;                       // 4096 blocks, tile-stride beyond
+        if (tiles > xcd_tiles_cap()) tiles = xcd_tiles_cap();   // 8 x cap blocks, tile-stride beyond
         if (xcd_v1(*lv, 8)) hipLaunchKernelGGL((hash_fwd_f32_xcd_kernel<0, true>), dim3(8 * tiles), dim3(256), 0, s, xyzs, table, *lv, n_max, n_dev, nm, enc_pairs, out);
         else hipLaunchKernelGGL((hash_fwd_f32_xcd_kernel<0, false>), dim3(8 * tiles), dim3(256), 0, s, xyzs, table, *lv, n_max, n_dev, nm, enc_pairs, out);
         NGP_LAUNCH_CHECK();
@@ -624,7 +630,7 @@ int ngp_hash_fwd_bf16_ex(const float* xyzs, const uint16_t* table, const ngp_has
     if (enc_pairs && lv->n_levels != 16) return -1;
     if (lv->n_levels == 16 && (n_max >= 4096 || enc_pairs)) {
         int tiles = (n_max + 127) / 128;
-        if (tiles > 512) tiles = 512;
+        if (tiles > xcd_tiles_cap()) tiles = xcd_tiles_cap();
         if (xcd_v1(*lv, 4)) hipLaunchKernelGGL((hash_fwd_f32_xcd_kernel<1, true>), dim3(8 * tiles), dim3(256), 0, s, xyzs, t, *lv, n_max, n_dev, nm, enc_pairs, out);
         else hipLaunchKernelGGL((hash_fwd_f32_xcd_kernel<1, false>), dim3(8 * tiles), dim3(256), 0, s, xyzs, t, *lv, n_max, n_dev, nm, enc_pairs, out);
     } else {
@@ -699,7 +705,7 @@ int ngp_hash_fwd_f16_ex(const float* xyzs, const uint16_t* table, const ngp_hash
     if (n_max <= 0) return 0;
     if (lv->n_levels != 16 || lv->n_features != 2) return -1;
     int tiles = (n_max + 127) / 128;
-    if (tiles > 512) tiles = 512;
+    if (tiles > xcd_tiles_cap()) tiles = xcd_tiles_cap();
     const XyzNorm nm = {normalize, lo, hi};
     if (xcd_v1(*lv, 4))
         hipLaunchKernelGGL((hash_fwd_f32_xcd_kernel<2, true>), dim3(8 * tiles), dim3(256), 0, (hipStream_t)stream, xyzs,
