@@ -53,6 +53,9 @@ TRAINER_KERNELS = {
     "ngp_hash_bwd_f32_sliced": ("hash_bwd_f32", "hbm", 12 + 128 + 1024 + 1024, "live"),   # LDS-sliced form (prep + main launch)
     "ngp_hash_bwd_sliced_main": ("hash_bwd_f32", "hbm", 12 + 128 + 1024 + 1024, "live"),  # ... its main launch (what the trainer issues)
     "ngp_hash_bwd_sliced_main_slabs": ("hash_bwd_f32", "hbm", 12 + 128 + 1024 + 1024, "live"),  # ... + the sum of the MLP backward's slabs at its head (round 4)
+    # round 5: ... with the table's optimizer in its flush (the hashed levels never leave as a gradient): priced below as the scatter-add's
+    # algorithmic bytes + the bytes the optimizer part really moves (12 B per parameter read, 12 B per touched parameter written)
+    "ngp_hash_bwd_sliced_main_adam": ("hash_bwd_f32", "hbm", 12 + 128 + 1024 + 1024, "live"),
     "ngp_hash_bwd_sliced_prep": ("hash_bwd_prep", "hbm", 12 + 12 + 16 * 8, "live"),        # ... its prepass (in line, before the MLP backward)
     "ngp_hash_bwd_f16_live": ("hash_bwd_f16", "hbm", 12 + 128 + 512 + 512, "live"),
     "ngp_hash_bwd_sliced_main_f16": ("hash_bwd_f16", "hbm", 12 + 128 + 512 + 512, "live"),    # half2 encoder, LDS-sliced form
@@ -81,6 +84,10 @@ def parse(argv=None):
                          "lego = trained-Lego fixture bitfield, random50 = seeded 50%% (initialisation regime), ones = all occupied")
     ap.add_argument("--condition", type=int, default=1024,
                     help="--regime scene: untimed, seeded optimisation steps on the scene before the warm-up (multiple of 16)")
+    ap.add_argument("--no-deterministic-condition", dest="det_condition", action="store_false",
+                    help="--regime scene, trainer path: by default the untimed conditioning steps run in the trainer's deterministic mode "
+                         "(ray-order packing, one owner per table slice, no float atomics: two processes end conditioning in the same "
+                         "state); warm-up and timed steps always run the default fast path")
     ap.add_argument("--pool", type=int, default=32, help="--regime scene: resident batches the steps cycle through")
     ap.add_argument("--step-trace", default=None, help="diagnostic: write per-step host/device times of the timed region to FILE")
     ap.add_argument("--kernel-events-every", type=int, default=4,
@@ -314,6 +321,8 @@ def _is_headline(args):
 
 # the other BASELINE.json configs (and the initialisation regime of SURVEY 8d), as short runs attached to the headline line
 OTHER_CONFIGS = [
+    ("C2-modules-path", "the headline workload through the reference's own surface: modules.rendering.render + autograd + torch Adam / "
+                        "GradScaler / CosineAnnealingLR, the loop train.py:168-201 runs (the drop-in boundary, not FusedTrainer)", ["--path", "modules"]),
     ("C2-bf16-table", "BASELINE config 2 as worded: bf16 storage copy of the fp32 master table", ["--table", "bf16"]),
     ("C5-half2", "BASELINE config 5: half2 encoder (hash_encoder_half semantics) + fp16 MFMA MLP", ["--half"]),
     ("C3-garden", "BASELINE config 3 shape: scale 16, 6 cascades, max_res 4096, 65 536 rays, distortion loss; analytic unbounded scene, model conditioned 512 steps", ["--scene", "garden", "--condition", "512"]),
@@ -335,7 +344,8 @@ def other_configs(args, ctx):
             res.append({"name": name, "what": what, "args": " ".join(extra), "value": o["value"], "unit": "rays/s", "ms_per_step": o["ms_per_step"],
                         "steps": o["steps"], "warmup": o["warmup"], "dtype": o["dtype"], "rays_per_gpu": o["config"]["rays_per_gpu"],
                         "rm_samples_per_ray": o["rm_samples_per_ray"], "vr_samples_per_ray": o["vr_samples_per_ray"],
-                        "live_samples_per_step": o["live_samples_per_step"], "samples_per_sec": o["samples_per_sec"],
+                        "live_samples_per_step": o["live_samples_per_step"], "ns_per_live_sample": o.get("ns_per_live_sample"),
+                        "samples_per_sec": o["samples_per_sec"], "path": o["config"]["path"],
                         "grid_updates_in_timed_region": o["config"]["grid_updates_in_timed_region"],
                         "dominant_kernel": roof.get("kernel"), "dominant_kernel_ms": roof.get("avg_launch_ms"), "frac": roof.get("frac"),
                         "bound": roof.get("bound"), "achieved": roof.get("achieved"), "roofline_unit": roof.get("unit"),
@@ -550,11 +560,16 @@ def _measure(args, ctx, brief):
     # ---- untimed conditioning: the model becomes a (partly) trained model of the scene its targets come from --------------
     base = 0
     t_cond = 0.0
+    det_cond = bool(scene and use_trainer and args.det_condition and args.condition > 0)
     if scene:
         fence()
         t0 = time.perf_counter()
+        if det_cond:
+            trainer.set_deterministic(True)
         for i in range(args.condition):
             step(i, prefetch=args.prefetch, log=False)
+        if det_cond:
+            trainer.set_deterministic(False)
         fence()
         t_cond = time.perf_counter() - t0
         base = args.condition
@@ -696,9 +711,23 @@ def _measure(args, ctx, brief):
             n4 = (hi_ - lo_) // 4
             touched4 = int(((trainer.table_m[lo_:hi_].view(-1, 4) != 0) | (trainer.table_v[lo_:hi_].view(-1, 4) != 0)).any(1).sum())
             adam_bytes = 48.0 * n4 + 80.0 * touched4 + (8.0 * touched4 if (args.half or args.table == "bf16") else 0.0)
+            copy16_b = 2.0 if (args.half or args.table == "bf16") else 0.0
+
+            def adam_range_bytes(n_):                          # the same count for a launch over the first n_ floats of the table
+                n4_ = int(n_) // 4
+                t4_ = int(((trainer.table_m[:n_].view(-1, 4) != 0) | (trainer.table_v[:n_].view(-1, 4) != 0)).any(1).sum()) if n4_ else 0
+                return 48.0 * n4_ + 80.0 * t4_ + 4.0 * copy16_b * t4_
+            # round 5: the part of the table whose optimizer runs in the scatter-add's flush -- m, v, p read for every parameter, p, m, v
+            # [+ the 16-bit copy] written for the touched ones
+            npre_ = trainer._adam_prefix.get(0) if getattr(trainer, "_flush_adam", False) else None
+            flush_bytes = 0.0
+            if npre_ is not None and npre_ >= 0:
+                n_fl = trainer.nt - npre_
+                t_fl = int(((trainer.table_m[npre_:trainer.nt] != 0) | (trainer.table_v[npre_:trainer.nt] != 0)).sum())
+                flush_bytes = 12.0 * n_fl + (12.0 + copy16_b) * t_fl
             # critical-path gaps on the sampled steps (each includes the two event packets in between): prepass end -> MLP backward
             # start, MLP backward end -> scatter-add start
-            ev_b = warm_events.get("ngp_mlp_bwd_live_parts", []) or warm_events.get("ngp_mlp_bwd_live", []); ev_m = warm_events.get("ngp_hash_bwd_sliced_main_slabs", []) or warm_events.get("ngp_hash_bwd_sliced_main", [])
+            ev_b = warm_events.get("ngp_mlp_bwd_live_parts", []) or warm_events.get("ngp_mlp_bwd_live", []); ev_m = warm_events.get("ngp_hash_bwd_sliced_main_adam", []) or warm_events.get("ngp_hash_bwd_sliced_main_slabs", []) or warm_events.get("ngp_hash_bwd_sliced_main", [])
             ev_p = warm_events.get("ngp_hash_bwd_sliced_prep", [])
             if ev_b and len(ev_b) == len(ev_m) == len(ev_p):
                 gaps["mlp_bwd_end_to_scatter_start_us"] = float(np.mean([b[1].elapsed_time(m[0]) for b, m in zip(ev_b, ev_m)])) * 1e3
@@ -729,7 +758,9 @@ def _measure(args, ctx, brief):
                         n_dev = a[4] if name in ("ngp_hash_fwd_f32_ex", "ngp_hash_fwd_bf16_ex", "ngp_hash_fwd_f16_ex", "ngp_mlp_fwd_ex") else None
                         units = float(a[3]) if (n_dev is not None and getattr(n_dev, "value", 1) is None) else float(marched)
                     if unit == "param":
-                        work = adam_bytes
+                        work = adam_bytes if units >= n4 * 4 else adam_range_bytes(units)
+                    elif name == "ngp_hash_bwd_sliced_main_adam":
+                        work = per_unit * units + flush_bytes
                     else:
                         work = per_unit * units + ((40 if name == "ngp_march_train_fused" else 8) * marched if key == "march_count" else 0)
                     rec = agg.setdefault(key, [0, 0.0, 0.0, bound, per_unit, "sample" if unit in ("n_arg", "live") else unit, 0.0])
@@ -767,6 +798,16 @@ def _measure(args, ctx, brief):
                 "launched on the side stream under the scatter-add's tail and the optimizer pass: the event-to-event time includes waiting "
                 "for the scatter-add's workgroups to retire (their 128-VGPR waves fill the register files) and the slowdown of running "
                 "beside the optimizer; alone the launch takes ~45-55 us (rocprofv3 / profiles/microbench/march_waves.py)")
+        if "hash_bwd_f32" in rooflines and use_trainer and trainer.hash_bwd == "sliced" and flush_bytes > 0:
+            r_ = rooflines["hash_bwd_f32"]
+            r_["optimizer_in_flush"] = {
+                "bytes_per_launch": flush_bytes, "parameters": trainer.nt - npre_,
+                "scatter_add_only": {"achieved": float(r_["work_per_unit"] * r_["avg_units_per_launch"] / (r_["avg_launch_ms"] * 1e-3) / 1e9),
+                                     "frac": float(r_["work_per_unit"] * r_["avg_units_per_launch"] / (r_["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS)},
+                "note": "this launch is the scatter-add AND torch.optim.Adam for the table levels whose slices have one owner (92 % of the "
+                        "C2 table): `achieved` = (2188 B x live samples + the optimizer bytes it really moves: 12 B per parameter read, "
+                        "12 B per touched parameter written) / launch time; `scatter_add_only` prices the same launch time with the "
+                        "scatter-add's bytes alone (comparable with rounds 2-4, whose optimizer was a separate 64 us launch)"}
         if "hash_bwd_f32" in rooflines and use_trainer and trainer.hash_bwd == "sliced":
             rooflines["hash_bwd_f32"]["note"] = (
                 "bytes = SURVEY 8(d)'s algorithmic figure for the reference's autodiff scatter (2188 B per live sample: position, "
@@ -807,6 +848,8 @@ def _measure(args, ctx, brief):
                                          "boxes at radii 1.5-10), exponentially spaced integration per ray, black background") if garden else
                                         "analytic Lego-shape scene (ngp_hip/synthetic.py), dense-integration radiance per ray, white background",
                              "conditioning_steps": args.condition, "conditioning_seconds": t_cond, "pool_batches": n_pool,
+                             "conditioning_mode": ("deterministic (ray-order packing, one owner per table slice, no float atomics; the warm-up "
+                                                   "and timed steps run the default path)") if det_cond else "default path",
                              "occupancy": "the model's own grid (update every 16 steps; all-cell warm-up for steps < 256)"})
             if use_trainer:
                 workload["loss_at_end"] = trainer.last_loss()
@@ -853,6 +896,7 @@ def _measure(args, ctx, brief):
                                                          if (bool(event_pool) or not use_trainer) else False)},
             "samples_per_sec": rm * world / elapsed, "rm_samples_per_ray": rm / total_rays * world, "vr_samples_per_ray": vr / total_rays * world,
             "live_samples_per_step": live_avg,
+            "ns_per_live_sample": (elapsed / args.steps * 1e9 / live_avg) if (live_avg and use_trainer) else None,
             "ms_per_step_no_prefetch": None if elapsed_np is None else elapsed_np / args.steps * 1e3,
             "kernels": ks, "critical_path_gaps": gaps, "roofline": roof, "rooflines": rooflines,
         }

@@ -261,6 +261,24 @@ int ngp_hash_bwd_sliced_main_slabs(const float* dout, const ngp_hash_levels* lv,
 int ngp_hash_bwd_sliced_main_levels(const float* dout, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev, int enc_pairs,
                                     float* dtable, int32_t* found_inf, const void* workspace, long long workspace_bytes,
                                     unsigned int level_mask, int max_blocks, void* stream);
+/* Round 5 -- scatter-add WITH the optimizer (replaces train.py:197-201 on the path modules/hash_encoder.py:269 feeds; one GPU).
+ * The owner of a slice that is not replicated over sample ranges (every level of 64 slices = 2^19 entries: the hashed levels)
+ * holds that slice's complete gradient in LDS when its task ends; instead of adding it to dtable for ngp_adam_all_ex to read
+ * back, it applies the same torch.optim.Adam update (eps as given, unscale by state_f[1], skip when state_i[4]) to EVERY entry of
+ * its slice of table / table_m / table_v and refreshes table_bf16 (nullable): 24 B per parameter instead of 40.  The remaining
+ * (coarse, replicated) levels still accumulate into dtable; they occupy table floats [0, ngp_hash_bwd_sliced_adam_prefix(lv)),
+ * and the caller runs ngp_adam_all_ex over exactly that range afterwards.  Results are bit-identical to
+ * ngp_hash_bwd_sliced_main + ngp_adam_all_ex over the whole table (tests/test_gpu_flush_adam.py).
+ * state_f / state_i must hold THIS step's decision already: run ngp_train_prologue before this call; the inf flag it consumes comes
+ * from ngp_mlp_bwd_live[_parts], which checks the d_enc values this kernel reads (this entry point does not write found_inf).
+ * mlp_dw_parts / n_parts / mlp_dw: the optional slab sum of ngp_hash_bwd_sliced_main_slabs (NULL / 0: none).
+ * _adam_prefix returns -2 (and _main_adam -2) when the level table has no non-replicated levels. */
+long long ngp_hash_bwd_sliced_adam_prefix(const ngp_hash_levels* lv);
+int ngp_hash_bwd_sliced_main_adam(const float* dout, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev, int enc_pairs,
+                                  float* dtable, const void* workspace, long long workspace_bytes, const float* mlp_dw_parts,
+                                  int n_parts, float* mlp_dw, float* table, float* table_m, float* table_v, uint16_t* table_bf16,
+                                  const float* state_f, const int32_t* state_i, float beta1, float beta2, float eps,
+                                  void* stream);
 /* the half2 encoder's backward (hash_encoder_half.py:163-213) over the same prepass: dtable_f16 = fp16 pairs [entries][2]; the
  * encoder's fp16 arithmetic per contribution (cell cast to f16, w * g rounded to f16), the owner's f64 sum rounded to fp16 once */
 int ngp_hash_bwd_sliced_main_f16(const float* dout, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev, int enc_pairs,
@@ -270,6 +288,13 @@ int ngp_hash_bwd_sliced_main_f16(const float* dout, const ngp_hash_levels* lv, i
  * tasks[xoff[x] .. xoff[x] + xlen[x]); returns the number of tasks or -2 when the level table cannot be expressed */
 int ngp_hash_bwd_sliced_plan(const ngp_hash_levels* lv, uint16_t* tasks, int max_tasks, uint16_t* xoff /*[8]*/, uint16_t* xlen /*[8]*/,
                              uint8_t* nrep /*[NGP_MAX_LEVELS]*/, uint32_t* merge_mask, uint32_t* single_mask);
+/* Deterministic mode of the sliced scatter-add, per host thread (default 0; returns the previous setting).  The default plan
+ * replicates the coarse levels over sample ranges whose owners meet in dtable with float atomics (order-dependent at ~1e-7) and
+ * pre-sums equal-cell runs in groups that depend on which wave took which piece of the sample list.  With on != 0 every slice has ONE
+ * owner (no float atomics; with _main_adam the optimizer runs in the flush of EVERY level, _adam_prefix = 0) and a pre-summing
+ * group never spans two pieces: the result is a function of the inputs.  Slower on the coarse levels; bench.py conditions its model
+ * in this mode so that two processes reach the same state. */
+int ngp_hash_bwd_sliced_deterministic(int on);
 /* diagnostics: per-TASK task word + wall-clock stamps into a device buffer of 8 * 1536 uint64 (one 8-word row per task of the
  * plan, at most 1536 tasks; NULL = off, the default) */
 int ngp_hash_bwd_sliced_debug(void* device_buffer);
@@ -392,9 +417,13 @@ int ngp_sample_rays(const float* poses /*[n_img,3,4]*/, const float* directions 
  * sample  : m uniform cells (u_cell [m] in [0,1) -> Morton code) + m picks from the list (u_pick [m]) -> Morton indices [2m] and jittered
  *           world positions [2m,3] (u_jit [2m,3]); s = min(2^(c-1), scale), half_grid = s / grid_size
  * all_cells: warm-up variant, cell i = Morton code i
- * scatter : tmp[indices[i]] = sigmas[i] (indices == NULL: identity)
- * merge   : grid = grid < 0 ? grid : max(grid*decay, tmp); stats[0] += sum, stats[1] += count of positive cells (zero stats first)
- * pack    : bitfield bit = grid > min(stats[0]/stats[1], density_threshold) */
+ * scatter : tmp[indices[i]] = sigmas[i] (indices == NULL: identity); a cell drawn twice keeps whichever write lands last, like the
+ *           reference's fresh[c, indices] = density.  scatter_max: the largest of them wins (the same one on every run; sigmas > 0)
+ * merge   : grid = grid < 0 ? grid : max(grid*decay, tmp); the sum and count of the positive cells leave as per-block partials in
+ *           stats[2..] (stats: ngp_occ_stats_floats() floats, no initialisation needed; round 5: no float atomics -- the mean is the
+ *           occupancy threshold and must not depend on the order blocks finish in)
+ * pack    : every block adds the partials up in one fixed order (stats[0] = sum, stats[1] = count are written for the caller);
+ *           bitfield bit = grid > min(stats[0]/stats[1], density_threshold).  n_bytes must be the merge's n / 8. */
 int ngp_occ_compact(const float* density_grid, float threshold, int n_cells, int32_t* list, int32_t* count,
                     int32_t* scratch /*[1024]*/, void* stream);
 /* m ascending U(0,1) values per set without sorting (normalised partial sums of m + 1 unit exponentials: the order statistics
@@ -405,8 +434,10 @@ int ngp_occ_sample(const float* u_cell, const float* u_pick, const float* u_jit,
                    int m, int grid_size, float s, float half_grid, int32_t* indices, float* xyzs, void* stream);
 int ngp_occ_all_cells(const float* u_jit, int n_cells, int grid_size, float s, float half_grid, float* xyzs, void* stream);
 int ngp_occ_scatter(const int32_t* indices, const float* sigmas, int n, float* tmp, void* stream);
+int ngp_occ_scatter_max(const int32_t* indices, const float* sigmas, int n, float* tmp, void* stream);
+int ngp_occ_stats_floats(void);
 int ngp_occ_merge(float* density_grid, const float* tmp, float decay, int n, float* stats, void* stream);
-int ngp_occ_pack(const float* density_grid, const float* stats, float density_threshold, int n_bytes, uint8_t* bitfield,
+int ngp_occ_pack(const float* density_grid, float* stats, float density_threshold, int n_bytes, uint8_t* bitfield,
                  void* stream);
 
 #ifdef __cplusplus

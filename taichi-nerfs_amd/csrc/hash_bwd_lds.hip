@@ -72,6 +72,7 @@ struct BwdPlan {
     int32_t n_blocks;
     uint32_t merge_mask;                  // bit l: pre-sum equal-cell runs on level l
     uint32_t diag;                        // timing experiments (-DNGP_BWD_DIAG builds): 1 no LDS adds, 2 no gathers, 4 no accumulate
+    uint32_t det;                         // ngp_hash_bwd_sliced_deterministic: run pre-summing groups hits per super-chunk (see bwd_task)
     uint8_t nrep[NGP_MAX_LEVELS];         // replicas (sample ranges) per slice of level l
     uint16_t task[BW_MAX_TASKS];          // level | slice << 4 | rep << 10; XCD x owns task[xoff[x] .. xoff[x] + xlen[x])
     uint16_t xoff[8], xlen[8];
@@ -284,6 +285,7 @@ struct LevelParams {
     bool dense;
     SliceMap map;
     uint32_t diag;           // diagnostics only (NGP_BWD_DIAG): bit 0 = skip the LDS adds, bit 1 = skip the gathers
+    uint32_t det;
 };
 struct Hit {
     float x, y, z, g0, g1;
@@ -602,6 +604,19 @@ __device__ __forceinline__ void bwd_task(const LevelParams P, const int level, c
                 } while (64 * pass < total);
             }
         }
+        if ((K == KIND_MERGE || K == KIND_MERGE0) && P.det && qlen > 0) {
+            // deterministic mode: a run-pre-summing batch never spans two super-chunks, so WHICH hits share a 16-lane row (and
+            // therefore how their f32 pre-sums round) depends on the chunk's content only, not on which wave took which chunk
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const bool v0 = lane < qlen, v1 = lane + 64 < qlen;
+            const int i0 = v0 ? (int)q[(qhead + lane) & (BW_Q - 1)] : 0, i1 = v1 ? (int)q[(qhead + 64 + lane) & (BW_Q - 1)] : 0;
+            const Batch nxt = load_batch(level, i0, v0, i1, v1, xyzc, dout, plane, enc_pairs, nl, found_inf, P.diag, HALF);
+            accumulate_batch<KIND>(P, sl, false, pend, slice, found_inf);
+            pend = nxt;
+            __builtin_amdgcn_wave_barrier();
+            qhead = (qhead + 128) & (BW_Q - 1); qlen = 0;
+        }
         cur = nxtw; sc = sc_next;
     }
     if (qlen > 0) {
@@ -661,14 +676,35 @@ struct MlpSlabs {                     // optional extra work of the main launch:
     float* dW;
 };
 
-template <bool HALF>
+// Round 5: the optimizer rides in the flush.  The owner of a NON-replicated slice (nrep == 1: every hashed level of a 2^19-entry
+// table) holds the complete, final gradient of its 8192 entries in LDS when its task ends.  Instead of adding it to the gradient
+// table -- only for the optimizer launch to read it back, clear it and stream p / m / v (train.py:197-201: 32 B per parameter, a
+// 64 us launch at 0.92 of its own roofline) -- the owner applies torch.optim.Adam's update right there: read m, v, p of EVERY entry
+// of the slice (the moments keep decaying where g = 0), write p, m, v [+ the 16-bit storage copy].  24 B per parameter instead of 40,
+// and the optimizer launch shrinks to the replicated coarse levels + the MLP.  The skip / step decision (GradScaler) therefore has
+// to exist BEFORE this launch: the MLP backward flags non-finite d_enc / dW (the scatter-add's own input check is the same
+// condition), ngp_train_prologue runs in front of the scatter-add, and the kernel reads SI_SKIP like the optimizer kernels do.
+// The arithmetic is adam_table_pass's (ngp_device.h), per entry instead of per float4 group: the group form only differs in which
+// all-zero entries it visits, and an all-zero entry (g = m = v = 0) is an exact fixed point -- bit-identical tables, moments and
+// copies (tests/test_gpu_flush_adam.py).
+struct FlushAdam {
+    float* p;                    // fp32 master table [entries * 2]; NULL: no optimizer in the flush
+    float* m;
+    float* v;
+    uint16_t* shadow;            // 16-bit storage copy refreshed with p (ADAM == 2: bf16), or NULL
+    const float* sf;             // optimizer state (include/ngp_hip.h): SF_INV_SCALE, SF_LR, SF_BC1, SF_BC2_SQRT as the prologue left them
+    const int32_t* si;           // SI_SKIP
+    float beta1, beta2, eps;
+};
+
+template <bool HALF, int ADAM>
 __global__ void __launch_bounds__(BW_THREADS) hash_bwd_lds_kernel(const float* __restrict__ xyzc,
                                                                   const unsigned long long* __restrict__ bitmap, size_t wstride,
                                                                   const float* __restrict__ dout, ngp_hash_levels lv, int n,
                                                                   const int32_t* __restrict__ n_dev, int enc_pairs, BwdPlan plan,
                                                                   void* __restrict__ dtable /* f32 pairs; HALF: f16 pairs */,
                                                                   int32_t* __restrict__ found_inf, uint32_t* __restrict__ ctr,
-                                                                  unsigned long long* __restrict__ dbg, MlpSlabs mlp) {
+                                                                  unsigned long long* __restrict__ dbg, MlpSlabs mlp, FlushAdam ad) {
     __shared__ double slice[2 * BW_SLICE_ENTRIES];
     __shared__ uint32_t queues[BW_WAVES * BW_Q];
     __shared__ uint32_t next_sc;
@@ -685,7 +721,8 @@ __global__ void __launch_bounds__(BW_THREADS) hash_bwd_lds_kernel(const float* _
     }
     const size_t plane = (size_t)n;
     if (n_dev) n = min(n, *n_dev);
-    if (n <= 0) return;
+    if (n <= 0 && !ADAM) return;          // (ADAM: a step without live samples still decays the moments -- the tasks run on empty ranges)
+    if (n < 0) n = 0;
     const int tid = threadIdx.x;
     // PERSISTENT workgroups (one per CU) take tasks from the queue of the XCD they actually run on; a workgroup whose XCD has
     // run dry steals from the BACK of the fullest other queue (the queues are sorted longest task first, so what is stolen
@@ -719,6 +756,7 @@ __global__ void __launch_bounds__(BW_THREADS) hash_bwd_lds_kernel(const float* _
     else P.mode = (P.size != 0 && (P.size & (P.size - 1)) == 0) ? 1u : 2u;
     P.map = slice_map(P.size, P.res, P.dense);
     P.diag = plan.diag;
+    P.det = plan.det;
     const bool single = P.size <= (uint32_t)BW_SLICE_ENTRIES;           // one slice: every sample is a hit, no bitmap
     const bool merge = (plan.merge_mask >> level) & 1u;
     const bool hashed = !P.dense && P.mode == 1u && P.res < (1u << BW_SLICE_LOG2) && !single;
@@ -757,6 +795,55 @@ __global__ void __launch_bounds__(BW_THREADS) hash_bwd_lds_kernel(const float* _
             if (nrep == 1) dh[h] = dh[h] + val;
             else if (!(val.x == (_Float16)0 && val.y == (_Float16)0))
                 __builtin_amdgcn_global_atomic_fadd_v2f16((__attribute__((address_space(1))) half2v*)(dh + h), val);
+        }
+    } else if (ADAM && nrep == 1) {
+        // the optimizer in the flush (see FlushAdam): UNR entries per thread and trip with all their loads in flight
+        const bool skip = ad.si[SI_SKIP] != 0;
+        const float inv_scale = ad.sf[SF_INV_SCALE], step_size = ad.sf[SF_LR] / ad.sf[SF_BC1], bc2_sqrt = ad.sf[SF_BC2_SQRT];
+        const float beta1 = ad.beta1, beta2 = ad.beta2, eps = ad.eps;
+        float2* p2 = reinterpret_cast<float2*>(ad.p) + P.offset;
+        float2* m2 = reinterpret_cast<float2*>(ad.m) + P.offset;
+        float2* v2 = reinterpret_cast<float2*>(ad.v) + P.offset;
+        uint32_t* sh = reinterpret_cast<uint32_t*>(ad.shadow) + P.offset;
+        constexpr int UNR = 4;
+        for (int j0 = tid; j0 < BW_SLICE_ENTRIES; j0 += UNR * BW_THREADS) {
+            double2 a[UNR];
+            float2 pi[UNR], mi[UNR], vi[UNR];
+            uint32_t h[UNR];
+            bool in[UNR];
+#pragma unroll
+            for (int k = 0; k < UNR; ++k) {
+                const int j = j0 + k * BW_THREADS;
+                h[k] = entry_of(P.map, sl, (uint32_t)j);
+                in[k] = !skip && h[k] < P.size;
+                const uint32_t hc = in[k] ? h[k] : 0u;
+                mi[k] = m2[hc]; vi[k] = v2[hc]; pi[k] = p2[hc];
+            }
+#pragma unroll
+            for (int k = 0; k < UNR; ++k) {
+                const int j = j0 + k * BW_THREADS;
+                a[k] = s2[j];
+                if (a[k].x != 0.0 || a[k].y != 0.0) s2[j] = make_double2(0.0, 0.0);      // the next task starts from a clean slice
+            }
+#pragma unroll
+            for (int k = 0; k < UNR; ++k) {
+                // what the two-launch path hands the optimizer: 0 + (float)sum (the gradient slot is clear at the start of a step)
+                const float gx = 0.0f + (float)a[k].x, gy = 0.0f + (float)a[k].y;
+                float2 mk = mi[k], vk = vi[k], pk = pi[k];
+                if (!in[k] || (gx == 0.f && gy == 0.f && mk.x == 0.f && mk.y == 0.f && vk.x == 0.f && vk.y == 0.f)) continue;   // exact fixed point
+#define NGP_ADAM1(c, g)                                                       \
+                {                                                             \
+                    const float gr = (g) * inv_scale;                         \
+                    mk.c = mk.c + (gr - mk.c) * (1.0f - beta1);               \
+                    vk.c = vk.c * beta2 + gr * gr * (1.0f - beta2);           \
+                    const float denom = sqrtf(vk.c) / bc2_sqrt + eps;         \
+                    pk.c = pk.c - step_size * (mk.c / denom);                 \
+                }
+                NGP_ADAM1(x, gx) NGP_ADAM1(y, gy)
+#undef NGP_ADAM1
+                p2[h[k]] = pk; m2[h[k]] = mk; v2[h[k]] = vk;
+                if (ADAM == 2) sh[h[k]] = f32_to_bf16_bits(pk.x) | (f32_to_bf16_bits(pk.y) << 16);
+            }
         }
     } else {
     float2* dl = reinterpret_cast<float2*>(reinterpret_cast<float*>(dtable) + 2 * (size_t)P.offset);
@@ -806,9 +893,10 @@ struct Knobs {
     int rep_target = 48, merge_res = 128, dense_min_rep = 8;
     uint32_t level_mask = 0xffffffffu, diag = 0u;
     int blocks = 0;                            // -DNGP_BWD_DIAG: fewer persistent workgroups (contention experiment)
+    bool deterministic = false;                // ngp_hash_bwd_sliced_deterministic(1): no sample-range replicas (no float atomics), see there
     bool operator==(const Knobs& o) const {
         return rep_target == o.rep_target && merge_res == o.merge_res && dense_min_rep == o.dense_min_rep && level_mask == o.level_mask &&
-               diag == o.diag && blocks == o.blocks;
+               diag == o.diag && blocks == o.blocks && deterministic == o.deterministic;
     }
 };
 static Knobs read_knobs() {
@@ -823,14 +911,16 @@ static Knobs read_knobs() {
 #endif
     return k;
 }
+static thread_local bool g_bwd_deterministic = false;
 static const Knobs& knobs() {
     static const bool dynamic = getenv("NGP_BWD_KNOBS_DYNAMIC") != nullptr;
     static const Knobs fixed = read_knobs();
-#ifndef NGP_BWD_DIAG
-    if (!dynamic) return fixed;
-#endif
     static thread_local Knobs k;
+#ifndef NGP_BWD_DIAG
+    if (!dynamic) { k = fixed; k.deterministic = g_bwd_deterministic; return k; }
+#endif
     k = read_knobs();
+    k.deterministic = g_bwd_deterministic;
     return k;
 }
 
@@ -858,6 +948,7 @@ static bool build_plan_with(const ngp_hash_levels& lv, BwdPlan& plan, uint32_t& 
         if (l < lv.begin_fast_hash_level && ns > 1 && nrep < dense_min_rep) nrep = dense_min_rep;
         if (nrep < 1) nrep = 1;
         if (nrep > 63) nrep = 63;
+        if (K.deterministic) nrep = 1;        // one owner per slice: its flush is a plain read-modify-write (or the optimizer), no float atomics
         lvls[l] = {l, ns, nrep, ((level_mask >> l) & 1u) ? ns * nrep : 0};
         plan.nrep[l] = (uint8_t)nrep;
         if (ns == 1) single_mask |= 1u << l;
@@ -865,6 +956,7 @@ static bool build_plan_with(const ngp_hash_levels& lv, BwdPlan& plan, uint32_t& 
     }
     for (int l = lv.n_levels; l < NGP_MAX_LEVELS; ++l) plan.nrep[l] = 1;
     plan.diag = K.diag;                   // timing experiments only (-DNGP_BWD_DIAG builds): wrong results
+    plan.det = K.deterministic ? 1u : 0u;
     // XCD-aware order (block b runs on XCD b % 8, one 1024-thread block per CU): the owners of one level read the same
     // position / gradient lines, and they only find them in L2 if they run on the same XCD at about the same time (measured:
     // a hashed level's owners take 52 us when the level has an XCD to itself, 115 us when its 64 owners are spread over all
@@ -951,7 +1043,7 @@ struct PlanCache {
 // level_mask / max_blocks: ngp_hash_bwd_sliced_main_levels -- the scatter-add of a level group in a launch of its own, on fewer
 // than 256 workgroups when something else (a collective) has to find free CUs beside it
 static const BwdPlan* get_plan(const ngp_hash_levels& lv, uint32_t& single_mask, uint32_t level_mask = 0xffffffffu, int max_blocks = 0) {
-    static thread_local PlanCache cache[6];                      // two tables alternate in a process that trains and evaluates,
+    static thread_local PlanCache cache[8];                      // two tables alternate in a process that trains and evaluates,
     static thread_local int victim = 0;                          // each possibly split into a few level groups
     Knobs K = knobs();
     K.level_mask &= level_mask;
@@ -959,7 +1051,7 @@ static const BwdPlan* get_plan(const ngp_hash_levels& lv, uint32_t& single_mask,
     for (PlanCache& c : cache)
         if (c.valid && memcmp(&c.key, &lv, sizeof(lv)) == 0 && c.knobs == K) { single_mask = c.single_mask; return c.ok ? &c.plan : nullptr; }
     PlanCache& c = cache[victim];
-    victim = (victim + 1) % 6;
+    victim = (victim + 1) % 8;
     c.valid = true; c.key = lv; c.knobs = K;
     c.ok = build_plan_uncached(lv, c.plan, c.single_mask, K);
     single_mask = c.single_mask;
@@ -992,6 +1084,19 @@ extern "C" {
 // diagnostics: when set to a device buffer of 8 * BW_MAX_TASKS (= 8 * 1536) u64, every task of the main kernel records its task
 // word, 100 MHz wall-clock stamps (begin, after LDS init, wave 0 done, all waves done, after flush), its XCC id and the sample count
 int ngp_hash_bwd_sliced_debug(void* device_buffer) { g_bwd_debug = (unsigned long long*)device_buffer; return 0; }
+
+// Deterministic mode (per host thread; default off).  The default plan replicates the coarse levels over sample ranges whose owners
+// meet in the gradient table with float atomics (order-dependent at ~1e-7), and pre-sums equal-cell runs in groups that depend on
+// which wave took which super-chunk.  With on != 0 every slice has ONE owner (plain read-modify-write / the optimizer in the flush
+// for every level) and a pre-summing group never spans two super-chunks: the result depends on the inputs only (up to the f64
+// slice sums, which are exact unless an entry's terms span more than 2^29).  Slower on the coarse levels (one workgroup sees every
+// sample of level 0); bench.py conditions its model in this mode so that two processes reach the same state, then switches it off
+// for the timed steps.  Returns the previous setting.
+int ngp_hash_bwd_sliced_deterministic(int on) {
+    const int was = g_bwd_deterministic ? 1 : 0;
+    g_bwd_deterministic = on != 0;
+    return was;
+}
 
 // host-side introspection (no GPU needed; tests/test_sliced_plan.py): the task plan the main launch would use for this level
 // table.  tasks[k] = level | slice << 4 | replica << 10 for k < return value; XCD x owns tasks[xoff[x] .. xoff[x] + xlen[x]);
@@ -1049,27 +1154,44 @@ int ngp_hash_bwd_sliced_prep(const float* xyzs, const ngp_hash_levels* lv, int n
     return 0;
 }
 
+// First level whose slice owners are not replicated (nrep == 1), provided those levels are exactly [first, n_levels): the levels
+// the flush can run the optimizer for.  -1 when there is no such suffix.
+static int adam_first_level(const ngp_hash_levels& lv, const BwdPlan& plan) {
+    int first = lv.n_levels;
+    while (first > 0 && plan.nrep[first - 1] == 1) --first;
+    for (int l = 0; l < first; ++l)
+        if (plan.nrep[l] == 1) return -1;
+    return first < lv.n_levels ? first : -1;
+}
+
 static int sliced_main(bool half, const float* dout, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev, int enc_pairs,
                        void* dtable, int32_t* found_inf, const void* workspace, long long workspace_bytes, void* stream,
-                       uint32_t level_mask = 0xffffffffu, int max_blocks = 0, MlpSlabs mlp = MlpSlabs{nullptr, 0, nullptr}) {
+                       uint32_t level_mask = 0xffffffffu, int max_blocks = 0, MlpSlabs mlp = MlpSlabs{nullptr, 0, nullptr},
+                       FlushAdam ad = FlushAdam{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f}) {
     if (n_max <= 0) return 0;
     if (enc_pairs && !(lv->n_features == 2 && lv->n_levels == 16)) return -1;
     if (!workspace || workspace_bytes < ngp_hash_bwd_sliced_workspace(lv, n_max)) return -1;
     uint32_t single_mask;
     const BwdPlan* plan = get_plan(*lv, single_mask, level_mask, max_blocks);
     if (!plan) return -2;
-    if (plan->n_blocks <= 0) return 0;
+    if (ad.p && (half || adam_first_level(*lv, *plan) < 0)) return -2;
     const WsLayout W = ws_layout(*lv, n_max);
     const char* base = reinterpret_cast<const char*>(workspace);
     const float* xyzc = reinterpret_cast<const float*>(base);
     const unsigned long long* bitmap = reinterpret_cast<const unsigned long long*>(base + W.off_bitmap);
     uint32_t* ctr = reinterpret_cast<uint32_t*>(const_cast<char*>(base) + W.off_ctr);
-    if (half)
-        hipLaunchKernelGGL(hash_bwd_lds_kernel<true>, dim3(plan->n_blocks), dim3(BW_THREADS), 0, (hipStream_t)stream, xyzc, bitmap, W.words,
-                           dout, *lv, n_max, n_dev, enc_pairs, *plan, dtable, found_inf, ctr, g_bwd_debug, mlp);
-    else
-        hipLaunchKernelGGL(hash_bwd_lds_kernel<false>, dim3(plan->n_blocks), dim3(BW_THREADS), 0, (hipStream_t)stream, xyzc, bitmap, W.words,
-                           dout, *lv, n_max, n_dev, enc_pairs, *plan, dtable, found_inf, ctr, g_bwd_debug, mlp);
+    if (plan->n_blocks <= 0) {
+        // nothing to scatter (an empty level mask): the slab sum the caller was promised still has to happen
+        return mlp.parts ? ngp_mlp_dw_reduce(mlp.parts, mlp.n_parts, mlp.dW, stream) : 0;
+    }
+#define NGP_BWD_LAUNCH(H, A)                                                                                                        \
+    hipLaunchKernelGGL((hash_bwd_lds_kernel<H, A>), dim3(plan->n_blocks), dim3(BW_THREADS), 0, (hipStream_t)stream, xyzc, bitmap,    \
+                       W.words, dout, *lv, n_max, n_dev, enc_pairs, *plan, dtable, found_inf, ctr, g_bwd_debug, mlp, ad)
+    if (half) NGP_BWD_LAUNCH(true, 0);
+    else if (ad.p && ad.shadow) NGP_BWD_LAUNCH(false, 2);
+    else if (ad.p) NGP_BWD_LAUNCH(false, 1);
+    else NGP_BWD_LAUNCH(false, 0);
+#undef NGP_BWD_LAUNCH
     NGP_LAUNCH_CHECK();
     return 0;
 }
@@ -1105,6 +1227,33 @@ int ngp_hash_bwd_sliced_main_f16(const float* dout, const ngp_hash_levels* lv, i
                                  uint16_t* dtable_f16, int32_t* found_inf, const void* workspace, long long workspace_bytes,
                                  void* stream) {
     return sliced_main(true, dout, lv, n_max, n_dev, enc_pairs, dtable_f16, found_inf, workspace, workspace_bytes, stream);
+}
+
+// Round 5: scatter-add + optimizer.  The levels whose slices are not replicated over sample ranges (every level of 64 slices: the
+// hashed levels of a 2^19-entry table) never write `dtable`: their owners apply Adam (torch.optim.Adam arithmetic, exactly
+// ngp_adam_all_ex's) to table / table_m / table_v [+ the bf16 copy] when they flush.  The other levels' gradient goes to dtable as
+// before; the caller runs ngp_adam_all_ex over floats [0, ngp_hash_bwd_sliced_adam_prefix(lv)) afterwards.  state_f / state_i must
+// already hold THIS step's decision (ngp_train_prologue in front of this call; the inf flag comes from the MLP backward, which
+// checks the very d_enc values this kernel reads).  mlp_dw_parts / n_parts / mlp_dw: optional slab sum as in _main_slabs.
+// Returns -2 when the level table has no such levels (the caller keeps the two-launch path).
+long long ngp_hash_bwd_sliced_adam_prefix(const ngp_hash_levels* lv) {
+    if (!lv) return -1;
+    uint32_t sm;
+    const BwdPlan* plan = get_plan(*lv, sm);
+    if (!plan) return -2;
+    const int first = adam_first_level(*lv, *plan);
+    if (first < 0) return -2;
+    return (long long)lv->offset[first] * lv->n_features;
+}
+
+int ngp_hash_bwd_sliced_main_adam(const float* dout, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev, int enc_pairs,
+                                  float* dtable, const void* workspace, long long workspace_bytes, const float* mlp_dw_parts,
+                                  int n_parts, float* mlp_dw, float* table, float* table_m, float* table_v, uint16_t* table_bf16,
+                                  const float* state_f, const int32_t* state_i, float beta1, float beta2, float eps, void* stream) {
+    if (!table || !table_m || !table_v || !state_f || !state_i) return -1;
+    const MlpSlabs mlp = (mlp_dw_parts && mlp_dw && n_parts > 0) ? MlpSlabs{mlp_dw_parts, n_parts, mlp_dw} : MlpSlabs{nullptr, 0, nullptr};
+    return sliced_main(false, dout, lv, n_max, n_dev, enc_pairs, dtable, nullptr, workspace, workspace_bytes, stream, 0xffffffffu, 0, mlp,
+                       FlushAdam{table, table_m, table_v, table_bf16, state_f, state_i, beta1, beta2, eps});
 }
 
 int ngp_hash_bwd_f32_sliced(const float* xyzs, const float* dout, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev,

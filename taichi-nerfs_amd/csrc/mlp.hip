@@ -120,28 +120,43 @@ __global__ void __launch_bounds__(256) mlp_pack_kernel(const float* __restrict__
 // include/ngp_hip.h) followed by the fp16 fragment repack for the next step, in ONE block -- replaces two launches.
 // Adam on the 9408 MLP weights, then the fp16 fragment repack for the next step (one block: the repack reads what the block's
 // own threads just wrote)
+// Round 5: the block is the whole launch once the table's optimizer rides in the scatter-add's flush (hash_bwd_lds.hip), so its
+// latency counts: every thread requests its ten weights' p / g / m / v at once (one round trip instead of ten dependent ones), the
+// updated weights are also kept in LDS, and the repack reads them from there instead of from memory the block has just written.
 __device__ __forceinline__ void adam_mlp_pack_block(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, const float* __restrict__ sf,
                                                     const int32_t* __restrict__ si, float beta1, float beta2, float eps,
                                                     int pairs, half_t* __restrict__ wpack) {
+    __shared__ float wl[9408];
     const bool skip = si[SI_SKIP] != 0;
     const float inv_scale = sf[SF_INV_SCALE], step_size = sf[SF_LR] / sf[SF_BC1], bc2_sqrt = sf[SF_BC2_SQRT];
-    for (int i = threadIdx.x; i < 9408; i += blockDim.x) {
+    constexpr int PER = (9408 + 1023) / 1024;
+    float pi[PER], gi[PER], mi[PER], vi[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int i = (int)threadIdx.x + 1024 * k, ic = i < 9408 ? i : 0;
+        pi[k] = p[ic]; gi[k] = g[ic]; mi[k] = m[ic]; vi[k] = v[ic];
+    }
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int i = (int)threadIdx.x + 1024 * k;
+        if (i >= 9408) continue;
         if (!skip) {
-            const float gr = g[i] * inv_scale;
-            const float mi = m[i] + (gr - m[i]) * (1.0f - beta1);
-            const float vi = v[i] * beta2 + gr * gr * (1.0f - beta2);
-            const float denom = sqrtf(vi) / bc2_sqrt + eps;
-            p[i] = p[i] - step_size * (mi / denom);
-            m[i] = mi; v[i] = vi;
+            const float gr = gi[k] * inv_scale;
+            const float mk = mi[k] + (gr - mi[k]) * (1.0f - beta1);
+            const float vk = vi[k] * beta2 + gr * gr * (1.0f - beta2);
+            const float denom = sqrtf(vk) / bc2_sqrt + eps;
+            pi[k] = pi[k] - step_size * (mk / denom);
+            p[i] = pi[k]; m[i] = mk; v[i] = vk;
         }
         g[i] = 0.0f;
+        wl[i] = pi[k];
     }
     __syncthreads();
-    // one 16-byte fragment slot (8 halfs) per work item: eight independent weight loads in flight per thread
+    // one 16-byte fragment slot (8 halfs) per work item
     for (int item = threadIdx.x; item < N_ALL_FRAGS * 64; item += blockDim.x) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) pack_one(8 * item + j, p, p + 2048, p + 3072, p + 5120, p + 9216, pairs, wpack);
+        for (int j = 0; j < 8; ++j) pack_one(8 * item + j, wl, wl + 2048, wl + 3072, wl + 5120, wl + 9216, pairs, wpack);
     }
 }
 
@@ -720,377 +735,9 @@ __global__ void __launch_bounds__(768) mlp_bwd_kernel(const float* __restrict__ 
     if (found_inf && (bad || bad_denc)) *found_inf = 1;
 }
 
-// ---- backward kernel, register-resident form (round 4) ---------------------------------------------------------------------
-// The LDS form above spends 62 % of a round in its three store -> barrier -> transposing-read -> MFMA -> barrier phases, with all
-// 12 waves of the CU in the same phase (profiles/r03_mlp_bwd_experiments.txt).  This form has no image, no barrier and no
-// cross-wave traffic inside the loop: a wave keeps ALL 40 dW tiles (160 accumulator registers of the unified 512-entry file) and
-// transposes its dZ / X fragments through the matrix core itself.  A data-path fragment is a B operand (lane = sample n, eight
-// k-slots of features); fed as the A operand against a 0/1 SELECTION fragment it yields
-//     T[sample][f] = sum_k X[k][sample] * Sel[k][f]      (exact: one non-zero term, f16 -> f32 -> f16)
-// in the D layout, lane = feature f, registers = samples 4g..4g+3.  Two 16-sample tiles side by side are the A / B operand of a
-// K = 32 MFMA that contracts over the 32 samples of an iteration:  dW[out][in] += dZ^T[out][s] * X^T[in][s].
-// Per 32 samples: 84 data-path MFMAs as before + 60 transposes + 40 dW MFMAs, ~120 extra VALU (the f32 -> f16 packs), no LDS
-// traffic besides the weight fragments (read once for both tiles).  The MFMA pipe was 14 % busy in the LDS form; it is the
-// resource with room.  One wave per SIMD (4-wave blocks, up to 512 registers): the first version ran 2 waves per SIMD with one tile
-// each, K = 16 contractions and 256 registers -- 160 of them accumulators --, and the compiler had to serialise every
-// transpose -> pack -> accumulate chain through one temporary (s_nop 7 behind each MFMA): 100 us against the LDS form's 75.  Two
-// independent tiles in one instruction stream give it the MFMAs to put into those gaps.
-// At the end of its persistent loop a block sums its 4 waves' accumulators through an LDS buffer (4 serial read-add-write steps,
-// lanes own their addresses) and leaves as line-coalesced global atomics, one set per block as before.
-constexpr int RW = 4;                      // waves per block: 1 per SIMD
-constexpr int N_SEL = 4;                   // selection fragments behind the weight image: lo, hi, enc tile 0, enc tile 1
-constexpr int SEL_LO = N_ALL_FRAGS, SEL_HI = N_ALL_FRAGS + 1, SEL_E0 = N_ALL_FRAGS + 2;
-constexpr int N_DW_TILES = 40;             // L4 16, L3 8, L1 8, L2 4, L5 4
-constexpr int T_L4 = 0, T_L3 = 16, T_L1 = 24, T_L2 = 32, T_L5 = 36;
-
-// [16 samples][16 selected features] of B-operand fragment `b`, transposed: lane = feature, registers = samples 4g..4g+3
-__device__ __forceinline__ half4 tr_sel(const half8& b, const half8& sel) {
-    const floatx4 zero = {0.f, 0.f, 0.f, 0.f};
-    return to_h4(NGP_MFMA(b, sel, zero));
-}
-// the same for the two tiles of an iteration: the K = 32 (samples) operand of a dW MFMA
-__device__ __forceinline__ half8 tr_sel2(const half8& b0, const half8& b1, const half8& sel) {
-    return cat_h4(tr_sel(b0, sel), tr_sel(b1, sel));
-}
-
-// acc += A B with the accumulator pinned to the ACCUMULATOR half of the register file ("a" constraint).  With the builtin the
-// register allocator keeps MFMA results in arch VGPRs and uses the AGPRs as spill space: 1036 v_accvgpr_read / _write per
-// iteration around the 40 dW MFMAs (105 us).  The asm statement is opaque to hipcc's hazard padding: the operands may have been
-// written by the v_cvt_pk just before it (VALU write -> MFMA operand read: s_nop 1); an accumulator is touched once per iteration.
-__device__ __forceinline__ void mfma_acc(floatx4& acc, const half8& a, const half8& b) {
-#ifdef NGP_REG_NO_DW          // (timing builds, profiles/microbench/mlp_time.py: the iteration without its 40 dW MFMAs)
-    asm volatile("" :: "v"(a), "v"(b));
-#else
-    asm("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+#ifdef NGP_MLP_BWD_REG          // round 4's register-resident form: a recorded negative, built on request only (see the file's header)
+#include "../../profiles/microbench/mlp_bwd_reg_kernel.inc"
 #endif
-}
-
-// A weight fragment parked in the accumulator half of the register file.  get(): the reads are opaque to hipcc's hazard padding,
-// and the consumer is an MFMA operand (VALU write -> MFMA read), hence the trailing s_nop 1.
-struct AFrag {
-    uint32_t a0, a1, a2, a3;
-    __device__ __forceinline__ void put(const half8& w) {
-        typedef unsigned int uintx4 __attribute__((ext_vector_type(4)));
-        const uintx4 u = __builtin_bit_cast(uintx4, w);
-        asm volatile("v_accvgpr_write_b32 %0, %4\n\tv_accvgpr_write_b32 %1, %5\n\tv_accvgpr_write_b32 %2, %6\n\tv_accvgpr_write_b32 %3, %7"
-                     : "=a"(a0), "=a"(a1), "=a"(a2), "=a"(a3) : "v"(u[0]), "v"(u[1]), "v"(u[2]), "v"(u[3]));
-    }
-    __device__ __forceinline__ half8 get() const {
-        typedef unsigned int uintx4 __attribute__((ext_vector_type(4)));
-        uintx4 u;
-        asm("v_accvgpr_read_b32 %0, %4\n\tv_accvgpr_read_b32 %1, %5\n\tv_accvgpr_read_b32 %2, %6\n\tv_accvgpr_read_b32 %3, %7\n\ts_nop 1"
-            : "=v"(u[0]), "=v"(u[1]), "=v"(u[2]), "=v"(u[3]) : "a"(a0), "a"(a1), "a"(a2), "a"(a3));
-        return __builtin_bit_cast(half8, u);
-    }
-};
-constexpr int N_AFRAG = 20;
-__device__ __forceinline__ constexpr int afrag_slot(int id) {          // F_W4 (8), B_W5T (4), B_W4T (8); -1: stays in a VGPR
-    return (id >= F_W4 && id < F_W5) ? id - F_W4 : ((id >= B_W5T && id < B_W3T) ? 8 + id - B_W5T : -1);
-}
-
-// weight index of element (tile t, register r, lane) of the dW accumulator set; -1 for the padding rows of layer 5
-__device__ __forceinline__ int dw_index(int t, int r, int lane, int pairs) {
-    const int n = lane & 15, g = lane >> 4, row = 4 * g + r;
-    if (t < T_L3) { const int mt = t >> 2, nt = t & 3; return OFF_W4 + (16 * mt + row) * 64 + 16 * nt + n; }
-    if (t < T_L1) { const int mt = (t - T_L3) >> 1, nt = (t - T_L3) & 1; return OFF_W3 + (16 * mt + row) * 32 + 16 * nt + n; }
-    if (t < T_L2) {
-        const int mt = (t - T_L1) >> 1, nt = (t - T_L1) & 1;
-        return OFF_W1 + (16 * mt + row) * 32 + enc_feat(pairs, (16 * nt + n) >> 3, n & 7);
-    }
-    if (t < T_L5) return OFF_W2 + row * 64 + 16 * (t - T_L2) + n;
-    return row < 3 ? OFF_W5 + row * 64 + 16 * (t - T_L5) + n : -1;
-}
-
-// PAIRS / LIST (pair-major encoding planes; compacted live list) are template parameters so that the uniform branches on them do
-// not cut the loop body into basic blocks: the two tiles of an iteration interleave only inside one block.
-template <bool PAIRS, bool LIST>
-__global__ void __launch_bounds__(64 * RW) mlp_bwd_reg_kernel(const float* __restrict__ enc, const float* __restrict__ dirs,
-                                                               const half_t* __restrict__ wpack, const float* __restrict__ dsigmas,
-                                                               const half_t* __restrict__ drgbs, int S,
-                                                               const int32_t* __restrict__ n_dev, const int32_t* __restrict__ idx_,
-                                                               float* __restrict__ d_enc, float* __restrict__ dW,
-                                                               float* __restrict__ parts /*[gridDim.x][N_W] or NULL*/,
-                                                               int32_t* __restrict__ found_inf) {
-    constexpr int pairs = PAIRS ? 1 : 0;
-    const int32_t* __restrict__ idx = LIST ? idx_ : nullptr;
-#ifdef NGP_MLP_DIAG
-    const unsigned long long dbg_t0 = __builtin_readcyclecounter();
-#define REG_T(k) do { if (blockIdx.x < 4 && (threadIdx.x & 63) == 0) ngp_mlp_dbg[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (k)] = __builtin_readcyclecounter() - dbg_t0; } while (0)
-#else
-#define REG_T(k) do { } while (0)
-#endif
-    typedef unsigned int uintx4 __attribute__((ext_vector_type(4)));
-    // d_enc as a buffer: [n_max rows x 128 B] (the host entry point refuses more than 4 GB - 1)
-    const auto d_enc_rsrc = __builtin_amdgcn_make_buffer_rsrc(d_enc, 0, (int)(unsigned)((size_t)S * 128u), 0x00020000);
-    // the four waves' reduction buffers (40 KB each), used once at the end
-    __shared__ __attribute__((aligned(16))) unsigned char smem[RW * N_DW_TILES * 256 * 4];
-    static_assert(RW * N_DW_TILES * 256 * 4 <= 160 * 1024, "LDS budget");
-    const size_t plane = (size_t)S;
-    if (n_dev) S = min(S, *n_dev);
-    const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
-    // ALL 46 fragments live in registers for the whole persistent loop: with one wave per SIMD an LDS read in front of an MFMA is
-    // an exposed ~100-cycle wait.  26 stay in arch VGPRs, 20 (the W4 / W4^T / W5^T fragments) are parked in the accumulator half
-    // beside the 160 dW accumulators and come back with four v_accvgpr_read per use.  Every wave reads its lanes' 16-byte pieces
-    // straight from the packed image in global memory (1 KB per fragment and wave, L2 hits): no LDS staging, no block barrier.
-    half8 wreg[N_ALL_FRAGS + N_SEL];
-    AFrag wacc[N_AFRAG];
-    {
-        const half8* __restrict__ wg = reinterpret_cast<const half8*>(wpack);
-        half8 tmp[N_ALL_FRAGS];
-#pragma unroll
-        for (int id = 0; id < N_ALL_FRAGS; ++id) tmp[id] = wg[id * 64 + lane];
-#pragma unroll
-        for (int id = 0; id < N_ALL_FRAGS; ++id) {
-            if (afrag_slot(id) >= 0) wacc[afrag_slot(id)].put(tmp[id]); else wreg[id] = tmp[id];
-        }
-    }
-#pragma unroll
-    for (int f = 0; f < N_SEL; ++f) {                              // the four selection fragments (one lane's 8 k-slots each)
-        half8 sfrag;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            bool one;
-            if (f == 0) one = j < 4 && 4 * g + j == n;
-            else if (f == 1) one = j >= 4 && 4 * g + (j - 4) == n;
-            else one = 8 * g + j == 16 * (f - 2) + n;
-            sfrag[j] = one ? (half_t)1.0f : (half_t)0.0f;
-        }
-        wreg[N_ALL_FRAGS + f] = sfrag;
-    }
-    auto W = [&](int id) -> half8 { return afrag_slot(id) >= 0 ? wacc[afrag_slot(id)].get() : wreg[id]; };
-    REG_T(0);
-    const int n_iter = (S + 31) >> 5;
-    const int wave = blockIdx.x * RW + wv, n_waves = gridDim.x * RW;
-    const floatx4 zero = {0.f, 0.f, 0.f, 0.f};
-    const half4 hzero = {(half_t)0, (half_t)0, (half_t)0, (half_t)0};
-    floatx4 acc[N_DW_TILES];
-#pragma unroll
-    for (int t = 0; t < N_DW_TILES; ++t) acc[t] = zero;
-    bool bad_denc = false;
-
-    // Inputs are requested one iteration ahead and the list entries they are addressed by TWO iterations ahead, both at the top of an
-    // iteration and both consumed at the top of the next one: the dependent entry -> inputs chain never makes the single wave of
-    // a SIMD wait for memory in the middle of its math.
-    BwdRaw raw[2];
-    int entry[2];                                      // list entries of the NEXT iteration's samples (loaded, not yet looked at)
-#pragma unroll
-    for (int tt = 0; tt < 2; ++tt) {
-        const int smp0 = wave * 32 + 16 * tt + n;
-        bwd_request(raw[tt], enc, dirs, dsigmas, drgbs, smp0 < S ? bwd_entry<LIST>(smp0, S, idx) : -1, g, pairs, plane);
-        entry[tt] = bwd_entry<LIST>((wave + n_waves) * 32 + 16 * tt + n, S, idx);
-    }
-    for (int it = wave; it < n_iter; it += n_waves) {
-        TileFwd t[2];
-        half4 dz5[2];
-        float dsig[2];
-        BwdIn in[2];
-        int src_next[2];
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
-            bwd_take(in[tt], raw[tt], g);
-            src_next[tt] = (it + n_waves) * 32 + 16 * tt + n < S ? entry[tt] : -1;
-            // materialise the selects HERE (an empty asm the optimiser cannot look through): otherwise they are sunk to their uses
-            // in the middle of the iteration, the old `raw` registers stay live across the loads below, and the copy into the
-            // loop-carried register lands behind an s_waitcnt vmcnt(0) in the middle of the math
-            asm volatile("" : "+v"(in[tt].e0.x), "+v"(in[tt].e0.y), "+v"(in[tt].e0.z), "+v"(in[tt].e0.w), "+v"(in[tt].e1.x),
-                         "+v"(in[tt].e1.y), "+v"(in[tt].e1.z), "+v"(in[tt].e1.w));
-            asm volatile("" : "+v"(in[tt].dx), "+v"(in[tt].dy), "+v"(in[tt].dz), "+v"(in[tt].dsig), "+v"(in[tt].rg), "+v"(in[tt].b),
-                         "+v"(src_next[tt]));
-        }
-        // All of the iteration's loads are issued HERE, behind the selects that free the `raw` / `entry` registers and in front of
-        // the math: left to itself the scheduler sinks them to the end of the (single-block) iteration to shorten live ranges and
-        // waits for them on the spot -- list entry, then inputs: two exposed memory latencies per iteration with one wave per SIMD.
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
-            entry[tt] = bwd_entry<LIST>((it + 2 * n_waves) * 32 + 16 * tt + n, S, idx);
-#ifdef NGP_REG_NO_LOAD        // (timing builds: every iteration re-reads the wave's first samples -- cache hits)
-            bwd_request(raw[tt], enc, dirs, dsigmas, drgbs, wave * 32 + 16 * tt + n, g, pairs, plane);
-#else
-            bwd_request(raw[tt], enc, dirs, dsigmas, drgbs, src_next[tt], g, pairs, plane);
-#endif
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
-            tile_forward_frags<true, true>(W, g, in[tt].e0, in[tt].e1, in[tt].dx, in[tt].dy, in[tt].dz, t[tt]);
-            dz5[tt] = hzero;
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {                                                       // sigmoid_backward (rows 0..2 of g == 0)
-                const float y = (float)t[tt].rgb[r];
-                dz5[tt][r] = (half_t)(in[tt].drgb(r) * ((1.0f - y) * y));          // (zero gradient on lanes g != 0)
-            }
-            dsig[tt] = in[tt].dsig;
-        }
-        const half8 sel_lo = W(SEL_LO), sel_hi = W(SEL_HI);
-        // ---- layer 5: dW5 = dZ5 a4^T, dZ4 = (W5^T dZ5) o [a4 > 0]
-        half4 dz4[2][4];
-        {
-            half8 b_dz5[2], ba[2][2];
-#pragma unroll
-            for (int tt = 0; tt < 2; ++tt) {
-                b_dz5[tt] = cat_h4(dz5[tt], hzero);
-                ba[tt][0] = cat_h4(t[tt].a4[0], t[tt].a4[1]); ba[tt][1] = cat_h4(t[tt].a4[2], t[tt].a4[3]);
-            }
-            const half8 zT = tr_sel2(b_dz5[0], b_dz5[1], sel_lo);
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
-                mfma_acc(acc[T_L5 + nt], zT, tr_sel2(ba[0][nt >> 1], ba[1][nt >> 1], (nt & 1) ? sel_hi : sel_lo));
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                const half8 w = W(B_W5T + mt);
-#pragma unroll
-                for (int tt = 0; tt < 2; ++tt) dz4[tt][mt] = mask_h4(NGP_MFMA(w, b_dz5[tt], zero), t[tt].a4[mt]);
-            }
-        }
-        // ---- layer 4: dW4 = dZ4 a3^T, dZ3 = (W4^T dZ4) o [a3 > 0]
-        half4 dz3[2][4];
-        {
-            half8 bz[2][2], ba[2][2];
-#pragma unroll
-            for (int tt = 0; tt < 2; ++tt) {
-                bz[tt][0] = cat_h4(dz4[tt][0], dz4[tt][1]); bz[tt][1] = cat_h4(dz4[tt][2], dz4[tt][3]);
-                ba[tt][0] = cat_h4(t[tt].a3[0], t[tt].a3[1]); ba[tt][1] = cat_h4(t[tt].a3[2], t[tt].a3[3]);
-            }
-            half8 xT[4];
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) xT[nt] = tr_sel2(ba[0][nt >> 1], ba[1][nt >> 1], (nt & 1) ? sel_hi : sel_lo);
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                const half8 zT = tr_sel2(bz[0][mt >> 1], bz[1][mt >> 1], (mt & 1) ? sel_hi : sel_lo);
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) mfma_acc(acc[T_L4 + 4 * mt + nt], zT, xT[nt]);
-            }
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                const half8 w0 = W(B_W4T + 2 * mt), w1 = W(B_W4T + 2 * mt + 1);
-#pragma unroll
-                for (int tt = 0; tt < 2; ++tt) {
-                    floatx4 d = NGP_MFMA(w0, bz[tt][0], zero);
-                    d = NGP_MFMA(w1, bz[tt][1], d);
-                    dz3[tt][mt] = mask_h4(d, t[tt].a3[mt]);
-                }
-            }
-        }
-        // ---- layer 3: dW3 = dZ3 in3^T, dh = W3^T[h part] dZ3 (+ the density head's TruncExp gradient)
-        half4 dz2[2];
-        {
-            half8 bz[2][2];
-#pragma unroll
-            for (int tt = 0; tt < 2; ++tt) { bz[tt][0] = cat_h4(dz3[tt][0], dz3[tt][1]); bz[tt][1] = cat_h4(dz3[tt][2], dz3[tt][3]); }
-            const half8 x0 = tr_sel2(t[0].b_in3, t[1].b_in3, sel_lo), x1 = tr_sel2(t[0].b_in3, t[1].b_in3, sel_hi);
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                const half8 zT = tr_sel2(bz[0][mt >> 1], bz[1][mt >> 1], (mt & 1) ? sel_hi : sel_lo);
-                mfma_acc(acc[T_L3 + 2 * mt], zT, x0);
-                mfma_acc(acc[T_L3 + 2 * mt + 1], zT, x1);
-            }
-            const half8 w0 = W(B_W3T + 0), w1 = W(B_W3T + 1);
-#pragma unroll
-            for (int tt = 0; tt < 2; ++tt) {
-                floatx4 dh = NGP_MFMA(w0, bz[tt][0], zero);
-                dh = NGP_MFMA(w1, bz[tt][1], dh);
-                dz2[tt] = to_h4(dh);
-                // TruncExp backward, networks.py:28-30 (row 0 of g == 0; dsig is 0 on the other lanes)
-                const float h0 = (float)t[tt].h[0];
-                const half_t gs = (half_t)(dsig[tt] * fast_exp(fminf(fmaxf(h0, -15.0f), 15.0f)));
-                dz2[tt][0] = (half_t)((float)dz2[tt][0] + (g == 0 ? (float)gs : 0.0f));
-            }
-        }
-        // ---- layer 2: dW2 = dZ2 a1^T, dZ1 = (W2^T dZ2) o [a1 > 0]
-        half4 dz1[2][4];
-        {
-            half8 b_dz2[2], ba[2][2];
-#pragma unroll
-            for (int tt = 0; tt < 2; ++tt) {
-                b_dz2[tt] = cat_h4(dz2[tt], hzero);
-                ba[tt][0] = cat_h4(t[tt].a1[0], t[tt].a1[1]); ba[tt][1] = cat_h4(t[tt].a1[2], t[tt].a1[3]);
-            }
-            const half8 zT = tr_sel2(b_dz2[0], b_dz2[1], sel_lo);
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
-                mfma_acc(acc[T_L2 + nt], zT, tr_sel2(ba[0][nt >> 1], ba[1][nt >> 1], (nt & 1) ? sel_hi : sel_lo));
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                const half8 w = W(B_W2T + mt);
-#pragma unroll
-                for (int tt = 0; tt < 2; ++tt) dz1[tt][mt] = mask_h4(NGP_MFMA(w, b_dz2[tt], zero), t[tt].a1[mt]);
-            }
-        }
-        // ---- layer 1: dW1 = dZ1 enc^T, d_enc = W1^T dZ1
-        {
-            half8 bz[2][2];
-#pragma unroll
-            for (int tt = 0; tt < 2; ++tt) { bz[tt][0] = cat_h4(dz1[tt][0], dz1[tt][1]); bz[tt][1] = cat_h4(dz1[tt][2], dz1[tt][3]); }
-            // (d_enc first: its stores are the iteration's last memory operations, the earlier they are issued the better)
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                const half8 w0 = W(B_W1T + 2 * mt), w1 = W(B_W1T + 2 * mt + 1);
-#pragma unroll
-                for (int tt = 0; tt < 2; ++tt) {
-                    const int smp = it * 32 + 16 * tt + n;
-                    floatx4 d = NGP_MFMA(w0, bz[tt][0], zero);
-                    d = NGP_MFMA(w1, bz[tt][1], d);
-                    bad_denc |= !(isfinite(d[0]) && isfinite(d[1]) && isfinite(d[2]) && isfinite(d[3]));
-                    // buffer store: a lane past the end gets an out-of-range offset and the hardware drops its store.  (A branch
-                    // around the store makes the waitcnt bookkeeping assume it may not have been issued, and the next iteration then
-                    // waits for THESE stores before it may touch its prefetched inputs.)
-                    const uint32_t off = pairs ? (uint32_t)((((size_t)(4 * mt + g) * plane + smp) * 16)) : (uint32_t)smp * 128u + (16 * mt + 4 * g) * 4;
-#ifdef NGP_REG_NO_STORE       // (timing builds: every store dropped by the range check)
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4, d), d_enc_rsrc, smp < 0 ? off : 0xffffffffu, 0, 0);
-#else
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4, d), d_enc_rsrc, smp < S ? off : 0xffffffffu, 0, 0);
-#endif
-                }
-            }
-            const half8 e0T = tr_sel2(t[0].b_enc, t[1].b_enc, W(SEL_E0));
-            const half8 e1T = tr_sel2(t[0].b_enc, t[1].b_enc, W(SEL_E0 + 1));
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                const half8 zT = tr_sel2(bz[0][mt >> 1], bz[1][mt >> 1], (mt & 1) ? sel_hi : sel_lo);
-                mfma_acc(acc[T_L1 + 2 * mt], zT, e0T);
-                mfma_acc(acc[T_L1 + 2 * mt + 1], zT, e1T);
-            }
-        }
-    }
-
-    REG_T(1);
-    asm volatile("s_nop 15" ::: "memory");      // (the last asm MFMA's result vs. the compiler's v_accvgpr_read below: opaque to hipcc)
-    // ---- block reduction of the 4 waves' accumulator sets: every wave writes its 40 KB into its own LDS buffer, then the block sums the four buffers element-wise and leaves as line-coalesced
-    // global atomics.  (One buffer and four serial read-add-write steps took 18 k cycles; all 256 blocks starting their atomics
-    // at weight 0 at the same moment another 16-34 k: same-address atomics serialise, so a block starts at its own offset.)
-    bool bad = false;
-    if (!dW && !parts) { if (found_inf && bad_denc) *found_inf = 1; return; }      // (weight gradients not wanted: d_enc only)
-    {
-        floatx4* mine = reinterpret_cast<floatx4*>(smem) + wv * (N_DW_TILES * 64);
-#pragma unroll
-        for (int t = 0; t < N_DW_TILES; ++t) {
-            const floatx4 a = acc[t];
-            bad |= !(isfinite(a[0]) && isfinite(a[1]) && isfinite(a[2]) && isfinite(a[3]));
-            mine[t * 64 + lane] = a;
-        }
-    }
-    __syncthreads();
-    REG_T(2);
-    const float* red = reinterpret_cast<const float*>(smem);
-    const int e0 = (int)((blockIdx.x * 37u) % (unsigned)N_DW_TILES) * 256;
-    for (int i = threadIdx.x; i < N_DW_TILES * 256; i += blockDim.x) {
-        // element e of a buffer = (tile t, lane l, register r) at (t * 64 + l) * 4 + r; walk it so that adjacent threads are
-        // adjacent lanes n of one register: 16 consecutive weights per 16 threads
-        int e = i + e0;
-        if (e >= N_DW_TILES * 256) e -= N_DW_TILES * 256;
-        const int t = e >> 8, r = (e >> 6) & 3, l = e & 63;
-        const int at = (t * 64 + l) * 4 + r;
-        const float v = (red[at] + red[N_DW_TILES * 256 + at]) + (red[2 * N_DW_TILES * 256 + at] + red[3 * N_DW_TILES * 256 + at]);
-        const int w = dw_index(t, r, l, pairs);
-        if (w < 0) continue;
-        if (parts) parts[(size_t)blockIdx.x * N_W + w] = v;            // the block's slab (complete: every weight has one owner)
-        else if (v != 0.0f) unsafeAtomicAdd(dW + w, v);
-    }
-    if (found_inf && (bad || bad_denc)) *found_inf = 1;
-    REG_T(3);
-#undef REG_T
-}
 
 }  // namespace ngp
 
@@ -1189,18 +836,12 @@ int ngp_mlp_fwd(const float* enc, const float* dirs, const uint16_t* wpack, int 
 static int mlp_bwd_launch(const float* enc, const float* dirs, const uint16_t* wpack, const float* dsigmas, const uint16_t* drgbs,
                           int n_max, const int32_t* n_dev, const int32_t* live_idx, int enc_pairs, float* d_enc, float* dW,
                           float* parts, int32_t* found_inf, void* stream) {
-    // NGP_MLP_BWD=reg: round 4's register-resident form (4-wave blocks, profiles/r04_mlp_bwd_experiments.txt: slower); default:
-    // the LDS-image form (12-wave blocks).  Read per call so that profiles/microbench/mlp_time.py can alternate the two on
-    // identical inputs in one process.
-    const char* form = getenv("NGP_MLP_BWD");
+    // the LDS-image form (12-wave blocks).  -DNGP_MLP_BWD_REG builds also carry round 4's register-resident form (a recorded
+    // negative: profiles/microbench/mlp_bwd_reg_kernel.inc), selected per call with NGP_MLP_BWD=reg
     int blocks;
-    if (!(form && form[0] == 'r')) {
-        blocks = ((n_max + 31) / 32 + BG - 1) / BG;
-        if (blocks > 256) blocks = 256;                       // one 12-wave block per CU: 3 waves per SIMD
-        if (blocks < 1) blocks = 1;
-        hipLaunchKernelGGL(mlp_bwd_kernel, dim3(blocks), dim3(64 * BW), 0, (hipStream_t)stream, enc, dirs, (const half_t*)wpack, dsigmas,
-                           (const half_t*)drgbs, n_max, n_dev, live_idx, enc_pairs, d_enc, dW, parts, found_inf);
-    } else {
+#ifdef NGP_MLP_BWD_REG
+    const char* form = getenv("NGP_MLP_BWD");
+    if (form && form[0] == 'r') {
         if ((long long)n_max * 128 > 0xffffffffLL) return -1;   // (d_enc is addressed through a 32-bit buffer descriptor)
         blocks = ((n_max + 31) / 32 + RW - 1) / RW;
         if (blocks > 256) blocks = 256;                       // one 4-wave block per CU: 1 wave per SIMD (160 accumulator registers)
@@ -1211,7 +852,15 @@ static int mlp_bwd_launch(const float* enc, const float* dirs, const uint16_t* w
         if (enc_pairs) { if (live_idx) NGP_BWD_REG(true, true); else NGP_BWD_REG(true, false); }
         else { if (live_idx) NGP_BWD_REG(false, true); else NGP_BWD_REG(false, false); }
 #undef NGP_BWD_REG
+        NGP_LAUNCH_CHECK();
+        return blocks;
     }
+#endif
+    blocks = ((n_max + 31) / 32 + BG - 1) / BG;
+    if (blocks > 256) blocks = 256;                           // one 12-wave block per CU: 3 waves per SIMD
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(mlp_bwd_kernel, dim3(blocks), dim3(64 * BW), 0, (hipStream_t)stream, enc, dirs, (const half_t*)wpack, dsigmas,
+                       (const half_t*)drgbs, n_max, n_dev, live_idx, enc_pairs, d_enc, dW, parts, found_inf);
     NGP_LAUNCH_CHECK();
     return blocks;
 }

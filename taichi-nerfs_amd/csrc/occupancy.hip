@@ -114,9 +114,29 @@ __global__ void __launch_bounds__(256) occ_scatter_kernel(const int32_t* __restr
     if (i < n) tmp[indices ? indices[i] : i] = sigmas[i];
 }
 
-// grid = where(grid < 0, grid, max(grid*decay, tmp)) (:281-284) and the sum / count of the positive cells (:286)
+// deterministic form of the scatter: a cell drawn twice (the uniform and the occupied half overlap, and both halves draw with
+// replacement) is written by two threads with different jittered densities, and the reference's fresh[c, indices] = density keeps
+// whichever write lands last.  Here the LARGEST wins -- one of the values the race could have kept, the same one on every run
+// (densities are exp(.) > 0, whose float order is their bit patterns' integer order; tmp starts at 0).
+__global__ void __launch_bounds__(256) occ_scatter_max_kernel(const int32_t* __restrict__ indices, const float* __restrict__ sigmas, int n,
+                                                              float* __restrict__ tmp) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float s = sigmas[i];
+    if (s > 0.0f) atomicMax(reinterpret_cast<int*>(tmp) + (indices ? indices[i] : i), __float_as_int(s));
+}
+
+// grid = where(grid < 0, grid, max(grid*decay, tmp)) (:281-284) and the sum / count of the positive cells (:286).  Round 5: every
+// block leaves its partial (sum, count) in stats[2 + 2 b ..] instead of two float atomics on stats[0..1] -- the mean is the
+// occupancy threshold, and a sum whose order changes from run to run moves cells that sit on the threshold in and out of the grid.
+constexpr int OCC_MERGE_MAX_BLOCKS = 512;
+__host__ __device__ __forceinline__ int occ_merge_blocks(long n) {
+    long blocks = (n + 255) / 256;
+    blocks = (blocks + 3) / 4;                 // float4 per thread
+    return (int)(blocks > OCC_MERGE_MAX_BLOCKS ? OCC_MERGE_MAX_BLOCKS : (blocks < 1 ? 1 : blocks));
+}
 __global__ void __launch_bounds__(256) occ_merge_kernel(float* __restrict__ grid, const float* __restrict__ tmp, float decay, int n,
-                                                        float* __restrict__ stats /*[0] sum, [1] count*/) {
+                                                        float* __restrict__ stats /*[2 + 2 * 512]: [0] sum, [1] count, then per-block partials*/) {
     float sum = 0.f, cnt = 0.f;
     const int n4 = n >> 2;
     float4* g4 = reinterpret_cast<float4*>(grid);
@@ -141,15 +161,24 @@ __global__ void __launch_bounds__(256) occ_merge_kernel(float* __restrict__ grid
     if ((threadIdx.x & 63) == 0) { ps[threadIdx.x >> 6] = sum; pc[threadIdx.x >> 6] = cnt; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        unsafeAtomicAdd(stats, ps[0] + ps[1] + ps[2] + ps[3]);
-        unsafeAtomicAdd(stats + 1, pc[0] + pc[1] + pc[2] + pc[3]);
+        stats[2 + 2 * blockIdx.x] = (ps[0] + ps[1]) + (ps[2] + ps[3]);
+        stats[3 + 2 * blockIdx.x] = (pc[0] + pc[1]) + (pc[2] + pc[3]);
     }
 }
 
-// packbits with threshold = min(mean density, density_threshold) read from device memory (:286-290)
-__global__ void __launch_bounds__(256) occ_pack_kernel(const float4* __restrict__ grid, const float* __restrict__ stats, float thr_max,
+// packbits with threshold = min(mean density, density_threshold) (:286-290).  Every block adds the merge kernel's partials up
+// itself, in one fixed order (4 KB from L2; no extra launch, no atomics), block 0 also leaves the totals in stats[0..1].
+__global__ void __launch_bounds__(256) occ_pack_kernel(const float4* __restrict__ grid, float* __restrict__ stats, int n_partials, float thr_max,
                                                        int n_bytes, uint8_t* __restrict__ out) {
-    const float thr = fminf(stats[0] / stats[1], thr_max);
+    __shared__ float ps[4], pc[4];
+    float s = 0.f, c = 0.f;
+    for (int b = threadIdx.x; b < n_partials; b += 256) { s += stats[2 + 2 * b]; c += stats[3 + 2 * b]; }
+    s = wave_sum(s); c = wave_sum(c);
+    if ((threadIdx.x & 63) == 0) { ps[threadIdx.x >> 6] = s; pc[threadIdx.x >> 6] = c; }
+    __syncthreads();
+    const float total = (ps[0] + ps[1]) + (ps[2] + ps[3]), count = (pc[0] + pc[1]) + (pc[2] + pc[3]);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { stats[0] = total; stats[1] = count; }
+    const float thr = fminf(total / count, thr_max);
     for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < n_bytes; n += gridDim.x * blockDim.x) {
         const float4 a = grid[2 * (size_t)n], b = grid[2 * (size_t)n + 1];
         uint32_t bits = 0;
@@ -263,22 +292,28 @@ int ngp_occ_scatter(const int32_t* indices, const float* sigmas, int n, float* t
     return 0;
 }
 
-int ngp_occ_merge(float* density_grid, const float* tmp, float decay, int n, float* stats, void* stream) {
+int ngp_occ_scatter_max(const int32_t* indices, const float* sigmas, int n, float* tmp, void* stream) {
     if (n <= 0) return 0;
-    int blocks = (n + 255) / 256;
-    blocks = (blocks + 3) / 4;                 // float4 per thread
-    if (blocks > 512) blocks = 512;            // two same-address atomics per block at ~12 ns each: keep the block count moderate
-    hipLaunchKernelGGL(occ_merge_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, density_grid, tmp, decay, n, stats);
+    hipLaunchKernelGGL(occ_scatter_max_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, indices, sigmas, n, tmp);
     NGP_LAUNCH_CHECK();
     return 0;
 }
 
-int ngp_occ_pack(const float* density_grid, const float* stats, float density_threshold, int n_bytes, uint8_t* bitfield, void* stream) {
+int ngp_occ_stats_floats(void) { return 2 + 2 * OCC_MERGE_MAX_BLOCKS; }
+
+int ngp_occ_merge(float* density_grid, const float* tmp, float decay, int n, float* stats, void* stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(occ_merge_kernel, dim3(occ_merge_blocks(n)), dim3(256), 0, (hipStream_t)stream, density_grid, tmp, decay, n, stats);
+    NGP_LAUNCH_CHECK();
+    return 0;
+}
+
+int ngp_occ_pack(const float* density_grid, float* stats, float density_threshold, int n_bytes, uint8_t* bitfield, void* stream) {
     if (n_bytes <= 0) return 0;
     int blocks = (n_bytes + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(occ_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float4*)density_grid, stats,
-                       density_threshold, n_bytes, bitfield);
+                       occ_merge_blocks(8L * n_bytes), density_threshold, n_bytes, bitfield);
     NGP_LAUNCH_CHECK();
     return 0;
 }

@@ -17,10 +17,8 @@ INCLUDE = os.path.join(os.path.dirname(PKG_ROOT), "include")
 LIB_PATH = os.path.join(CSRC, "libngp_hip.so")
 SOURCES = ["march.hip", "hash_grid.hip", "hash_bwd_lds.hip", "composite.hip", "sh_grid.hip", "mlp.hip", "optim.hip", "distortion.hip", "occupancy.hip", "rays.hip"]
 HEADERS = ["ngp_device.h", "hash_common.h"]
-# -amdgpu-mfma-vgpr-form: builtin MFMAs keep their results in arch VGPRs even in a kernel that also pins accumulators to AGPRs through
-# inline asm (csrc/mlp.hip, mlp_bwd_reg_kernel); without it every MFMA result of that kernel is written to ONE AGPR quad and read
-# back with v_accvgpr_read (the data path serialises).  No other kernel's code changes with the flag.
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-mllvm", "-amdgpu-mfma-vgpr-form"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+FLAGS_STAMP = LIB_PATH + ".flags"      # the flags the in-tree .so was built with: a flag change rebuilds
 
 NGP_MAX_LEVELS = 16
 
@@ -43,12 +41,22 @@ def _sources():
     return [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
 
 
+def _flags():
+    return HIPCC_FLAGS + os.environ.get("NGP_HIPCC_EXTRA", "").split()   # e.g. -DNGP_BWD_DIAG for the timing experiments in profiles/microbench
+
+
 def needs_build():
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
     deps = _sources() + [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(INCLUDE, "ngp_hip.h")]
-    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+    if any(os.path.getmtime(d) > t for d in deps if os.path.exists(d)):
+        return True
+    # a library built with other flags (a -D... diagnostic build left in the tree) is stale too; no stamp = a prebuilt library that
+    # travelled without one: trusted when no extra flags are asked for
+    if os.path.exists(FLAGS_STAMP):
+        return open(FLAGS_STAMP).read().split() != _flags()
+    return bool(os.environ.get("NGP_HIPCC_EXTRA", "").split())
 
 
 def build(force=False, verbose=False):
@@ -59,14 +67,15 @@ def build(force=False, verbose=False):
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build libngp_hip.so")
     tmp = LIB_PATH + ".tmp.%d" % os.getpid()
-    extra = os.environ.get("NGP_HIPCC_EXTRA", "").split()             # e.g. -DNGP_BWD_DIAG for the timing experiments in profiles/microbench
-    cmd = [hipcc] + HIPCC_FLAGS + extra + ["-o", tmp] + _sources()
+    cmd = [hipcc] + _flags() + ["-o", tmp] + _sources()
     if verbose:
         print(" ".join(cmd))
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
     os.replace(tmp, LIB_PATH)
+    with open(FLAGS_STAMP, "w") as f:
+        f.write(" ".join(_flags()))
     return LIB_PATH
 
 
@@ -109,11 +118,14 @@ SIGNATURES = {
     "ngp_hash_bwd_f16_live": [_P, _P, _LV, _I, _P, _P, _I, _F, _F, _I, _P, _P, _P],
     "ngp_hash_bwd_sliced_workspace": [_LV, _I],
     "ngp_hash_bwd_sliced_debug": [_P],
+    "ngp_hash_bwd_sliced_deterministic": [_I],
     "ngp_hash_bwd_sliced_plan": [_LV, _P, _I, _P, _P, _P, _P, _P],
     "ngp_hash_bwd_sliced_prep": [_P, _LV, _I, _P, _P, _I, _F, _F, _P, ctypes.c_longlong, _P],
     "ngp_hash_bwd_sliced_main": [_P, _LV, _I, _P, _I, _P, _P, _P, ctypes.c_longlong, _P],
     "ngp_hash_bwd_sliced_main_slabs": [_P, _LV, _I, _P, _I, _P, _I, _P, _P, ctypes.c_longlong, _P, _I, _P, _P],
     "ngp_hash_bwd_sliced_main_levels": [_P, _LV, _I, _P, _I, _P, _P, _P, ctypes.c_longlong, ctypes.c_uint32, _I, _P],
+    "ngp_hash_bwd_sliced_adam_prefix": [_LV],
+    "ngp_hash_bwd_sliced_main_adam": [_P, _LV, _I, _P, _I, _P, _P, ctypes.c_longlong, _P, _I, _P, _P, _P, _P, _P, _P, _P, _F, _F, _F, _P],
     "ngp_hash_bwd_sliced_main_f16": [_P, _LV, _I, _P, _I, _P, _P, _P, ctypes.c_longlong, _P],
     "ngp_hash_bwd_f32_sliced": [_P, _P, _LV, _I, _P, _P, _I, _F, _F, _I, _P, _P, _P, ctypes.c_longlong, _P],
     "ngp_sh16_fwd": [_P, _I, _P, _P],
@@ -155,6 +167,8 @@ SIGNATURES = {
     "ngp_occ_sample": [_P, _P, _P, _P, _P, _I, _I, _F, _F, _P, _P, _P],
     "ngp_occ_all_cells": [_P, _I, _I, _F, _F, _P, _P],
     "ngp_occ_scatter": [_P, _P, _I, _P, _P],
+    "ngp_occ_scatter_max": [_P, _P, _I, _P, _P],
+    "ngp_occ_stats_floats": [],
     "ngp_occ_merge": [_P, _P, _F, _I, _P, _P],
     "ngp_occ_pack": [_P, _P, _F, _I, _P, _P],
     "ngp_morton3d": [_P, _I, _P, _P],
@@ -162,7 +176,7 @@ SIGNATURES = {
     "ngp_packbits": [_P, _F, _I, _P, _P],
 }
 
-_LONGLONG_RESULT = {"ngp_hash_bwd_sliced_workspace"}       # byte counts; every other entry point returns an int status
+_LONGLONG_RESULT = {"ngp_hash_bwd_sliced_workspace", "ngp_hash_bwd_sliced_adam_prefix"}       # byte counts; every other entry point returns an int status
 _lib = None
 
 

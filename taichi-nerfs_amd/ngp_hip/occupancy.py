@@ -4,6 +4,7 @@ Same algorithm as the reference (and as NGP.update_density_grid's torch formulat
 per cascade, either all cells (warm-up) or M = G^3/4 uniform cells + M cells drawn from the occupied set; a jittered point
 per cell; density there; decay/max merge; bitfield threshold = min(mean positive density, density_threshold)."""
 import ctypes
+import os
 
 import torch
 
@@ -31,7 +32,7 @@ class OccupancyUpdater:
         self.enc = torch.empty(n_max, 32, **f32)
         self.sigmas = torch.empty(n_max, **f32)
         self.tmp = torch.empty(model.cascades, G3, **f32)
-        self.stats = torch.zeros(2, **f32)
+        self.stats = torch.zeros(self.L.ngp_occ_stats_floats(), **f32)        # [0] sum, [1] count, then the merge kernel's per-block partials
         self.wpack = torch.empty(self.L.ngp_mlp_wpack_halfs(), device=dev, dtype=torch.float16)
         lvs = getattr(getattr(model, "pos_encoder", None), "levels_struct", None)     # (None: a grid driven with density_fn only)
         self.enc_pairs = 1 if (lvs is not None and lvs.n_levels == 16 and lvs.n_features == 2) else 0
@@ -44,6 +45,7 @@ class OccupancyUpdater:
         torch.rand for cascade c's in-cell jitter; `uniforms(c)` -> (u_cell [M], u_pick [M]) replacing the sorted uniforms that
         choose the cells; `density_fn(c, xyzs [n, 3], indices [n] or None)` -> sigmas [n] replacing the hash-grid + MLP density."""
         m, L, st = self.model, self.L, _stream()
+        det = bool(getattr(m, "_ngp_deterministic", False)) or os.environ.get("NGP_DETERMINISTIC", "0") == "1"
         G, G3, C = m.grid_size, m.grid_size**3, m.cascades
         grid = m.density_grid
         if not grid.is_contiguous():
@@ -99,8 +101,12 @@ class OccupancyUpdater:
             if density_fn is None:
                 check(L.ngp_mlp_fwd_ex(_ptr(self.enc), _ptr(None), _ptr(self.wpack), n, _ptr(None), self.enc_pairs, _ptr(self.sigmas),
                                        _ptr(None), st), "ngp_mlp_fwd_ex")
-            check(L.ngp_occ_scatter(idx_ptr, _ptr(self.sigmas), n, _ptr(tmp_c), st), "ngp_occ_scatter")
-        self.stats.zero_()
+            # (deterministic mode, FusedTrainer.set_deterministic / NGP_DETERMINISTIC=1: of the densities drawn for one cell the largest
+            # is kept instead of whichever write lands last)
+            if det and not warmup:
+                check(L.ngp_occ_scatter_max(idx_ptr, _ptr(self.sigmas), n, _ptr(tmp_c), st), "ngp_occ_scatter_max")
+            else:
+                check(L.ngp_occ_scatter(idx_ptr, _ptr(self.sigmas), n, _ptr(tmp_c), st), "ngp_occ_scatter")
         check(L.ngp_occ_merge(_ptr(grid), _ptr(self.tmp), float(decay), C * G3, _ptr(self.stats), st), "ngp_occ_merge")
         check(L.ngp_occ_pack(_ptr(grid), _ptr(self.stats), float(density_threshold), C * G3 // 8, _ptr(m.density_bitfield), st),
               "ngp_occ_pack")

@@ -199,6 +199,20 @@ class FusedTrainer:
         # group's reduce-scatter travels while the next group is still being accumulated; every rank owns the rank-th 1/world of
         # EACH group.  Default off until a multi-GPU run has decided.  NGP_COMM_STUB=1 replaces every collective
         # by its local part (bench.py: the step without communication, i.e. what of comm_ms is exposed).
+        # Round 5, one GPU: the table's optimizer rides in the scatter-add's flush (ngp_hash_bwd_sliced_main_adam: the owner of a
+        # non-replicated slice applies Adam to its 8192 entries instead of writing their gradient out for another launch to read
+        # back); the optimizer launch shrinks to the replicated coarse levels [0, _adam_prefix) + the MLP.  The GradScaler decision
+        # then has to exist before the scatter-add: the prologue moves in front of it (the MLP backward raises the inf flag on the
+        # same d_enc values the scatter-add would).  NGP_FLUSH_ADAM=0: the two-launch path (bit-identical results).
+        self._flush_adam = os.environ.get("NGP_FLUSH_ADAM", "1") != "0"
+        self._adam_prefix = {}                # per scatter-add mode: floats of the table the flush does NOT update (-2: not expressible)
+        # Deterministic mode (set_deterministic / NGP_DETERMINISTIC=1; bench.py conditions its model in it so that two processes
+        # reach the same state): rays packed in ray order (count / scan / write chain), the live list in ray order
+        # (ngp_live_compact), every table slice owned by one workgroup (ngp_hash_bwd_sliced_deterministic: no float atomics), the
+        # occupancy update without its two order-dependent spots (ngp_hip/occupancy.py).  Same kernels, same arithmetic per sample;
+        # what changes is the ORDER in which floating-point sums are formed, which is fixed.  Slower (~1.5 ms per step at C2).
+        self.deterministic = False
+        self.set_deterministic(os.environ.get("NGP_DETERMINISTIC", "0") == "1")
         self._comm_stub = os.environ.get("NGP_COMM_STUB", "0") == "1"
         self._pending_comm = []
         self._groups = None
@@ -206,6 +220,19 @@ class FusedTrainer:
                 and lvs.n_features == 2):
             self._groups = self._make_groups(lvs, os.environ.get("NGP_COMM_GROUPS", "8,0"))
         self.repack()
+
+    def set_deterministic(self, on):
+        self.deterministic = bool(on)
+        self.model._ngp_deterministic = self.deterministic          # read by ngp_hip/occupancy.py
+        return self
+
+    def _scatter_mode(self):
+        """Tell the library which task plan this trainer's scatter-add launches use (a per-thread switch of the library)."""
+        want = 1 if self.deterministic else 0
+        if getattr(_lib_mod, "_det_state", 0) != want:
+            self.L.ngp_hash_bwd_sliced_deterministic(want)
+            _lib_mod._det_state = want
+        return want
 
     def repack(self):
         """Rebuild the fp16 MFMA weight image from the fp32 master weights (call after loading a checkpoint into the
@@ -304,6 +331,10 @@ class FusedTrainer:
         L, st, n = self.L, _stream(), rays_o.shape[0]
         if coarse is None:
             coarse = self._coarse_bits(cfg, A)
+        if noise is None and self.deterministic:
+            # same counter-based jitter as the one-launch march draws in-kernel, as an explicit vector for the ray-order chain
+            from .ops import rng_uniform
+            noise = rng_uniform(int(torch.randint(0, 2**62, (), dtype=torch.int64)), n, self.dev)
         if noise is None and self.march_fused and self._march_rng:
             # the per-ray jitter (torch.rand_like, ray_march.py:138) is drawn inside the march kernel from a counter-based
             # generator keyed by (seed, ray); the seed comes from torch's CPU generator, so torch.manual_seed() still fixes the
@@ -316,7 +347,7 @@ class FusedTrainer:
             return
         if noise is None:
             noise = torch.rand(n, device=self.dev, dtype=torch.float32)                     # ray_march.py:138
-        if self.march_fused:
+        if self.march_fused and not self.deterministic:
             # one launch: count, block-wise allocation of the output ranges (rays in block-completion order, like the reference's
             # atomic packing), expansion.  NGP_MARCH_FUSED=0: the count / scan / write chain (rays packed in ray order)
             check(L.ngp_march_train_fused(_ptr(rays_o), _ptr(rays_d), _ptr(None), _ptr(cfg.bitfield), _ptr(coarse), _ptr(noise),
@@ -432,7 +463,7 @@ class FusedTrainer:
             # composite forward + MSE gradient + composite backward, one launch -- and, as a by-product, the compacted list of
             # the LIVE samples (those in front of each ray's early-termination point; the rest have exact-zero gradients) that
             # the MLP backward and the scatter-add run over
-            fused_live = self.live_backward
+            fused_live = self.live_backward and not self.deterministic      # (deterministic: the ray-ordered list of ngp_live_compact)
             check(L.ngp_composite_train_fused_live(_ptr(A.sigmas), _ptr(A.rgbs), 1, _ptr(M.deltas), _ptr(M.ts), _ptr(rays_a),
                                                    _ptr(target), self.bg, _ptr(sf), cfg.T_threshold, n, _ptr(vr_per_ray), _ptr(opacity),
                                                    _ptr(depth), _ptr(rgb), _ptr(A.ws), _ptr(A.d_sigmas), _ptr(A.d_rgbs), _ptr(sq_err),
@@ -452,6 +483,7 @@ class FusedTrainer:
         # a second stream underneath the MLP backward, but the two share the VALU (87 us overlapped vs 43 alone) and the
         # cross-stream join cost 23 us between the prepass's end and the scatter-add's start: in line it is 17 us per step faster
         sliced = self.hash_bwd == "sliced"          # (half2 encoder: same prepass, main pass with its fp16 arithmetic + fp16 table)
+        det = self._scatter_mode()
         if sliced:
             ws = A.sliced_ws(cfg.levels)
             rc = L.ngp_hash_bwd_sliced_prep(_ptr(M.xyzs), ctypes.byref(cfg.levels), A.cap, _ptr(cnt), _ptr(live_idx), 1, cfg.lo, cfg.hi,
@@ -482,6 +514,13 @@ class FusedTrainer:
             check(L.ngp_mlp_dw_reduce(_ptr(self.mlp_parts), n_parts, _ptr(self.mlp_grad), st), "ngp_mlp_dw_reduce")
         if hook is not None and self._prefetch_at <= 3:
             hook(); hook = None                                             # position 3: under the scatter-add and the optimizer
+        if reduce_in_scatter and self._flush_adam:
+            npre = self._adam_prefix.get(det)
+            if npre is None:
+                npre = int(L.ngp_hash_bwd_sliced_adam_prefix(ctypes.byref(cfg.levels)))
+                npre = self._adam_prefix[det] = npre if npre % 4 == 0 else -2
+            if npre >= 0:
+                return self._tail_flush_adam(A, M, cfg, cnt, P, ws, n_parts, st, hook, total, vr_per_ray, rgb, opacity, depth, sq_err, npre)
         if self._groups is not None and sliced and not self._grads_only:
             self._tail_overlapped(A, cfg, cnt, P, ws, found, st, hook, None)
             return {"rm_samples": total, "vr_per_ray": vr_per_ray, "rgb": rgb, "opacity": opacity, "depth": depth, "rays_a": rays_a,
@@ -546,6 +585,30 @@ class FusedTrainer:
                                     _ptr(self.mlp_v), _ptr(sf), _ptr(si), self.beta1, self.beta2, self.eps, P, _ptr(self.wpack), st),
                   "ngp_adam_all_ex")
         return {"rm_samples": total, "vr_per_ray": vr_per_ray, "rgb": rgb, "opacity": opacity, "depth": depth, "rays_a": rays_a,
+                "deltas": M.deltas, "ts": M.ts, "sq_err": sq_err}
+
+    def _tail_flush_adam(self, A, M, cfg, cnt, P, ws, n_parts, st, hook, total, vr_per_ray, rgb, opacity, depth, sq_err, npre):
+        """Prologue -> scatter-add with the optimizer in its flush -> Adam on the replicated coarse levels + the MLP (one GPU, fp32
+        master table with or without the bf16 copy; see __init__)."""
+        L, sf, si = self.L, self.state_f, self.state_i
+        check(L.ngp_train_prologue(_ptr(sf), _ptr(si), self.lr0, self.eta_min, self.t_max, self.beta1, self.beta2, self.growth,
+                                   self.backoff, self.growth_interval, st), "ngp_train_prologue")
+        copy16 = self.copy16_store[:self.nt] if self.copy16_store is not None else None
+        check(L.ngp_hash_bwd_sliced_main_adam(_ptr(A.d_enc), ctypes.byref(cfg.levels), A.cap, _ptr(cnt), P, _ptr(self.table_grad), _ptr(ws),
+                                              ws.numel(), _ptr(self.mlp_parts), n_parts, _ptr(self.mlp_grad), _ptr(self.table),
+                                              _ptr(self.table_m), _ptr(self.table_v), _ptr(copy16), _ptr(sf), _ptr(si), self.beta1,
+                                              self.beta2, self.eps, st), "ngp_hash_bwd_sliced_main_adam")
+        if hook is not None:
+            hook()                                                          # position 4
+        kind = 1 if copy16 is not None else 0
+        if npre > 0:
+            check(L.ngp_adam_all_ex(_ptr(self.table), _ptr(self.table_grad), 0, _ptr(self.table_m), _ptr(self.table_v), npre,
+                                    _ptr(copy16), kind, _ptr(self.mlp_flat), _ptr(self.mlp_grad), _ptr(self.mlp_m), _ptr(self.mlp_v),
+                                    _ptr(sf), _ptr(si), self.beta1, self.beta2, self.eps, P, _ptr(self.wpack), st), "ngp_adam_all_ex")
+        else:
+            check(L.ngp_adam_mlp_pack(_ptr(self.mlp_flat), _ptr(self.mlp_grad), _ptr(self.mlp_m), _ptr(self.mlp_v), _ptr(sf), _ptr(si),
+                                      self.beta1, self.beta2, self.eps, P, _ptr(self.wpack), st), "ngp_adam_mlp_pack")
+        return {"rm_samples": total, "vr_per_ray": vr_per_ray, "rgb": rgb, "opacity": opacity, "depth": depth, "rays_a": M.rays_a,
                 "deltas": M.deltas, "ts": M.ts, "sq_err": sq_err}
 
     def _composite_with_distortion(self, A, M, target, cfg, n, vr_per_ray, opacity, depth, rgb):

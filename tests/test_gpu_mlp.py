@@ -175,11 +175,11 @@ def test_pair_major_layout_equals_natural_layout(hip_lib):
     torch.testing.assert_close(gt_p, gt_nat, rtol=1e-4, atol=1e-5 * gt_nat.abs().max().item())
 
 
-@pytest.mark.parametrize("form", ["lds", "reg"])
+@pytest.mark.parametrize("form", ["lds"])       # ("reg": round 4's register-resident form, only in -DNGP_MLP_BWD_REG builds now)
 @pytest.mark.parametrize("n", [1, 47, 20000])
 def test_backward_forms_and_slab_reduction(hip_lib, monkeypatch, form, n):
-    """Both backward kernels (the LDS-image form, the default, and round 4's register-resident form, NGP_MLP_BWD=reg) and both
-    ways the weight gradients leave them -- float atomics on dW, or per-block slabs + ngp_mlp_dw_reduce (what the trainer
+    """The backward kernel (the LDS-image form; a -DNGP_MLP_BWD_REG build also answers NGP_MLP_BWD=reg) and both
+    ways the weight gradients leave it -- float atomics on dW, or per-block slabs + ngp_mlp_dw_reduce (what the trainer
     uses) -- give the same d_enc bit for bit and the same dW up to the summation order; a live list in reverse order too."""
     import ctypes
     from ngp_hip import lib, ops

@@ -73,3 +73,26 @@ def test_plan_covers_every_slice_replica_once(log2_t, max_res):
 def test_plan_refuses_other_feature_counts():
     lv = ops.make_levels(2**19, 16, 16, 1024, 4)
     assert plan_of(lv)[0] == -2
+
+
+def test_flush_adam_prefix_and_deterministic_plan():
+    """Round 5: the levels whose slices have one owner (nrep == 1) are a suffix of the level table; ngp_hash_bwd_sliced_adam_prefix
+    names where it starts (in table floats).  In deterministic mode every level has one owner per slice: prefix 0, tasks = slices."""
+    L = lib.load()
+    lv = ops.make_levels(2**19, 16, 16, 1024, 2)
+    try:
+        n, tasks, xoff, xlen, nrep, mm, sm = plan_of(lv)
+        first = min(l for l in range(16) if nrep[l] == 1)
+        assert all(nrep[l] == 1 for l in range(first, 16)) and all(nrep[l] > 1 for l in range(first))
+        assert L.ngp_hash_bwd_sliced_adam_prefix(ctypes.byref(lv)) == 2 * int(lv.offset[first])
+        assert L.ngp_hash_bwd_sliced_deterministic(1) == 0
+        n_d, tasks_d, _, xlen_d, nrep_d, mm_d, _ = plan_of(lv)
+        sizes = [int(lv.map_size[l]) for l in range(16)]
+        assert all(int(r) == 1 for r in nrep_d) and n_d == sum((s + SLICE - 1) // SLICE for s in sizes) == int(xlen_d.sum())
+        assert mm_d == mm                                           # run pre-summing stays (its grouping is what becomes order-free)
+        assert L.ngp_hash_bwd_sliced_adam_prefix(ctypes.byref(lv)) == 0
+    finally:
+        assert L.ngp_hash_bwd_sliced_deterministic(0) in (0, 1)
+    assert plan_of(lv)[0] == n
+    small = ops.make_levels(2**15, 16, 16, 512, 2)                  # no level of 64 slices: nothing for the flush to own
+    assert L.ngp_hash_bwd_sliced_adam_prefix(ctypes.byref(small)) == -2
