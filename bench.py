@@ -668,6 +668,8 @@ def _measure(args, ctx, brief):
     # ---- N > 1, after the timed region (untimed): the same K steps with every collective replaced by its local part (FusedTrainer
     # `_comm_stub`): ms_per_step minus this is the communication the step really waits for (round 3 reported comm_ms as exposed)
     elapsed_stub = None
+    # (the stubbed steps below let the ranks drift apart: everything the line reports about the model's state is read before them)
+    loss_at_end = trainer.last_loss() if (use_trainer and scene) else None
     if use_trainer and world > 1 and not args.graph and not brief:
         i0 = base + args.warmup + args.steps
         i0 += (-i0) % 16
@@ -714,7 +716,8 @@ def _measure(args, ctx, brief):
             copy16_b = 2.0 if (args.half or args.table == "bf16") else 0.0
 
             def adam_range_bytes(n_):                          # the same count for a launch over the first n_ floats of the table
-                n4_ = int(n_) // 4
+                n_ = int(n_)
+                n4_ = n_ // 4
                 t4_ = int(((trainer.table_m[:n_].view(-1, 4) != 0) | (trainer.table_v[:n_].view(-1, 4) != 0)).any(1).sum()) if n4_ else 0
                 return 48.0 * n4_ + 80.0 * t4_ + 4.0 * copy16_b * t4_
             # round 5: the part of the table whose optimizer runs in the scatter-add's flush -- m, v, p read for every parameter, p, m, v
@@ -852,7 +855,7 @@ def _measure(args, ctx, brief):
                                                    "and timed steps run the default path)") if det_cond else "default path",
                              "occupancy": "the model's own grid (update every 16 steps; all-cell warm-up for steps < 256)"})
             if use_trainer:
-                workload["loss_at_end"] = trainer.last_loss()
+                workload["loss_at_end"] = loss_at_end
         if garden:
             text = ("360_v2 Garden shape (BASELINE C3): %d rays/GPU/step, scale 16, 6 cascades 128^3, hash grid L=16 F=2 "
                     "T=2^19 max_res=4096 (%s table), exp_step_factor 1/256, %s, "

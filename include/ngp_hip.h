@@ -363,6 +363,12 @@ int ngp_adam_amp_prologue(float* state_f, int32_t* state_i, const float* grad_sc
 /* p, g, m, v: n floats each (n % 4 == 0, 16-byte aligned); g is unscaled on the fly and zero-filled. */
 int ngp_adam_step(float* p, float* g, float* m, float* v, long long n, const float* state_f,
                   const int32_t* state_i, float beta1, float beta2, float eps, void* stream);
+/* The same pass over up to NGP_ADAM_MULTI_MAX tensors in ONE launch (host arrays of device pointers and element counts, read at
+ * call time): what an optimizer over model.parameters() -- the table and the five weight matrices, train.py:143-149 -- needs per
+ * step instead of one launch per tensor. */
+#define NGP_ADAM_MULTI_MAX 16
+int ngp_adam_multi(int n_tensors, float* const* p, float* const* g, float* const* m, float* const* v, const long long* n,
+                   const float* state_f, const int32_t* state_i, float beta1, float beta2, float eps, void* stream);
 /* Same pass, additionally refreshing p_bf16 (n bf16, round-to-nearest-even) -- the table ngp_hash_fwd_bf16_ex gathers from.
  * BASELINE config 2 names a bf16 hash grid; the reference itself has fp32 (hash_encoder.py) and fp16 (hash_encoder_half.py)
  * tables only, so the semantics here are "fp32 master + 16-bit storage copy", as hash_encoder_half.py:367 does for fp16. */

@@ -1,6 +1,7 @@
 """apex.optimizers.FusedAdam as the reference's train.py:143-149 constructs it (`FusedAdam(model.parameters(), lr=..., eps=1e-15)`),
-on top of the C ABI's one-pass Adam (`ngp_adam_step`, csrc/optim.hip: unscale + moments + update in a single sweep over p/g/m/v;
-parameter groups never touched by a step are skipped as exact fixed points).
+on top of the C ABI's one-pass Adam (`ngp_adam_multi`, csrc/optim.hip: unscale + moments + update + gradient clearing in a single
+sweep over p/g/m/v of every tensor of a parameter group, one launch; float4 groups never touched by a step are skipped as exact
+fixed points).
 
 What the unchanged driver gains over its torch.optim.Adam fall-back: torch's GradScaler.step() makes a separate unscale pass over
 every gradient and then READS THE INF FLAG BACK to the host before it may call step() -- one host sync per iteration.  This class
@@ -32,12 +33,42 @@ class FusedAdam(torch.optim.Optimizer):
         self.set_grad_none = set_grad_none
         self._L = _lib.load()
         self._sf = self._si = None
+        self._multi = {}                     # group index -> (parameter identities, ctypes pointer / count arrays)
 
     def zero_grad(self, set_to_none=None):
         return super().zero_grad(self.set_grad_none if set_to_none is None else set_to_none)
 
+    # The bias-correction step count and the skip counter live in small device tensors (the kernels read them; nothing is read
+    # back).  They are part of the optimizer's state: a resume that dropped them would restart the bias correction.
+    def state_dict(self):
+        sd = super().state_dict()
+        if self._sf is not None:
+            sd["ngp_group_state"] = [(f.detach().clone(), i.detach().clone()) for f, i in zip(self._sf, self._si)]
+        return sd
+
+    def load_state_dict(self, state_dict):
+        sd = dict(state_dict)
+        gs = sd.pop("ngp_group_state", None)
+        super().load_state_dict(sd)
+        if gs is not None:
+            self._sf = [f.detach().clone() for f, _ in gs]
+            self._si = [i.detach().clone() for _, i in gs]
+        self._multi = {}
+
+    def _check(self, p, g):
+        if (not p.is_cuda or p.dtype != torch.float32 or g.dtype != torch.float32 or not p.is_contiguous() or not g.is_contiguous()
+                or p.numel() % 4 or p.data_ptr() % 16 or g.data_ptr() % 16):
+            raise NotImplementedError("compat FusedAdam: parameters and gradients must be contiguous, 16-byte aligned fp32 "
+                                      "CUDA tensors with a multiple of 4 elements (got {} {})".format(tuple(p.shape), p.dtype))
+
     @torch.no_grad()
     def step(self, closure=None):
+        """One optimisation step: per parameter group a one-thread prologue (skip decision, bias corrections) and ONE multi-tensor
+        launch over every parameter that has a gradient (`ngp_adam_multi`; round 4: one launch per tensor).  Unlike apex / torch,
+        the sweep leaves `p.grad` ZERO-FILLED (the unscale, the update and the clearing are one pass over p / g / m / v): a caller
+        that accumulates gradients over several backward passes per step() is unaffected, one that inspects `p.grad` after step()
+        sees zeros.  GradScaler still runs its own `_check_inf_per_device` pass over the gradients before it calls this (torch's
+        code); what `_step_supports_amp_scaling` removes is the host read-back of the flag and the separate unscale pass."""
         loss = None
         if closure is not None:
             with torch.enable_grad():
@@ -58,16 +89,33 @@ class FusedAdam(torch.optim.Optimizer):
                 raise TypeError("grad_scale / found_inf must be float32 device tensors (torch.cuda.amp.GradScaler's are)")
             _lib.check(L.ngp_adam_amp_prologue(_ptr(sf), _ptr(si), _ptr(scale), _ptr(found), float(group["lr"]), float(b1), float(b2),
                                                _stream()), "ngp_adam_amp_prologue")
-            for p in ps:
-                g = p.grad
-                if (not p.is_cuda or p.dtype != torch.float32 or g.dtype != torch.float32 or not p.is_contiguous() or not g.is_contiguous()
-                        or p.numel() % 4 or p.data_ptr() % 16 or g.data_ptr() % 16):
-                    raise NotImplementedError("compat FusedAdam: parameters and gradients must be contiguous, 16-byte aligned fp32 "
-                                              "CUDA tensors with a multiple of 4 elements (got {} {})".format(tuple(p.shape), p.dtype))
-                st = self.state[p]
-                if not st:
-                    st["exp_avg"], st["exp_avg_sq"] = torch.zeros_like(p), torch.zeros_like(p)
-                _lib.check(L.ngp_adam_step(_ptr(p), _ptr(g), _ptr(st["exp_avg"]), _ptr(st["exp_avg_sq"]), ctypes.c_longlong(p.numel()),
-                                           _ptr(sf), _ptr(si), float(b1), float(b2), float(group["eps"]), _stream()), "ngp_adam_step")
-                _touched(p, g)       # written through raw pointers: version-keyed caches (the encoders' 16-bit table copies) must see it
+            st = _stream()
+            for c0 in range(0, len(ps), _MULTI_MAX):
+                chunk = ps[c0:c0 + _MULTI_MAX]
+                key = (gi, c0)
+                ident = tuple((id(p), p.data_ptr()) for p in chunk)
+                ent = self._multi.get(key)
+                if ent is None or ent[0] != ident:
+                    k = len(chunk)
+                    P, G, M, V = ((ctypes.c_void_p * k)() for _ in range(4))
+                    N = (ctypes.c_longlong * k)()
+                    for j, p in enumerate(chunk):
+                        self._check(p, p.grad)
+                        state = self.state[p]
+                        if not state:
+                            state["exp_avg"], state["exp_avg_sq"] = torch.zeros_like(p), torch.zeros_like(p)
+                        P[j], M[j], V[j], N[j] = p.data_ptr(), state["exp_avg"].data_ptr(), state["exp_avg_sq"].data_ptr(), p.numel()
+                    ent = self._multi[key] = (ident, P, G, M, V, N)
+                _, P, G, M, V, N = ent
+                for j, p in enumerate(chunk):                      # autograd hands out fresh gradient tensors every step
+                    g = p.grad
+                    if g.dtype != torch.float32 or not g.is_contiguous() or g.data_ptr() % 16:
+                        self._check(p, g)
+                    G[j] = g.data_ptr()
+                _lib.check(L.ngp_adam_multi(len(chunk), P, G, M, V, N, _ptr(sf), _ptr(si), float(b1), float(b2), float(group["eps"]), st),
+                           "ngp_adam_multi")
+            _touched(*ps, *[p.grad for p in ps])            # written through raw pointers: version-keyed caches (the encoders' 16-bit table copies) must see it
         return loss
+
+
+_MULTI_MAX = 16                      # NGP_ADAM_MULTI_MAX (include/ngp_hip.h)

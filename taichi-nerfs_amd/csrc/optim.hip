@@ -92,6 +92,24 @@ __global__ void __launch_bounds__(256) adam_kernel(float4* __restrict__ p, float
     adam_table_pass<SHADOW>(p, g, m, v, n4, sf, si, beta1, beta2, eps, shadow, (long)blockIdx.x, (long)gridDim.x);
 }
 
+// Multi-tensor form (compat/apex FusedAdam: the reference's train.py:143-149 hands it model.parameters() = the table + five weight
+// matrices): ONE launch sweeps all of a parameter group's tensors instead of one launch per tensor.  Every block walks the tensor
+// list and takes its grid-stride share of each (the table dominates; the small matrices cost a few trips).
+struct AdamMulti {
+    float4* p[NGP_ADAM_MULTI_MAX];
+    float4* g[NGP_ADAM_MULTI_MAX];
+    float4* m[NGP_ADAM_MULTI_MAX];
+    float4* v[NGP_ADAM_MULTI_MAX];
+    long n4[NGP_ADAM_MULTI_MAX];
+    int count;
+};
+__global__ void __launch_bounds__(256) adam_multi_kernel(AdamMulti T, const float* __restrict__ sf, const int32_t* __restrict__ si,
+                                                         float beta1, float beta2, float eps) {
+    for (int t = 0; t < T.count; ++t)
+        adam_table_pass<0>(T.p[t], T.g[t], T.m[t], T.v[t], T.n4[t], sf, si, beta1, beta2, eps, (uint2*)nullptr, (long)blockIdx.x,
+                           (long)gridDim.x);
+}
+
 __global__ void __launch_bounds__(256) cast_bf16_kernel(const float4* __restrict__ src, uint2* __restrict__ dst, long n4) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         const float4 a = src[i];
@@ -206,6 +224,26 @@ int ngp_adam_step(float* p, float* g, float* m, float* v, long long n, const flo
     if (blocks > 256L * 16) blocks = 256L * 16;
     hipLaunchKernelGGL(adam_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (float4*)p, (float4*)g, (float4*)m,
                        (float4*)v, n4, state_f, state_i, beta1, beta2, eps, (uint2*)nullptr);
+    NGP_LAUNCH_CHECK();
+    return 0;
+}
+
+int ngp_adam_multi(int n_tensors, float* const* p, float* const* g, float* const* m, float* const* v, const long long* n,
+                   const float* state_f, const int32_t* state_i, float beta1, float beta2, float eps, void* stream) {
+    if (n_tensors <= 0) return 0;
+    if (n_tensors > NGP_ADAM_MULTI_MAX || !p || !g || !m || !v || !n) return -1;
+    AdamMulti T;
+    long most = 0;
+    T.count = n_tensors;
+    for (int t = 0; t < n_tensors; ++t) {
+        if (n[t] <= 0 || n[t] % 4 != 0 || !p[t] || !g[t] || !m[t] || !v[t]) return -1;
+        T.p[t] = (float4*)p[t]; T.g[t] = (float4*)g[t]; T.m[t] = (float4*)m[t]; T.v[t] = (float4*)v[t];
+        T.n4[t] = (long)(n[t] / 4);
+        if (T.n4[t] > most) most = T.n4[t];
+    }
+    long blocks = (most + 255) / 256;
+    if (blocks > 256L * 16) blocks = 256L * 16;
+    hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, T, state_f, state_i, beta1, beta2, eps);
     NGP_LAUNCH_CHECK();
     return 0;
 }

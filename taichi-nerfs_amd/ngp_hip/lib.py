@@ -152,6 +152,7 @@ SIGNATURES = {
     "ngp_train_prologue_reduce": [_P, _P, _F, _F, _I, _F, _F, _F, _F, _I, _P, _I, _P, _P],
     "ngp_adam_amp_prologue": [_P, _P, _P, _P, _F, _F, _F, _P],
     "ngp_adam_step": [_P, _P, _P, _P, ctypes.c_longlong, _P, _P, _F, _F, _F, _P],
+    "ngp_adam_multi": [_I, _P, _P, _P, _P, _P, _P, _P, _F, _F, _F, _P],
     "ngp_adam_step_bf16": [_P, _P, _P, _P, ctypes.c_longlong, _P, _P, _F, _F, _F, _P, _P],
     "ngp_cast_f32_bf16": [_P, _P, ctypes.c_longlong, _P],
     "ngp_adam_all": [_P, _P, _P, _P, ctypes.c_longlong, _P, _P, _P, _P, _P, _P, _P, _F, _F, _F, _I, _P, _P],

@@ -489,7 +489,14 @@ class FusedTrainer:
             rc = L.ngp_hash_bwd_sliced_prep(_ptr(M.xyzs), ctypes.byref(cfg.levels), A.cap, _ptr(cnt), _ptr(live_idx), 1, cfg.lo, cfg.hi,
                                             _ptr(ws), ws.numel(), st)
             if rc == -2:
-                self.hash_bwd, sliced = "atomic", False                  # level table not expressible as <= 64 LDS slices per level
+                # level table not expressible as <= 64 LDS slices per level: the float-atomic kernel from here on.  The overlapped
+                # exchange is built on per-level-group launches of the sliced kernel and shards the optimizer BY GROUP; falling
+                # through to the contiguous shard layout with the group layout still recorded would make state_dict() /
+                # sync_master() gather the wrong ranges -- a trainer configured that way cannot continue
+                if self._groups is not None:
+                    raise RuntimeError("NGP_COMM_OVERLAP=1 needs the LDS-sliced scatter-add, which this level table does not fit "
+                                       "(ngp_hash_bwd_sliced_prep returned -2); unset NGP_COMM_OVERLAP")
+                self.hash_bwd, sliced = "atomic", False
             else:
                 check(rc, "ngp_hash_bwd_sliced_prep")
         # weight gradients leave the launch as per-block slabs (plain stores) instead of 256 x 9408 same-address float atomics (13 us
@@ -849,6 +856,11 @@ class FusedTrainer:
             prefetch = (prefetch[0].contiguous().float(), prefetch[1].contiguous().float())
         self.stats = self._launch(rays_o.contiguous().float(), rays_d.contiguous().float(), target.contiguous().float(), prefetch,
                                   src, src_next, noise)
+        if self._pending_comm and prefetch is None:
+            # overlapped exchange: the all-gathers of this step are waited for at the start of the NEXT step -- fine inside a training
+            # loop that names its next batch, but a caller that does not (the last step before an evaluation render through
+            # model(), a checkpoint through model.state_dict()) must not read a table that is still arriving
+            self.finish_comm()
         return self.stats
 
     def compute_gradients(self, rays_o, rays_d, target, noise=None):
@@ -942,6 +954,24 @@ class FusedTrainer:
         # the model's weights were loaded alongside: the fp32 master IS the checkpoint now, on every shard -- nothing left to gather
         self._master_stale = False
         self.repack()                          # refresh the fp16 MFMA image and the 16-bit table copy from the master
+
+    def close(self):
+        """Release what the trainer holds outside torch's allocator: the low-priority side stream (ngp_stream_create_low_priority).
+        Idempotent; also called when the trainer is garbage-collected."""
+        side, self._side = getattr(self, "_side", None), None
+        if side is not None and getattr(self, "_side_prio", None) is not None:
+            try:
+                side.synchronize()
+                self.L.ngp_stream_destroy(ctypes.c_void_p(side.cuda_stream))
+            except Exception:
+                pass
+            self._side_prio = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def last_loss(self):
         """MSE of the last step (host sync: logging only)."""

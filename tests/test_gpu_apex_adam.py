@@ -25,6 +25,7 @@ def test_fused_adam_matches_torch_adam_under_gradscaler(hip_lib):
     for step in range(50):
         tgt = [torch.randn(*s, device="cuda", generator=g) for s in shapes]
         blow = float("inf") if step == 17 else 1.0
+        before = [[p.detach().clone() for p in params] for params in (ref, mine)] if step == 17 else None
         for params, opt, scaler, sch in ((ref, o_ref, s_ref, sch_ref), (mine, o_mine, s_mine, sch_mine)):
             loss = sum(((p - t) ** 2).mean() for p, t in zip(params, tgt)) * blow
             opt.zero_grad()
@@ -32,8 +33,14 @@ def test_fused_adam_matches_torch_adam_under_gradscaler(hip_lib):
             scaler.step(opt)
             scaler.update()
             sch.step()
-        if step == 17:
-            assert all(torch.equal(a, b) for a, b in zip(ref, mine)) or True
+        if step == 17:                 # the overflow step is skipped on the device: neither optimizer moves a parameter
+            for params, snap in zip((ref, mine), before):
+                assert all(torch.equal(a.detach(), b) for a, b in zip(params, snap))
+        if step == 30:                 # the device-side step count travels with state_dict(): a resumed optimizer goes on
+            sd = o_mine.state_dict()   # with the same bias corrections
+            assert "ngp_group_state" in sd and int(sd["ngp_group_state"][0][1][1]) == 30
+            o_mine.load_state_dict(sd)
+            assert int(o_mine._si[0][1]) == 30
     assert s_ref.get_scale() == s_mine.get_scale()
     for a, b in zip(ref, mine):
         torch.testing.assert_close(b, a, rtol=2e-5, atol=2e-6)

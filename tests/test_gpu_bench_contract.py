@@ -50,11 +50,18 @@ def test_bench_configs_array(hip_lib):
     d = json.loads(lines[0])
     assert d["config"]["grid_updates_in_timed_region"] in (0, 1)
     names = [c["name"] for c in d["configs"]]
-    assert names == ["C2-bf16-table", "C5-half2", "C3-garden", "C2-65536-rays", "C2-init-random50"], names
+    assert names == ["C2-modules-path", "C2-bf16-table", "C5-half2", "C3-garden", "C2-65536-rays", "C2-init-random50"], names
     for c in d["configs"]:
         assert "error" not in c, c
-        assert c["value"] > 0 and c["ms_per_step"] > 0 and 0 < c["frac"] <= 1.0 and c["dominant_kernel"], c
+        assert c["value"] > 0 and c["ms_per_step"] > 0, c
         assert abs(c["value"] - c["rays_per_gpu"] / (c["ms_per_step"] * 1e-3)) / c["value"] < 1e-6
+        if c["name"] == "C2-modules-path":         # the reference-surface loop (modules + torch optimizer) in every line
+            assert c["path"] == "modules+torch.optim" and c["rm_samples_per_ray"] > 0
+        else:
+            assert c["path"].startswith("FusedTrainer") and 0 < c["frac"] <= 1.0 and c["dominant_kernel"], c
+    # round 5: the headline carries its per-live-sample cost at the top level (the driver keeps top-level keys)
+    assert d["live_samples_per_step"] > 0 and abs(d["ns_per_live_sample"] - d["ms_per_step"] * 1e6 / d["live_samples_per_step"]) < 1e-6
+    assert "deterministic" in d["config"]["workload_state"]["conditioning_mode"]
 
 
 def test_bench_self_launches_two_ranks(hip_lib):

@@ -142,7 +142,9 @@ def test_flush_adam_bit_identical_to_two_launch_path(hip_lib, copy):
         for name in ("table", "m", "v") + (("copy",) if copy else ()):
             a, b = getattr(A, name), getattr(Bs, name)
             assert torch.equal(_bits(a[prefix:]), _bits(b[prefix:])), "%s: %s differs on the flush-owned levels" % (tag, name)
-            np.testing.assert_allclose(b[:prefix].float().cpu().numpy(), a[:prefix].float().cpu().numpy(), rtol=1e-6, atol=1e-9,
+            # (replicas of a coarse slice meet in the gradient table with float atomics: ~1e-7 of the gradient, in both paths)
+            ref_ = a[:prefix].float().cpu().numpy()
+            np.testing.assert_allclose(b[:prefix].float().cpu().numpy(), ref_, rtol=1e-4, atol=1e-6 * float(np.abs(ref_).max()) + 1e-30,
                                        err_msg="%s: %s, replicated levels" % (tag, name))
         for name in ("mlp", "mlp_m", "mlp_v", "wpack"):
             assert torch.equal(_bits(getattr(A, name)), _bits(getattr(Bs, name))), "%s: %s" % (tag, name)
