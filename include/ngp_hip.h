@@ -100,6 +100,15 @@ int ngp_march_train_fused_rng(const float* rays_o, const float* rays_d, const fl
                               const uint32_t* coarse, unsigned long long seed, int cascades, int grid_size, float scale,
                               float exp_step_factor, int max_samples, int n_rays, float* stage, int32_t* ctr, int32_t* rays_a,
                               int32_t* total, float* xyzs, float* dirs, float* deltas, float* ts, void* stream);
+/* Round 5: the same launch with its SHAPE chosen by the caller (the side-stream prefetch of FusedTrainer puts the march underneath
+ * other kernels of the step): block_waves in {4, 8, 16} waves per block (16 = the entry points above), lds_pad_bytes of dynamic
+ * LDS the kernel never touches (caps the blocks one CU takes at a time; 0 = none).  noise == NULL: jitter rng_uniform(seed, r),
+ * else the vector (seed ignored).  Per ray the samples are bit for bit those of every other form (ray_march.py:8-123). */
+int ngp_march_train_fused_shaped(const float* rays_o, const float* rays_d, const float* hits_t, const uint8_t* density_bitfield,
+                                 const uint32_t* coarse, const float* noise, unsigned long long seed, int cascades, int grid_size,
+                                 float scale, float exp_step_factor, int max_samples, int n_rays, int block_waves, int lds_pad_bytes,
+                                 float* stage, int32_t* ctr, int32_t* rays_a, int32_t* total, float* xyzs, float* dirs, float* deltas,
+                                 float* ts, void* stream);
 int ngp_rng_uniform(unsigned long long seed, int n, float* out, void* stream);
 int ngp_march_train_scan(const int32_t* counts, int n_rays, int32_t* rays_a /*[n,3]*/,
                          int32_t* total /*[1]*/, void* stream);

@@ -324,16 +324,21 @@ __device__ unsigned long long ngp_march_dbg[4 * 8192];
 // rays take their ranges with atomic adds (ray_march.py:76-80), and unlike the count / scan / write chain above, which packs
 // in ray order and costs two more launches (14 + 15-24 us) behind the count.  ctr[0] = allocation counter, ctr[1] = finished
 // blocks: the last block publishes total = ctr[0] and clears both, so the pair needs zeroing only once, at allocation.
-template <bool CONST_DT, int G, bool CASC1>
-__global__ void __launch_bounds__(1024) march_fused_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+// Round 5: WAVES per block is a template parameter (16 = rounds 3-4's block).  The per-ray result does not depend on it (every
+// synchronisation of march_rays_of_wave is wave-local); what it changes is how the launch shares a CU with the kernels it is put
+// underneath: a 4-wave block (8 rays at G = 32) asks for one wave slot per SIMD and 52 VGPRs each, `lds_pad` bytes of dynamic LDS it
+// never touches cap how many such blocks a CU takes (ngp_march_train_fused_shaped).
+template <bool CONST_DT, int G, bool CASC1, int WAVES>
+__global__ void __launch_bounds__(64 * WAVES) march_fused_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
                                                            const float2* __restrict__ hits_t, const uint8_t* __restrict__ bits,
                                                            const float* __restrict__ noise, MarchParams p, int max_samples, int n_rays,
                                                            const uint32_t* __restrict__ coarse, float2* __restrict__ stage,
                                                            int32_t* __restrict__ ctr, int32_t* __restrict__ rays_a,
                                                            int32_t* __restrict__ total, float* __restrict__ xyzs,
                                                            float* __restrict__ dirs, float* __restrict__ deltas, float* __restrict__ ts) {
-    constexpr int GROUPS = 64 / G, RPB = 16 * GROUPS;      // rays per block: 32 at G = 32
-    __shared__ unsigned long long chain[16][GROUPS];
+    constexpr int GROUPS = 64 / G, RPB = WAVES * GROUPS;   // rays per block: 32 at G = 32, WAVES = 16
+    static_assert(RPB <= 64, "wave 0 scans the block's ray counts with one wave scan");
+    __shared__ unsigned long long chain[WAVES][GROUPS];
     __shared__ uint32_t coarse_s[MARCH_MAX_COARSE_WORDS];
     __shared__ int s_off[RPB];
     const bool use_coarse = load_coarse(p, coarse, coarse_s);
@@ -346,8 +351,8 @@ __global__ void __launch_bounds__(1024) march_fused_kernel(const float* __restri
     const int n = march_rays_of_wave<CONST_DT, G, CASC1>(rays_o, rays_d, hits_t, bits, noise, p, max_samples, n_rays, coarse_s, use_coarse,
                                                          stage, chain[wv], first, o, d);
 #ifdef NGP_MARCH_DIAG
-    if (lane == 0 && blockIdx.x * 16 + wv < 8192) {
-        unsigned long long* q = ngp_march_dbg + 4 * (blockIdx.x * 16 + wv);
+    if (lane == 0 && blockIdx.x * WAVES + wv < 8192) {
+        unsigned long long* q = ngp_march_dbg + 4 * (blockIdx.x * WAVES + wv);
         q[0] = t_w0; q[1] = wall_clock64(); q[3] = (unsigned long long)n;
     }
 #endif
@@ -389,7 +394,7 @@ __global__ void __launch_bounds__(1024) march_fused_kernel(const float* __restri
     // it, and both are executed by the L2 in arrival order.  A release / acquire pair at agent scope would say the same to the
     // memory model at the price of the write-back measured above; tests assert total == sum of the per-ray counts on every case.)
 #ifdef NGP_MARCH_DIAG
-    if (lane == 0 && blockIdx.x * 16 + wv < 8192) ngp_march_dbg[4 * (blockIdx.x * 16 + wv) + 2] = wall_clock64();
+    if (lane == 0 && blockIdx.x * WAVES + wv < 8192) ngp_march_dbg[4 * (blockIdx.x * WAVES + wv) + 2] = wall_clock64();
 #endif
     if (threadIdx.x == 0) {
         if (atomicAdd(&ctr[1], 1) == (int)gridDim.x - 1) {
@@ -635,21 +640,27 @@ int ngp_march_train_count_ex(const float* rays_o, const float* rays_d, const flo
 static int march_train_fused(const float* rays_o, const float* rays_d, const float* hits_t, const uint8_t* density_bitfield,
                              const uint32_t* coarse, const float* noise, bool rng, unsigned long long seed, int cascades, int grid_size,
                              float scale, float exp_step_factor, int max_samples, int n_rays, float* stage, int32_t* ctr, int32_t* rays_a,
-                             int32_t* total, float* xyzs, float* dirs, float* deltas, float* ts, void* stream, long long capacity = 0) {
+                             int32_t* total, float* xyzs, float* dirs, float* deltas, float* ts, void* stream, long long capacity = 0,
+                             int block_waves = 16, int lds_pad = 0) {
     if (n_rays <= 0) return 0;
     if (!ctr || !rays_a || !total || (!rng && !noise) || capacity < 0) return -1;
+    if ((block_waves != 16 && block_waves != 8 && block_waves != 4) || lds_pad < 0 || lds_pad > 150 * 1024) return -1;
     MarchParams p = make_march_params(cascades, grid_size, scale, exp_step_factor);
     p.rng = rng ? 1 : 0; p.rng_seed = seed; p.capacity = capacity;
     hipStream_t s = (hipStream_t)stream;
-    constexpr int RPB = 16 * (64 / MARCH_GROUP);
-#define NGP_LAUNCH_MARCH(CD, C1)                                                                                                   \
-    hipLaunchKernelGGL((march_fused_kernel<CD, MARCH_GROUP, C1>), dim3((n_rays + RPB - 1) / RPB), dim3(1024), 0, s, rays_o, rays_d,    \
-                       (const float2*)hits_t, density_bitfield, noise, p, max_samples, n_rays, coarse, (float2*)stage, ctr, rays_a,     \
-                       total, xyzs, dirs, deltas, ts)
+    const int rpb = block_waves * (64 / MARCH_GROUP);
+#define NGP_LAUNCH_MARCH_W(CD, C1, W)                                                                                               \
+    hipLaunchKernelGGL((march_fused_kernel<CD, MARCH_GROUP, C1, W>), dim3((n_rays + rpb - 1) / rpb), dim3(64 * W), (size_t)lds_pad, s,   \
+                       rays_o, rays_d, (const float2*)hits_t, density_bitfield, noise, p, max_samples, n_rays, coarse, (float2*)stage,  \
+                       ctr, rays_a, total, xyzs, dirs, deltas, ts)
+#define NGP_LAUNCH_MARCH(CD, C1)                                                                                                    \
+    do { if (block_waves == 16) NGP_LAUNCH_MARCH_W(CD, C1, 16); else if (block_waves == 8) NGP_LAUNCH_MARCH_W(CD, C1, 8);           \
+         else NGP_LAUNCH_MARCH_W(CD, C1, 4); } while (0)
     const bool cd = exp_step_factor == 0.0f, c1 = cascades == 1;
     if (cd && c1) NGP_LAUNCH_MARCH(true, true); else if (cd) NGP_LAUNCH_MARCH(true, false);
     else if (c1) NGP_LAUNCH_MARCH(false, true); else NGP_LAUNCH_MARCH(false, false);
 #undef NGP_LAUNCH_MARCH
+#undef NGP_LAUNCH_MARCH_W
     NGP_LAUNCH_CHECK();
     return 0;
 }
@@ -681,6 +692,20 @@ int ngp_march_train_fused_rng(const float* rays_o, const float* rays_d, const fl
                               int32_t* total, float* xyzs, float* dirs, float* deltas, float* ts, void* stream) {
     return march_train_fused(rays_o, rays_d, hits_t, density_bitfield, coarse, nullptr, true, seed, cascades, grid_size, scale,
                              exp_step_factor, max_samples, n_rays, stage, ctr, rays_a, total, xyzs, dirs, deltas, ts, stream);
+}
+
+// ... with the launch SHAPE chosen by the caller: block_waves in {4, 8, 16} waves per block (16 = every other entry point), and
+// lds_pad bytes of untouched dynamic LDS per block, which cap the blocks a CU takes at once (160 KB / (pad + ~1 KB)).  Per ray the
+// result is the other entry points' bit for bit; what changes is the block-completion order the rays' ranges are packed in (rays_a
+// says where, as always) and how the launch shares the chip with a kernel running beside it (FusedTrainer's prefetched march).
+int ngp_march_train_fused_shaped(const float* rays_o, const float* rays_d, const float* hits_t, const uint8_t* density_bitfield,
+                                 const uint32_t* coarse, const float* noise, unsigned long long seed, int cascades, int grid_size,
+                                 float scale, float exp_step_factor, int max_samples, int n_rays, int block_waves, int lds_pad_bytes,
+                                 float* stage, int32_t* ctr, int32_t* rays_a, int32_t* total, float* xyzs, float* dirs, float* deltas,
+                                 float* ts, void* stream) {
+    return march_train_fused(rays_o, rays_d, hits_t, density_bitfield, coarse, noise, noise == nullptr, seed, cascades, grid_size, scale,
+                             exp_step_factor, max_samples, n_rays, stage, ctr, rays_a, total, xyzs, dirs, deltas, ts, stream, 0,
+                             block_waves, lds_pad_bytes);
 }
 
 __global__ void rng_uniform_kernel(unsigned long long seed, int n, float* __restrict__ out) {

@@ -96,6 +96,8 @@ SIGNATURES = {
     "ngp_march_train_fused": [_P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "ngp_march_train_fused_cap": [_P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _I, _I, ctypes.c_longlong, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "ngp_march_train_fused_rng": [_P, _P, _P, _P, _P, ctypes.c_ulonglong, _I, _I, _F, _F, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "ngp_march_train_fused_shaped": [_P, _P, _P, _P, _P, _P, ctypes.c_ulonglong, _I, _I, _F, _F, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P,
+                                     _P, _P],
     "ngp_rng_uniform": [ctypes.c_ulonglong, _I, _P, _P],
     "ngp_march_train_write": [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P],
     "ngp_march_test": [_P, _P, _P, _P, _P, _I, _I, _F, _F, _I, _I, _P, _P, _P, _P, _P, _P],

@@ -124,11 +124,12 @@ def march_train(rays_o, rays_d, hits_t, density_bitfield, noise, cascades, scale
 
 
 def march_train_fused(rays_o, rays_d, hits_t, density_bitfield, noise, cascades, scale, exp_step_factor, grid_size, max_samples,
-                      capacity=None, seed=None):
+                      capacity=None, seed=None, shape=None):
     """ngp_march_train_fused: the same samples per ray as march_train() in ONE launch, the rays packed in block-completion order
     (rays_a[r] = (r, start, count)); outputs are sized for `capacity` samples (default n * max_samples), the first `total` valid --
     with a smaller capacity the kernel drops what does not fit (compare the returned total with it).  hits_t may be None (slab
-    test inline).  noise=None + seed: the jitter is drawn in the kernel, ray r gets rng_uniform(seed, r)."""
+    test inline).  noise=None + seed: the jitter is drawn in the kernel, ray r gets rng_uniform(seed, r).  shape = (waves per
+    block in {4, 8, 16}, bytes of idle dynamic LDS per block): ngp_march_train_fused_shaped (full-capacity outputs only)."""
     _dev(rays_o, torch.float32, "rays_o"); _dev(rays_d, torch.float32, "rays_d")
     _dev(density_bitfield, torch.uint8, "density_bitfield")
     if noise is None:
@@ -147,7 +148,15 @@ def march_train_fused(rays_o, rays_d, hits_t, density_bitfield, noise, cascades,
     xyzs, dirs = torch.empty(cap, 3, device=dev, dtype=torch.float32), torch.empty(cap, 3, device=dev, dtype=torch.float32)
     deltas, ts = torch.empty(cap, device=dev, dtype=torch.float32), torch.empty(cap, device=dev, dtype=torch.float32)
     coarse = coarse_bitfield(density_bitfield, cascades, grid_size)
-    if noise is None:
+    if shape is not None:
+        if cap < n * int(max_samples):
+            raise ValueError("the shaped form writes into arrays of n * max_samples rows")
+        check(L.ngp_march_train_fused_shaped(_ptr(rays_o), _ptr(rays_d), _ptr(hits_t), _ptr(density_bitfield), _ptr(coarse), _ptr(noise),
+                                             int(seed or 0), int(cascades), int(grid_size), float(scale), float(exp_step_factor),
+                                             int(max_samples), n, int(shape[0]), int(shape[1]), _ptr(stage), _ptr(ctr), _ptr(rays_a),
+                                             _ptr(total), _ptr(xyzs), _ptr(dirs), _ptr(deltas), _ptr(ts), _stream()),
+              "ngp_march_train_fused_shaped")
+    elif noise is None:
         if cap < n * int(max_samples):
             raise ValueError("the seeded form writes into arrays of n * max_samples rows")
         check(L.ngp_march_train_fused_rng(_ptr(rays_o), _ptr(rays_d), _ptr(hits_t), _ptr(density_bitfield), _ptr(coarse), int(seed),

@@ -174,6 +174,12 @@ class FusedTrainer:
         # (with world > 1 the default is 4: the march then runs underneath the gradient exchange -- RCCL's kernels occupy a few
         # workgroups and wait on xGMI -- instead of competing with the VALU-bound kernels of the step for issue slots)
         self._prefetch_at = int(_os.environ.get("NGP_PREFETCH_AT", "3" if self.world == 1 else "4"))
+        # Round 5: the SHAPE of the prefetched launch (ngp_march_train_fused_shaped): "waves per block, idle LDS bytes per block",
+        # e.g. "4,82944" = 4-wave blocks, at most one per CU.  With the table's optimizer inside the scatter-add there is no
+        # HBM-bound launch left to hide a 16-wave-per-CU march under; a narrow march asks every CU for one wave slot per SIMD and
+        # runs beside whatever the step is doing.  Unset: the 16-wave block every other march launch uses.
+        shape = _os.environ.get("NGP_MARCH_SHAPE", "")
+        self._march_shape = tuple(int(x) for x in shape.split(",")) if shape else None
         self._coarse_ver = None
         self.sync_occupancy = True            # world > 1: broadcast rank 0's occupancy after every update_density_grid()
         # bench.py: callable -> (record this step?, list); every collective of the step is then bracketed by two HIP events on the
@@ -326,11 +332,18 @@ class FusedTrainer:
             self._coarse_ver = ver
         return coarse
 
-    def _march(self, M, rays_o, rays_d, cfg, A, coarse=None, noise=None):
+    def _march(self, M, rays_o, rays_d, cfg, A, coarse=None, noise=None, shape=None):
         """ray-AABB + count/scan/write into march set M on the CURRENT stream."""
         L, st, n = self.L, _stream(), rays_o.shape[0]
         if coarse is None:
             coarse = self._coarse_bits(cfg, A)
+        if shape is not None and noise is None and self.march_fused and self._march_rng and not self.deterministic:
+            seed = int(torch.randint(0, 2**62, (), dtype=torch.int64))
+            check(L.ngp_march_train_fused_shaped(_ptr(rays_o), _ptr(rays_d), _ptr(None), _ptr(cfg.bitfield), _ptr(coarse), _ptr(None), seed,
+                                                 cfg.cascades, cfg.grid_size, cfg.scale, cfg.exp_step_factor, cfg.max_samples, n,
+                                                 int(shape[0]), int(shape[1]), _ptr(M.stage), _ptr(M.ctr), _ptr(M.rays_a), _ptr(M.total),
+                                                 _ptr(M.xyzs), _ptr(M.dirs), _ptr(M.deltas), _ptr(M.ts), st), "ngp_march_train_fused_shaped")
+            return
         if noise is None and self.deterministic:
             # same counter-based jitter as the one-launch march draws in-kernel, as an explicit vector for the ray-order chain
             from .ops import rng_uniform
@@ -394,7 +407,7 @@ class FusedTrainer:
                     start.wait(self._side)
                     if nxt.ready is not None:
                         nxt.ready.wait(self._side)                          # an unconsumed earlier prefetch into the same set
-                    self._march(nxt, prefetch[0], prefetch[1], cfg, A)
+                    self._march(nxt, prefetch[0], prefetch[1], cfg, A, shape=self._march_shape)
                     nxt.ready = nxt.ev_ready
                     nxt.ready.record(self._side)
                 nxt.src = None if src_next is None else (src_next[0], src_next[1], src_next[0]._version, src_next[1]._version)

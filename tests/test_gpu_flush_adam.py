@@ -143,8 +143,10 @@ def test_flush_adam_bit_identical_to_two_launch_path(hip_lib, copy):
             a, b = getattr(A, name), getattr(Bs, name)
             assert torch.equal(_bits(a[prefix:]), _bits(b[prefix:])), "%s: %s differs on the flush-owned levels" % (tag, name)
             # (replicas of a coarse slice meet in the gradient table with float atomics: ~1e-7 of the gradient, in both paths)
+            # (the 16-bit copy of such an entry can land on the other side of a rounding boundary: one bf16 ulp = 2^-8 relative)
             ref_ = a[:prefix].float().cpu().numpy()
-            np.testing.assert_allclose(b[:prefix].float().cpu().numpy(), ref_, rtol=1e-4, atol=1e-6 * float(np.abs(ref_).max()) + 1e-30,
+            np.testing.assert_allclose(b[:prefix].float().cpu().numpy(), ref_, rtol=2.0**-7 if name == "copy" else 1e-4,
+                                       atol=1e-6 * float(np.abs(ref_).max()) + 1e-30,
                                        err_msg="%s: %s, replicated levels" % (tag, name))
         for name in ("mlp", "mlp_m", "mlp_v", "wpack"):
             assert torch.equal(_bits(getattr(A, name)), _bits(getattr(Bs, name))), "%s: %s" % (tag, name)

@@ -182,6 +182,39 @@ def test_march_train_fused_cascades_exp_step_ragged(oracle, hip_lib):
     _check_fused_march(ref, g2, n)
 
 
+@pytest.mark.parametrize("shape", [(4, 0), (4, 81 * 1024), (8, 40 * 1024), (16, 0)])
+def test_march_train_fused_shaped_bit_exact_per_ray(oracle, lego_batch, shape):
+    """Round 5: ngp_march_train_fused_shaped -- 4- / 8- / 16-wave blocks, with and without the idle LDS that caps the blocks per CU:
+    per ray the oracle's samples bit for bit (explicit jitter vector), ragged ray count, and the in-kernel jitter form against the
+    vector form of the same seed."""
+    o, d, noise, bits = lego_batch
+    n = 4096 - 13
+    o, d, noise = o[:n], d[:n], noise[:n]
+    hits = oracle.ray_aabb(o, d, 0.5)
+    ref = oracle.march_train(o, d, hits, bits, noise, 1, 0.5, 0.0, 128, 1024)
+    g = ops.march_train_fused(dev(o), dev(d), None, dev(bits), dev(noise), 1, 0.5, 0.0, 128, 1024, shape=shape)
+    _check_fused_march(ref, g, n)
+    u = ops.rng_uniform(77, n).cpu().numpy()
+    ref = oracle.march_train(o, d, hits, bits, u, 1, 0.5, 0.0, 128, 1024)
+    g = ops.march_train_fused(dev(o), dev(d), dev(hits), dev(bits), None, 1, 0.5, 0.0, 128, 1024, seed=77, shape=shape)
+    _check_fused_march(ref, g, n)
+    # six cascades + exponential stepping + truncation through the same shapes
+    o3, d3 = synthetic.garden_rays(1024, seed=5)
+    bits3 = synthetic.ball_slab_bitfield(6, 16.0, seed=7)
+    nz = np.random.default_rng(2).random(1024, dtype=np.float32)
+    hits3 = oracle.ray_aabb(o3, d3, 16.0)
+    ref = oracle.march_train(o3, d3, hits3, bits3, nz, 6, 16.0, 1 / 256, 128, 37)
+    g = ops.march_train_fused(dev(o3), dev(d3), dev(hits3), dev(bits3), dev(nz), 6, 16.0, 1 / 256, 128, 37, shape=shape)
+    _check_fused_march(ref, g, 1024)
+
+
+def test_march_train_fused_shaped_rejects_bad_shapes(hip_lib, lego_batch):
+    o, d, noise, bits = lego_batch
+    for shape in ((3, 0), (32, 0), (4, -1), (4, 200 * 1024)):
+        with pytest.raises(RuntimeError):
+            ops.march_train_fused(dev(o[:64]), dev(d[:64]), None, dev(bits), dev(noise[:64]), 1, 0.5, 0.0, 128, 64, shape=shape)
+
+
 def test_march_test_bit_exact(oracle, lego_batch):
     o, d, _, bits = lego_batch
     o, d = o[:4096], d[:4096]
