@@ -56,6 +56,7 @@ TRAINER_KERNELS = {
     # round 5: ... with the table's optimizer in its flush (the hashed levels never leave as a gradient): priced below as the scatter-add's
     # algorithmic bytes + the bytes the optimizer part really moves (12 B per parameter read, 12 B per touched parameter written)
     "ngp_hash_bwd_sliced_main_adam": ("hash_bwd_f32", "hbm", 12 + 128 + 1024 + 1024, "live"),
+    "ngp_hash_bwd_sliced_main_adam_step": ("hash_bwd_f32", "hbm", 12 + 128 + 1024 + 1024, "live"),   # ... + the step's scalar bookkeeping
     "ngp_hash_bwd_sliced_prep": ("hash_bwd_prep", "hbm", 12 + 12 + 16 * 8, "live"),        # ... its prepass (in line, before the MLP backward)
     "ngp_hash_bwd_f16_live": ("hash_bwd_f16", "hbm", 12 + 128 + 512 + 512, "live"),
     "ngp_hash_bwd_sliced_main_f16": ("hash_bwd_f16", "hbm", 12 + 128 + 512 + 512, "live"),    # half2 encoder, LDS-sliced form
@@ -308,6 +309,11 @@ def main():
     out = measure(args, ctx)
     if rank == 0 and world == 1 and args.configs and _is_headline(args):
         out["configs"] = other_configs(args, ctx)
+    if world > 1 and args.configs and _is_headline(args) and args.comm == "f32" and args.shard and not os.environ.get("NGP_COMM_OVERLAP"):
+        # ONE invocation decides the multi-GPU defaults: the other exchange variants run in the same process group, behind the headline
+        cv = comm_variants(args, ctx, out)                      # (every rank runs them; rank 0 keeps the records)
+        if rank == 0:
+            out["configs"] = cv
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
@@ -354,6 +360,71 @@ def other_configs(args, ctx):
         except Exception as e:                   # a failing side config must not take the headline line with it
             res.append({"name": name, "what": what, "args": " ".join(extra), "error": "%s: %s" % (type(e).__name__, e)})
         res[-1]["wall_seconds_incl_setup"] = time.perf_counter() - t0
+    return res
+
+
+# N > 1: the gradient-exchange variants FusedTrainer offers, each measured in the same process group right after the headline leg
+# (which is the first entry: in-line fp32 reduce-scatter / all-gather, sharded optimizer).  A variant = extra arguments + environment.
+COMM_VARIANTS = [
+    ("overlap-8,0", "NGP_COMM_OVERLAP=1: the scatter-add issued per level group (8-15, then 0-7), a group's reduce-scatter in flight under "
+                    "the next group's launch, all-gathers waited for at the next step's forward", [], {"NGP_COMM_OVERLAP": "1", "NGP_COMM_GROUPS": "8,0"}),
+    ("bf16-comm+bf16-table", "--comm bf16 --table bf16: the gradient travels as bf16, the parameters come back as the 16-bit copy the "
+                             "forward reads (half the bytes both ways)", ["--comm", "bf16", "--table", "bf16"], {}),
+    ("no-shard-all-reduce", "--no-shard: SURVEY 8(e)'s single all-reduce of one flat fp32 bucket + replicated Adam (north_star's wording)",
+     ["--no-shard"], {}),
+]
+COMM_MODEL_BW_GBS = (150.0, 300.0, 450.0)                      # DESIGN.md section 7's bus-bandwidth rows
+
+
+def _comm_record(name, what, extra, env, o, world):
+    """One exchange variant as a `configs` entry: the line's communication fields + the bus bandwidth they imply + DESIGN 7's model."""
+    per, nbytes = o.get("comm_breakdown_ms") or {}, o.get("comm_bytes_per_rank_per_step") or {}
+    # bus bytes in RCCL's own convention: (N-1)/N of the payload per reduce-scatter / all-gather, twice that per all-reduce
+    moved = float(sum(v * (2.0 if k.startswith("all_reduce") else 1.0) for k, v in nbytes.items() if isinstance(v, (int, float))))
+    frac = (world - 1) / world
+    comm_ms = o.get("comm_ms")
+    bus = moved * frac / (comm_ms * 1e-3) / 1e9 if (comm_ms and moved) else None
+    stub = o.get("ms_per_step_comm_stubbed")
+    model = None
+    if stub:
+        # T = the measured step without communication + (N-1)/N * bytes / BW for the payload this variant moves
+        model = {"%d_GBs" % int(bw): {"ms_per_step": stub + moved * frac / (bw * 1e9) * 1e3,
+                                      "rays_per_s": o["config"]["global_batch"] / ((stub + moved * frac / (bw * 1e9) * 1e3) * 1e-3)}
+                 for bw in COMM_MODEL_BW_GBS}
+    return {"name": name, "what": what, "args": " ".join(extra), "env": env, "value": o["value"], "unit": "rays/s", "n_gpus": world,
+            "ms_per_step": o["ms_per_step"], "steps": o["steps"], "comm_ms": comm_ms, "exposed_comm_ms": o.get("exposed_comm_ms"),
+            "ms_per_step_comm_stubbed": stub, "comm_breakdown_ms": per, "comm_bytes_per_rank_per_step": nbytes,
+            "bus_bandwidth_GBs": bus, "bus_bandwidth_note": "payload bytes x (N-1)/N (x 2 for an all-reduce) / comm_ms (in-line collectives: the "
+            "step waits for each; overlapped: what it still waited for, so the figure overstates the link rate there)",
+            "design7_model_at_bus_bandwidth": model, "parallelism": o["config"].get("parallelism"),
+            "live_samples_per_step": o.get("live_samples_per_step")}
+
+
+def comm_variants(args, ctx, headline):
+    world, rank = ctx["world"], ctx["rank"]
+    res = []
+    if rank == 0:
+        res.append(_comm_record("inline-f32 (headline)", "the line above: reduce-scatter(AVG) fp32 -> Adam on the own 1/N -> all-gather fp32, "
+                                "in line on the step's stream", [], {}, headline, world))
+    for name, what, extra, env in COMM_VARIANTS:
+        sub = parse(["--gpus", str(world), "--steps", str(args.steps), "--warmup", str(args.warmup), "--condition", str(args.condition),
+                     "--kernel-events-every", str(args.kernel_events_every), "--no-cpu-baseline", "--no-configs"] + extra)
+        saved = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            o = measure(sub, ctx)
+            if rank == 0:
+                res.append(_comm_record(name, what, extra, env, o, world))
+        except Exception as e:                       # (raised on every rank alike: argument / setup errors)
+            if rank == 0:
+                res.append({"name": name, "what": what, "args": " ".join(extra), "env": env, "error": "%s: %s" % (type(e).__name__, e)})
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        dist.barrier()
     return res
 
 
@@ -730,7 +801,7 @@ def _measure(args, ctx, brief):
                 flush_bytes = 12.0 * n_fl + (12.0 + copy16_b) * t_fl
             # critical-path gaps on the sampled steps (each includes the two event packets in between): prepass end -> MLP backward
             # start, MLP backward end -> scatter-add start
-            ev_b = warm_events.get("ngp_mlp_bwd_live_parts", []) or warm_events.get("ngp_mlp_bwd_live", []); ev_m = warm_events.get("ngp_hash_bwd_sliced_main_adam", []) or warm_events.get("ngp_hash_bwd_sliced_main_slabs", []) or warm_events.get("ngp_hash_bwd_sliced_main", [])
+            ev_b = warm_events.get("ngp_mlp_bwd_live_parts", []) or warm_events.get("ngp_mlp_bwd_live", []); ev_m = warm_events.get("ngp_hash_bwd_sliced_main_adam_step", []) or warm_events.get("ngp_hash_bwd_sliced_main_adam", []) or warm_events.get("ngp_hash_bwd_sliced_main_slabs", []) or warm_events.get("ngp_hash_bwd_sliced_main", [])
             ev_p = warm_events.get("ngp_hash_bwd_sliced_prep", [])
             if ev_b and len(ev_b) == len(ev_m) == len(ev_p):
                 gaps["mlp_bwd_end_to_scatter_start_us"] = float(np.mean([b[1].elapsed_time(m[0]) for b, m in zip(ev_b, ev_m)])) * 1e3
@@ -762,7 +833,7 @@ def _measure(args, ctx, brief):
                         units = float(a[3]) if (n_dev is not None and getattr(n_dev, "value", 1) is None) else float(marched)
                     if unit == "param":
                         work = adam_bytes if units >= n4 * 4 else adam_range_bytes(units)
-                    elif name == "ngp_hash_bwd_sliced_main_adam":
+                    elif name in ("ngp_hash_bwd_sliced_main_adam", "ngp_hash_bwd_sliced_main_adam_step"):
                         work = per_unit * units + flush_bytes
                     else:
                         work = per_unit * units + ((40 if name == "ngp_march_train_fused" else 8) * marched if key == "march_count" else 0)

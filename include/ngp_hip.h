@@ -288,6 +288,16 @@ int ngp_hash_bwd_sliced_main_adam(const float* dout, const ngp_hash_levels* lv, 
                                   int n_parts, float* mlp_dw, float* table, float* table_m, float* table_v, uint16_t* table_bf16,
                                   const float* state_f, const int32_t* state_i, float beta1, float beta2, float eps,
                                   void* stream);
+/* The same launch with the step's scalar bookkeeping inside it (ngp_train_prologue's arguments; train.py:197-201): every workgroup
+ * evaluates the GradScaler / schedule decision on a private copy of state_f / state_i when it starts (as the previous step left
+ * them + this step's inf flag from the MLP backward), its flushes use that copy, and the last workgroup out stores it -- after the
+ * launch state_f / state_i are exactly what ngp_train_prologue would have left, and no one-thread launch sits in front of the
+ * scatter-add.  Bit-identical to ngp_train_prologue + ngp_hash_bwd_sliced_main_adam (tests/test_gpu_flush_adam.py). */
+int ngp_hash_bwd_sliced_main_adam_step(const float* dout, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev, int enc_pairs,
+                                       float* dtable, const void* workspace, long long workspace_bytes, const float* mlp_dw_parts,
+                                       int n_parts, float* mlp_dw, float* table, float* table_m, float* table_v, uint16_t* table_bf16,
+                                       float* state_f, int32_t* state_i, float lr0, float eta_min, int t_max, float beta1, float beta2,
+                                       float eps, float growth, float backoff, int growth_interval, void* stream);
 /* the half2 encoder's backward (hash_encoder_half.py:163-213) over the same prepass: dtable_f16 = fp16 pairs [entries][2]; the
  * encoder's fp16 arithmetic per contribution (cell cast to f16, w * g rounded to f16), the owner's f64 sum rounded to fp16 once */
 int ngp_hash_bwd_sliced_main_f16(const float* dout, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev, int enc_pairs,

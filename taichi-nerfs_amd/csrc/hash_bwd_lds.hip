@@ -697,6 +697,21 @@ struct FlushAdam {
     float beta1, beta2, eps;
 };
 
+// ... and so does the step's scalar bookkeeping (ngp_train_prologue: skip decision, loss-scale update, learning rate, bias
+// corrections).  It has to run between the MLP backward (which raises the inf flag) and the first flush; as a launch of its own
+// that is one thread for 6 us plus a 4 us gap in front of a 200 us kernel.  Instead every workgroup evaluates it on a private LDS
+// copy of the state when it starts (the same inputs, the same arithmetic: the same result in all 256), the flushes read that copy,
+// and the LAST workgroup out -- the one that already resets the queue heads -- publishes it.  No workgroup reads the global state
+// after that store: being last out means every other workgroup has finished.
+struct StepSchedule {
+    float* sf;                   // NULL: the caller ran ngp_train_prologue itself
+    int32_t* si;
+    float lr0, eta_min;
+    int t_max;
+    float growth, backoff;
+    int growth_interval;
+};
+
 template <bool HALF, int ADAM>
 __global__ void __launch_bounds__(BW_THREADS) hash_bwd_lds_kernel(const float* __restrict__ xyzc,
                                                                   const unsigned long long* __restrict__ bitmap, size_t wstride,
@@ -704,8 +719,22 @@ __global__ void __launch_bounds__(BW_THREADS) hash_bwd_lds_kernel(const float* _
                                                                   const int32_t* __restrict__ n_dev, int enc_pairs, BwdPlan plan,
                                                                   void* __restrict__ dtable /* f32 pairs; HALF: f16 pairs */,
                                                                   int32_t* __restrict__ found_inf, uint32_t* __restrict__ ctr,
-                                                                  unsigned long long* __restrict__ dbg, MlpSlabs mlp, FlushAdam ad) {
+                                                                  unsigned long long* __restrict__ dbg, MlpSlabs mlp, FlushAdam ad_in,
+                                                                  StepSchedule sch) {
     __shared__ double slice[2 * BW_SLICE_ENTRIES];
+    __shared__ float s_sf[8];
+    __shared__ int32_t s_si[8];
+    FlushAdam ad = ad_in;
+    const bool own_schedule = ADAM != 0 && sch.sf != nullptr;
+    if (own_schedule) {
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { s_sf[k] = sch.sf[k]; s_si[k] = sch.si[k]; }
+            train_prologue_thread(s_sf, s_si, sch.lr0, sch.eta_min, sch.t_max, ad.beta1, ad.beta2, sch.growth, sch.backoff,
+                                  sch.growth_interval);
+        }
+        ad.sf = s_sf; ad.si = s_si;          // (read by the flushes, all of which sit behind the barrier after the first claim)
+    }
     __shared__ uint32_t queues[BW_WAVES * BW_Q];
     __shared__ uint32_t next_sc;
     __shared__ uint32_t s_claim;
@@ -879,6 +908,10 @@ __global__ void __launch_bounds__(BW_THREADS) hash_bwd_lds_kernel(const float* _
         if (atomicAdd(&ctr[8], 1u) == gridDim.x - 1u) {
             for (int x = 0; x < 8; ++x) ctr[x] = 0u;
             ctr[8] = 0u;
+            if (own_schedule) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { sch.sf[k] = s_sf[k]; sch.si[k] = s_si[k]; }
+            }
         }
     }
 }
@@ -1167,7 +1200,8 @@ static int adam_first_level(const ngp_hash_levels& lv, const BwdPlan& plan) {
 static int sliced_main(bool half, const float* dout, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev, int enc_pairs,
                        void* dtable, int32_t* found_inf, const void* workspace, long long workspace_bytes, void* stream,
                        uint32_t level_mask = 0xffffffffu, int max_blocks = 0, MlpSlabs mlp = MlpSlabs{nullptr, 0, nullptr},
-                       FlushAdam ad = FlushAdam{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f}) {
+                       FlushAdam ad = FlushAdam{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f},
+                       StepSchedule sch = StepSchedule{nullptr, nullptr, 0.f, 0.f, 0, 0.f, 0.f, 0}) {
     if (n_max <= 0) return 0;
     if (enc_pairs && !(lv->n_features == 2 && lv->n_levels == 16)) return -1;
     if (!workspace || workspace_bytes < ngp_hash_bwd_sliced_workspace(lv, n_max)) return -1;
@@ -1186,7 +1220,7 @@ static int sliced_main(bool half, const float* dout, const ngp_hash_levels* lv, 
     }
 #define NGP_BWD_LAUNCH(H, A)                                                                                                        \
     hipLaunchKernelGGL((hash_bwd_lds_kernel<H, A>), dim3(plan->n_blocks), dim3(BW_THREADS), 0, (hipStream_t)stream, xyzc, bitmap,    \
-                       W.words, dout, *lv, n_max, n_dev, enc_pairs, *plan, dtable, found_inf, ctr, g_bwd_debug, mlp, ad)
+                       W.words, dout, *lv, n_max, n_dev, enc_pairs, *plan, dtable, found_inf, ctr, g_bwd_debug, mlp, ad, sch)
     if (half) NGP_BWD_LAUNCH(true, 0);
     else if (ad.p && ad.shadow) NGP_BWD_LAUNCH(false, 2);
     else if (ad.p) NGP_BWD_LAUNCH(false, 1);
@@ -1254,6 +1288,21 @@ int ngp_hash_bwd_sliced_main_adam(const float* dout, const ngp_hash_levels* lv, 
     const MlpSlabs mlp = (mlp_dw_parts && mlp_dw && n_parts > 0) ? MlpSlabs{mlp_dw_parts, n_parts, mlp_dw} : MlpSlabs{nullptr, 0, nullptr};
     return sliced_main(false, dout, lv, n_max, n_dev, enc_pairs, dtable, nullptr, workspace, workspace_bytes, stream, 0xffffffffu, 0, mlp,
                        FlushAdam{table, table_m, table_v, table_bf16, state_f, state_i, beta1, beta2, eps});
+}
+
+// ... and with the step's scalar bookkeeping (ngp_train_prologue's arguments) evaluated inside the launch: state_f / state_i are
+// read as the previous step left them (+ the inf flag of this step's MLP backward) and hold this step's decision when the launch
+// has finished -- what the remaining optimizer launch (ngp_adam_all_ex over the replicated levels + the MLP) then reads.
+int ngp_hash_bwd_sliced_main_adam_step(const float* dout, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev, int enc_pairs,
+                                       float* dtable, const void* workspace, long long workspace_bytes, const float* mlp_dw_parts,
+                                       int n_parts, float* mlp_dw, float* table, float* table_m, float* table_v, uint16_t* table_bf16,
+                                       float* state_f, int32_t* state_i, float lr0, float eta_min, int t_max, float beta1, float beta2,
+                                       float eps, float growth, float backoff, int growth_interval, void* stream) {
+    if (!table || !table_m || !table_v || !state_f || !state_i || t_max <= 0 || n_max <= 0) return -1;
+    const MlpSlabs mlp = (mlp_dw_parts && mlp_dw && n_parts > 0) ? MlpSlabs{mlp_dw_parts, n_parts, mlp_dw} : MlpSlabs{nullptr, 0, nullptr};
+    return sliced_main(false, dout, lv, n_max, n_dev, enc_pairs, dtable, nullptr, workspace, workspace_bytes, stream, 0xffffffffu, 0, mlp,
+                       FlushAdam{table, table_m, table_v, table_bf16, state_f, state_i, beta1, beta2, eps},
+                       StepSchedule{state_f, state_i, lr0, eta_min, t_max, growth, backoff, growth_interval});
 }
 
 int ngp_hash_bwd_f32_sliced(const float* xyzs, const float* dout, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev,

@@ -179,6 +179,37 @@ __device__ __forceinline__ void mlp_dw_reduce_block(const float* __restrict__ pa
 
 enum { SI_ITER = 0, SI_OPT_STEP = 1, SI_GROWTH = 2, SI_FOUND_INF = 3, SI_SKIP = 4, SI_SKIPPED_TOTAL = 5 };
 
+// The training step's scalar bookkeeping (reference train.py:197-201: GradScaler.step's skip decision, GradScaler.update,
+// CosineAnnealingLR.step, Adam's bias corrections), one thread, on the state layout of include/ngp_hip.h.  sf / si may be LDS
+// copies: the scatter-add of round 5 (hash_bwd_lds.hip) runs it per workgroup on a private copy and lets the last workgroup out
+// publish the result, which removes the one-thread launch (6 us + a 4 us gap) from in front of it.
+__device__ __forceinline__ void train_prologue_thread(float* __restrict__ sf, int32_t* __restrict__ si, float lr0, float eta_min, int t_max,
+                                                      float beta1, float beta2, float growth, float backoff, int growth_interval) {
+    const int iter = si[SI_ITER];
+    const int found = si[SI_FOUND_INF];
+    const float scale = sf[SF_LOSS_SCALE];
+    sf[SF_INV_SCALE] = 1.0f / scale;                                         // GradScaler.unscale_
+    si[SI_SKIP] = found ? 1 : 0;
+    // CosineAnnealingLR closed form; scheduler.step() runs every iteration, skipped or not (train.py:201)
+    const float c = cosf(3.14159265358979323846f * (float)(iter < t_max ? iter : t_max) / (float)t_max);
+    sf[SF_LR] = eta_min + (lr0 - eta_min) * 0.5f * (1.0f + c);
+    if (!found) {
+        const int step = si[SI_OPT_STEP] + 1;
+        si[SI_OPT_STEP] = step;
+        sf[SF_BC1] = 1.0f - powf(beta1, (float)step);
+        sf[SF_BC2_SQRT] = sqrtf(1.0f - powf(beta2, (float)step));
+        int g = si[SI_GROWTH] + 1;                                           // GradScaler.update, growth branch
+        if (g >= growth_interval) { sf[SF_LOSS_SCALE] = scale * growth; g = 0; }
+        si[SI_GROWTH] = g;
+    } else {
+        sf[SF_LOSS_SCALE] = scale * backoff;                                 // GradScaler.update, backoff branch
+        si[SI_GROWTH] = 0;
+        si[SI_SKIPPED_TOTAL] += 1;
+    }
+    si[SI_FOUND_INF] = 0;
+    si[SI_ITER] = iter + 1;
+}
+
 // round-to-nearest-even f32 -> bf16 (what torch's .bfloat16() does); NaN stays NaN
 __device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {
     uint32_t u = __float_as_uint(f);

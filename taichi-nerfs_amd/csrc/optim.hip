@@ -15,33 +15,7 @@
 namespace ngp {
 
 
-__device__ __forceinline__ void train_prologue_thread(float* __restrict__ sf, int32_t* __restrict__ si, float lr0, float eta_min, int t_max,
-                                                      float beta1, float beta2, float growth, float backoff, int growth_interval) {
-    const int iter = si[SI_ITER];
-    const int found = si[SI_FOUND_INF];
-    const float scale = sf[SF_LOSS_SCALE];
-    sf[SF_INV_SCALE] = 1.0f / scale;                                         // GradScaler.unscale_
-    si[SI_SKIP] = found ? 1 : 0;
-    // CosineAnnealingLR closed form; scheduler.step() runs every iteration, skipped or not (train.py:201)
-    const float c = cosf(3.14159265358979323846f * (float)(iter < t_max ? iter : t_max) / (float)t_max);
-    sf[SF_LR] = eta_min + (lr0 - eta_min) * 0.5f * (1.0f + c);
-    if (!found) {
-        const int step = si[SI_OPT_STEP] + 1;
-        si[SI_OPT_STEP] = step;
-        sf[SF_BC1] = 1.0f - powf(beta1, (float)step);
-        sf[SF_BC2_SQRT] = sqrtf(1.0f - powf(beta2, (float)step));
-        int g = si[SI_GROWTH] + 1;                                           // GradScaler.update, growth branch
-        if (g >= growth_interval) { sf[SF_LOSS_SCALE] = scale * growth; g = 0; }
-        si[SI_GROWTH] = g;
-    } else {
-        sf[SF_LOSS_SCALE] = scale * backoff;                                 // GradScaler.update, backoff branch
-        si[SI_GROWTH] = 0;
-        si[SI_SKIPPED_TOTAL] += 1;
-    }
-    si[SI_FOUND_INF] = 0;
-    si[SI_ITER] = iter + 1;
-}
-
+// (train_prologue_thread, the one-thread GradScaler / schedule decision, lives in ngp_device.h: round 5's scatter-add runs it too)
 __global__ void train_prologue_kernel(float* __restrict__ sf, int32_t* __restrict__ si, float lr0, float eta_min, int t_max,
                                       float beta1, float beta2, float growth, float backoff, int growth_interval) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;

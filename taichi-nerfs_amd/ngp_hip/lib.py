@@ -127,6 +127,8 @@ SIGNATURES = {
     "ngp_hash_bwd_sliced_main_slabs": [_P, _LV, _I, _P, _I, _P, _I, _P, _P, ctypes.c_longlong, _P, _I, _P, _P],
     "ngp_hash_bwd_sliced_main_levels": [_P, _LV, _I, _P, _I, _P, _P, _P, ctypes.c_longlong, ctypes.c_uint32, _I, _P],
     "ngp_hash_bwd_sliced_adam_prefix": [_LV],
+    "ngp_hash_bwd_sliced_main_adam_step": [_P, _LV, _I, _P, _I, _P, _P, ctypes.c_longlong, _P, _I, _P, _P, _P, _P, _P, _P, _P, _F, _F, _I, _F, _F,
+                                           _F, _F, _F, _I, _P],
     "ngp_hash_bwd_sliced_main_adam": [_P, _LV, _I, _P, _I, _P, _P, ctypes.c_longlong, _P, _I, _P, _P, _P, _P, _P, _P, _P, _F, _F, _F, _P],
     "ngp_hash_bwd_sliced_main_f16": [_P, _LV, _I, _P, _I, _P, _P, _P, ctypes.c_longlong, _P],
     "ngp_hash_bwd_f32_sliced": [_P, _P, _LV, _I, _P, _P, _I, _F, _F, _I, _P, _P, _P, ctypes.c_longlong, _P],

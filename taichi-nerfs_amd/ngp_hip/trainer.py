@@ -153,8 +153,15 @@ class FusedTrainer:
         # launch (scatter-add 190 -> 210 us, march 235 us: profiles/r04_rocprofv3_timed_region_equal_priority.txt); at low priority
         # it takes the CUs the scatter-add's workgroups leave as they retire (A/B on one box, 2 x 200 steps each: 0.882-0.894 vs
         # 0.911-0.923 us per 1000 live samples)
+        # Round 5 (one GPU, fp32 master table): the table's optimizer moved into the scatter-add, the HBM-bound launch the march used to
+        # hide under is gone, and a 16-wave-per-CU march under the scatter-add now outlives the step (its blocks only get CUs as the
+        # persistent workgroups retire: profiles/r05_rocprofv3_timed_region_march_under_scatter.txt, the next step's gather waits
+        # 21 us for it).  profiles/r05_march_placement.txt: issued at the START of the step as 4-wave blocks on a default-priority
+        # stream it costs least (1.287 vs 1.305 ns per live sample under the scatter-add, 1.323 in line).
+        self._one_gpu_flush = (self.world == 1 and not self.half and os.environ.get("NGP_FLUSH_ADAM", "1") != "0"
+                               and self.hash_bwd == "sliced")
         self._side_prio = None
-        if os.environ.get("NGP_SIDE_PRIORITY", "low") == "low":
+        if os.environ.get("NGP_SIDE_PRIORITY", "default" if self._one_gpu_flush else "low") == "low":
             h, lo, hi = ctypes.c_void_p(), ctypes.c_int(), ctypes.c_int()
             check(self.L.ngp_stream_create_low_priority(ctypes.byref(h), ctypes.byref(lo), ctypes.byref(hi)), "ngp_stream_create_low_priority")
             self._side = torch.cuda.ExternalStream(h.value, device=dev)
@@ -173,13 +180,14 @@ class FusedTrainer:
         import os as _os
         # (with world > 1 the default is 4: the march then runs underneath the gradient exchange -- RCCL's kernels occupy a few
         # workgroups and wait on xGMI -- instead of competing with the VALU-bound kernels of the step for issue slots)
-        self._prefetch_at = int(_os.environ.get("NGP_PREFETCH_AT", "3" if self.world == 1 else "4"))
+        self._prefetch_at = int(_os.environ.get("NGP_PREFETCH_AT", "0" if self._one_gpu_flush else ("3" if self.world == 1 else "4")))
         # Round 5: the SHAPE of the prefetched launch (ngp_march_train_fused_shaped): "waves per block, idle LDS bytes per block",
         # e.g. "4,82944" = 4-wave blocks, at most one per CU.  With the table's optimizer inside the scatter-add there is no
         # HBM-bound launch left to hide a 16-wave-per-CU march under; a narrow march asks every CU for one wave slot per SIMD and
-        # runs beside whatever the step is doing.  Unset: the 16-wave block every other march launch uses.
-        shape = _os.environ.get("NGP_MARCH_SHAPE", "")
-        self._march_shape = tuple(int(x) for x in shape.split(",")) if shape else None
+        # runs beside whatever the step is doing.  Default "4,0" on one GPU with the optimizer in the flush, else (and "16,0") the
+        # 16-wave block every other march launch uses.
+        shape = _os.environ.get("NGP_MARCH_SHAPE", "4,0" if self._one_gpu_flush else "")
+        self._march_shape = tuple(int(x) for x in shape.split(",")) if shape and shape != "16,0" else None
         self._coarse_ver = None
         self.sync_occupancy = True            # world > 1: broadcast rank 0's occupancy after every update_density_grid()
         # bench.py: callable -> (record this step?, list); every collective of the step is then bracketed by two HIP events on the
@@ -211,6 +219,7 @@ class FusedTrainer:
         # then has to exist before the scatter-add: the prologue moves in front of it (the MLP backward raises the inf flag on the
         # same d_enc values the scatter-add would).  NGP_FLUSH_ADAM=0: the two-launch path (bit-identical results).
         self._flush_adam = os.environ.get("NGP_FLUSH_ADAM", "1") != "0"
+        self._fold_prologue = True            # ... and the step's scalar bookkeeping inside that launch (ngp_hash_bwd_sliced_main_adam_step)
         self._adam_prefix = {}                # per scatter-add mode: floats of the table the flush does NOT update (-2: not expressible)
         # Deterministic mode (set_deterministic / NGP_DETERMINISTIC=1; bench.py conditions its model in it so that two processes
         # reach the same state): rays packed in ray order (count / scan / write chain), the live list in ray order
@@ -611,13 +620,22 @@ class FusedTrainer:
         """Prologue -> scatter-add with the optimizer in its flush -> Adam on the replicated coarse levels + the MLP (one GPU, fp32
         master table with or without the bf16 copy; see __init__)."""
         L, sf, si = self.L, self.state_f, self.state_i
-        check(L.ngp_train_prologue(_ptr(sf), _ptr(si), self.lr0, self.eta_min, self.t_max, self.beta1, self.beta2, self.growth,
-                                   self.backoff, self.growth_interval, st), "ngp_train_prologue")
         copy16 = self.copy16_store[:self.nt] if self.copy16_store is not None else None
-        check(L.ngp_hash_bwd_sliced_main_adam(_ptr(A.d_enc), ctypes.byref(cfg.levels), A.cap, _ptr(cnt), P, _ptr(self.table_grad), _ptr(ws),
-                                              ws.numel(), _ptr(self.mlp_parts), n_parts, _ptr(self.mlp_grad), _ptr(self.table),
-                                              _ptr(self.table_m), _ptr(self.table_v), _ptr(copy16), _ptr(sf), _ptr(si), self.beta1,
-                                              self.beta2, self.eps, st), "ngp_hash_bwd_sliced_main_adam")
+        if self._fold_prologue:
+            # the GradScaler / schedule decision is evaluated inside the scatter-add launch (no one-thread launch in front of it)
+            check(L.ngp_hash_bwd_sliced_main_adam_step(_ptr(A.d_enc), ctypes.byref(cfg.levels), A.cap, _ptr(cnt), P, _ptr(self.table_grad),
+                                                       _ptr(ws), ws.numel(), _ptr(self.mlp_parts), n_parts, _ptr(self.mlp_grad),
+                                                       _ptr(self.table), _ptr(self.table_m), _ptr(self.table_v), _ptr(copy16), _ptr(sf),
+                                                       _ptr(si), self.lr0, self.eta_min, self.t_max, self.beta1, self.beta2, self.eps,
+                                                       self.growth, self.backoff, self.growth_interval, st),
+                  "ngp_hash_bwd_sliced_main_adam_step")
+        else:
+            check(L.ngp_train_prologue(_ptr(sf), _ptr(si), self.lr0, self.eta_min, self.t_max, self.beta1, self.beta2, self.growth,
+                                       self.backoff, self.growth_interval, st), "ngp_train_prologue")
+            check(L.ngp_hash_bwd_sliced_main_adam(_ptr(A.d_enc), ctypes.byref(cfg.levels), A.cap, _ptr(cnt), P, _ptr(self.table_grad), _ptr(ws),
+                                                  ws.numel(), _ptr(self.mlp_parts), n_parts, _ptr(self.mlp_grad), _ptr(self.table),
+                                                  _ptr(self.table_m), _ptr(self.table_v), _ptr(copy16), _ptr(sf), _ptr(si), self.beta1,
+                                                  self.beta2, self.eps, st), "ngp_hash_bwd_sliced_main_adam")
         if hook is not None:
             hook()                                                          # position 4
         kind = 1 if copy16 is not None else 0

@@ -84,7 +84,21 @@ def test_bench_self_launches_two_ranks(hip_lib):
     assert d["comm_overlap"] == {"enabled": False, "level_groups": None}
     assert set(d["comm_breakdown_ms"]) == {"reduce_scatter_table_grad", "all_reduce_mlp_grad_and_flag", "all_gather_table"}
     assert d["comm_bytes_per_rank_per_step"]["reduce_scatter_table_grad"] >= 4 * 11420064
-    assert "configs" not in d and "cpu_baseline" not in d
+    assert "cpu_baseline" not in d
+    # round 5: ONE invocation measures every exchange variant in the same process group -- the headline (in-line
+    # fp32, sharded optimizer) and, behind it, the overlapped exchange, the 16-bit exchange and the unsharded all-reduce -- each with
+    # its communication time, the measured exposed part, the bus bandwidth they imply and DESIGN 7's model beside it
+    cfgs = d["configs"]
+    assert [c["name"] for c in cfgs] == ["inline-f32 (headline)", "overlap-8,0", "bf16-comm+bf16-table", "no-shard-all-reduce"]
+    for c in cfgs:
+        assert "error" not in c, c
+        assert c["comm_ms"] > 0 and c["ms_per_step_comm_stubbed"] > 0 and c["exposed_comm_ms"] is not None and c["bus_bandwidth_GBs"] > 0
+        assert set(c["design7_model_at_bus_bandwidth"]) == {"150_GBs", "300_GBs", "450_GBs"}
+    assert cfgs[0]["ms_per_step"] == d["ms_per_step"]
+    assert any(k.startswith("wait_reduce_scatter_group") for k in cfgs[1]["comm_breakdown_ms"])
+    b_f32 = sum(cfgs[0]["comm_bytes_per_rank_per_step"].values()); b_16 = sum(cfgs[2]["comm_bytes_per_rank_per_step"].values())
+    assert 0.45 < b_16 / b_f32 < 0.55
+    assert set(cfgs[3]["comm_breakdown_ms"]) == {"all_reduce_flat_bucket"} or "all_reduce" in " ".join(cfgs[3]["comm_breakdown_ms"])
 
 
 def test_bench_two_ranks_overlapped_exchange(hip_lib):

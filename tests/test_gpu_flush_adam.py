@@ -69,8 +69,11 @@ def _bits(t):
     return t.view(torch.int32) if t.dtype == torch.float32 else t.view(torch.int16)
 
 
+@pytest.mark.parametrize("fold", [False, True], ids=["prologue-launch", "prologue-in-scatter"])
 @pytest.mark.parametrize("copy", [False, True], ids=["f32", "bf16copy"])
-def test_flush_adam_bit_identical_to_two_launch_path(hip_lib, copy):
+def test_flush_adam_bit_identical_to_two_launch_path(hip_lib, copy, fold):
+    """fold: ngp_hash_bwd_sliced_main_adam_step -- the GradScaler / schedule decision evaluated inside the scatter-add launch (every
+    workgroup on a private copy of the state, the last one out publishes it) instead of by ngp_train_prologue in front of it."""
     L = ops._lib()
     lv = ops.make_levels(2**19, 16, 16, 1024, 2)                    # the C2 table
     nt = lv.total_entries * 2
@@ -123,11 +126,18 @@ def test_flush_adam_bit_identical_to_two_launch_path(hip_lib, copy):
         # ---- B: prologue, scatter-add with the optimizer in its flush, optimizer over the replicated levels only
         Bs = S.clone()
         prep()
-        _prologue(L, Bs)
-        assert L.ngp_hash_bwd_sliced_main_adam(ops._ptr(d_buf), ctypes.byref(lv), cap, ops._ptr(cnt), 0, ops._ptr(Bs.g), ops._ptr(ws),
-                                               ws.numel(), ops._ptr(parts), 3, ops._ptr(Bs.mlp_g), ops._ptr(Bs.table), ops._ptr(Bs.m),
-                                               ops._ptr(Bs.v), ops._ptr(Bs.copy), ops._ptr(Bs.sf), ops._ptr(Bs.si), B1, B2, EPS,
-                                               ops._stream()) == 0
+        if fold:
+            assert L.ngp_hash_bwd_sliced_main_adam_step(ops._ptr(d_buf), ctypes.byref(lv), cap, ops._ptr(cnt), 0, ops._ptr(Bs.g), ops._ptr(ws),
+                                                        ws.numel(), ops._ptr(parts), 3, ops._ptr(Bs.mlp_g), ops._ptr(Bs.table),
+                                                        ops._ptr(Bs.m), ops._ptr(Bs.v), ops._ptr(Bs.copy), ops._ptr(Bs.sf), ops._ptr(Bs.si),
+                                                        LR0, ETA_MIN, T_MAX, B1, B2, EPS, GROWTH, BACKOFF, GROWTH_INTERVAL,
+                                                        ops._stream()) == 0
+        else:
+            _prologue(L, Bs)
+            assert L.ngp_hash_bwd_sliced_main_adam(ops._ptr(d_buf), ctypes.byref(lv), cap, ops._ptr(cnt), 0, ops._ptr(Bs.g), ops._ptr(ws),
+                                                   ws.numel(), ops._ptr(parts), 3, ops._ptr(Bs.mlp_g), ops._ptr(Bs.table), ops._ptr(Bs.m),
+                                                   ops._ptr(Bs.v), ops._ptr(Bs.copy), ops._ptr(Bs.sf), ops._ptr(Bs.si), B1, B2, EPS,
+                                                   ops._stream()) == 0
         # the flush-owned levels never touch the gradient table
         assert float(Bs.g[prefix:].abs().max()) == 0.0
         assert L.ngp_adam_all_ex(ops._ptr(Bs.table), ops._ptr(Bs.g), 0, ops._ptr(Bs.m), ops._ptr(Bs.v), prefix, ops._ptr(Bs.copy), kind,
