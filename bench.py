@@ -45,6 +45,9 @@ TRAINER_KERNELS = {
     "ngp_hash_fwd_f32_ex": ("hash_fwd_f32", "hbm", 12 + 1024 + 128, "sample"),
     "ngp_hash_fwd_f32": ("hash_fwd_f32", "hbm", 12 + 1024 + 128, "n_arg"),       # occupancy-update encodes (exact n = arg 3)
     "ngp_mlp_fwd_ex": ("mlp_fwd", "mfma", 18816, "sample"),
+    # round 5, chunked forward (multi-cascade scenes): one launch per round over a list of samples; units = the step's shaded samples / rounds
+    "ngp_hash_fwd_list": ("hash_fwd_f32", "hbm", 12 + 1024 + 128, "shaded"),
+    "ngp_mlp_fwd_list": ("mlp_fwd", "mfma", 18816, "shaded"),
     "ngp_mlp_bwd_ex": ("mlp_bwd", "mfma", 37632, "sample"),
     "ngp_hash_bwd_f32_ex": ("hash_bwd_f32", "hbm", 12 + 128 + 1024 + 1024, "sample"),
     "ngp_mlp_bwd_live": ("mlp_bwd", "mfma", 37632, "live"),                        # backward kernels run on the live-sample list
@@ -351,6 +354,7 @@ def other_configs(args, ctx):
                         "steps": o["steps"], "warmup": o["warmup"], "dtype": o["dtype"], "rays_per_gpu": o["config"]["rays_per_gpu"],
                         "rm_samples_per_ray": o["rm_samples_per_ray"], "vr_samples_per_ray": o["vr_samples_per_ray"],
                         "live_samples_per_step": o["live_samples_per_step"], "ns_per_live_sample": o.get("ns_per_live_sample"),
+                        "shaded_samples_last_step": o.get("shaded_samples_last_step"),
                         "samples_per_sec": o["samples_per_sec"], "path": o["config"]["path"],
                         "grid_updates_in_timed_region": o["config"]["grid_updates_in_timed_region"],
                         "dominant_kernel": roof.get("kernel"), "dominant_kernel_ms": roof.get("avg_launch_ms"), "frac": roof.get("frac"),
@@ -518,6 +522,7 @@ def _measure(args, ctx, brief):
         model.density_bitfield.copy_(bits)
 
     trainer = None
+    opt_name = None
     if use_trainer:
         from ngp_hip.trainer import FusedTrainer
         trainer = FusedTrainer(model, lr=1e-2, max_steps=20000, init_scale=2.0**16 if args.half else 2.0**19, world_size=world,
@@ -525,7 +530,24 @@ def _measure(args, ctx, brief):
                                grad_comm_dtype=torch.bfloat16 if args.comm == "bf16" else torch.float32,
                                shard_optimizer=args.shard if world > 1 else None)
     else:
-        opt = torch.optim.Adam(model.parameters(), 1e-2, eps=1e-15, fused=True)
+        # train.py:143-156 picks apex.optimizers.FusedAdam when `import apex` works and torch.optim.Adam otherwise.  With this package's
+        # compat/ directory on the path (how scripts/run_reference_train.py runs the unchanged driver) the import resolves to
+        # compat/apex: one multi-tensor launch on ngp_adam_multi that takes GradScaler's scale and inf flag on the device.
+        # NGP_BENCH_TORCH_ADAM=1: the driver's fall-back, torch.optim.Adam(fused=True).
+        opt_name = "torch.optim.Adam(fused=True)"
+        opt = None
+        if os.environ.get("NGP_BENCH_TORCH_ADAM", "0") != "1":
+            compat_dir = os.path.join(ROOT, "taichi-nerfs_amd", "compat")
+            if compat_dir not in sys.path:
+                sys.path.append(compat_dir)
+            try:
+                import apex
+                opt = apex.optimizers.FusedAdam(model.parameters(), lr=1e-2, eps=1e-15)
+                opt_name = "apex.optimizers.FusedAdam (compat/apex: ngp_adam_multi)"
+            except ImportError:
+                opt = None
+        if opt is None:
+            opt = torch.optim.Adam(model.parameters(), 1e-2, eps=1e-15, fused=True)
         sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, 20000, 1e-2 / 30)
         scaler = torch.amp.GradScaler("cuda", init_scale=2.0**16 if args.half else 2.0**19)
         reducer = GradReducer(model, world) if world > 1 else None
@@ -776,6 +798,7 @@ def _measure(args, ctx, brief):
         if use_trainer:
             marched = rm / max(args.steps, 1)                  # marched samples per step (launches are sized for the arena)
             live_avg = (float(live_log[:n_st].sum(dtype=torch.int64)) / max(n_st, 1)) if trainer.live_backward else marched
+            shaded_last = trainer.shaded_samples()             # chunked forward: what the last timed step shaded (None: everything)
             # the dense Adam pass skips float4 groups that never received a gradient (g = m = v = 0: exact fixed points) after
             # reading g, m, v; everything else reads p too and writes p, m, v and the zeroed g.  Bytes it really moves:
             # (sharded optimizer: this rank's pass covers its 1/N of the table only)
@@ -826,6 +849,8 @@ def _measure(args, ctx, brief):
                         units = float(a[3])
                     elif unit == "live":
                         units = float(live_avg)
+                    elif unit == "shaded":
+                        units = float(shaded_last or 0) / max(len(trainer._chunk_rounds), 1)
                     else:
                         # _ex launches: device-side count (the marched samples of the step) unless n_dev is NULL
                         # (occupancy-update encodes: exact n = arg 3)
@@ -837,7 +862,7 @@ def _measure(args, ctx, brief):
                         work = per_unit * units + flush_bytes
                     else:
                         work = per_unit * units + ((40 if name == "ngp_march_train_fused" else 8) * marched if key == "march_count" else 0)
-                    rec = agg.setdefault(key, [0, 0.0, 0.0, bound, per_unit, "sample" if unit in ("n_arg", "live") else unit, 0.0])
+                    rec = agg.setdefault(key, [0, 0.0, 0.0, bound, per_unit, "sample" if unit in ("n_arg", "live", "shaded") else unit, 0.0])
                     rec[0] += 1; rec[1] += e0.elapsed_time(e1); rec[2] += work; rec[6] += units
             for key, (n_l, tot_ms, tot_work, bound, per_unit, unit, tot_units) in agg.items():
                 ks[key] = {"launches": n_l, "avg_ms": tot_ms / n_l, "total_ms": tot_ms, "avg_units": tot_units / n_l}
@@ -963,13 +988,14 @@ def _measure(args, ctx, brief):
                        "parallelism": parallelism,
                        # one or two ~1.1 ms occupancy-update steps in a 20-step window move the average by +-5 %: compare runs by this
                        "grid_updates_in_timed_region": grid_updates,
-                       "path": ("FusedTrainer" + ("+hipGraph" if args.graph else "")) if use_trainer else "modules+torch.optim",
+                       "path": ("FusedTrainer" + ("+hipGraph" if args.graph else "")) if use_trainer else "modules + %s + torch GradScaler / CosineAnnealingLR" % opt_name,
                        "kernel_events_in_timed_region": ((("every step" if ev_every == 1 else "every %d-th step" % ev_every)
                                                           + (", around %s only (the kernel that dominated the warm-up steps, where every "
                                                              "kernel is bracketed)" % sorted(_Probe.only) if _Probe.only else ""))
                                                          if (bool(event_pool) or not use_trainer) else False)},
             "samples_per_sec": rm * world / elapsed, "rm_samples_per_ray": rm / total_rays * world, "vr_samples_per_ray": vr / total_rays * world,
             "live_samples_per_step": live_avg,
+            "shaded_samples_last_step": (trainer.shaded_samples() if use_trainer else None),
             "ns_per_live_sample": (elapsed / args.steps * 1e9 / live_avg) if (live_avg and use_trainer) else None,
             "ms_per_step_no_prefetch": None if elapsed_np is None else elapsed_np / args.steps * 1e3,
             "kernels": ks, "critical_path_gaps": gaps, "roofline": roof, "rooflines": rooflines,

@@ -147,6 +147,13 @@ int ngp_hash_fwd_f32_ex(const float* xyzs, const float* table, const ngp_hash_le
 int ngp_hash_fwd_bf16_ex(const float* xyzs, const uint16_t* table, const ngp_hash_levels* lv, int n_max,
                          const int32_t* n_dev, int normalize, float lo, float hi, int enc_pairs, float* out,
                          void* stream);
+/* Round 5 -- the same encoder over a LIST of samples (the chunked forward below): rows list[0 .. *n_list) of xyzs are encoded into
+ * the same rows of out (16 levels x 2 features; pair-major planes of stride n_max when enc_pairs).  table_kind 0: fp32 table,
+ * 1: its bf16 storage copy.  Bit-identical per row to ngp_hash_fwd_f32_ex / _bf16_ex (hash_encoder.py:89-143).  Returns -2 where
+ * the specialised kernel does not apply (other table shapes; tables of 4 GB and more): the caller encodes every row instead. */
+int ngp_hash_fwd_list(const float* xyzs, const void* table, int table_kind, const ngp_hash_levels* lv, int n_max,
+                      const int32_t* n_list, const int32_t* list, int normalize, float lo, float hi, int enc_pairs, float* out,
+                      void* stream);
 /* found_inf (nullable): set to 1 when a non-finite incoming gradient is seen -- GradScaler's inf/nan check
  * (train.py:199) done where the data passes instead of in an extra pass over the 45.7 MB gradient. */
 int ngp_hash_bwd_f32_ex(const float* xyzs, const float* dout, const ngp_hash_levels* lv, int n_max,
@@ -202,6 +209,18 @@ int ngp_composite_train_fused(const float* sigmas, const void* rgbs, int rgbs_is
                               const float* loss_scale, float T_threshold, int n_rays, int32_t* vr_per_ray,
                               float* opacity, float* depth, float* rgb, float* ws, float* d_sigmas, void* d_rgbs,
                               float* sq_err, void* stream);
+/* Round 5 -- chunked forward: do not shade what compositing will never read.  The reference shades every marched sample and then
+ * ignores those behind T <= T_threshold (volume_train.py:38); its evaluation loop (rendering.py:62-158) already shades in rounds
+ * and drops finished rays.  One call per round: samples [begin, begin + len) of every ray still alive are appended to `list`
+ * (count[0] += their number; count_zero, nullable, is set to 0 for a later round's counter).  begin > 0: the ray's transmittance
+ * state T_state[row of rays_a] (n_rays floats) is first advanced over [prev_begin, begin) -- which must have been shaded -- as
+ * T *= exp(-sum sigma delta), and the ray is retired when T <= thr_stop; begin == 0 initialises the state.  begin / len / prev_begin
+ * must be multiples of 64 and thr_stop at most half the compositing threshold: ngp_composite_train_* read a ray 64 samples at a
+ * time and skip a group when T <= threshold at its start, so every group they read has then been shaded.  Per ray rgb / opacity /
+ * depth / ws / vr and every gradient are those of shading everything (tests/test_gpu_chunked.py). */
+int ngp_chunk_schedule(const int32_t* rays_a, const float* sigmas, const float* deltas, int n_rays, int begin, int len,
+                       int prev_begin, float thr_stop, float* T_state, int32_t* list, int32_t* count, int32_t* count_zero,
+                       void* stream);
 /* The same launch, and the compacted live-sample list of ngp_live_compact as a by-product: every 16-ray block appends its rays'
  * first vr[r] samples to live_idx at an offset it takes from live_total with ONE atomic add, so the list is in block-completion
  * order (each ray contiguous) -- the *_live kernels do not depend on the order.  live_total[0] must be 0 at launch; live_zero
@@ -348,6 +367,10 @@ int ngp_mlp_fwd_ex(const float* enc, const float* dirs, const uint16_t* wpack, i
 int ngp_mlp_bwd_ex(const float* enc, const float* dirs, const uint16_t* wpack, const float* dsigmas,
                    const uint16_t* drgbs, int n_max, const int32_t* n_dev, int enc_pairs, float* d_enc, float* dW,
                    int32_t* found_inf, void* stream);
+/* Round 5 -- the forward over a LIST of samples: position j < *n_list shades sample list[j] (reads its enc row and direction, writes
+ * its sigma / rgb; networks.py:136-166).  Bit-identical per sample to ngp_mlp_fwd_ex. */
+int ngp_mlp_fwd_list(const float* enc, const float* dirs, const uint16_t* wpack, int n_max, const int32_t* n_list,
+                     const int32_t* list, int enc_pairs, float* sigmas, uint16_t* rgbs, void* stream);
 
 /* Stream plumbing for a caller that runs the march of the NEXT batch on a second stream (FusedTrainer): events that order two
  * streams of THIS device without the system-scope cache write-back + invalidate a default HIP event performs when it is recorded
@@ -388,6 +411,9 @@ int ngp_adam_step(float* p, float* g, float* m, float* v, long long n, const flo
 #define NGP_ADAM_MULTI_MAX 16
 int ngp_adam_multi(int n_tensors, float* const* p, float* const* g, float* const* m, float* const* v, const long long* n,
                    const float* state_f, const int32_t* state_i, float beta1, float beta2, float eps, void* stream);
+/* GradScaler's inf / nan check (train.py:199, torch.amp.GradScaler._check_inf_per_device) over the same tensor list, read-only:
+ * found_inf[0] (a float32 device scalar, cleared by the caller) becomes 1.0f when any gradient value is not finite. */
+int ngp_check_finite_multi(int n_tensors, const float* const* g, const long long* n, float* found_inf, void* stream);
 /* Same pass, additionally refreshing p_bf16 (n bf16, round-to-nearest-even) -- the table ngp_hash_fwd_bf16_ex gathers from.
  * BASELINE config 2 names a bf16 hash grid; the reference itself has fp32 (hash_encoder.py) and fp16 (hash_encoder_half.py)
  * tables only, so the semantics here are "fp32 master + 16-bit storage copy", as hash_encoder_half.py:367 does for fp16. */

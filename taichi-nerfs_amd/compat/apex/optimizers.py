@@ -34,6 +34,8 @@ class FusedAdam(torch.optim.Optimizer):
         self._L = _lib.load()
         self._sf = self._si = None
         self._multi = {}                     # group index -> (parameter identities, ctypes pointer / count arrays)
+        self._found = {}                     # device -> float32 [1]: this optimizer's own inf flag (step(grad_scaler=...))
+        self._pending = []
 
     def zero_grad(self, set_to_none=None):
         return super().zero_grad(self.set_grad_none if set_to_none is None else set_to_none)
@@ -62,19 +64,37 @@ class FusedAdam(torch.optim.Optimizer):
                                       "CUDA tensors with a multiple of 4 elements (got {} {})".format(tuple(p.shape), p.dtype))
 
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, grad_scaler=None):
         """One optimisation step: per parameter group a one-thread prologue (skip decision, bias corrections) and ONE multi-tensor
         launch over every parameter that has a gradient (`ngp_adam_multi`; round 4: one launch per tensor).  Unlike apex / torch,
         the sweep leaves `p.grad` ZERO-FILLED (the unscale, the update and the clearing are one pass over p / g / m / v): a caller
         that accumulates gradients over several backward passes per step() is unaffected, one that inspects `p.grad` after step()
-        sees zeros.  GradScaler still runs its own `_check_inf_per_device` pass over the gradients before it calls this (torch's
-        code); what `_step_supports_amp_scaling` removes is the host read-back of the flag and the separate unscale pass."""
+        sees zeros.
+
+        grad_scaler (round 5): `torch.amp.GradScaler.step(optimizer)` passes itself to an optimizer that declares
+        `_step_supports_amp_scaling` and whose step() takes this keyword -- apex's own FusedAdam has the same signature -- and then
+        leaves the inf check to the optimizer.  It is done here as ONE read-only launch over the group's gradients
+        (`ngp_check_finite_multi`) instead of torch's `_check_inf_per_device` (a pass that rewrites every gradient, behind ~40 us of
+        Python per step); the flag is recorded where `GradScaler.update()` looks for it, the unscale happens inside the Adam sweep, and
+        nothing is read back.  torch announces (FutureWarning, once) that it will stop passing the scaler one day; without the
+        keyword the attributes `grad_scale` / `found_inf` it sets instead are honoured as before."""
         loss = None
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
         L = self._L
         scale, found = getattr(self, "grad_scale", None), getattr(self, "found_inf", None)
+        own_check = False
+        if grad_scaler is not None and grad_scaler.is_enabled():
+            from torch.amp.grad_scaler import OptState
+            state = grad_scaler._per_optimizer_states[id(self)]
+            if state["stage"] is OptState.READY:                   # nobody has unscaled / checked these gradients yet: do it here
+                own_check = True
+                scale = grad_scaler._get_scale_async()
+            else:                                                  # scaler.unscale_(optimizer) ran: gradients are unscaled, flags recorded
+                scale = None
+                flags = list(state["found_inf_per_device"].values())
+                found = flags[0] if len(flags) == 1 else sum(f.to(flags[0].device) for f in flags)
         for gi, group in enumerate(self.param_groups):
             ps = [p for p in group["params"] if p.grad is not None]
             if not ps:
@@ -85,11 +105,8 @@ class FusedAdam(torch.optim.Optimizer):
                 self._si = [torch.zeros(8, device=dev, dtype=torch.int32) for _ in self.param_groups]
             sf, si = self._sf[gi], self._si[gi]
             b1, b2 = group["betas"]
-            if scale is not None and (scale.dtype != torch.float32 or found.dtype != torch.float32):
-                raise TypeError("grad_scale / found_inf must be float32 device tensors (torch.cuda.amp.GradScaler's are)")
-            _lib.check(L.ngp_adam_amp_prologue(_ptr(sf), _ptr(si), _ptr(scale), _ptr(found), float(group["lr"]), float(b1), float(b2),
-                                               _stream()), "ngp_adam_amp_prologue")
             st = _stream()
+            chunks = []
             for c0 in range(0, len(ps), _MULTI_MAX):
                 chunk = ps[c0:c0 + _MULTI_MAX]
                 key = (gi, c0)
@@ -101,10 +118,10 @@ class FusedAdam(torch.optim.Optimizer):
                     N = (ctypes.c_longlong * k)()
                     for j, p in enumerate(chunk):
                         self._check(p, p.grad)
-                        state = self.state[p]
-                        if not state:
-                            state["exp_avg"], state["exp_avg_sq"] = torch.zeros_like(p), torch.zeros_like(p)
-                        P[j], M[j], V[j], N[j] = p.data_ptr(), state["exp_avg"].data_ptr(), state["exp_avg_sq"].data_ptr(), p.numel()
+                        state_p = self.state[p]
+                        if not state_p:
+                            state_p["exp_avg"], state_p["exp_avg_sq"] = torch.zeros_like(p), torch.zeros_like(p)
+                        P[j], M[j], V[j], N[j] = p.data_ptr(), state_p["exp_avg"].data_ptr(), state_p["exp_avg_sq"].data_ptr(), p.numel()
                     ent = self._multi[key] = (ident, P, G, M, V, N)
                 _, P, G, M, V, N = ent
                 for j, p in enumerate(chunk):                      # autograd hands out fresh gradient tensors every step
@@ -112,9 +129,29 @@ class FusedAdam(torch.optim.Optimizer):
                     if g.dtype != torch.float32 or not g.is_contiguous() or g.data_ptr() % 16:
                         self._check(p, g)
                     G[j] = g.data_ptr()
-                _lib.check(L.ngp_adam_multi(len(chunk), P, G, M, V, N, _ptr(sf), _ptr(si), float(b1), float(b2), float(group["eps"]), st),
+                chunks.append((len(chunk), P, G, M, V, N))
+            if own_check:
+                if gi == 0 or found is None or found.device != dev:
+                    found = self._found.get(dev)
+                    if found is None:
+                        found = self._found[dev] = torch.zeros(1, device=dev, dtype=torch.float32)
+                    else:
+                        found.zero_()
+                    grad_scaler._per_optimizer_states[id(self)]["found_inf_per_device"][dev] = found
+                for k, P, G, M, V, N in chunks:
+                    _lib.check(L.ngp_check_finite_multi(k, G, N, _ptr(found), st), "ngp_check_finite_multi")
+            if scale is not None and (scale.dtype != torch.float32 or found is None or found.dtype != torch.float32):
+                raise TypeError("grad_scale / found_inf must be float32 device tensors (torch.cuda.amp.GradScaler's are)")
+            self._pending.append((gi, group, sf, si, b1, b2, chunks, st, ps))
+        # every group's flag is complete before any group is updated: one overflow skips the whole step (GradScaler's semantics)
+        for gi, group, sf, si, b1, b2, chunks, st, ps in self._pending:
+            _lib.check(L.ngp_adam_amp_prologue(_ptr(sf), _ptr(si), _ptr(scale), _ptr(found), float(group["lr"]), float(b1), float(b2),
+                                               st), "ngp_adam_amp_prologue")
+            for k, P, G, M, V, N in chunks:
+                _lib.check(L.ngp_adam_multi(k, P, G, M, V, N, _ptr(sf), _ptr(si), float(b1), float(b2), float(group["eps"]), st),
                            "ngp_adam_multi")
             _touched(*ps, *[p.grad for p in ps])            # written through raw pointers: version-keyed caches (the encoders' 16-bit table copies) must see it
+        self._pending.clear()
         return loss
 
 

@@ -319,6 +319,59 @@ __global__ void __launch_bounds__(256) composite_test_kernel(const float* __rest
     depth[r] += dep; opacity[r] += op;                                               // :53-54
 }
 
+// ---- chunked forward (round 5): which samples are worth shading next ---------------------------------------------------------------
+// On scenes whose rays saturate long before their marched samples end (C3: 182 marched, 44 composited samples per ray) the
+// reference shades everything the march emitted and then ignores what lies behind T <= 1e-4 (volume_train.py:38; its own
+// evaluation loop, rendering.py:62-158, already shades in rounds and drops finished rays).  FusedTrainer does the same for training:
+// the samples of a ray are shaded in CHUNKS [begin, begin + len) of its marched range, chunk boundaries at multiples of 64 (the
+// compositing kernels read a ray 64 samples at a time and never touch a 64-sample group once T <= thr at its start), and a ray
+// whose transmittance after the chunks shaded so far is at or below `thr_stop` gets no further chunk.  thr_stop = thr / 2: the
+// estimate here is exp(-sum sigma delta), the compositing kernels form the running product of (1 - a) -- equal up to rounding, so
+// every group they read has been shaded; what lies behind is never read, never contributes (its gradients are exact zeros in the
+// reference too).  One wave per ray, 16 rays per block, one returning atomic per block for the block's range of the list.
+__global__ void __launch_bounds__(1024) chunk_schedule_kernel(const int32_t* __restrict__ rays_a, const float* __restrict__ sigmas,
+                                                              const float* __restrict__ deltas, int n_rays, int begin, int len,
+                                                              int prev_begin, float thr_stop, float* __restrict__ T_state,
+                                                              int32_t* __restrict__ list, int32_t* __restrict__ count,
+                                                              int32_t* __restrict__ count_zero) {
+    __shared__ int s_off[16];
+    const int wave = threadIdx.x >> 6, lane = lane_id(), nw = blockDim.x >> 6;
+    const int n = blockIdx.x * nw + wave;
+    const bool has_ray = n < n_rays;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && count_zero) *count_zero = 0;
+    int start = 0, N = 0, c = 0;
+    if (has_ray) {
+        start = rays_a[3 * n + 1]; N = rays_a[3 * n + 2];
+        float T = 1.0f;
+        if (begin > 0) {
+            T = T_state[n];
+            if (T > 0.0f) {
+                float sum = 0.0f;
+                const int hi = min(begin, N);
+                for (int j = prev_begin + lane; j < hi; j += NGP_WAVE) sum += sigmas[(size_t)start + j] * deltas[(size_t)start + j];
+                sum = wave_sum(sum);
+                T = T * expf(-sum);
+                if (!(T > thr_stop)) T = 0.0f;                  // (NaN included: the compositing kernels stop at a NaN as well)
+            }
+        }
+        if (lane == 0) T_state[n] = T;
+        c = (T > 0.0f && begin < N) ? min(len, N - begin) : 0;
+    }
+    if (lane == 0) s_off[wave] = c;
+    __syncthreads();
+    if (wave == 0) {
+        const int v = lane < nw ? s_off[lane] : 0;
+        const int inc = wave_scan_add_i(v, lane);
+        int base = 0;
+        if (lane == NGP_WAVE - 1 && inc > 0) base = atomicAdd(count, inc);
+        base = __shfl(base, NGP_WAVE - 1, NGP_WAVE);
+        if (lane < nw) s_off[lane] = base + inc - v;
+    }
+    __syncthreads();
+    const int b = s_off[wave];
+    for (int k = lane; k < c; k += NGP_WAVE) list[b + k] = start + begin + k;
+}
+
 }  // namespace ngp
 
 using namespace ngp;
@@ -409,6 +462,22 @@ int ngp_composite_test(const float* sigmas, const void* rgbs, int rgbs_is_half, 
     else
         hipLaunchKernelGGL(composite_test_kernel<false>, grid, block, 0, (hipStream_t)stream, sigmas, rgbs, deltas, ts, pack_info,
                            alive_indices, T_threshold, n_alive, opacity, depth, rgb);
+    NGP_LAUNCH_CHECK();
+    return 0;
+}
+
+// Round 5, chunked forward: append samples [begin, begin + len) of every ray that is still alive to `list` (count[0] += their
+// number; count_zero[0] = 0 for a later launch; both nullable only for count_zero).  begin > 0: the ray's transmittance state
+// T_state[row of rays_a] is first advanced over [prev_begin, begin) (which must have been shaded) and the ray retired when it is
+// <= thr_stop; begin == 0 initialises the state.  begin, len, prev_begin: multiples of 64.
+int ngp_chunk_schedule(const int32_t* rays_a, const float* sigmas, const float* deltas, int n_rays, int begin, int len, int prev_begin,
+                       float thr_stop, float* T_state, int32_t* list, int32_t* count, int32_t* count_zero, void* stream) {
+    if (n_rays <= 0) return 0;
+    if (!rays_a || !T_state || !list || !count || begin < 0 || len <= 0 || prev_begin < 0 || prev_begin > begin) return -1;
+    if ((begin | len | prev_begin) & 63) return -1;
+    if (begin > 0 && (!sigmas || !deltas)) return -1;
+    hipLaunchKernelGGL(chunk_schedule_kernel, dim3((n_rays + 15) / 16), dim3(1024), 0, (hipStream_t)stream, rays_a, sigmas, deltas, n_rays,
+                       begin, len, prev_begin, thr_stop, T_state, list, count, count_zero);
     NGP_LAUNCH_CHECK();
     return 0;
 }

@@ -834,32 +834,32 @@ __global__ void __launch_bounds__(BW_THREADS) hash_bwd_lds_kernel(const float* _
         float2* m2 = reinterpret_cast<float2*>(ad.m) + P.offset;
         float2* v2 = reinterpret_cast<float2*>(ad.v) + P.offset;
         uint32_t* sh = reinterpret_cast<uint32_t*>(ad.shadow) + P.offset;
-        constexpr int UNR = 4;
-        for (int j0 = tid; j0 < BW_SLICE_ENTRIES; j0 += UNR * BW_THREADS) {
-            double2 a[UNR];
+        // ONE trip: a thread owns BW_SLICE_ENTRIES / BW_THREADS = 8 entries and requests the moments and the parameter of all of them
+        // before it touches anything (24 eight-byte loads in flight, 48 VGPRs: the task's registers are dead here); the LDS sums are
+        // read one entry at a time underneath.  (Two trips of four entries: two exposed round trips per flush, ~2.5 flushes per
+        // workgroup and launch.)
+        constexpr int UNR = BW_SLICE_ENTRIES / BW_THREADS;
+        static_assert(UNR * BW_THREADS == BW_SLICE_ENTRIES, "one trip covers the slice");
+        {
             float2 pi[UNR], mi[UNR], vi[UNR];
             uint32_t h[UNR];
-            bool in[UNR];
 #pragma unroll
             for (int k = 0; k < UNR; ++k) {
-                const int j = j0 + k * BW_THREADS;
+                const int j = tid + k * BW_THREADS;
                 h[k] = entry_of(P.map, sl, (uint32_t)j);
-                in[k] = !skip && h[k] < P.size;
-                const uint32_t hc = in[k] ? h[k] : 0u;
+                const uint32_t hc = (!skip && h[k] < P.size) ? h[k] : 0u;
                 mi[k] = m2[hc]; vi[k] = v2[hc]; pi[k] = p2[hc];
             }
 #pragma unroll
             for (int k = 0; k < UNR; ++k) {
-                const int j = j0 + k * BW_THREADS;
-                a[k] = s2[j];
-                if (a[k].x != 0.0 || a[k].y != 0.0) s2[j] = make_double2(0.0, 0.0);      // the next task starts from a clean slice
-            }
-#pragma unroll
-            for (int k = 0; k < UNR; ++k) {
+                const int j = tid + k * BW_THREADS;
+                const double2 a = s2[j];
+                if (a.x != 0.0 || a.y != 0.0) s2[j] = make_double2(0.0, 0.0);            // the next task starts from a clean slice
                 // what the two-launch path hands the optimizer: 0 + (float)sum (the gradient slot is clear at the start of a step)
-                const float gx = 0.0f + (float)a[k].x, gy = 0.0f + (float)a[k].y;
+                const float gx = 0.0f + (float)a.x, gy = 0.0f + (float)a.y;
                 float2 mk = mi[k], vk = vi[k], pk = pi[k];
-                if (!in[k] || (gx == 0.f && gy == 0.f && mk.x == 0.f && mk.y == 0.f && vk.x == 0.f && vk.y == 0.f)) continue;   // exact fixed point
+                const bool in = !skip && h[k] < P.size;
+                if (!in || (gx == 0.f && gy == 0.f && mk.x == 0.f && mk.y == 0.f && vk.x == 0.f && vk.y == 0.f)) continue;   // exact fixed point
 #define NGP_ADAM1(c, g)                                                       \
                 {                                                             \
                     const float gr = (g) * inv_scale;                         \

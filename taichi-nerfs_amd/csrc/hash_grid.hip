@@ -181,10 +181,15 @@ __global__ void __launch_bounds__(256) hash_fwd_f32_kernel(const float* __restri
 // corners_flat: an iteration used to be four dependent memory round trips (x, y, z each behind a branch of norm01, then the
 // gathers) and ~60 scalar branches; it is now the gathers' round trip alone.  V1 = the round-1..3 loop (NGP_HASH_FWD_V1=1), kept
 // for the A/B in profiles/r04_hash_fwd_loop_experiment.txt.
-template <int MODE, bool V1 = false>
+// LIST (round 5, the chunked forward of FusedTrainer on scenes whose rays terminate long before their marched samples end): the
+// launch encodes the samples list[0 .. *n_dev) -- position j reads xyzs[list[j]] and writes row list[j] of `out` -- instead of
+// the first *n_dev rows.  The list entry of the iteration after next is requested where the next position is, so the indirection
+// adds no round trip to the loop.
+template <int MODE, bool V1 = false, bool LIST = false>
 __global__ void __launch_bounds__(256) hash_fwd_f32_xcd_kernel(const float* __restrict__ xyzs, const float* __restrict__ table,
                                                                ngp_hash_levels lv, int n, const int32_t* __restrict__ n_dev,
-                                                               XyzNorm nm, int enc_pairs, float* __restrict__ out) {
+                                                               XyzNorm nm, int enc_pairs, float* __restrict__ out,
+                                                               const int32_t* __restrict__ list = nullptr) {
     __shared__ LevelLDS L;
     load_levels(lv, L);
     const size_t plane = (size_t)n;                       // pair-major plane stride = buffer capacity
@@ -253,8 +258,10 @@ __global__ void __launch_bounds__(256) hash_fwd_f32_xcd_kernel(const float* __re
         float2* o_prev = nullptr;
         float2 r_prev = make_float2(0.0f, 0.0f);
         float p[3];
+        int s_cur = LIST ? list[min(i, n - 1)] : min(i, n - 1);                       // the sample this iteration encodes ...
+        int s_next = LIST ? list[min(i + stride, n - 1)] : 0;                         // ... and the next one's (LIST only)
         {
-            const float* q = xyzs + 3 * (size_t)min(i, n - 1);
+            const float* q = xyzs + 3 * (size_t)s_cur;
             p[0] = q[0]; p[1] = q[1]; p[2] = q[2];
         }
         for (; i < n; i += stride) {
@@ -266,8 +273,10 @@ __global__ void __launch_bounds__(256) hash_fwd_f32_xcd_kernel(const float* __re
 #pragma unroll
                 for (int k = 0; k < 3; ++k) xyz[k] = (p[k] - lo) / den;
             }
+            int s_next2 = 0;
+            if constexpr (LIST) s_next2 = list[min(i + 2 * stride, n - 1)];
             {
-                const float* q = xyzs + 3 * (size_t)min(i + stride, n - 1);
+                const float* q = xyzs + 3 * (size_t)(LIST ? s_next : min(i + stride, n - 1));
                 p[0] = q[0]; p[1] = q[1]; p[2] = q[2];
             }
             Corners c;
@@ -276,13 +285,23 @@ __global__ void __launch_bounds__(256) hash_fwd_f32_xcd_kernel(const float* __re
 #pragma unroll
                 for (int ci = 0; ci < 8; ++ci) c.idx[ci] = h_raw[ci] % lr.size;
             }
+#ifdef NGP_HASH_FWD_DIAG
+            // timing experiment (profiles/microbench/encoder_ab.py NGP_HASH_FWD_FREE_LEVELS): the gathers of the levels in the mask
+            // all read entry 0 of the level -- one line, always in the vector L1 -- i.e. what staging those levels' tables in LDS
+            // could at best buy; results are wrong by construction
+            if ((nm.enabled >> (8 + level)) & 1) {
+#pragma unroll
+                for (int ci = 0; ci < 8; ++ci) c.idx[ci] = 0u;
+            }
+#endif
             float2 v[8];
             gather(level_off, c, v);
             // the PREVIOUS iteration's result is written here, underneath this iteration's gathers: gfx950 counts loads and stores
             // in one counter, so a store issued last in the loop body is what the next iteration's first wait would sit on
             if (o_prev) *o_prev = r_prev;
             r_prev = blend(c, v);
-            o_prev = out_at(i);
+            o_prev = out_at(LIST ? s_cur : i);
+            if constexpr (LIST) { s_cur = s_next; s_next = s_next2; }
         }
         if (o_prev) *o_prev = r_prev;
     }
@@ -599,7 +618,10 @@ int ngp_hash_fwd_f32_ex(const float* xyzs, const float* table, const ngp_hash_le
     if (lv->n_levels < 1 || lv->n_levels > NGP_MAX_LEVELS) return -1;
     const int grid = grid_for((long long)n_max * lv->n_levels, 256);
     hipStream_t s = (hipStream_t)stream;
-    const XyzNorm nm = {normalize, lo, hi};
+    XyzNorm nm = {normalize, lo, hi};
+#ifdef NGP_HASH_FWD_DIAG
+    if (const char* e = getenv("NGP_HASH_FWD_FREE_LEVELS")) nm.enabled |= (int)(strtoul(e, nullptr, 0) & 0xffffu) << 8;
+#endif
     if (enc_pairs && !(lv->n_features == 2 && lv->n_levels == 16)) return -1;
     if (lv->n_features == 2 && lv->n_levels == 16 && (n_max >= 4096 || enc_pairs)) {
         int tiles = (n_max + 127) / 128;
@@ -616,6 +638,24 @@ int ngp_hash_fwd_f32_ex(const float* xyzs, const float* table, const ngp_hash_le
         case 8: hipLaunchKernelGGL(hash_fwd_f32_kernel<8>, dim3(grid), dim3(256), 0, s, xyzs, table, *lv, n_max, n_dev, nm, out); break;
         default: return -1;
     }
+    NGP_LAUNCH_CHECK();
+    return 0;
+}
+
+// The fused path's encoder over a LIST of samples (round 5): rows list[0 .. *n_list) of xyzs are encoded into the same rows of out
+// (16 levels x 2 features, natural or pair-major planes of stride n_max).  table_kind 0: fp32 table, 1: its bf16 storage copy.
+// Returns -2 where the specialised kernel does not apply (other table shapes, tables of 4 GB and more): the caller encodes everything.
+int ngp_hash_fwd_list(const float* xyzs, const void* table, int table_kind, const ngp_hash_levels* lv, int n_max, const int32_t* n_list,
+                      const int32_t* list, int normalize, float lo, float hi, int enc_pairs, float* out, void* stream) {
+    if (n_max <= 0) return 0;
+    if (!n_list || !list || table_kind < 0 || table_kind > 1) return -1;
+    if (!(lv->n_features == 2 && lv->n_levels == 16) || xcd_v1(*lv, table_kind ? 4 : 8)) return -2;
+    const XyzNorm nm = {normalize, lo, hi};
+    int tiles = (n_max + 127) / 128;
+    if (tiles > xcd_tiles_cap()) tiles = xcd_tiles_cap();
+    const float* t = reinterpret_cast<const float*>(table);
+    if (table_kind) hipLaunchKernelGGL((hash_fwd_f32_xcd_kernel<1, false, true>), dim3(8 * tiles), dim3(256), 0, (hipStream_t)stream, xyzs, t, *lv, n_max, n_list, nm, enc_pairs, out, list);
+    else hipLaunchKernelGGL((hash_fwd_f32_xcd_kernel<0, false, true>), dim3(8 * tiles), dim3(256), 0, (hipStream_t)stream, xyzs, t, *lv, n_max, n_list, nm, enc_pairs, out, list);
     NGP_LAUNCH_CHECK();
     return 0;
 }

@@ -368,33 +368,58 @@ __device__ __forceinline__ FwdIn fwd_take(const FwdIn& raw, bool ok) {
     return in;
 }
 
-template <bool COLOR, bool PAIRS>
+// LIST (round 5, the chunked forward): trip positions index a list of samples -- position j shades sample list[j] (reads its enc
+// row and direction, writes its sigma / rgb) -- instead of the samples themselves; the list entries of the trip after next are
+// requested with the next trip's inputs, so the indirection stays off the trip's critical path.
+template <bool COLOR, bool PAIRS, bool LIST = false>
 __global__ void __launch_bounds__(256) mlp_fwd_kernel(const float* __restrict__ enc, const float* __restrict__ dirs,
                                                       const half_t* __restrict__ wpack, int S,
                                                       const int32_t* __restrict__ n_dev, float* __restrict__ sigmas,
-                                                      half_t* __restrict__ rgbs) {
+                                                      half_t* __restrict__ rgbs, const int32_t* __restrict__ list = nullptr) {
     __shared__ half8 wl[N_FWD_FRAGS * 64];
     const size_t plane = (size_t)S;
     if (n_dev) S = min(S, *n_dev);
     const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
     const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), n_waves = gridDim.x * (blockDim.x >> 6);
     const int n_iter = (S + 31) >> 5;
+    if (LIST && S <= 0) return;          // (an empty list: entry 0 is not a list entry -- nothing may be dereferenced through it)
+    // LIST: a position past the end reads entry 0 of the list, which exists
+    auto entry = [&](int pos) -> int { return LIST ? list[(pos < S) ? pos : 0] : pos; };
     FwdIn nxt[2];
+    int s_cur[2] = {0, 0}, s_nxt[2], s_nxt2[2] = {0, 0};
 #pragma unroll
-    for (int tt = 0; tt < 2; ++tt) fwd_request<COLOR, PAIRS>(nxt[tt], enc, dirs, wave * 32 + 16 * tt + n, S, g, plane);
+    for (int tt = 0; tt < 2; ++tt) {
+        s_nxt[tt] = entry(wave * 32 + 16 * tt + n);
+        if (LIST) s_nxt2[tt] = entry((wave + n_waves) * 32 + 16 * tt + n);
+    }
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        if (LIST) fwd_request<COLOR, PAIRS>(nxt[tt], enc, dirs, (wave * 32 + 16 * tt + n < S) ? s_nxt[tt] : 0, (int)plane, g, plane);
+        else fwd_request<COLOR, PAIRS>(nxt[tt], enc, dirs, wave * 32 + 16 * tt + n, S, g, plane);
+    }
     load_wpack<256, COLOR ? N_FWD_FRAGS : F_W3>(wpack, wl);          // (behind the first trip's input request: both in flight together)
     for (int it = wave; it < n_iter; it += n_waves) {
         FwdIn cur[2];
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt) cur[tt] = fwd_take(nxt[tt], it * 32 + 16 * tt + n < S);
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt) fwd_request<COLOR, PAIRS>(nxt[tt], enc, dirs, (it + n_waves) * 32 + 16 * tt + n, S, g, plane);
+        for (int tt = 0; tt < 2; ++tt) { cur[tt] = fwd_take(nxt[tt], it * 32 + 16 * tt + n < S); s_cur[tt] = s_nxt[tt]; }
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
-            const int smp = it * 32 + 16 * tt + n;
+            const int pos = (it + n_waves) * 32 + 16 * tt + n;
+            if (LIST) {
+                s_nxt[tt] = s_nxt2[tt];
+                s_nxt2[tt] = entry((it + 2 * n_waves) * 32 + 16 * tt + n);
+                fwd_request<COLOR, PAIRS>(nxt[tt], enc, dirs, (pos < S) ? s_nxt[tt] : 0, (int)plane, g, plane);
+            } else {
+                fwd_request<COLOR, PAIRS>(nxt[tt], enc, dirs, pos, S, g, plane);
+            }
+        }
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const int pos = it * 32 + 16 * tt + n;
+            const int smp = LIST ? s_cur[tt] : pos;
             TileFwd t;
             tile_forward_regs<COLOR>(wl, lane, g, cur[tt].e0, cur[tt].e1, cur[tt].dx, cur[tt].dy, cur[tt].dz, t);
-            if (smp < S && g == 0) {
+            if (pos < S && g == 0) {
                 sigmas[smp] = t.sigma;
                 if (COLOR) { rgbs[3 * (size_t)smp] = t.rgb[0]; rgbs[3 * (size_t)smp + 1] = t.rgb[1]; rgbs[3 * (size_t)smp + 2] = t.rgb[2]; }
             }
@@ -824,6 +849,20 @@ int ngp_mlp_fwd_ex(const float* enc, const float* dirs, const uint16_t* wpack, i
     if (dirs && rgbs) { if (enc_pairs) NGP_FWD(true, true, dirs, rgbs); else NGP_FWD(true, false, dirs, rgbs); }
     else { if (enc_pairs) NGP_FWD(false, true, nullptr, nullptr); else NGP_FWD(false, false, nullptr, nullptr); }
 #undef NGP_FWD
+    NGP_LAUNCH_CHECK();
+    return 0;
+}
+
+// The forward over a LIST of samples (round 5: the chunked forward): position j < *n_list shades sample list[j].  Entries must be
+// valid rows (< n_max) -- including any beyond *n_list that a lane past the end may touch as entry 0.
+int ngp_mlp_fwd_list(const float* enc, const float* dirs, const uint16_t* wpack, int n_max, const int32_t* n_list, const int32_t* list,
+                     int enc_pairs, float* sigmas, uint16_t* rgbs, void* stream) {
+    if (n_max <= 0) return 0;
+    if (!n_list || !list || !dirs || !rgbs) return -1;
+    if (enc_pairs) hipLaunchKernelGGL((mlp_fwd_kernel<true, true, true>), dim3(mlp_grid(n_max)), dim3(256), 0, (hipStream_t)stream, enc, dirs,
+                                      (const half_t*)wpack, n_max, n_list, sigmas, (half_t*)rgbs, list);
+    else hipLaunchKernelGGL((mlp_fwd_kernel<true, false, true>), dim3(mlp_grid(n_max)), dim3(256), 0, (hipStream_t)stream, enc, dirs,
+                            (const half_t*)wpack, n_max, n_list, sigmas, (half_t*)rgbs, list);
     NGP_LAUNCH_CHECK();
     return 0;
 }

@@ -84,6 +84,25 @@ __global__ void __launch_bounds__(256) adam_multi_kernel(AdamMulti T, const floa
                            (long)gridDim.x);
 }
 
+// GradScaler's inf / nan check over up to NGP_ADAM_MULTI_MAX gradient tensors in ONE read-only pass (torch's own check,
+// _amp_foreach_non_finite_check_and_unscale_ with a unit scale, reads AND rewrites every gradient: twice the traffic, and tens of
+// microseconds of Python in front of it).  found[0] = 1.0f when any value is not finite; the caller clears it beforehand.
+struct FiniteMulti {
+    const float4* g[NGP_ADAM_MULTI_MAX];
+    long n4[NGP_ADAM_MULTI_MAX];
+    int count;
+};
+__global__ void __launch_bounds__(256) check_finite_multi_kernel(FiniteMulti T, float* __restrict__ found) {
+    bool bad = false;
+    for (int t = 0; t < T.count; ++t)
+        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < T.n4[t]; i += (long)gridDim.x * blockDim.x) {
+            const float4 a = T.g[t][i];
+            // x - x is 0 for every finite x and NaN for inf / NaN: one test for the four lanes' sum of such differences
+            bad |= !(((a.x - a.x) + (a.y - a.y)) + ((a.z - a.z) + (a.w - a.w)) == 0.0f);
+        }
+    if (__any(bad) && (threadIdx.x & 63) == 0) *found = 1.0f;
+}
+
 __global__ void __launch_bounds__(256) cast_bf16_kernel(const float4* __restrict__ src, uint2* __restrict__ dst, long n4) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         const float4 a = src[i];
@@ -218,6 +237,25 @@ int ngp_adam_multi(int n_tensors, float* const* p, float* const* g, float* const
     long blocks = (most + 255) / 256;
     if (blocks > 256L * 16) blocks = 256L * 16;
     hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, T, state_f, state_i, beta1, beta2, eps);
+    NGP_LAUNCH_CHECK();
+    return 0;
+}
+
+int ngp_check_finite_multi(int n_tensors, const float* const* g, const long long* n, float* found_inf, void* stream) {
+    if (n_tensors <= 0) return 0;
+    if (n_tensors > NGP_ADAM_MULTI_MAX || !g || !n || !found_inf) return -1;
+    FiniteMulti T;
+    long most = 0;
+    T.count = n_tensors;
+    for (int t = 0; t < n_tensors; ++t) {
+        if (n[t] <= 0 || n[t] % 4 != 0 || !g[t]) return -1;
+        T.g[t] = (const float4*)g[t];
+        T.n4[t] = (long)(n[t] / 4);
+        if (T.n4[t] > most) most = T.n4[t];
+    }
+    long blocks = (most + 255) / 256;
+    if (blocks > 256L * 16) blocks = 256L * 16;
+    hipLaunchKernelGGL(check_finite_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, T, found_inf);
     NGP_LAUNCH_CHECK();
     return 0;
 }

@@ -21,9 +21,10 @@ class TrainResults(dict):
     next render() can no longer overwrite.  This package's own distortion loss reads the arena rows in place (`padded()`):
     `rays_a` addresses them identically, so train.py with --distortion_loss_w > 0 runs without the host read."""
 
-    def __init__(self, data, padded, arena=None):
+    def __init__(self, data, padded, arena=None, lazy=None):
         super().__init__(data)
         self._padded = padded
+        self._lazy = dict(lazy or {})        # key -> thunk: small reductions only a log line reads (rm_samples, vr_samples)
         self._arena, self._generation = arena, (arena.generation if arena is not None else None)
 
     def padded(self, key):
@@ -31,25 +32,30 @@ class TrainResults(dict):
         return self._padded[key]
 
     def __missing__(self, key):
+        if key in self._lazy:
+            value = self._lazy.pop(key)()
+            self[key] = value
+            return value
         if key not in self._padded:
             raise KeyError(key)
         if self._arena is not None and self._arena.generation != self._generation:
             raise RuntimeError("render(): results[%r] of a training render was first read after a later training render with the same ray "
                                "count had reused its sample arena; read it before the next render(), or set NGP_FUSED_RENDER=0 for "
                                "the reference's per-call buffers" % key)
-        n_live = int(dict.__getitem__(self, 'rm_samples'))
+        n_live = int(self['rm_samples'])
         value = self._padded[key][:n_live].clone()
         self[key] = value
         return value
 
     def __contains__(self, key):
-        return dict.__contains__(self, key) or key in self._padded
+        return dict.__contains__(self, key) or key in self._padded or key in self._lazy
 
     def get(self, key, default=None):
         return self[key] if key in self else default
 
     def keys(self):
-        return list(dict.keys(self)) + [k for k in self._padded if not dict.__contains__(self, k)]
+        return (list(dict.keys(self)) + [k for k in self._lazy if not dict.__contains__(self, k)]
+                + [k for k in self._padded if not dict.__contains__(self, k)])
 
     def items(self):
         return [(k, self[k]) for k in self.keys()]
@@ -70,6 +76,7 @@ class TrainResults(dict):
             value = self[key]
             dict.pop(self, key, None)
             self._padded.pop(key, None)
+            self._lazy.pop(key, None)
             return value
         if default:
             return default[0]
@@ -97,6 +104,9 @@ def _background(exp_step_factor, device):
 def render(model, rays_o, rays_d, test_time=False, exp_step_factor=0, T_threshold=1e-4, max_samples=MAX_SAMPLES):
     """rays_o, rays_d: [N,3].  Returns the reference's result dictionary (rgb, depth, opacity, ...)."""
     rays_o, rays_d = rays_o.contiguous().float(), rays_d.contiguous().float()      # geometry is fp32 (ray_utils.py:50)
+    if not test_time and getattr(model, 'fused_train_ok', None) is not None and model.fused_train_ok(rays_o):
+        # the fused training render does the slab test of intersection.py:22-37 inside its march launch (same arithmetic, same hits_t)
+        return _render_rays_train(model, rays_o, rays_d, None, exp_step_factor, T_threshold)
     hits_t = ray_aabb_intersection(rays_o, rays_d, model.scale)
     if test_time:
         if rays_o.is_cuda and os.environ.get("NGP_FUSED_EVAL", "1") != "0":
@@ -181,16 +191,18 @@ def _render_rays_train(model, rays_o, rays_d, hits_t, exp_step_factor, T_thresho
     if getattr(model, 'fused_train_ok', None) is not None and model.fused_train_ok(rays_o):
         # one autograd node, no host sync; the per-sample outputs stay in the N*MAX_SAMPLES arena until somebody reads them
         # through the result dictionary (TrainResults: reference-shaped [S] tensors on first access)
-        from ngp_hip.fused import FusedTrainRender, RenderConfig
-        cfg = RenderConfig(model, exp_step_factor, T_threshold, MAX_SAMPLES)
-        rgb, opacity, depth, ws, rm_samples, vr_samples, rays_a = FusedTrainRender.apply(
-            rays_o.contiguous().float(), rays_d.contiguous().float(), hits_t, model.pos_encoder.hash_table,
-            *model._mlp_weights(), cfg)
-        rgb = rgb + _background(exp_step_factor, rays_o.device) * (1 - opacity)[:, None]
-        from ngp_hip.fused import TrainArena
+        from ngp_hip.fused import FusedTrainRender, RenderConfig, TrainArena
+        cfg = RenderConfig.cached(model, exp_step_factor, T_threshold, MAX_SAMPLES)
+        # (the background blend of :219-226 is part of the node; rm_samples / vr_samples are read by train.py's log lines only:
+        # the two reductions are formed when somebody asks)
+        rgb, opacity, depth, ws, total, vr_per_ray, rays_a = FusedTrainRender.apply(
+            rays_o, rays_d, hits_t, model.pos_encoder.hash_table, *model._mlp_weights(), cfg)
         A = TrainArena.get(rays_o.device, rays_o.shape[0], MAX_SAMPLES)
-        return TrainResults({'rm_samples': rm_samples, 'vr_samples': vr_samples, 'opacity': opacity, 'depth': depth, 'rgb': rgb,
-                             'rays_a': rays_a}, {'deltas': A.deltas, 'ts': A.ts, 'ws': ws}, A)
+        return TrainResults({'opacity': opacity, 'depth': depth, 'rgb': rgb, 'rays_a': rays_a},
+                            {'deltas': A.deltas, 'ts': A.ts, 'ws': ws}, A,
+                            lazy={'rm_samples': lambda: total[0], 'vr_samples': lambda: vr_per_ray.sum()})
+    if hits_t is None:
+        hits_t = ray_aabb_intersection(rays_o, rays_d, model.scale)
     rays_a, xyzs, dirs, deltas, ts, rm_samples = raymarching_train(
         rays_o, rays_d, hits_t, model.density_bitfield, model.cascades, model.scale, exp_step_factor, model.grid_size,
         MAX_SAMPLES)

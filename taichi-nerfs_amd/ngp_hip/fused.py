@@ -43,6 +43,7 @@ class TrainArena:
         self.d_enc = torch.empty(cap, 32, **f32)
         self.wpack = torch.empty(_lib_mod.load().ngp_mlp_wpack_halfs(), device=device, dtype=torch.float16)
         self._coarse = {}
+        self._coarse_key = None            # (bitfield data_ptr, torch version) the coarse table was built from
         self._scratch = {}
         self.live_idx = torch.empty(cap, device=device, dtype=torch.int32)     # compacted backward: indices of the live samples
         self._live_off = torch.empty(n_rays, device=device, dtype=torch.int32)
@@ -102,9 +103,14 @@ class FusedTrainRender(torch.autograd.Function):
         total = torch.empty(1, **i32)
         noise = torch.rand(n, **f32)                                            # ray_march.py:138
         coarse = A.coarse_for(cfg)
-        check(L.ngp_bitfield_coarsen(_ptr(cfg.bitfield), cfg.cascades, cfg.grid_size, _ptr(coarse), st), "ngp_bitfield_coarsen")
-        # the whole march in one launch; the rays' ranges are packed in block-completion order (rays_a says where), like the
-        # reference's own atomic packing (ray_march.py:76-80)
+        # the 8^3-block shortcut table follows the bitfield: rebuilt when the bitfield tensor was written to (every writer moves its
+        # torch version counter -- in-place torch ops by themselves, the raw-pointer kernels through ops._touched), not every call
+        key = (cfg.bitfield.data_ptr(), cfg.bitfield._version, cfg.cascades)
+        if A._coarse_key != key:
+            check(L.ngp_bitfield_coarsen(_ptr(cfg.bitfield), cfg.cascades, cfg.grid_size, _ptr(coarse), st), "ngp_bitfield_coarsen")
+            A._coarse_key = key
+        # the whole march in one launch (hits_t None: the slab test of intersection.py:22-37 inline, same arithmetic); the rays'
+        # ranges are packed in block-completion order (rays_a says where), like the reference's own atomic packing (ray_march.py:76-80)
         check(L.ngp_march_train_fused(_ptr(rays_o), _ptr(rays_d), _ptr(hits_t), _ptr(cfg.bitfield), _ptr(coarse), _ptr(noise),
                                       cfg.cascades, cfg.grid_size, cfg.scale, cfg.exp_step_factor, cfg.max_samples, n,
                                       _ptr(A.stage), _ptr(A.march_ctr), _ptr(rays_a), _ptr(total), _ptr(A.xyzs), _ptr(A.dirs),
@@ -133,10 +139,14 @@ class FusedTrainRender(torch.autograd.Function):
         ctx.cfg, ctx.arena, ctx.table_numel, ctx.table_shape, ctx.generation = cfg, A, table.numel(), table.shape, A.generation
         ctx.save_for_backward(rays_a, total, opacity, depth, rgb, vr_per_ray)
         ctx.set_materialize_grads(False)
-        rm = total[0]
-        vr = vr_per_ray.sum()
-        ctx.mark_non_differentiable(rm, vr, rays_a)
-        return rgb, opacity, depth, A.ws, rm, vr, rays_a
+        # the background blend of rendering.py:219-226 (white behind synthetic scenes, black behind real ones) happens HERE, on a copy
+        # of the composited colour (the backward kernel wants the unblended one): three small torch kernels and their three autograd
+        # nodes per step otherwise; its gradient -- d opacity -= bg * sum_c g_rgb -- is folded into backward() below
+        rgb_out = rgb
+        if cfg.bg != 0.0:
+            rgb_out = torch.addcmul(rgb, (1.0 - opacity).unsqueeze(1), cfg.bg_vec(dev))
+        ctx.mark_non_differentiable(total, vr_per_ray, rays_a)
+        return rgb_out, opacity, depth, A.ws, total, vr_per_ray, rays_a
 
     @staticmethod
     def backward(ctx, g_rgb, g_opacity, g_depth, g_ws, _g_rm, _g_vr, _g_ra):
@@ -159,6 +169,9 @@ class FusedTrainRender(torch.autograd.Function):
         if g_rgb is None:
             g_rgb = torch.zeros(n, 3, device=dev, dtype=torch.float32)
         g_opacity, g_depth, g_ws = f32(g_opacity), f32(g_depth), f32(g_ws)
+        if cfg.bg != 0.0:                                                 # rgb_out = rgb + bg (1 - opacity): the blend's share of d opacity
+            g_bg = g_rgb.sum(1) * (-cfg.bg)
+            g_opacity = g_bg if g_opacity is None else g_opacity + g_bg
         check(L.ngp_composite_train_bwd(_ptr(g_opacity), _ptr(g_depth), _ptr(g_rgb), _ptr(g_ws), _ptr(A.sigmas), _ptr(A.rgbs), 1,
                                         _ptr(A.deltas), _ptr(A.ts), _ptr(rays_a), _ptr(opacity), _ptr(depth), _ptr(rgb),
                                         _ptr(A.ws), cfg.T_threshold, n, _ptr(A.d_sigmas), _ptr(A.d_rgbs), st),
@@ -225,3 +238,30 @@ class RenderConfig:
         self.table_bf16 = enc.table_bf16() if getattr(enc, "table_dtype", torch.float32) == torch.bfloat16 else None
         # half2 encoder: the fp16 copy of the fp32 master the kernels gather from (re-cast when the parameter changed, :367)
         self.table_f16 = enc.table_f16() if getattr(model, "half_opt", False) else None
+        self.bg = 1.0 if self.exp_step_factor == 0 else 0.0                  # rendering.py:219-226
+        self._bg_vec = None
+
+    def bg_vec(self, device):
+        if self._bg_vec is None or self._bg_vec.device != device:
+            self._bg_vec = torch.full((1, 3), self.bg, device=device, dtype=torch.float32)
+        return self._bg_vec
+
+    @classmethod
+    def cached(cls, model, exp_step_factor, T_threshold, max_samples):
+        """One RenderConfig per (model, scalars), re-used across render() calls (the training loop builds the same one every step);
+        what can change between calls -- the bitfield tensor and the 16-bit table copies, re-cast when the parameter moved -- is
+        refreshed."""
+        key = (float(exp_step_factor), float(T_threshold), int(max_samples), float(model.scale), int(model.cascades))
+        slot = model.__dict__.get("_ngp_render_cfg")
+        if slot is None or slot[0] != key:
+            slot = (key, cls(model, exp_step_factor, T_threshold, max_samples))
+            model.__dict__["_ngp_render_cfg"] = slot
+            return slot[1]
+        cfg = slot[1]
+        cfg.bitfield = model.density_bitfield
+        enc = model.pos_encoder
+        if cfg.table_bf16 is not None:
+            cfg.table_bf16 = enc.table_bf16()
+        if cfg.table_f16 is not None:
+            cfg.table_f16 = enc.table_f16()
+        return cfg

@@ -99,6 +99,9 @@ SIGNATURES = {
     "ngp_march_train_fused_shaped": [_P, _P, _P, _P, _P, _P, ctypes.c_ulonglong, _I, _I, _F, _F, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P,
                                      _P, _P],
     "ngp_rng_uniform": [ctypes.c_ulonglong, _I, _P, _P],
+    "ngp_hash_fwd_list": [_P, _P, _I, _LV, _I, _P, _P, _I, _F, _F, _I, _P, _P],
+    "ngp_mlp_fwd_list": [_P, _P, _P, _I, _P, _P, _I, _P, _P, _P],
+    "ngp_chunk_schedule": [_P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P],
     "ngp_march_train_write": [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P],
     "ngp_march_test": [_P, _P, _P, _P, _P, _I, _I, _F, _F, _I, _I, _P, _P, _P, _P, _P, _P],
     "ngp_hash_fwd_f32": [_P, _P, _LV, _I, _P, _P],
@@ -157,6 +160,7 @@ SIGNATURES = {
     "ngp_adam_amp_prologue": [_P, _P, _P, _P, _F, _F, _F, _P],
     "ngp_adam_step": [_P, _P, _P, _P, ctypes.c_longlong, _P, _P, _F, _F, _F, _P],
     "ngp_adam_multi": [_I, _P, _P, _P, _P, _P, _P, _P, _F, _F, _F, _P],
+    "ngp_check_finite_multi": [_I, _P, _P, _P, _P],
     "ngp_adam_step_bf16": [_P, _P, _P, _P, ctypes.c_longlong, _P, _P, _F, _F, _F, _P, _P],
     "ngp_cast_f32_bf16": [_P, _P, ctypes.c_longlong, _P],
     "ngp_adam_all": [_P, _P, _P, _P, ctypes.c_longlong, _P, _P, _P, _P, _P, _P, _P, _F, _F, _F, _I, _P, _P],

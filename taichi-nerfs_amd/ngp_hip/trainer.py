@@ -39,7 +39,7 @@ class FusedTrainer:
     def __init__(self, model, lr=1e-2, betas=(0.9, 0.999), eps=1e-15, max_steps=20000, eta_min=None, init_scale=2.0**19,
                  growth_factor=2.0, backoff_factor=0.5, growth_interval=2000, exp_step_factor=0.0, T_threshold=1e-4,
                  max_samples=1024, process_group=None, world_size=None, grad_comm_dtype=torch.float32,
-                 distortion_loss_w=0.0, shard_optimizer=None):
+                 distortion_loss_w=0.0, shard_optimizer=None, chunked_forward=None):
         if not model.use_fused_mlp:
             raise ValueError("FusedTrainer needs the default architecture (L=16, F=2 hash grid, 64-wide MLPs)")
         self.half = bool(model.half_opt)              # half2 encoder (hash_encoder_half.py): f16 table copy, f16 gradient buffer
@@ -56,6 +56,29 @@ class FusedTrainer:
         self.exp_step_factor, self.T_threshold, self.max_samples = float(exp_step_factor), float(T_threshold), int(max_samples)
         self.bg = 1.0 if exp_step_factor == 0 else 0.0                    # rendering.py:219-226
         self.distortion_loss_w = float(distortion_loss_w)                # train.py:194-195 (0 = off, the reference default)
+        # Round 5 -- chunked forward: shade a ray's samples in growing chunks (64, 64, 128, 256, ...) and stop at the chunk in which
+        # its transmittance falls to the compositing threshold, instead of shading everything the march emitted (the reference shades
+        # all of it and ignores what lies behind T <= 1e-4, volume_train.py:38; on the C3 shape that is 3 of 4 samples).  Results per
+        # ray and all gradients are unchanged (tests/test_gpu_chunked.py); `rm_samples` stays the MARCHED count, shaded_samples()
+        # reports what was shaded.  Default: on for multi-cascade / exponentially stepped scenes (where rays run far past their
+        # surfaces), off for the bounded synthetic ones (C2: 45 marched vs 43 composited samples per ray -- five rounds of three
+        # launches would cost more than they save); chunked_forward=True / False or NGP_CHUNKED_FWD=1 / 0 override.
+        ck = os.environ.get("NGP_CHUNKED_FWD")
+        if chunked_forward is None and ck is not None:
+            chunked_forward = ck == "1"
+        if chunked_forward is None:
+            chunked_forward = float(exp_step_factor) > 0 or int(model.cascades) > 1
+        self.chunked = bool(chunked_forward) and not self.half and int(max_samples) % 64 == 0 and int(max_samples) >= 128
+        self._chunk_rounds = []
+        if self.chunked:
+            b, l, pb = 0, 64, 0
+            while b < int(max_samples):
+                l = min(l, int(max_samples) - b)
+                self._chunk_rounds.append((b, l, pb))
+                pb, b = b, b + l
+                l = b                                  # 64, 64, 128, 256, 512: every boundary a multiple of 64
+        self._chunk_counts = None                      # [2, rounds] int32: list lengths per round, one set per step parity
+        self._chunk_T = {}
         # backward over the samples in front of each ray's early-termination point only (NGP_LIVE_BACKWARD=0: over all of them)
         self.live_backward = os.environ.get("NGP_LIVE_BACKWARD", "1") != "0"
         self.march_fused = os.environ.get("NGP_MARCH_FUSED", "1") != "0"
@@ -158,8 +181,11 @@ class FusedTrainer:
         # persistent workgroups retire: profiles/r05_rocprofv3_timed_region_march_under_scatter.txt, the next step's gather waits
         # 21 us for it).  profiles/r05_march_placement.txt: issued at the START of the step as 4-wave blocks on a default-priority
         # stream it costs least (1.287 vs 1.305 ns per live sample under the scatter-add, 1.323 in line).
+        # (C3 shape -- six cascades, exponential stepping -- is the other way round: the march is 1.3 ms of ALU work and the scatter-add
+        # 2.3 ms, so round 4's arrangement, 16-wave blocks at low priority under the scatter-add, hides it best: 13.5 M rays/s against
+        # 12.4 at the start of the step, profiles/r05_bench_garden_c3_march_placement.txt.)
         self._one_gpu_flush = (self.world == 1 and not self.half and os.environ.get("NGP_FLUSH_ADAM", "1") != "0"
-                               and self.hash_bwd == "sliced")
+                               and self.hash_bwd == "sliced" and not (float(exp_step_factor) > 0 or int(model.cascades) > 1))
         self._side_prio = None
         if os.environ.get("NGP_SIDE_PRIORITY", "default" if self._one_gpu_flush else "low") == "low":
             h, lo, hi = ctypes.c_void_p(), ctypes.c_int(), ctypes.c_int()
@@ -387,7 +413,7 @@ class FusedTrainer:
     def _launch(self, rays_o, rays_d, target, prefetch=None, src=None, src_next=None, noise=None):
         self.finish_comm()                   # (overlapped exchange: the previous step's all-gathers, before the table is read)
         n = rays_o.shape[0]
-        cfg = RenderConfig(self.model, self.exp_step_factor, self.T_threshold, self.max_samples)
+        cfg = RenderConfig.cached(self.model, self.exp_step_factor, self.T_threshold, self.max_samples)
         A = TrainArena.get(self.dev, n, self.max_samples)
         sets = self._march_sets(n)
         M = sets[self._cur]
@@ -428,6 +454,8 @@ class FusedTrainer:
         # clear both counters on the stream before going on (stale counts would be added to, silently).
         if self._launch_incomplete:
             self._live_pair.zero_()
+            if self._chunk_counts is not None:
+                self._chunk_counts.zero_()
         self._launch_incomplete = True
         cur, self._cur = self._cur, 1 - self._cur
         if self._graph is None:
@@ -461,21 +489,11 @@ class FusedTrainer:
         sq_err = torch.empty(n, **f32)
         found = ctypes.c_void_p(si.data_ptr() + 4 * _SI_FOUND_INF)
         P = self.enc_pairs
-        if self.half:
-            check(L.ngp_hash_fwd_f16_ex(_ptr(M.xyzs), _ptr(self.table_f16), ctypes.byref(cfg.levels), A.cap, _ptr(total), 1, cfg.lo,
-                                        cfg.hi, P, _ptr(A.enc), st), "ngp_hash_fwd_f16_ex")
-        elif self.table_bf16 is not None:
-            check(L.ngp_hash_fwd_bf16_ex(_ptr(M.xyzs), _ptr(self.table_bf16), ctypes.byref(cfg.levels), A.cap, _ptr(total), 1, cfg.lo,
-                                         cfg.hi, P, _ptr(A.enc), st), "ngp_hash_fwd_bf16_ex")
-        else:
-            check(L.ngp_hash_fwd_f32_ex(_ptr(M.xyzs), _ptr(self.table), ctypes.byref(cfg.levels), A.cap, _ptr(total), 1, cfg.lo,
-                                        cfg.hi, P, _ptr(A.enc), st), "ngp_hash_fwd_f32_ex")
-        if hook is not None and self._prefetch_at == 1:
-            hook(); hook = None
-        check(L.ngp_mlp_fwd_ex(_ptr(A.enc), _ptr(M.dirs), _ptr(self.wpack), A.cap, _ptr(total), P, _ptr(A.sigmas), _ptr(A.rgbs), st),
-              "ngp_mlp_fwd_ex")
-        if hook is not None and self._prefetch_at == 2:
-            hook(); hook = None
+        done = False
+        if self.chunked:
+            done, hook = self._shade_chunked(M, n, cfg, A, P, st, hook)
+        if not done:
+            hook = self._shade_all(M, cfg, A, P, st, total, hook)
         par = M.index
         live_total, live_next = self._live_pair[par:par + 1], self._live_pair[1 - par:2 - par]
         fused_live = False
@@ -615,6 +633,66 @@ class FusedTrainer:
                   "ngp_adam_all_ex")
         return {"rm_samples": total, "vr_per_ray": vr_per_ray, "rgb": rgb, "opacity": opacity, "depth": depth, "rays_a": rays_a,
                 "deltas": M.deltas, "ts": M.ts, "sq_err": sq_err}
+
+    def _shade_all(self, M, cfg, A, P, st, total, hook):
+        """Encode + MLP forward over every marched sample (reference networks.py:136-166 on all of raymarching_train's output)."""
+        L = self.L
+        if self.half:
+            check(L.ngp_hash_fwd_f16_ex(_ptr(M.xyzs), _ptr(self.table_f16), ctypes.byref(cfg.levels), A.cap, _ptr(total), 1, cfg.lo,
+                                        cfg.hi, P, _ptr(A.enc), st), "ngp_hash_fwd_f16_ex")
+        elif self.table_bf16 is not None:
+            check(L.ngp_hash_fwd_bf16_ex(_ptr(M.xyzs), _ptr(self.table_bf16), ctypes.byref(cfg.levels), A.cap, _ptr(total), 1, cfg.lo,
+                                         cfg.hi, P, _ptr(A.enc), st), "ngp_hash_fwd_bf16_ex")
+        else:
+            check(L.ngp_hash_fwd_f32_ex(_ptr(M.xyzs), _ptr(self.table), ctypes.byref(cfg.levels), A.cap, _ptr(total), 1, cfg.lo,
+                                        cfg.hi, P, _ptr(A.enc), st), "ngp_hash_fwd_f32_ex")
+        if hook is not None and self._prefetch_at == 1:
+            hook(); hook = None
+        check(L.ngp_mlp_fwd_ex(_ptr(A.enc), _ptr(M.dirs), _ptr(self.wpack), A.cap, _ptr(total), P, _ptr(A.sigmas), _ptr(A.rgbs), st),
+              "ngp_mlp_fwd_ex")
+        if hook is not None and self._prefetch_at == 2:
+            hook(); hook = None
+        return hook
+
+    def _shade_chunked(self, M, n, cfg, A, P, st, hook):
+        """Encode + MLP forward in rounds over the samples compositing can still reach (see __init__; csrc/composite.hip
+        chunk_schedule_kernel).  Returns False when the level table does not fit the list encoder (the caller shades everything)."""
+        L = self.L
+        R = len(self._chunk_rounds)
+        if self._chunk_counts is None:
+            self._chunk_counts = torch.zeros(2, R, device=self.dev, dtype=torch.int32)
+        T_state = self._chunk_T.get(n)
+        if T_state is None:
+            T_state = self._chunk_T[n] = torch.empty(n, device=self.dev, dtype=torch.float32)
+        par = M.index
+        c_cur = self._chunk_counts.data_ptr() + 4 * R * par             # this step's list lengths; the other parity's set is cleared
+        c_oth = self._chunk_counts.data_ptr() + 4 * R * (1 - par)       # round by round for the next step
+        table, kind = (self.table_bf16, 1) if self.table_bf16 is not None else (self.table, 0)
+        lst = A.live_idx                    # (free until the composite kernel writes the backward's live list into it)
+        for r, (b, l, pb) in enumerate(self._chunk_rounds):
+            cnt = ctypes.c_void_p(c_cur + 4 * r)
+            check(L.ngp_chunk_schedule(_ptr(M.rays_a), _ptr(A.sigmas), _ptr(M.deltas), n, b, l, pb, 0.5 * cfg.T_threshold, _ptr(T_state),
+                                       _ptr(lst), cnt, ctypes.c_void_p(c_oth + 4 * r), st), "ngp_chunk_schedule")
+            rc = L.ngp_hash_fwd_list(_ptr(M.xyzs), _ptr(table), kind, ctypes.byref(cfg.levels), A.cap, cnt, _ptr(lst), 1,
+                                     cfg.lo, cfg.hi, P, _ptr(A.enc), st)
+            if rc == -2 and r == 0:                                        # level table outside the list encoder: shade everything
+                self._chunk_counts.zero_()
+                self.chunked = False
+                return False, hook
+            check(rc, "ngp_hash_fwd_list")
+            if r == 0 and hook is not None and self._prefetch_at == 1:
+                hook(); hook = None
+            check(L.ngp_mlp_fwd_list(_ptr(A.enc), _ptr(M.dirs), _ptr(self.wpack), A.cap, cnt, _ptr(lst), P, _ptr(A.sigmas),
+                                     _ptr(A.rgbs), st), "ngp_mlp_fwd_list")
+        if hook is not None and self._prefetch_at == 2:
+            hook(); hook = None
+        return True, hook
+
+    def shaded_samples(self):
+        """Samples the most recent step shaded (chunked forward; None when every marched sample is shaded).  One host read."""
+        if not self.chunked or self._chunk_counts is None:
+            return None
+        return int(self._chunk_counts[1 - self._cur].sum())
 
     def _tail_flush_adam(self, A, M, cfg, cnt, P, ws, n_parts, st, hook, total, vr_per_ray, rgb, opacity, depth, sq_err, npre):
         """Prologue -> scatter-add with the optimizer in its flush -> Adam on the replicated coarse levels + the MLP (one GPU, fp32

@@ -48,6 +48,41 @@ def test_fused_adam_matches_torch_adam_under_gradscaler(hip_lib):
     assert int(o_mine._si[0][1]) == 49
 
 
+def test_fused_adam_takes_the_scaler_and_runs_its_own_inf_check(hip_lib):
+    """Round 5: GradScaler.step() hands itself to FusedAdam.step(grad_scaler=...) (apex's signature) and then skips its own
+    `_check_inf_per_device`; the optimizer's read-only check (ngp_check_finite_multi) records the flag where GradScaler.update()
+    reads it.  Also the other order a training loop may use: scaler.unscale_(optimizer) first (gradient clipping), then step."""
+    import warnings
+    from apex.optimizers import FusedAdam
+    torch.manual_seed(4)
+    ref = [torch.nn.Parameter(torch.randn(512, 4, device="cuda")), torch.nn.Parameter(torch.randn(64, device="cuda"))]
+    mine = [torch.nn.Parameter(p.detach().clone()) for p in ref]
+    o_ref, o_mine = torch.optim.Adam(ref, 1e-2, eps=1e-15), FusedAdam(mine, lr=1e-2, eps=1e-15)
+    s_ref, s_mine = torch.amp.GradScaler("cuda", init_scale=2.0**12, growth_interval=5), torch.amp.GradScaler("cuda", init_scale=2.0**12, growth_interval=5)
+    calls = []
+    orig = s_mine._check_inf_per_device
+    s_mine._check_inf_per_device = lambda opt: (calls.append(1), orig(opt))[1]
+    g = torch.Generator(device="cuda").manual_seed(6)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", FutureWarning)            # torch's notice that the keyword will go away one day
+        for step in range(24):
+            tgt = [torch.randn_like(p, generator=None) if False else torch.randn(p.shape, device="cuda", generator=g) for p in ref]
+            blow = float("nan") if step in (6, 15) else 1.0
+            for params, opt, scaler in ((ref, o_ref, s_ref), (mine, o_mine, s_mine)):
+                loss = sum(((p - t) ** 2).mean() for p, t in zip(params, tgt)) * blow
+                opt.zero_grad()
+                scaler.scale(loss).backward()
+                if step % 2:                                       # every other step: unscale first, as a clipping loop would
+                    scaler.unscale_(opt)
+                scaler.step(opt)
+                scaler.update()
+    assert len(calls) == 0                                         # torch's own check pass never ran for the compat optimizer
+    assert s_ref.get_scale() == s_mine.get_scale()
+    for a, b in zip(ref, mine):
+        torch.testing.assert_close(b, a, rtol=2e-5, atol=2e-6)
+    assert int(o_mine._si[0][5]) == 2 and int(o_mine._si[0][1]) == 22
+
+
 def test_fused_adam_without_scaler_and_rejects_unsupported(hip_lib):
     from apex.optimizers import FusedAdam
     p = torch.nn.Parameter(torch.randn(256, device="cuda"))

@@ -56,7 +56,8 @@ def test_bench_configs_array(hip_lib):
         assert c["value"] > 0 and c["ms_per_step"] > 0, c
         assert abs(c["value"] - c["rays_per_gpu"] / (c["ms_per_step"] * 1e-3)) / c["value"] < 1e-6
         if c["name"] == "C2-modules-path":         # the reference-surface loop (modules + torch optimizer) in every line
-            assert c["path"] == "modules+torch.optim" and c["rm_samples_per_ray"] > 0
+            # (the optimizer train.py:143-156 would pick: compat/apex FusedAdam when importable, torch.optim.Adam otherwise)
+            assert c["path"].startswith("modules + ") and "Adam" in c["path"] and c["rm_samples_per_ray"] > 0
         else:
             assert c["path"].startswith("FusedTrainer") and 0 < c["frac"] <= 1.0 and c["dominant_kernel"], c
     # round 5: the headline carries its per-live-sample cost at the top level (the driver keeps top-level keys)
