@@ -619,7 +619,12 @@ def _measure(args, ctx, brief):
         k = state["k"]
         if log and k % STAT_EVERY == 0 and k // STAT_EVERY < stat_log.shape[0]:
             stat_log[k // STAT_EVERY, 0].copy_(out["rm_samples"][0])
-            vr_log[k // STAT_EVERY, 0] = out["vr_per_ray"].sum()
+            if trainer.live_backward:
+                # the live samples ARE the composited ones (the first vr[r] samples of every ray): their count is on the device already --
+                # no reduction kernel + copy on the step's stream for a number the line only reports
+                vr_log[k // STAT_EVERY, 0].copy_(trainer._live_total[0])
+            else:
+                vr_log[k // STAT_EVERY, 0] = out["vr_per_ray"].sum()
             live_log[k // STAT_EVERY, 0].copy_(trainer._live_total[0])
         state["k"] = k + 1
 
@@ -888,8 +893,8 @@ def _measure(args, ctx, brief):
         # which records the workload state it was taken in); it is attached only if that state matches this run within 15 %
         # (two runs of the same command end their conditioning 5-12 % apart in live samples per step: float-atomic order in the
         # MLP weight gradients), otherwise traffic stays null -- a counter value from another state says nothing about this one
-        pmc_path = next((q for q in (os.path.join(ROOT, "profiles", f) for f in ("r04_pmc.json", "r03_pmc.json", "r02_pmc.json")) if os.path.exists(q)),
-                        os.path.join(ROOT, "profiles", "r04_pmc.json"))
+        pmc_path = next((q for q in (os.path.join(ROOT, "profiles", f) for f in ("r05_pmc.json", "r04_pmc.json", "r03_pmc.json", "r02_pmc.json")) if os.path.exists(q)),
+                        os.path.join(ROOT, "profiles", "r05_pmc.json"))
         pmc_name = "profiles/" + os.path.basename(pmc_path)
         traffic_src = None
         if "march_count" in rooflines and use_trainer and args.prefetch and not args.graph:

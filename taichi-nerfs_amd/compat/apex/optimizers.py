@@ -36,6 +36,15 @@ class FusedAdam(torch.optim.Optimizer):
         self._multi = {}                     # group index -> (parameter identities, ctypes pointer / count arrays)
         self._found = {}                     # device -> float32 [1]: this optimizer's own inf flag (step(grad_scaler=...))
         self._pending = []
+        # GradScaler.step() looks for the `grad_scaler` keyword with inspect.signature(optimizer.step) on EVERY call (~35 us of
+        # Python through torch's hook wrapper around step); a function that carries __signature__ answers from it
+        step_fn = type(self).step
+        if not hasattr(step_fn, "__signature__"):
+            try:
+                import inspect
+                step_fn.__signature__ = inspect.signature(step_fn)
+            except (TypeError, ValueError, AttributeError):
+                pass
 
     def zero_grad(self, set_to_none=None):
         return super().zero_grad(self.set_grad_none if set_to_none is None else set_to_none)
