@@ -45,6 +45,7 @@ def main():
     torch.manual_seed(23)
     model = NGP(scale=0.5, max_res=1024).to(dev)
     tr = FusedTrainer(model, lr=1e-2, max_steps=20000)
+    tr._adaptive_prefetch = False            # this script sets position / shape / stream itself
     pool = []
     for b in range(16):
         o, d = synthetic.lego_rays(args.rays, seed=1000 + 97 * b)
@@ -53,8 +54,8 @@ def main():
     thr = 0.01 * 1024 / 3**0.5
     # the two side streams a configuration picks from
     side_def = torch.cuda.Stream(device=dev)
-    if tr._side_prio is not None:
-        side_low = tr._side
+    if tr._side_low is not None:
+        side_low = tr._side_low
     else:
         h, lo, hi = ctypes.c_void_p(), ctypes.c_int(), ctypes.c_int()
         check(L.ngp_stream_create_low_priority(ctypes.byref(h), ctypes.byref(lo), ctypes.byref(hi)), "ngp_stream_create_low_priority")

@@ -35,6 +35,7 @@ _SI_ITER, _SI_OPT_STEP, _SI_FOUND_INF, _SI_SKIPPED = 0, 1, 3, 5
 
 
 class FusedTrainer:
+    _MARCH_NARROW_MAX = 1_000_000          # marched samples per step up to which the prefetched march goes to the start of the step
 
     def __init__(self, model, lr=1e-2, betas=(0.9, 0.999), eps=1e-15, max_steps=20000, eta_min=None, init_scale=2.0**19,
                  growth_factor=2.0, backoff_factor=0.5, growth_interval=2000, exp_step_factor=0.0, T_threshold=1e-4,
@@ -184,14 +185,31 @@ class FusedTrainer:
         # (C3 shape -- six cascades, exponential stepping -- is the other way round: the march is 1.3 ms of ALU work and the scatter-add
         # 2.3 ms, so round 4's arrangement, 16-wave blocks at low priority under the scatter-add, hides it best: 13.5 M rays/s against
         # 12.4 at the start of the step, profiles/r05_bench_garden_c3_march_placement.txt.)
+        # Which of the two is right depends on how heavy the march is, and that changes during a training run (a young model's occupancy
+        # grid is dense: 260 samples per ray; a trained one's is sparse: 45).  Measured on one box, same round: C2 (8192 rays, 376 k
+        # marched samples) 17.1 M rays/s with the narrow march at the start of the step against 16.6 under the scatter-add; the
+        # initialisation regime (2.1 M marched) 3.5 M against 4.0; 65 536 rays per step (2.8 M marched) 20.9 against 21.9.  So the
+        # trainer ADAPTS: the side stream copies each prefetched march's sample count to pinned host memory (asynchronously: nothing
+        # waits for it) and the next hooks read whatever has arrived -- at most a few steps old.  Up to _MARCH_NARROW_MAX marched
+        # samples: start of the step, 4-wave blocks, default priority; above: before the scatter-add, 16-wave blocks, low priority.
+        # Any of NGP_PREFETCH_AT / NGP_MARCH_SHAPE / NGP_SIDE_PRIORITY pins the arrangement instead.
         self._one_gpu_flush = (self.world == 1 and not self.half and os.environ.get("NGP_FLUSH_ADAM", "1") != "0"
-                               and self.hash_bwd == "sliced" and not (float(exp_step_factor) > 0 or int(model.cascades) > 1))
+                               and self.hash_bwd == "sliced")
+        pinned = any(k in os.environ for k in ("NGP_PREFETCH_AT", "NGP_MARCH_SHAPE", "NGP_SIDE_PRIORITY"))
+        self._adaptive_prefetch = self._one_gpu_flush and not pinned
         self._side_prio = None
-        if os.environ.get("NGP_SIDE_PRIORITY", "default" if self._one_gpu_flush else "low") == "low":
+        self._side_default = self._side
+        self._side_low = None
+        if self._adaptive_prefetch or os.environ.get("NGP_SIDE_PRIORITY", "low") == "low":
             h, lo, hi = ctypes.c_void_p(), ctypes.c_int(), ctypes.c_int()
             check(self.L.ngp_stream_create_low_priority(ctypes.byref(h), ctypes.byref(lo), ctypes.byref(hi)), "ngp_stream_create_low_priority")
-            self._side = torch.cuda.ExternalStream(h.value, device=dev)
+            self._side_low = torch.cuda.ExternalStream(h.value, device=dev)
             self._side_prio = (lo.value, hi.value)
+            self._side = self._side_low
+        self._hook_at = 3
+        self._marched_host = None              # pinned [1] int32: sample count of a recent prefetched march (adaptive placement)
+        if self._adaptive_prefetch:
+            self._marched_host = torch.full((1,), 1 << 30, dtype=torch.int32).pin_memory()      # (unknown yet: assume a young, dense model)
         self._ev_start = self._DevEvent(self.L)              # main stream -> side stream: the prefetch may start
         self.prefetch_hits = 0                # steps that consumed a march prefetched by the previous step() call
         # where in the step the next batch's march is put on the side stream: 0 = at the start, 1 = after the hash gather
@@ -206,13 +224,13 @@ class FusedTrainer:
         import os as _os
         # (with world > 1 the default is 4: the march then runs underneath the gradient exchange -- RCCL's kernels occupy a few
         # workgroups and wait on xGMI -- instead of competing with the VALU-bound kernels of the step for issue slots)
-        self._prefetch_at = int(_os.environ.get("NGP_PREFETCH_AT", "0" if self._one_gpu_flush else ("3" if self.world == 1 else "4")))
+        self._prefetch_at = int(_os.environ.get("NGP_PREFETCH_AT", "3" if self.world == 1 else "4"))
         # Round 5: the SHAPE of the prefetched launch (ngp_march_train_fused_shaped): "waves per block, idle LDS bytes per block",
         # e.g. "4,82944" = 4-wave blocks, at most one per CU.  With the table's optimizer inside the scatter-add there is no
         # HBM-bound launch left to hide a 16-wave-per-CU march under; a narrow march asks every CU for one wave slot per SIMD and
-        # runs beside whatever the step is doing.  Default "4,0" on one GPU with the optimizer in the flush, else (and "16,0") the
-        # 16-wave block every other march launch uses.
-        shape = _os.environ.get("NGP_MARCH_SHAPE", "4,0" if self._one_gpu_flush else "")
+        # runs beside whatever the step is doing.  Unset (and "16,0"): the 16-wave block every other march launch uses -- except
+        # that on one GPU with the optimizer in the flush the trainer chooses per step (see _adaptive_prefetch above).
+        shape = _os.environ.get("NGP_MARCH_SHAPE", "")
         self._march_shape = tuple(int(x) for x in shape.split(",")) if shape and shape != "16,0" else None
         self._coarse_ver = None
         self.sync_occupancy = True            # world > 1: broadcast rank 0's occupancy after every update_density_grid()
@@ -435,19 +453,29 @@ class FusedTrainer:
             # underneath this step's kernels.
             nxt = sets[1 - self._cur]
 
+            at, shape, side = self._prefetch_at, self._march_shape, self._side
+            if self._adaptive_prefetch:
+                if int(self._marched_host[0]) <= self._MARCH_NARROW_MAX:
+                    at, shape, side = 0, (4, 0), self._side_default
+                else:
+                    at, shape, side = 3, None, self._side_low
+            self._hook_at = at
+
             def hook():
                 start = self._ev_start
                 start.record(torch.cuda.current_stream())                   # everything that still reads `nxt` is before this
-                with torch.cuda.stream(self._side):
-                    start.wait(self._side)
+                with torch.cuda.stream(side):
+                    start.wait(side)
                     if nxt.ready is not None:
-                        nxt.ready.wait(self._side)                          # an unconsumed earlier prefetch into the same set
-                    self._march(nxt, prefetch[0], prefetch[1], cfg, A, shape=self._march_shape)
+                        nxt.ready.wait(side)                                # an unconsumed earlier prefetch into the same set
+                    self._march(nxt, prefetch[0], prefetch[1], cfg, A, shape=shape)
                     nxt.ready = nxt.ev_ready
-                    nxt.ready.record(self._side)
+                    nxt.ready.record(side)
+                    if self._marched_host is not None:
+                        self._marched_host.copy_(nxt.total, non_blocking=True)   # behind the march, on the side stream: nobody waits
                 nxt.src = None if src_next is None else (src_next[0], src_next[1], src_next[0]._version, src_next[1]._version)
                 nxt.held = prefetch          # (possibly temporaries of step()): alive until the set is consumed or re-marched
-            if self._prefetch_at == 0 or self._graph is not None:
+            if at == 0 or self._graph is not None:
                 hook(); hook = None
         # The fused live list relies on the counter of this step's parity being 0 at launch (the composite kernel of the PREVIOUS
         # step cleared it).  A step that raised after the flip below never ran that kernel: if the last launch did not complete,
@@ -559,7 +587,7 @@ class FusedTrainer:
         reduce_in_prologue = single and not reduce_in_scatter
         if n_parts > 0 and not single:
             check(L.ngp_mlp_dw_reduce(_ptr(self.mlp_parts), n_parts, _ptr(self.mlp_grad), st), "ngp_mlp_dw_reduce")
-        if hook is not None and self._prefetch_at <= 3:
+        if hook is not None and self._hook_at <= 3:
             hook(); hook = None                                             # position 3: under the scatter-add and the optimizer
         if reduce_in_scatter and self._flush_adam:
             npre = self._adam_prefix.get(det)
@@ -646,11 +674,11 @@ class FusedTrainer:
         else:
             check(L.ngp_hash_fwd_f32_ex(_ptr(M.xyzs), _ptr(self.table), ctypes.byref(cfg.levels), A.cap, _ptr(total), 1, cfg.lo,
                                         cfg.hi, P, _ptr(A.enc), st), "ngp_hash_fwd_f32_ex")
-        if hook is not None and self._prefetch_at == 1:
+        if hook is not None and self._hook_at == 1:
             hook(); hook = None
         check(L.ngp_mlp_fwd_ex(_ptr(A.enc), _ptr(M.dirs), _ptr(self.wpack), A.cap, _ptr(total), P, _ptr(A.sigmas), _ptr(A.rgbs), st),
               "ngp_mlp_fwd_ex")
-        if hook is not None and self._prefetch_at == 2:
+        if hook is not None and self._hook_at == 2:
             hook(); hook = None
         return hook
 
@@ -680,11 +708,11 @@ class FusedTrainer:
                 self.chunked = False
                 return False, hook
             check(rc, "ngp_hash_fwd_list")
-            if r == 0 and hook is not None and self._prefetch_at == 1:
+            if r == 0 and hook is not None and self._hook_at == 1:
                 hook(); hook = None
             check(L.ngp_mlp_fwd_list(_ptr(A.enc), _ptr(M.dirs), _ptr(self.wpack), A.cap, cnt, _ptr(lst), P, _ptr(A.sigmas),
                                      _ptr(A.rgbs), st), "ngp_mlp_fwd_list")
-        if hook is not None and self._prefetch_at == 2:
+        if hook is not None and self._hook_at == 2:
             hook(); hook = None
         return True, hook
 
@@ -1067,7 +1095,7 @@ class FusedTrainer:
     def close(self):
         """Release what the trainer holds outside torch's allocator: the low-priority side stream (ngp_stream_create_low_priority).
         Idempotent; also called when the trainer is garbage-collected."""
-        side, self._side = getattr(self, "_side", None), None
+        side, self._side, self._side_low = getattr(self, "_side_low", None), None, None
         if side is not None and getattr(self, "_side_prio", None) is not None:
             try:
                 side.synchronize()
