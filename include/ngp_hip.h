@@ -383,6 +383,12 @@ int ngp_event_destroy(void* event);
  * own kernels leave free); *least / *greatest (nullable) = hipDeviceGetStreamPriorityRange. */
 int ngp_stream_create_low_priority(void** stream, int* least, int* greatest);
 int ngp_stream_destroy(void* stream);
+/* Pinned host memory + an asynchronous device-to-host copy on a stream of the caller's choice: a word the device reports into
+ * without anybody waiting for it (FusedTrainer: the sample count of each prefetched march, read by later steps to place the next
+ * one).  The caller frees the memory after synchronising the streams it copied on. */
+int ngp_host_alloc(void** host, long long bytes);
+int ngp_host_free(void* host);
+int ngp_copy_to_host_async(void* host, const void* dev, long long bytes, void* stream);
 
 /* ---- f-2  device-resident optimisation-step epilogue (reference train.py:193-201: mse_loss, GradScaler,
  * Adam(eps=1e-15), CosineAnnealingLR, zero_grad) -- see csrc/optim.hip.

@@ -182,6 +182,20 @@ int ngp_stream_create_low_priority(void** stream, int* lo, int* hi) {
 }
 int ngp_stream_destroy(void* stream) { return hipStreamDestroy((hipStream_t)stream) == hipSuccess ? 0 : -1; }
 
+// A host-visible word the device can report into without anybody waiting: pinned host memory owned by the caller through this
+// pair, and an asynchronous device-to-host copy on a stream of the caller's choice (FusedTrainer's side stream reports each
+// prefetched march's sample count this way; the host reads whatever has arrived).  Deliberately not torch's pinned tensors:
+// its caching host allocator records events on the copy's stream and would touch that stream again after ngp_stream_destroy.
+int ngp_host_alloc(void** host, long long bytes) {
+    if (!host || bytes <= 0) return -1;
+    return hipHostMalloc(host, (size_t)bytes, hipHostMallocDefault) == hipSuccess ? 0 : -1;
+}
+int ngp_host_free(void* host) { return hipHostFree(host) == hipSuccess ? 0 : -1; }
+int ngp_copy_to_host_async(void* host, const void* dev, long long bytes, void* stream) {
+    if (!host || !dev || bytes <= 0) return -1;
+    return hipMemcpyAsync(host, dev, (size_t)bytes, hipMemcpyDeviceToHost, (hipStream_t)stream) == hipSuccess ? 0 : -1;
+}
+
 int ngp_train_prologue(float* state_f, int32_t* state_i, float lr0, float eta_min, int t_max, float beta1, float beta2,
                        float growth, float backoff, int growth_interval, void* stream) {
     hipLaunchKernelGGL(train_prologue_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state_f, state_i, lr0, eta_min, t_max,

@@ -155,6 +155,9 @@ SIGNATURES = {
     "ngp_event_destroy": [_P],
     "ngp_stream_create_low_priority": [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)],
     "ngp_stream_destroy": [_P],
+    "ngp_host_alloc": [_P, ctypes.c_longlong],
+    "ngp_host_free": [_P],
+    "ngp_copy_to_host_async": [_P, _P, ctypes.c_longlong, _P],
     "ngp_train_prologue": [_P, _P, _F, _F, _I, _F, _F, _F, _F, _I, _P],
     "ngp_train_prologue_reduce": [_P, _P, _F, _F, _I, _F, _F, _F, _F, _I, _P, _I, _P, _P],
     "ngp_adam_amp_prologue": [_P, _P, _P, _P, _F, _F, _F, _P],

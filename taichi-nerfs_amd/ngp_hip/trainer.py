@@ -207,9 +207,12 @@ class FusedTrainer:
             self._side_prio = (lo.value, hi.value)
             self._side = self._side_low
         self._hook_at = 3
-        self._marched_host = None              # pinned [1] int32: sample count of a recent prefetched march (adaptive placement)
+        self._marched_host = None              # pinned host int32 (ngp_host_alloc): sample count of a recent prefetched march
         if self._adaptive_prefetch:
-            self._marched_host = torch.full((1,), 1 << 30, dtype=torch.int32).pin_memory()      # (unknown yet: assume a young, dense model)
+            h = ctypes.c_void_p()
+            check(self.L.ngp_host_alloc(ctypes.byref(h), 64), "ngp_host_alloc")
+            self._marched_host = h
+            ctypes.c_int32.from_address(h.value).value = 1 << 30          # (unknown yet: assume a young, dense model)
         self._ev_start = self._DevEvent(self.L)              # main stream -> side stream: the prefetch may start
         self.prefetch_hits = 0                # steps that consumed a march prefetched by the previous step() call
         # where in the step the next batch's march is put on the side stream: 0 = at the start, 1 = after the hash gather
@@ -455,7 +458,7 @@ class FusedTrainer:
 
             at, shape, side = self._prefetch_at, self._march_shape, self._side
             if self._adaptive_prefetch:
-                if int(self._marched_host[0]) <= self._MARCH_NARROW_MAX:
+                if ctypes.c_int32.from_address(self._marched_host.value).value <= self._MARCH_NARROW_MAX:
                     at, shape, side = 0, (4, 0), self._side_default
                 else:
                     at, shape, side = 3, None, self._side_low
@@ -471,8 +474,9 @@ class FusedTrainer:
                     self._march(nxt, prefetch[0], prefetch[1], cfg, A, shape=shape)
                     nxt.ready = nxt.ev_ready
                     nxt.ready.record(side)
-                    if self._marched_host is not None:
-                        self._marched_host.copy_(nxt.total, non_blocking=True)   # behind the march, on the side stream: nobody waits
+                    if self._marched_host is not None:                    # behind the march, on the side stream: nobody waits
+                        check(self.L.ngp_copy_to_host_async(self._marched_host, _ptr(nxt.total), 4, ctypes.c_void_p(side.cuda_stream)),
+                              "ngp_copy_to_host_async")
                 nxt.src = None if src_next is None else (src_next[0], src_next[1], src_next[0]._version, src_next[1]._version)
                 nxt.held = prefetch          # (possibly temporaries of step()): alive until the set is consumed or re-marched
             if at == 0 or self._graph is not None:
@@ -1096,6 +1100,17 @@ class FusedTrainer:
         """Release what the trainer holds outside torch's allocator: the low-priority side stream (ngp_stream_create_low_priority).
         Idempotent; also called when the trainer is garbage-collected."""
         side, self._side, self._side_low = getattr(self, "_side_low", None), None, None
+        host, self._marched_host = getattr(self, "_marched_host", None), None
+        dflt, self._side_default = getattr(self, "_side_default", None), None
+        if host is not None:                  # no copy into it may be in flight when it goes
+            try:
+                for s_ in (side, dflt):
+                    if s_ is not None:
+                        s_.synchronize()
+                self.L.ngp_host_free(host)
+            except Exception:
+                pass
+        self._adaptive_prefetch = False
         if side is not None and getattr(self, "_side_prio", None) is not None:
             try:
                 side.synchronize()
