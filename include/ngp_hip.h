@@ -390,6 +390,35 @@ int ngp_host_alloc(void** host, long long bytes);
 int ngp_host_free(void* host);
 int ngp_copy_to_host_async(void* host, const void* dev, long long bytes, void* stream);
 
+/* ---- the fused training render as ONE entry per direction (round 5; replaces the launch sequence of reference
+ * modules/rendering.py:161-228 + modules/networks.py:152-166 and their autograd backward for one batch of rays).  The caller keeps
+ * one argument block per sample arena and patches the per-call pointers; every buffer is caller-owned device memory.
+ * _fwd: [coarse occupancy table when rebuild_coarse] -> ngp_march_train_fused -> ngp_hash_fwd_{f32,bf16,f16}_ex -> ngp_mlp_pack ->
+ *       ngp_mlp_fwd_ex -> ngp_composite_train_fwd.
+ * _bwd: ngp_composite_train_bwd -> ngp_live_compact -> ngp_mlp_bwd_live -> ngp_hash_bwd_f32_sliced into dW / dtable, which the caller
+ *       hands over CLEARED (or the
+ *       float-atomic kernel when the level table does not fit it / force_atomic; table_kind 2: the half2 encoder's fp16 forms).
+ * Same kernels, same results as the individual entry points in that order (tests/test_gpu_fused.py). */
+typedef struct ngp_render_args {
+    const float* rays_o; const float* rays_d; const float* hits_t /*nullable: slab test inline*/; const float* noise /*[n_rays] jitter*/;
+    int32_t n_rays, max_samples;
+    const uint8_t* bitfield; uint32_t* coarse; int32_t rebuild_coarse, cascades, grid_size;
+    float scale, exp_step_factor, T_threshold;
+    const void* table; int32_t table_kind /*0 fp32, 1 bf16 copy, 2 f16 copy (half2 encoder)*/, enc_pairs;
+    const ngp_hash_levels* levels; float lo, hi;
+    const float* w[5]; uint16_t* wpack;
+    long long cap;                                   /* rows of the per-sample buffers below (n_rays * max_samples) */
+    float* stage; int32_t* march_ctr; float* xyzs; float* dirs; float* deltas; float* ts; float* enc; float* sigmas; uint16_t* rgbs; float* ws;
+    int32_t* rays_a; int32_t* total; int32_t* vr_per_ray; float* opacity; float* depth; float* rgb;          /* per-ray outputs */
+    const float* g_opacity; const float* g_depth; const float* g_rgb; const float* g_ws;                    /* backward: nullable but g_rgb */
+    float* d_sigmas; uint16_t* d_rgbs; float* d_enc; int32_t* live_off; int32_t* live_idx; int32_t* live_total;
+    void* workspace; long long workspace_bytes;      /* ngp_hash_bwd_sliced_workspace(levels, cap) bytes */
+    int32_t force_atomic, reserved;
+    float* dW /*[9408], cleared by the caller*/; void* dtable /*f32 [entries * 2]; table_kind 2: f16; cleared by the caller*/; long long dtable_bytes;
+} ngp_render_args;
+int ngp_render_train_fwd(const ngp_render_args* args, void* stream);
+int ngp_render_train_bwd(const ngp_render_args* args, void* stream);
+
 /* ---- f-2  device-resident optimisation-step epilogue (reference train.py:193-201: mse_loss, GradScaler,
  * Adam(eps=1e-15), CosineAnnealingLR, zero_grad) -- see csrc/optim.hip.
  * state_f[8] f32: [0] loss scale, [1] 1/scale of this step, [2] lr, [3] 1-beta1^t, [4] sqrt(1-beta2^t), [5] last loss

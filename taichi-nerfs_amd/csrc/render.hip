@@ -1,0 +1,68 @@
+// render.hip -- the fused training render of ngp_hip/fused.py as ONE C entry per direction (round 5).
+//
+// Replaces, for modules.rendering.render (train path, reference rendering.py:161-228 + networks.py:152-166), the ~9 ctypes launches and
+// ~90 pointer marshals per step of the Python autograd node: the forward entry issues [coarse occupancy table] -> one-launch march ->
+// hash-grid encode -> MFMA weight repack -> fused MLP forward -> compositing forward, the backward entry compositing backward ->
+// live-sample list -> fused MLP backward -> LDS-sliced scatter-add (float-atomic kernel where the level table does not fit it), on one
+// stream, through the same extern "C" entry points the operator path uses.  No new arithmetic lives here: only the launch sequence.
+// The argument block is a plain C struct (include/ngp_hip.h: ngp_render_args) the caller keeps per sample arena and patches per call.
+#include "ngp_device.h"
+#include "../../include/ngp_hip.h"
+
+extern "C" {
+
+int ngp_render_train_fwd(const ngp_render_args* a, void* stream) {
+    if (!a || a->n_rays <= 0 || !a->levels) return -1;
+    int rc = 0;
+    if (a->rebuild_coarse && a->coarse)
+        if ((rc = ngp_bitfield_coarsen(a->bitfield, a->cascades, a->grid_size, a->coarse, stream)) != 0) return rc;
+    if ((rc = ngp_march_train_fused(a->rays_o, a->rays_d, a->hits_t, a->bitfield, a->coarse, a->noise, a->cascades, a->grid_size, a->scale,
+                                    a->exp_step_factor, a->max_samples, a->n_rays, a->stage, a->march_ctr, a->rays_a, a->total, a->xyzs,
+                                    a->dirs, a->deltas, a->ts, stream)) != 0) return rc;
+    const int cap = (int)a->cap;
+    if (a->table_kind == 2)
+        rc = ngp_hash_fwd_f16_ex(a->xyzs, (const uint16_t*)a->table, a->levels, cap, a->total, 1, a->lo, a->hi, a->enc_pairs, a->enc, stream);
+    else if (a->table_kind == 1)
+        rc = ngp_hash_fwd_bf16_ex(a->xyzs, (const uint16_t*)a->table, a->levels, cap, a->total, 1, a->lo, a->hi, a->enc_pairs, a->enc, stream);
+    else
+        rc = ngp_hash_fwd_f32_ex(a->xyzs, (const float*)a->table, a->levels, cap, a->total, 1, a->lo, a->hi, a->enc_pairs, a->enc, stream);
+    if (rc != 0) return rc;
+    if ((rc = ngp_mlp_pack(a->w[0], a->w[1], a->w[2], a->w[3], a->w[4], a->enc_pairs, a->wpack, stream)) != 0) return rc;
+    if ((rc = ngp_mlp_fwd_ex(a->enc, a->dirs, a->wpack, cap, a->total, a->enc_pairs, a->sigmas, a->rgbs, stream)) != 0) return rc;
+    return ngp_composite_train_fwd(a->sigmas, a->rgbs, 1, a->deltas, a->ts, a->rays_a, a->T_threshold, a->n_rays, a->vr_per_ray, a->opacity,
+                                   a->depth, a->rgb, a->ws, stream);
+}
+
+// dW [9408] and dtable are ACCUMULATED into: the caller hands them over cleared (torch.zeros: a cached allocation + one fill kernel;
+// two hipMemsetAsync calls in here cost the host ~15 us each -- measured, profiles/r05_train_py_cprofile.txt -- more than the
+// consolidation of the launches saves).
+int ngp_render_train_bwd(const ngp_render_args* a, void* stream) {
+    if (!a || a->n_rays <= 0 || !a->levels || !a->dW || !a->dtable || !a->live_idx || !a->live_total || !a->live_off) return -1;
+    int rc = 0;
+    if ((rc = ngp_composite_train_bwd(a->g_opacity, a->g_depth, a->g_rgb, a->g_ws, a->sigmas, a->rgbs, 1, a->deltas, a->ts, a->rays_a,
+                                      a->opacity, a->depth, a->rgb, a->ws, a->T_threshold, a->n_rays, a->d_sigmas, a->d_rgbs, stream)) != 0)
+        return rc;
+    if ((rc = ngp_live_compact(a->rays_a, a->vr_per_ray, a->n_rays, a->live_off, a->live_idx, a->live_total, stream)) != 0) return rc;
+    const int cap = (int)a->cap;
+    if ((rc = ngp_mlp_bwd_live(a->enc, a->dirs, a->wpack, a->d_sigmas, a->d_rgbs, cap, a->live_total, a->live_idx, a->enc_pairs, a->d_enc,
+                               a->dW, nullptr, stream)) != 0) return rc;
+    if (a->table_kind == 2) {
+        // half2 encoder: the scatter-add with the encoder's fp16 arithmetic into an fp16 gradient table (hash_encoder_half.py:300-306)
+        rc = a->force_atomic ? -2 : ngp_hash_bwd_sliced_prep(a->xyzs, a->levels, cap, a->live_total, a->live_idx, 1, a->lo, a->hi, a->workspace,
+                                                             a->workspace_bytes, stream);
+        if (rc == -2)
+            return ngp_hash_bwd_f16_live(a->xyzs, a->d_enc, a->levels, cap, a->live_total, a->live_idx, 1, a->lo, a->hi, a->enc_pairs,
+                                         (uint16_t*)a->dtable, nullptr, stream);
+        if (rc != 0) return rc;
+        return ngp_hash_bwd_sliced_main_f16(a->d_enc, a->levels, cap, a->live_total, a->enc_pairs, (uint16_t*)a->dtable, nullptr, a->workspace,
+                                            a->workspace_bytes, stream);
+    }
+    rc = a->force_atomic ? -2 : ngp_hash_bwd_f32_sliced(a->xyzs, a->d_enc, a->levels, cap, a->live_total, a->live_idx, 1, a->lo, a->hi,
+                                                        a->enc_pairs, (float*)a->dtable, nullptr, a->workspace, a->workspace_bytes, stream);
+    if (rc == -2)            // level table not expressible as <= 64 LDS slices per level (or NGP_HASH_BWD=atomic)
+        rc = ngp_hash_bwd_f32_live(a->xyzs, a->d_enc, a->levels, cap, a->live_total, a->live_idx, 1, a->lo, a->hi, a->enc_pairs,
+                                   (float*)a->dtable, nullptr, stream);
+    return rc;
+}
+
+}  // extern "C"

@@ -44,12 +44,36 @@ class TrainArena:
         self.wpack = torch.empty(_lib_mod.load().ngp_mlp_wpack_halfs(), device=device, dtype=torch.float16)
         self._coarse = {}
         self._coarse_key = None            # (bitfield data_ptr, torch version) the coarse table was built from
+        self._args = None                  # ngp_render_args of this arena: static fields set once, per-call pointers patched
+        self._args_key = None
         self._scratch = {}
         self.live_idx = torch.empty(cap, device=device, dtype=torch.int32)     # compacted backward: indices of the live samples
         self._live_off = torch.empty(n_rays, device=device, dtype=torch.int32)
         # bumped by every FusedTrainRender.forward that overwrites the per-sample buffers; a backward whose forward is not the
         # latest one would silently differentiate the WRONG batch's activations, so it checks this stamp and raises instead
         self.generation = 0
+
+    def render_args(self, cfg):
+        """The argument block of ngp_render_train_fwd / _bwd for this arena and configuration: arena pointers and scalars are
+        written once, forward() / backward() patch what changes per call."""
+        key = (id(cfg), cfg.scale, cfg.cascades, cfg.grid_size, cfg.exp_step_factor, cfg.T_threshold, cfg.max_samples, cfg.enc_pairs)
+        if self._args is not None and self._args_key == key:
+            return self._args
+        a = _lib_mod.RenderArgs()
+        a.n_rays, a.max_samples, a.cap = self.n_rays, self.max_samples, self.cap
+        a.cascades, a.grid_size, a.scale, a.exp_step_factor, a.T_threshold = cfg.cascades, cfg.grid_size, cfg.scale, cfg.exp_step_factor, cfg.T_threshold
+        a.enc_pairs, a.lo, a.hi = cfg.enc_pairs, cfg.lo, cfg.hi
+        a.levels = ctypes.addressof(cfg.levels)
+        a.coarse = self.coarse_for(cfg).data_ptr()
+        for name in ("stage", "march_ctr", "xyzs", "dirs", "deltas", "ts", "enc", "sigmas", "rgbs", "ws", "d_sigmas", "d_rgbs", "d_enc",
+                     "live_idx", "wpack"):
+            setattr(a, name, getattr(self, name).data_ptr())
+        a.live_off = self._live_off.data_ptr()
+        ws = self.sliced_ws(cfg.levels)
+        a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+        a.force_atomic = 1 if os.environ.get("NGP_HASH_BWD", "sliced") == "atomic" else 0
+        self._args, self._args_key, self._args_cfg = a, key, cfg          # (cfg kept alive: a.levels points into it)
+        return a
 
     def sliced_ws(self, lv):
         """Scratch of the LDS-sliced scatter-add (compact positions + hit bitmaps for `cap` samples), allocated on first use.  Like
@@ -102,39 +126,32 @@ class FusedTrainRender(torch.autograd.Function):
         rays_a = torch.empty(n, 3, **i32)
         total = torch.empty(1, **i32)
         noise = torch.rand(n, **f32)                                            # ray_march.py:138
-        coarse = A.coarse_for(cfg)
-        # the 8^3-block shortcut table follows the bitfield: rebuilt when the bitfield tensor was written to (every writer moves its
-        # torch version counter -- in-place torch ops by themselves, the raw-pointer kernels through ops._touched), not every call
+        # ONE call for the whole launch sequence (csrc/render.hip: [coarse table] -> march -> encode -> weight repack -> MLP -> compositing)
+        # on a persistent argument block: the arena's pointers and the scalars were written when the block was made.
+        # The 8^3-block shortcut table follows the bitfield: rebuilt when the bitfield tensor was written to (every writer moves its
+        # torch version counter -- in-place torch ops by themselves, the raw-pointer kernels through ops._touched), not every call;
+        # hits_t None: the slab test of intersection.py:22-37 inside the march launch (same arithmetic).  The rays' ranges are packed in
+        # block-completion order (rays_a says where), like the reference's own atomic packing (ray_march.py:76-80).
+        a = A.render_args(cfg)
         key = (cfg.bitfield.data_ptr(), cfg.bitfield._version, cfg.cascades)
-        if A._coarse_key != key:
-            check(L.ngp_bitfield_coarsen(_ptr(cfg.bitfield), cfg.cascades, cfg.grid_size, _ptr(coarse), st), "ngp_bitfield_coarsen")
-            A._coarse_key = key
-        # the whole march in one launch (hits_t None: the slab test of intersection.py:22-37 inline, same arithmetic); the rays'
-        # ranges are packed in block-completion order (rays_a says where), like the reference's own atomic packing (ray_march.py:76-80)
-        check(L.ngp_march_train_fused(_ptr(rays_o), _ptr(rays_d), _ptr(hits_t), _ptr(cfg.bitfield), _ptr(coarse), _ptr(noise),
-                                      cfg.cascades, cfg.grid_size, cfg.scale, cfg.exp_step_factor, cfg.max_samples, n,
-                                      _ptr(A.stage), _ptr(A.march_ctr), _ptr(rays_a), _ptr(total), _ptr(A.xyzs), _ptr(A.dirs),
-                                      _ptr(A.deltas), _ptr(A.ts), st), "ngp_march_train_fused")
-        P = cfg.enc_pairs
-        if cfg.table_f16 is not None:            # the half2 encoder (NGP(half_opt=True), hash_encoder_half.py:218-368): f16 table, f16 arithmetic
-            check(L.ngp_hash_fwd_f16_ex(_ptr(A.xyzs), _ptr(cfg.table_f16), ctypes.byref(cfg.levels), A.cap, _ptr(total), 1, cfg.lo,
-                                        cfg.hi, P, _ptr(A.enc), st), "ngp_hash_fwd_f16_ex")
-        elif cfg.table_bf16 is not None:
-            check(L.ngp_hash_fwd_bf16_ex(_ptr(A.xyzs), _ptr(cfg.table_bf16), ctypes.byref(cfg.levels), A.cap, _ptr(total), 1, cfg.lo,
-                                         cfg.hi, P, _ptr(A.enc), st), "ngp_hash_fwd_bf16_ex")
-        else:
-            check(L.ngp_hash_fwd_f32_ex(_ptr(A.xyzs), _ptr(table), ctypes.byref(cfg.levels), A.cap, _ptr(total), 1, cfg.lo, cfg.hi, P,
-                                        _ptr(A.enc), st), "ngp_hash_fwd_f32_ex")
-        check(L.ngp_mlp_pack(_ptr(w1), _ptr(w2), _ptr(w3), _ptr(w4), _ptr(w5), P, _ptr(A.wpack), st), "ngp_mlp_pack")
-        check(L.ngp_mlp_fwd_ex(_ptr(A.enc), _ptr(A.dirs), _ptr(A.wpack), A.cap, _ptr(total), P, _ptr(A.sigmas), _ptr(A.rgbs), st),
-              "ngp_mlp_fwd_ex")
+        a.rebuild_coarse = 1 if A._coarse_key != key else 0
+        A._coarse_key = key
         vr_per_ray = torch.empty(n, **i32)
         opacity = torch.empty(n, **f32)
         depth = torch.empty(n, **f32)
         rgb = torch.empty(n, 3, **f32)
-        check(L.ngp_composite_train_fwd(_ptr(A.sigmas), _ptr(A.rgbs), 1, _ptr(A.deltas), _ptr(A.ts), _ptr(rays_a),
-                                        cfg.T_threshold, n, _ptr(vr_per_ray), _ptr(opacity), _ptr(depth), _ptr(rgb), _ptr(A.ws),
-                                        st), "ngp_composite_train_fwd")
+        a.rays_o, a.rays_d, a.hits_t, a.noise = rays_o.data_ptr(), rays_d.data_ptr(), (None if hits_t is None else hits_t.data_ptr()), noise.data_ptr()
+        a.bitfield = cfg.bitfield.data_ptr()
+        if cfg.table_f16 is not None:            # the half2 encoder (NGP(half_opt=True), hash_encoder_half.py:218-368): f16 table, f16 arithmetic
+            a.table, a.table_kind = cfg.table_f16.data_ptr(), 2
+        elif cfg.table_bf16 is not None:
+            a.table, a.table_kind = cfg.table_bf16.data_ptr(), 1
+        else:
+            a.table, a.table_kind = table.data_ptr(), 0
+        a.w[0], a.w[1], a.w[2], a.w[3], a.w[4] = w1.data_ptr(), w2.data_ptr(), w3.data_ptr(), w4.data_ptr(), w5.data_ptr()
+        a.rays_a, a.total, a.vr_per_ray = rays_a.data_ptr(), total.data_ptr(), vr_per_ray.data_ptr()
+        a.opacity, a.depth, a.rgb = opacity.data_ptr(), depth.data_ptr(), rgb.data_ptr()
+        check(L.ngp_render_train_fwd(ctypes.byref(a), st), "ngp_render_train_fwd")
         A.generation += 1
         ctx.cfg, ctx.arena, ctx.table_numel, ctx.table_shape, ctx.generation = cfg, A, table.numel(), table.shape, A.generation
         ctx.save_for_backward(rays_a, total, opacity, depth, rgb, vr_per_ray)
@@ -172,49 +189,28 @@ class FusedTrainRender(torch.autograd.Function):
         if cfg.bg != 0.0:                                                 # rgb_out = rgb + bg (1 - opacity): the blend's share of d opacity
             g_bg = g_rgb.sum(1) * (-cfg.bg)
             g_opacity = g_bg if g_opacity is None else g_opacity + g_bg
-        check(L.ngp_composite_train_bwd(_ptr(g_opacity), _ptr(g_depth), _ptr(g_rgb), _ptr(g_ws), _ptr(A.sigmas), _ptr(A.rgbs), 1,
-                                        _ptr(A.deltas), _ptr(A.ts), _ptr(rays_a), _ptr(opacity), _ptr(depth), _ptr(rgb),
-                                        _ptr(A.ws), cfg.T_threshold, n, _ptr(A.d_sigmas), _ptr(A.d_rgbs), st),
-              "ngp_composite_train_bwd")
+        # ONE call (csrc/render.hip): compositing backward -> live-sample list (the first vr_per_ray[r] samples of ray r: everything
+        # behind the early-termination point has exact-zero gradients) -> MLP backward over that list -> scatter-add in its
+        # LDS-sliced form (no global float atomics) when the level table fits it -- the same kernels FusedTrainer runs.  dW and the
+        # table gradient are accumulated into: cleared here.  half2 encoder: fp16 arithmetic into an fp16 gradient table (the reference's
+        # hash_grad, hash_encoder_half.py:300-306,350-352), handed to autograd widened to the fp32 parameter's dtype.
+        a = A.render_args(cfg)
+        half = cfg.table_f16 is not None
         dW = torch.zeros(MLP_N_WEIGHTS, device=dev, dtype=torch.float32)
-        P = cfg.enc_pairs
-        # backward over the LIVE samples only (the first vr_per_ray[r] of ray r: everything behind the early-termination point has
-        # exact-zero gradients), compacted into an index list; the scatter-add in its LDS-sliced form (no global float atomics)
-        # when the level table fits it -- the same kernels FusedTrainer runs
+        dtable = torch.zeros(ctx.table_numel, device=dev, dtype=torch.float16 if half else torch.float32)
         live_total = torch.empty(1, device=dev, dtype=torch.int32)
-        check(L.ngp_live_compact(_ptr(rays_a), _ptr(vr_per_ray), n, _ptr(A.live_off(n)), _ptr(A.live_idx), _ptr(live_total), st),
-              "ngp_live_compact")
-        check(L.ngp_mlp_bwd_live(_ptr(A.enc), _ptr(A.dirs), _ptr(A.wpack), _ptr(A.d_sigmas), _ptr(A.d_rgbs), A.cap, _ptr(live_total),
-                                 _ptr(A.live_idx), P, _ptr(A.d_enc), _ptr(dW), _ptr(None), st), "ngp_mlp_bwd_live")
-        if cfg.table_f16 is not None:
-            # half2 encoder: the scatter-add with the encoder's fp16 arithmetic into an fp16 gradient table (the reference's
-            # hash_grad, hash_encoder_half.py:300-306,350-352), handed to autograd widened to the fp32 parameter's dtype
-            grad_h = torch.zeros(ctx.table_numel, device=dev, dtype=torch.float16)
-            ws = A.sliced_ws(cfg.levels)
-            rc = L.ngp_hash_bwd_sliced_prep(_ptr(A.xyzs), ctypes.byref(cfg.levels), A.cap, _ptr(live_total), _ptr(A.live_idx), 1, cfg.lo,
-                                            cfg.hi, _ptr(ws), ws.numel(), st)
-            if rc == -2 or os.environ.get("NGP_HASH_BWD", "sliced") == "atomic":
-                check(L.ngp_hash_bwd_f16_live(_ptr(A.xyzs), _ptr(A.d_enc), ctypes.byref(cfg.levels), A.cap, _ptr(live_total),
-                                              _ptr(A.live_idx), 1, cfg.lo, cfg.hi, P, _ptr(grad_h), _ptr(None), st), "ngp_hash_bwd_f16_live")
-            else:
-                check(rc, "ngp_hash_bwd_sliced_prep")
-                check(L.ngp_hash_bwd_sliced_main_f16(_ptr(A.d_enc), ctypes.byref(cfg.levels), A.cap, _ptr(live_total), P, _ptr(grad_h),
-                                                     _ptr(None), _ptr(ws), ws.numel(), st), "ngp_hash_bwd_sliced_main_f16")
-            grads = [g.view(shape) for g, shape in zip(dW.split(MLP_SPLITS), MLP_SHAPES)]
-            return (None, None, None, grad_h.float().view(ctx.table_shape), *grads, None)
-        dtable = torch.zeros(ctx.table_numel, device=dev, dtype=torch.float32)
-        rc = -2
-        if os.environ.get("NGP_HASH_BWD", "sliced") != "atomic":
-            ws = A.sliced_ws(cfg.levels)
-            rc = L.ngp_hash_bwd_f32_sliced(_ptr(A.xyzs), _ptr(A.d_enc), ctypes.byref(cfg.levels), A.cap, _ptr(live_total), _ptr(A.live_idx),
-                                           1, cfg.lo, cfg.hi, P, _ptr(dtable), _ptr(None), _ptr(ws), ws.numel(), st)
-        if rc == -2:                                                      # level table not expressible as <= 64 LDS slices per level
-            check(L.ngp_hash_bwd_f32_live(_ptr(A.xyzs), _ptr(A.d_enc), ctypes.byref(cfg.levels), A.cap, _ptr(live_total),
-                                          _ptr(A.live_idx), 1, cfg.lo, cfg.hi, P, _ptr(dtable), _ptr(None), st), "ngp_hash_bwd_f32_live")
-        else:
-            check(rc, "ngp_hash_bwd_f32_sliced")
+        a.table_kind = 2 if half else (1 if cfg.table_bf16 is not None else 0)
+        a.rays_a, a.vr_per_ray = rays_a.data_ptr(), vr_per_ray.data_ptr()
+        a.opacity, a.depth, a.rgb = opacity.data_ptr(), depth.data_ptr(), rgb.data_ptr()
+        a.g_opacity = None if g_opacity is None else g_opacity.data_ptr()
+        a.g_depth = None if g_depth is None else g_depth.data_ptr()
+        a.g_ws = None if g_ws is None else g_ws.data_ptr()
+        a.g_rgb = g_rgb.data_ptr()
+        a.live_total = live_total.data_ptr()
+        a.dW, a.dtable, a.dtable_bytes = dW.data_ptr(), dtable.data_ptr(), dtable.numel() * dtable.element_size()
+        check(L.ngp_render_train_bwd(ctypes.byref(a), st), "ngp_render_train_bwd")
         grads = [g.view(shape) for g, shape in zip(dW.split(MLP_SPLITS), MLP_SHAPES)]
-        return (None, None, None, dtable.view(ctx.table_shape), *grads, None)
+        return (None, None, None, (dtable.float() if half else dtable).view(ctx.table_shape), *grads, None)
 
 
 class RenderConfig:

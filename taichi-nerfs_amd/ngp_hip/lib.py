@@ -15,7 +15,8 @@ PKG_ROOT = os.path.dirname(_HERE)
 CSRC = os.path.join(PKG_ROOT, "csrc")
 INCLUDE = os.path.join(os.path.dirname(PKG_ROOT), "include")
 LIB_PATH = os.path.join(CSRC, "libngp_hip.so")
-SOURCES = ["march.hip", "hash_grid.hip", "hash_bwd_lds.hip", "composite.hip", "sh_grid.hip", "mlp.hip", "optim.hip", "distortion.hip", "occupancy.hip", "rays.hip"]
+SOURCES = ["march.hip", "hash_grid.hip", "hash_bwd_lds.hip", "composite.hip", "sh_grid.hip", "mlp.hip", "optim.hip", "distortion.hip", "occupancy.hip", "rays.hip",
+           "render.hip"]
 HEADERS = ["ngp_device.h", "hash_common.h"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
 FLAGS_STAMP = LIB_PATH + ".flags"      # the flags the in-tree .so was built with: a flag change rebuilds
@@ -35,6 +36,27 @@ class HashLevels(ctypes.Structure):
         ("map_size", ctypes.c_uint32 * NGP_MAX_LEVELS),
         ("offset", ctypes.c_uint32 * NGP_MAX_LEVELS),
     ]
+
+
+def _render_fields():
+    P, I, F, LL = ctypes.c_void_p, ctypes.c_int32, ctypes.c_float, ctypes.c_longlong
+    ptrs = lambda *names: [(k, P) for k in names]
+    return (ptrs("rays_o", "rays_d", "hits_t", "noise") + [("n_rays", I), ("max_samples", I)]
+            + ptrs("bitfield", "coarse") + [("rebuild_coarse", I), ("cascades", I), ("grid_size", I)]
+            + [("scale", F), ("exp_step_factor", F), ("T_threshold", F)]
+            + [("table", P), ("table_kind", I), ("enc_pairs", I), ("levels", P), ("lo", F), ("hi", F)]
+            + [("w", P * 5), ("wpack", P), ("cap", LL)]
+            + ptrs("stage", "march_ctr", "xyzs", "dirs", "deltas", "ts", "enc", "sigmas", "rgbs", "ws")
+            + ptrs("rays_a", "total", "vr_per_ray", "opacity", "depth", "rgb")
+            + ptrs("g_opacity", "g_depth", "g_rgb", "g_ws")
+            + ptrs("d_sigmas", "d_rgbs", "d_enc", "live_off", "live_idx", "live_total")
+            + [("workspace", P), ("workspace_bytes", LL), ("force_atomic", I), ("reserved", I)]
+            + [("dW", P), ("dtable", P), ("dtable_bytes", LL)])
+
+
+class RenderArgs(ctypes.Structure):
+    """Mirror of `ngp_render_args` (include/ngp_hip.h): the argument block of ngp_render_train_fwd / _bwd."""
+    _fields_ = _render_fields()
 
 
 def _sources():
@@ -155,6 +177,8 @@ SIGNATURES = {
     "ngp_event_destroy": [_P],
     "ngp_stream_create_low_priority": [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)],
     "ngp_stream_destroy": [_P],
+    "ngp_render_train_fwd": [_P, _P],
+    "ngp_render_train_bwd": [_P, _P],
     "ngp_host_alloc": [_P, ctypes.c_longlong],
     "ngp_host_free": [_P],
     "ngp_copy_to_host_async": [_P, _P, ctypes.c_longlong, _P],

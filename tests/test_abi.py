@@ -30,6 +30,23 @@ def test_struct_layout_matches_header():
     assert ctypes.sizeof(HashLevels) == 16 + 4 * 16 * 4
 
 
+def test_render_args_layout_matches_header(tmp_path):
+    """ngp_render_args (the argument block of ngp_render_train_fwd / _bwd): the ctypes mirror has the C compiler's layout -- every field
+    at the offset gcc gives it in include/ngp_hip.h."""
+    import subprocess
+    from ngp_hip.lib import RenderArgs
+    names = [f[0] for f in RenderArgs._fields_]
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "%s"\nint main(void) {\n  printf("%%zu\\n", sizeof(ngp_render_args));\n%s  return 0;\n}\n'
+                   % (os.path.join(ROOT, "include", "ngp_hip.h"),
+                      "".join('  printf("%%zu\\n", offsetof(ngp_render_args, %s));\n' % n for n in names)))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-o", str(exe), str(src)], check=True)
+    out = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    assert out[0] == ctypes.sizeof(RenderArgs)
+    assert out[1:] == [getattr(RenderArgs, n).offset for n in names]
+
+
 def test_ops_refuse_cpu_tensors(hip_lib):
     """The product path has no CPU fallback: host tensors are rejected loudly."""
     import torch
