@@ -524,3 +524,75 @@ def test_mlp_slab_sum_in_scatter_launch_equals_other_paths(hip_lib, lego_bitfiel
     for a, b in ((outs[0], outs[1]), (outs[0], outs[2])):
         for x, y in zip(a, b):
             assert ((x - y).norm() / y.norm()).item() < 2e-4            # (summation order of the weight gradients; fp16 MLP)
+
+
+def test_prefetched_march_placement_adapts_to_the_march_it_follows(hip_lib, lego_bitfield, monkeypatch):
+    """Round 5: on one GPU with the optimizer in the scatter-add's flush the trainer places the next batch's march by the sample count
+    of recent marches, reported asynchronously by the side stream (ngp_copy_to_host_async into ngp_host_alloc memory): a light march
+    (trained-Lego occupancy: ~20 samples per ray) goes to the START of the step as 4-wave blocks, a heavy one (all cells occupied,
+    ~500 samples per ray) before the scatter-add as 16-wave blocks at low priority; with the result unchanged either way.  Setting
+    one of the three environment switches pins the arrangement."""
+    import ctypes
+    from ngp_hip.trainer import FusedTrainer
+    for k in ("NGP_PREFETCH_AT", "NGP_MARCH_SHAPE", "NGP_SIDE_PRIORITY"):
+        monkeypatch.delenv(k, raising=False)
+    n = 4096
+    m, o, d, target = _make(lego_bitfield, n=n)
+    tr = FusedTrainer(m, init_scale=2.0**10)
+    assert tr._adaptive_prefetch and tr._hook_at == 3
+    old_max = FusedTrainer._MARCH_NARROW_MAX
+    try:
+        FusedTrainer._MARCH_NARROW_MAX = 60 * n              # (the class threshold is in samples per step; scale it to this batch)
+        hits0 = tr.prefetch_hits
+        for i in range(6):
+            tr.step(o, d, target, prefetch=(o, d))
+            torch.cuda.synchronize()                         # the count of step i's prefetch has arrived before step i + 1 decides
+        light = ctypes.c_int32.from_address(tr._marched_host.value).value
+        assert 0 < light < 60 * n and tr._hook_at == 0 and tr.prefetch_hits - hits0 == 5
+        m.density_bitfield.fill_(255)                        # every cell occupied: the marches get ~20 x heavier
+        for i in range(4):
+            tr.step(o, d, target, prefetch=(o, d))
+            torch.cuda.synchronize()
+        heavy = ctypes.c_int32.from_address(tr._marched_host.value).value
+        assert heavy > 60 * n and tr._hook_at == 3
+    finally:
+        FusedTrainer._MARCH_NARROW_MAX = old_max
+    tr.close()
+    assert tr._marched_host is None and tr._side_low is None
+    monkeypatch.setenv("NGP_PREFETCH_AT", "2")
+    tr2 = FusedTrainer(_make(lego_bitfield, n=n)[0])
+    assert not tr2._adaptive_prefetch and tr2._prefetch_at == 2 and tr2._marched_host is None
+
+
+def test_host_word_and_finite_check_entries(hip_lib):
+    """The small entry points of round 5 on their own: pinned host memory + asynchronous device-to-host copy, and the read-only
+    multi-tensor inf / nan check GradScaler's decision rests on."""
+    import ctypes
+    from ngp_hip import ops
+    L = ops._lib()
+    h = ctypes.c_void_p()
+    assert L.ngp_host_alloc(ctypes.byref(h), 64) == 0 and h.value
+    src = torch.tensor([123456789, 7], device="cuda", dtype=torch.int32)
+    assert L.ngp_copy_to_host_async(h, ops._ptr(src), 8, ops._stream()) == 0
+    torch.cuda.synchronize()
+    assert (ctypes.c_int32 * 2).from_address(h.value)[:] == [123456789, 7]
+    assert L.ngp_host_free(h) == 0
+    assert L.ngp_host_alloc(None, 64) == -1 and L.ngp_copy_to_host_async(None, ops._ptr(src), 8, ops._stream()) == -1
+    g = torch.Generator(device="cuda").manual_seed(1)
+    ts = [torch.randn(n_, device="cuda", generator=g) for n_ in (4, 4096, 1 << 20, 12)]
+    P = (ctypes.c_void_p * 4)(*[t.data_ptr() for t in ts])
+    N = (ctypes.c_longlong * 4)(*[t.numel() for t in ts])
+    found = torch.zeros(1, device="cuda")
+    assert L.ngp_check_finite_multi(4, P, N, ops._ptr(found), ops._stream()) == 0
+    assert float(found) == 0.0
+    for which, pos, bad in ((0, 3, float("inf")), (2, (1 << 20) - 1, float("nan")), (3, 0, float("-inf")), (1, 2049, float("nan"))):
+        keep = float(ts[which][pos])
+        ts[which][pos] = bad
+        found.zero_()
+        assert L.ngp_check_finite_multi(4, P, N, ops._ptr(found), ops._stream()) == 0
+        assert float(found) == 1.0, (which, pos)
+        ts[which][pos] = keep
+    found.zero_()
+    assert L.ngp_check_finite_multi(4, P, N, ops._ptr(found), ops._stream()) == 0 and float(found) == 0.0
+    N[3] = 13                                                  # not a multiple of four
+    assert L.ngp_check_finite_multi(4, P, N, ops._ptr(found), ops._stream()) == -1
