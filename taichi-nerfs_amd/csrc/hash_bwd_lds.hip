@@ -838,6 +838,10 @@ __global__ void __launch_bounds__(BW_THREADS) hash_bwd_lds_kernel(const float* _
         // before it touches anything (24 eight-byte loads in flight, 48 VGPRs: the task's registers are dead here); the LDS sums are
         // read one entry at a time underneath.  (Two trips of four entries: two exposed round trips per flush, ~2.5 flushes per
         // workgroup and launch.)
+        // Measured and NOT kept (scripts/gpu_r05_n.sh): requesting them IN FRONT of the end-of-task barrier, so that the round trip
+        // hides in the 5-10 us over which the waves arrive there.  4 of the 8 entries early: scatter-add 218-223 -> 254-260 us; all 8:
+        // 297-298 us.  The values stay live across the barrier and the next task's claim, the allocator answers with 26 / 58 spilled
+        // registers per lane at the task boundaries, and the early waves' loads compete with the late waves' gathers.
         constexpr int UNR = BW_SLICE_ENTRIES / BW_THREADS;
         static_assert(UNR * BW_THREADS == BW_SLICE_ENTRIES, "one trip covers the slice");
         {
