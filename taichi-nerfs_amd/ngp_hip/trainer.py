@@ -37,6 +37,18 @@ _SI_ITER, _SI_OPT_STEP, _SI_FOUND_INF, _SI_SKIPPED = 0, 1, 3, 5
 class FusedTrainer:
     _MARCH_NARROW_MAX = 1_000_000          # marched samples per step up to which the prefetched march goes to the start of the step
 
+    @staticmethod
+    def chunk_rounds(max_samples):
+        """Rounds of the chunked forward as (begin, length, previous begin): 64, 64, 128, 256, 512, ... samples of every live ray,
+        every boundary a multiple of 64 (the compositing kernels read a ray 64 samples at a time), together covering max_samples."""
+        rounds, b, l, pb = [], 0, 64, 0
+        while b < max_samples:
+            l = min(l, max_samples - b)
+            rounds.append((b, l, pb))
+            pb, b = b, b + l
+            l = b
+        return rounds
+
     def __init__(self, model, lr=1e-2, betas=(0.9, 0.999), eps=1e-15, max_steps=20000, eta_min=None, init_scale=2.0**19,
                  growth_factor=2.0, backoff_factor=0.5, growth_interval=2000, exp_step_factor=0.0, T_threshold=1e-4,
                  max_samples=1024, process_group=None, world_size=None, grad_comm_dtype=torch.float32,
@@ -70,14 +82,7 @@ class FusedTrainer:
         if chunked_forward is None:
             chunked_forward = float(exp_step_factor) > 0 or int(model.cascades) > 1
         self.chunked = bool(chunked_forward) and not self.half and int(max_samples) % 64 == 0 and int(max_samples) >= 128
-        self._chunk_rounds = []
-        if self.chunked:
-            b, l, pb = 0, 64, 0
-            while b < int(max_samples):
-                l = min(l, int(max_samples) - b)
-                self._chunk_rounds.append((b, l, pb))
-                pb, b = b, b + l
-                l = b                                  # 64, 64, 128, 256, 512: every boundary a multiple of 64
+        self._chunk_rounds = self.chunk_rounds(int(max_samples)) if self.chunked else []
         self._chunk_counts = None                      # [2, rounds] int32: list lengths per round, one set per step parity
         self._chunk_T = {}
         # backward over the samples in front of each ray's early-termination point only (NGP_LIVE_BACKWARD=0: over all of them)
