@@ -314,7 +314,13 @@ def main():
         out["configs"] = other_configs(args, ctx)
     if world > 1 and args.configs and _is_headline(args) and args.comm == "f32" and args.shard and not os.environ.get("NGP_COMM_OVERLAP"):
         # ONE invocation decides the multi-GPU defaults: the other exchange variants run in the same process group, behind the headline
-        cv = comm_variants(args, ctx, out)                      # (every rank runs them; rank 0 keeps the records)
+        # The variants have never met a real multi-GPU node (no SCALE run in five rounds): the headline must survive one of them
+        # hanging.  Every rank arms a watchdog for the variants phase (NGP_BENCH_VARIANT_TIMEOUT seconds, default 240): when it fires,
+        # rank 0 prints the line with the records collected so far + `configs_incomplete`, and every rank leaves the process.
+        progress = {"configs": [], "current": None, "done": False}
+        _variant_watchdog(float(os.environ.get("NGP_BENCH_VARIANT_TIMEOUT", "240")), rank, out, progress)
+        cv = comm_variants(args, ctx, out, progress)            # (every rank runs them; rank 0 keeps the records)
+        progress["done"] = True
         if rank == 0:
             out["configs"] = cv
     if rank == 0:
@@ -370,12 +376,12 @@ def other_configs(args, ctx):
 # N > 1: the gradient-exchange variants FusedTrainer offers, each measured in the same process group right after the headline leg
 # (which is the first entry: in-line fp32 reduce-scatter / all-gather, sharded optimizer).  A variant = extra arguments + environment.
 COMM_VARIANTS = [
-    ("overlap-8,0", "NGP_COMM_OVERLAP=1: the scatter-add issued per level group (8-15, then 0-7), a group's reduce-scatter in flight under "
-                    "the next group's launch, all-gathers waited for at the next step's forward", [], {"NGP_COMM_OVERLAP": "1", "NGP_COMM_GROUPS": "8,0"}),
     ("bf16-comm+bf16-table", "--comm bf16 --table bf16: the gradient travels as bf16, the parameters come back as the 16-bit copy the "
                              "forward reads (half the bytes both ways)", ["--comm", "bf16", "--table", "bf16"], {}),
     ("no-shard-all-reduce", "--no-shard: SURVEY 8(e)'s single all-reduce of one flat fp32 bucket + replicated Adam (north_star's wording)",
      ["--no-shard"], {}),
+    ("overlap-8,0", "NGP_COMM_OVERLAP=1: the scatter-add issued per level group (8-15, then 0-7), a group's reduce-scatter in flight under "
+                    "the next group's launch, all-gathers waited for at the next step's forward", [], {"NGP_COMM_OVERLAP": "1", "NGP_COMM_GROUPS": "8,0"}),
 ]
 COMM_MODEL_BW_GBS = (150.0, 300.0, 450.0)                      # DESIGN.md section 7's bus-bandwidth rows
 
@@ -404,9 +410,30 @@ def _comm_record(name, what, extra, env, o, world):
             "live_samples_per_step": o.get("live_samples_per_step")}
 
 
-def comm_variants(args, ctx, headline):
+def _variant_watchdog(timeout_s, rank, out, progress):
+    import threading
+
+    def run():
+        t_end = time.monotonic() + timeout_s
+        while time.monotonic() < t_end:
+            if progress["done"]:
+                return
+            time.sleep(0.25)
+        if progress["done"]:
+            return
+        if rank == 0:
+            out["configs"] = list(progress["configs"])
+            out["configs_incomplete"] = "exchange variant %r did not finish within %.0f s: the line holds the headline leg and the variants completed before it" % (progress["current"], timeout_s)
+            print(json.dumps(out), flush=True)
+        else:
+            time.sleep(3.0)                      # (rank 0 prints first)
+        os._exit(0)
+    threading.Thread(target=run, daemon=True).start()
+
+
+def comm_variants(args, ctx, headline, progress=None):
     world, rank = ctx["world"], ctx["rank"]
-    res = []
+    res = progress["configs"] if progress is not None else []
     if rank == 0:
         res.append(_comm_record("inline-f32 (headline)", "the line above: reduce-scatter(AVG) fp32 -> Adam on the own 1/N -> all-gather fp32, "
                                 "in line on the step's stream", [], {}, headline, world))
@@ -415,6 +442,8 @@ def comm_variants(args, ctx, headline):
                      "--kernel-events-every", str(args.kernel_events_every), "--no-cpu-baseline", "--no-configs"] + extra)
         saved = {k: os.environ.get(k) for k in env}
         os.environ.update(env)
+        if progress is not None:
+            progress["current"] = name
         try:
             o = measure(sub, ctx)
             if rank == 0:
