@@ -1,6 +1,7 @@
 #!/bin/bash
 # round 5, GPU call K: A/B on ONE box of the fused render as one C entry per direction (HEAD) against the launch sequence in Python
 # (the previous commit's ngp_hip/fused.py, swapped in for the B legs): the unchanged train.py, 20 000 steps, twice each, alternating
+# (the B legs' file is made beforehand, outside the history:  mkdir -p scratch && git show 7e9a514:taichi-nerfs_amd/ngp_hip/fused.py > scratch/fused_before_entry.py)
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 O=gpurun_out/r05k; mkdir -p $O
