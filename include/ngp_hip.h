@@ -221,6 +221,10 @@ int ngp_composite_train_fused(const float* sigmas, const void* rgbs, int rgbs_is
 int ngp_chunk_schedule(const int32_t* rays_a, const float* sigmas, const float* deltas, int n_rays, int begin, int len,
                        int prev_begin, float thr_stop, float* T_state, int32_t* list, int32_t* count, int32_t* count_zero,
                        void* stream);
+/* The list of ngp_live_compact in block-completion order (each ray's samples contiguous; the *_live kernels do not depend on the
+ * order) from one launch with one atomic per 64 rays: live_total[0] must be 0 at launch, live_zero (nullable) is cleared. */
+int ngp_live_list(const int32_t* rays_a, const int32_t* vr_per_ray /*[n], by ray index*/, int n_rays, int32_t* live_idx,
+                  int32_t* live_total, int32_t* live_zero, void* stream);
 /* The same launch, and the compacted live-sample list of ngp_live_compact as a by-product: every 16-ray block appends its rays'
  * first vr[r] samples to live_idx at an offset it takes from live_total with ONE atomic add, so the list is in block-completion
  * order (each ray contiguous) -- the *_live kernels do not depend on the order.  live_total[0] must be 0 at launch; live_zero
@@ -426,6 +430,10 @@ int ngp_render_train_bwd(const ngp_render_args* args, void* stream);
  *                 kernels, consumed + cleared by the prologue), [4] skip flag of this step, [5] skipped steps so far */
 int ngp_mse_loss_grad(const float* rgb, const float* opacity, const float* target, float bg, int n_rays,
                       float* state_f, float* g_rgb, float* g_opacity, void* stream);
+/* ... per ray, from as many blocks as the batch needs: the same g_rgb / g_opacity (loss-scaled by state_f[0]) and, instead of the
+ * reduced loss, the per-ray squared error sq_err[r] (nullable) for whoever logs it (train.py:193). */
+int ngp_mse_loss_grad_rays(const float* rgb, const float* opacity, const float* target, float bg, int n_rays,
+                           const float* state_f, float* g_rgb, float* g_opacity, float* sq_err, void* stream);
 int ngp_train_prologue(float* state_f, int32_t* state_i, float lr0, float eta_min, int t_max, float beta1,
                        float beta2, float growth, float backoff, int growth_interval, void* stream);
 /* The prologue and, in the same launch, ngp_mlp_dw_reduce(dW_parts, n_parts, dW). */

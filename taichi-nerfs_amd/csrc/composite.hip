@@ -329,47 +329,75 @@ __global__ void __launch_bounds__(256) composite_test_kernel(const float* __rest
 // estimate here is exp(-sum sigma delta), the compositing kernels form the running product of (1 - a) -- equal up to rounding, so
 // every group they read has been shaded; what lies behind is never read, never contributes (its gradients are exact zeros in the
 // reference too).  One wave per ray, 16 rays per block, one returning atomic per block for the block's range of the list.
+// Block shape of the two list builders below: 16 lanes per ray, 64 rays per 1024-thread block, ONE returning atomic per block on the
+// list's counter.  (First version: a wave per ray, 16 rays per block = 4096 same-address atomics per launch at 65 536 rays -- ~12 ns
+// each: 50 us of a launch that moves 12 MB; profiles/r05_rocprofv3_garden_timed_region.txt.)
+constexpr int LIST_LANES = 16, LIST_RPB = 1024 / LIST_LANES;
+
+// appends `c` consecutive sample indices first .. first + c of this 16-lane group's ray to list (block-wise range allocation)
+__device__ __forceinline__ void list_append_block(int c, int first, int32_t* __restrict__ list, int32_t* __restrict__ count, int* s_off) {
+    const int grp = threadIdx.x / LIST_LANES, sub = threadIdx.x % LIST_LANES, lane = lane_id();
+    if (sub == 0) s_off[grp] = c;
+    __syncthreads();
+    if (threadIdx.x < NGP_WAVE) {                    // wave 0: LIST_RPB == 64 counts, one per lane
+        const int v = s_off[lane];
+        const int inc = wave_scan_add_i(v, lane);
+        int base = 0;
+        if (lane == NGP_WAVE - 1 && inc > 0) base = atomicAdd(count, inc);
+        base = __shfl(base, NGP_WAVE - 1, NGP_WAVE);
+        s_off[lane] = base + inc - v;
+    }
+    __syncthreads();
+    const int b = s_off[grp];
+    for (int k = sub; k < c; k += LIST_LANES) list[b + k] = first + k;
+}
+
 __global__ void __launch_bounds__(1024) chunk_schedule_kernel(const int32_t* __restrict__ rays_a, const float* __restrict__ sigmas,
                                                               const float* __restrict__ deltas, int n_rays, int begin, int len,
                                                               int prev_begin, float thr_stop, float* __restrict__ T_state,
                                                               int32_t* __restrict__ list, int32_t* __restrict__ count,
                                                               int32_t* __restrict__ count_zero) {
-    __shared__ int s_off[16];
-    const int wave = threadIdx.x >> 6, lane = lane_id(), nw = blockDim.x >> 6;
-    const int n = blockIdx.x * nw + wave;
-    const bool has_ray = n < n_rays;
+    static_assert(LIST_RPB == NGP_WAVE, "wave 0 scans the block's ray counts with one wave scan");
+    __shared__ int s_off[LIST_RPB];
+    const int grp = threadIdx.x / LIST_LANES, sub = threadIdx.x % LIST_LANES;
+    const int n = blockIdx.x * LIST_RPB + grp;
     if (blockIdx.x == 0 && threadIdx.x == 0 && count_zero) *count_zero = 0;
-    int start = 0, N = 0, c = 0;
-    if (has_ray) {
-        start = rays_a[3 * n + 1]; N = rays_a[3 * n + 2];
+    int start = 0, c = 0;
+    if (n < n_rays) {
+        start = rays_a[3 * n + 1];
+        const int N = rays_a[3 * n + 2];
         float T = 1.0f;
         if (begin > 0) {
             T = T_state[n];
             if (T > 0.0f) {
                 float sum = 0.0f;
                 const int hi = min(begin, N);
-                for (int j = prev_begin + lane; j < hi; j += NGP_WAVE) sum += sigmas[(size_t)start + j] * deltas[(size_t)start + j];
-                sum = wave_sum(sum);
+                for (int j = prev_begin + sub; j < hi; j += LIST_LANES) sum += sigmas[(size_t)start + j] * deltas[(size_t)start + j];
+#pragma unroll
+                for (int d = 1; d < LIST_LANES; d <<= 1) sum += __shfl_xor(sum, d, NGP_WAVE);      // (stays inside the 16-lane group)
                 T = T * expf(-sum);
                 if (!(T > thr_stop)) T = 0.0f;                  // (NaN included: the compositing kernels stop at a NaN as well)
             }
         }
-        if (lane == 0) T_state[n] = T;
+        if (sub == 0) T_state[n] = T;
         c = (T > 0.0f && begin < N) ? min(len, N - begin) : 0;
     }
-    if (lane == 0) s_off[wave] = c;
-    __syncthreads();
-    if (wave == 0) {
-        const int v = lane < nw ? s_off[lane] : 0;
-        const int inc = wave_scan_add_i(v, lane);
-        int base = 0;
-        if (lane == NGP_WAVE - 1 && inc > 0) base = atomicAdd(count, inc);
-        base = __shfl(base, NGP_WAVE - 1, NGP_WAVE);
-        if (lane < nw) s_off[lane] = base + inc - v;
-    }
-    __syncthreads();
-    const int b = s_off[wave];
-    for (int k = lane; k < c; k += NGP_WAVE) list[b + k] = start + begin + k;
+    list_append_block(c, start + begin, list, count, s_off);
+}
+
+// The live-sample list of ngp_live_compact in block-completion order (each ray contiguous; none of the *_live kernels depends on the
+// order): the first vr_per_ray[r] samples of every ray.  One launch that moves the list once -- ngp_live_compact's ray-ORDERED list
+// costs every block a scan over all rays (152 us at 65 536 rays) and stays what the deterministic mode uses.
+__global__ void __launch_bounds__(1024) live_list_kernel(const int32_t* __restrict__ rays_a, const int32_t* __restrict__ vr_per_ray,
+                                                         int n_rays, int32_t* __restrict__ live_idx, int32_t* __restrict__ live_total,
+                                                         int32_t* __restrict__ live_zero) {
+    __shared__ int s_off[LIST_RPB];
+    const int grp = threadIdx.x / LIST_LANES;
+    const int n = blockIdx.x * LIST_RPB + grp;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && live_zero) *live_zero = 0;
+    int start = 0, c = 0;
+    if (n < n_rays) { start = rays_a[3 * n + 1]; c = vr_per_ray[rays_a[3 * n]]; }
+    list_append_block(c, start, live_idx, live_total, s_off);
 }
 
 }  // namespace ngp
@@ -476,8 +504,21 @@ int ngp_chunk_schedule(const int32_t* rays_a, const float* sigmas, const float* 
     if (!rays_a || !T_state || !list || !count || begin < 0 || len <= 0 || prev_begin < 0 || prev_begin > begin) return -1;
     if ((begin | len | prev_begin) & 63) return -1;
     if (begin > 0 && (!sigmas || !deltas)) return -1;
-    hipLaunchKernelGGL(chunk_schedule_kernel, dim3((n_rays + 15) / 16), dim3(1024), 0, (hipStream_t)stream, rays_a, sigmas, deltas, n_rays,
+    hipLaunchKernelGGL(chunk_schedule_kernel, dim3((n_rays + LIST_RPB - 1) / LIST_RPB), dim3(1024), 0, (hipStream_t)stream, rays_a, sigmas, deltas, n_rays,
                        begin, len, prev_begin, thr_stop, T_state, list, count, count_zero);
+    NGP_LAUNCH_CHECK();
+    return 0;
+}
+
+// The live-sample list (the first vr_per_ray[r] samples of ray r, rays_a row order irrelevant) in block-completion order:
+// live_total[0] must be 0 at launch (live_zero, nullable, is cleared for a caller alternating two counters).  Same content as
+// ngp_live_compact's list, other order; one launch, one atomic per 64 rays.
+int ngp_live_list(const int32_t* rays_a, const int32_t* vr_per_ray, int n_rays, int32_t* live_idx, int32_t* live_total,
+                  int32_t* live_zero, void* stream) {
+    if (n_rays <= 0) return 0;
+    if (!rays_a || !vr_per_ray || !live_idx || !live_total) return -1;
+    hipLaunchKernelGGL(live_list_kernel, dim3((n_rays + LIST_RPB - 1) / LIST_RPB), dim3(1024), 0, (hipStream_t)stream, rays_a, vr_per_ray,
+                       n_rays, live_idx, live_total, live_zero);
     NGP_LAUNCH_CHECK();
     return 0;
 }

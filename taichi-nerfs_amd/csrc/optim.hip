@@ -298,6 +298,38 @@ int ngp_cast_f32_bf16(const float* src, uint16_t* dst, long long n, void* stream
     return 0;
 }
 
+// The same gradients from as many blocks as the rays need, and the per-ray squared error instead of the reduced loss (the reader sums
+// it when it logs -- like ngp_composite_train_fused's sq_err): the one-block form above walks 65 536 rays in 64 dependent trips (50 us).
+__global__ void __launch_bounds__(256) mse_loss_grad_rays_kernel(const float* __restrict__ rgb, const float* __restrict__ opacity,
+                                                                 const float* __restrict__ target, float bg, int n_rays,
+                                                                 const float* __restrict__ sf, float* __restrict__ g_rgb,
+                                                                 float* __restrict__ g_opacity, float* __restrict__ sq_err) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rays) return;
+    const float k = 2.0f / (3.0f * (float)n_rays) * sf[SF_LOSS_SCALE];
+    const float b = bg * (1.0f - opacity[r]);
+    float go = 0.0f, se = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float diff = (rgb[3 * r + c] + b) - target[3 * r + c];
+        se += diff * diff;
+        const float gr = k * diff;
+        g_rgb[3 * r + c] = gr;
+        go -= bg * gr;
+    }
+    g_opacity[r] = go;
+    if (sq_err) sq_err[r] = se;
+}
+
+int ngp_mse_loss_grad_rays(const float* rgb, const float* opacity, const float* target, float bg, int n_rays, const float* state_f,
+                           float* g_rgb, float* g_opacity, float* sq_err, void* stream) {
+    if (n_rays <= 0) return 0;
+    hipLaunchKernelGGL(mse_loss_grad_rays_kernel, dim3((n_rays + 255) / 256), dim3(256), 0, (hipStream_t)stream, rgb, opacity, target, bg,
+                       n_rays, state_f, g_rgb, g_opacity, sq_err);
+    NGP_LAUNCH_CHECK();
+    return 0;
+}
+
 int ngp_mse_loss_grad(const float* rgb, const float* opacity, const float* target, float bg, int n_rays, float* state_f,
                       float* g_rgb, float* g_opacity, void* stream) {
     if (n_rays <= 0) return 0;

@@ -123,6 +123,8 @@ SIGNATURES = {
     "ngp_rng_uniform": [ctypes.c_ulonglong, _I, _P, _P],
     "ngp_hash_fwd_list": [_P, _P, _I, _LV, _I, _P, _P, _I, _F, _F, _I, _P, _P],
     "ngp_mlp_fwd_list": [_P, _P, _P, _I, _P, _P, _I, _P, _P, _P],
+    "ngp_live_list": [_P, _P, _I, _P, _P, _P, _P],
+    "ngp_mse_loss_grad_rays": [_P, _P, _P, _F, _I, _P, _P, _P, _P, _P],
     "ngp_chunk_schedule": [_P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P],
     "ngp_march_train_write": [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P],
     "ngp_march_test": [_P, _P, _P, _P, _P, _I, _I, _F, _F, _I, _I, _P, _P, _P, _P, _P, _P],

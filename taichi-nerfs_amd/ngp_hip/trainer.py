@@ -548,9 +548,14 @@ class FusedTrainer:
                                                    _ptr(live_next if fused_live else None), st), "ngp_composite_train_fused_live")
         live_idx = A.live_idx
         if self.live_backward and not fused_live:                 # (distortion-loss path: its composite is the operator chain)
-            check(L.ngp_live_compact(_ptr(rays_a), _ptr(vr_per_ray), n, _ptr(A.live_off(n)), _ptr(live_idx), _ptr(live_total), st),
-                  "ngp_live_compact")
-        if not fused_live:
+            if self.deterministic:                                # the ray-ORDERED list (every block scans all rays: 152 us at 65 536 rays)
+                check(L.ngp_live_compact(_ptr(rays_a), _ptr(vr_per_ray), n, _ptr(A.live_off(n)), _ptr(live_idx), _ptr(live_total), st),
+                      "ngp_live_compact")
+                live_next.zero_()
+            else:                                                 # block-completion order, one atomic per 64 rays; clears the other counter
+                check(L.ngp_live_list(_ptr(rays_a), _ptr(vr_per_ray), n, _ptr(live_idx), _ptr(live_total), _ptr(live_next), st),
+                      "ngp_live_list")
+        elif not fused_live:
             live_next.zero_()
         if self.live_backward:
             cnt = live_total
@@ -783,14 +788,15 @@ class FusedTrainer:
         g_dist = (sf[_SF_LOSS_SCALE] * (self.distortion_loss_w / n)).expand(n).contiguous()
         check(L.ngp_distortion_bwd(_ptr(g_dist), _ptr(A.ws), _ptr(M.deltas), _ptr(M.ts), _ptr(ws_inc), _ptr(wts_inc), _ptr(rays_a), n,
                                    _ptr(g_ws), st), "ngp_distortion_bwd")
-        g_rgb, g_op = torch.empty(n, 3, **f32), torch.empty(n, **f32)
-        check(L.ngp_mse_loss_grad(_ptr(rgb), _ptr(opacity), _ptr(target), self.bg, n, _ptr(sf), _ptr(g_rgb), _ptr(g_op), st),
-              "ngp_mse_loss_grad")
+        g_rgb, g_op, sq_err = torch.empty(n, 3, **f32), torch.empty(n, **f32), torch.empty(n, **f32)
+        # per ray, from as many blocks as the batch needs; the squared error leaves per ray (summed by whoever logs the loss)
+        check(L.ngp_mse_loss_grad_rays(_ptr(rgb), _ptr(opacity), _ptr(target), self.bg, n, _ptr(sf), _ptr(g_rgb), _ptr(g_op), _ptr(sq_err), st),
+              "ngp_mse_loss_grad_rays")
         check(L.ngp_composite_train_bwd(_ptr(g_op), _ptr(None), _ptr(g_rgb), _ptr(g_ws), _ptr(A.sigmas), _ptr(A.rgbs), 1, _ptr(M.deltas),
                                         _ptr(M.ts), _ptr(rays_a), _ptr(opacity), _ptr(depth), _ptr(rgb), _ptr(A.ws), cfg.T_threshold, n,
                                         _ptr(A.d_sigmas), _ptr(A.d_rgbs), st), "ngp_composite_train_bwd")
         self._dist_loss = dist_loss
-        return None
+        return sq_err
 
     # ---- world > 1, sharded optimizer: reduce-scatter -> Adam on the own shard -> all-gather ------------------------------
     def _nccl(self):
@@ -1134,7 +1140,7 @@ class FusedTrainer:
         """MSE of the last step (host sync: logging only)."""
         se = self.stats.get("sq_err")
         if se is None and self.distortion_loss_w > 0 and self.stats:
-            return float(self.state_f[_SF_LOSS].item())                   # written by ngp_mse_loss_grad
+            return float(self.state_f[_SF_LOSS].item())                   # (a caller that ran ngp_mse_loss_grad itself)
         return float("nan") if se is None else float(se.sum().item()) / (3.0 * se.numel())
 
     def loss_scale(self):

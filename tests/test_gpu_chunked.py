@@ -217,3 +217,49 @@ def test_chunked_forward_defaults(hip_lib):
     assert [r[:2] for r in FusedTrainer(NGP(scale=16.0, max_res=4096).cuda(), exp_step_factor=1 / 256)._chunk_rounds] == \
         [(0, 64), (64, 64), (128, 128), (256, 256), (512, 512)]
     assert not FusedTrainer(NGP(scale=0.5, max_res=1024).cuda(), chunked_forward=True, max_samples=96).chunked
+
+
+def test_live_list_and_per_ray_mse_gradient_match_the_one_block_forms(hip_lib):
+    """Round 5, C3-sized batches: ngp_live_list (block-completion order, one atomic per 64 rays) holds the same samples as
+    ngp_live_compact's ray-ordered list; ngp_mse_loss_grad_rays gives bit-identical gradients to the one-block ngp_mse_loss_grad and a
+    per-ray squared error that sums to its loss."""
+    L = ops._lib()
+    rng = np.random.default_rng(4)
+    n = 70000 - 3
+    counts = rng.integers(0, 90, n).astype(np.int32)
+    counts[:3] = [0, 1, 64]
+    order = rng.permutation(n)
+    starts = np.zeros(n, np.int64)
+    starts[order] = np.concatenate([[0], np.cumsum(counts[order])[:-1]])
+    rays_a = np.stack([np.arange(n), starts, counts], 1).astype(np.int32)
+    perm_rows = rng.permutation(n)                                # rays_a rows in any order (the fused march's block-completion order)
+    ra = torch.from_numpy(rays_a[perm_rows]).cuda()
+    vr = torch.from_numpy((counts * rng.random(n)).astype(np.int32)).cuda()          # by RAY index
+    total = int(counts.sum())
+    a_idx, b_idx = torch.full((total + 64,), -1, device="cuda", dtype=torch.int32), torch.full((total + 64,), -1, device="cuda", dtype=torch.int32)
+    a_tot, b_tot = torch.zeros(1, device="cuda", dtype=torch.int32), torch.zeros(1, device="cuda", dtype=torch.int32)
+    other = torch.full((1,), 9, device="cuda", dtype=torch.int32)
+    off = torch.empty(n, device="cuda", dtype=torch.int32)
+    assert L.ngp_live_compact(ops._ptr(ra), ops._ptr(vr), n, ops._ptr(off), ops._ptr(a_idx), ops._ptr(a_tot), ops._stream()) == 0
+    assert L.ngp_live_list(ops._ptr(ra), ops._ptr(vr), n, ops._ptr(b_idx), ops._ptr(b_tot), ops._ptr(other), ops._stream()) == 0
+    torch.cuda.synchronize()
+    k = int(a_tot)
+    assert k == int(b_tot) == int(vr.sum()) and int(other) == 0
+    assert torch.equal(torch.sort(a_idx[:k]).values, torch.sort(b_idx[:k]).values) and int(b_idx[k]) == -1
+    # every ray's samples contiguous and ascending in the block-ordered list
+    raw = b_idx[:k].cpu().numpy()
+    assert (np.diff(raw) == 1).sum() >= k - n
+
+    g = torch.Generator(device="cuda").manual_seed(2)
+    rgb, op, tgt = torch.rand(n, 3, device="cuda", generator=g), torch.rand(n, device="cuda", generator=g), torch.rand(n, 3, device="cuda", generator=g)
+    sf = torch.zeros(8, device="cuda"); sf[0] = 2.0**14
+    for bg in (0.0, 1.0):
+        g1, o1 = torch.empty(n, 3, device="cuda"), torch.empty(n, device="cuda")
+        g2, o2, se = torch.empty(n, 3, device="cuda"), torch.empty(n, device="cuda"), torch.empty(n, device="cuda")
+        sf1 = sf.clone()
+        assert L.ngp_mse_loss_grad(ops._ptr(rgb), ops._ptr(op), ops._ptr(tgt), bg, n, ops._ptr(sf1), ops._ptr(g1), ops._ptr(o1), ops._stream()) == 0
+        assert L.ngp_mse_loss_grad_rays(ops._ptr(rgb), ops._ptr(op), ops._ptr(tgt), bg, n, ops._ptr(sf), ops._ptr(g2), ops._ptr(o2), ops._ptr(se),
+                                        ops._stream()) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(_bits(g1), _bits(g2)) and torch.equal(_bits(o1), _bits(o2))
+        assert abs(float(se.double().sum()) / (3 * n) - float(sf1[5])) < 1e-6 * float(sf1[5])
