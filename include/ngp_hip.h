@@ -337,6 +337,13 @@ int ngp_hash_bwd_sliced_plan(const ngp_hash_levels* lv, uint16_t* tasks, int max
  * group never spans two pieces: the result is a function of the inputs.  Slower on the coarse levels; bench.py conditions its model
  * in this mode so that two processes reach the same state. */
 int ngp_hash_bwd_sliced_deterministic(int on);
+/* Concentrated-scene plan (per host thread, default off; returns the previous setting): for scenes that fill a small part of the
+ * box (multi-cascade scenes) the coarse hashed levels (resolution <= 256) get sample-range replicas like the dense ones -- a few hot
+ * cells otherwise load a handful of slice owners with several times the mean (C3: the launch 2.2 ms with the XCDs busy 55 % of it;
+ * 1.7 ms in this mode).
+ * The levels that get replicas leave the set ngp_hash_bwd_sliced_main_adam updates in its flush (ngp_hash_bwd_sliced_adam_prefix
+ * says where that set starts). */
+int ngp_hash_bwd_sliced_concentrated(int on);
 /* diagnostics: per-TASK task word + wall-clock stamps into a device buffer of 8 * 1536 uint64 (one 8-word row per task of the
  * plan, at most 1536 tasks; NULL = off, the default) */
 int ngp_hash_bwd_sliced_debug(void* device_buffer);

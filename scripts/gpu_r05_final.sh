@@ -9,8 +9,18 @@ timeout 600 python bench.py --steps 20 --warmup 5 > $O/bench_steps20.json 2> $O/
 timeout 300 python bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-configs > $O/bench_steps200.json 2> /dev/null
 timeout 300 python bench.py > $O/bench_noflags.json 2> /dev/null
 NGP_BENCH_BACKEND=gloo NGP_BENCH_ONE_DEVICE=1 timeout 600 python bench.py --gpus 2 --steps 20 --warmup 5 --condition 256 > $O/bench_2ranks_gloo_one_gpu.json 2> $O/bench_2ranks.err
+G="--steps 20 --warmup 5 --no-configs --no-cpu-baseline --scene garden --condition 512"
+timeout 300 python bench.py $G > $O/garden_c3_default.json 2> /dev/null
+NGP_PREFETCH_AT=3 NGP_SIDE_PRIORITY=low timeout 300 python bench.py $G > $O/garden_c3_march16.json 2> /dev/null
+NGP_BWD_CONCENTRATED=0 timeout 300 python bench.py $G > $O/garden_c3_plan_off.json 2> /dev/null
+# (information for the next round, last in the call: the other heavy-march cases with the 4-wave low-priority march C3 now uses)
+H="--steps 20 --warmup 5 --no-configs --no-cpu-baseline"
+timeout 200 python bench.py $H --rays 65536 > $O/lego65536_default.json 2> /dev/null
+NGP_PREFETCH_AT=3 NGP_SIDE_PRIORITY=low NGP_MARCH_SHAPE=4,0 timeout 200 python bench.py $H --rays 65536 > $O/lego65536_march4.json 2> /dev/null
+timeout 200 python bench.py $H --regime random50 > $O/init_default.json 2> /dev/null
+NGP_PREFETCH_AT=3 NGP_SIDE_PRIORITY=low NGP_MARCH_SHAPE=4,0 timeout 200 python bench.py $H --regime random50 > $O/init_march4.json 2> /dev/null
 tail -n 4 $O/pytest_gpu.txt | head -2; tail -1 $O/smoke.txt
-for f in $O/bench_steps20.json $O/bench_steps200.json $O/bench_noflags.json $O/bench_2ranks_gloo_one_gpu.json; do python - "$f" <<'PY'
+for f in $O/bench_steps20.json $O/bench_steps200.json $O/bench_noflags.json $O/bench_2ranks_gloo_one_gpu.json $O/garden_c3_*.json $O/lego65536_*.json $O/init_*.json; do python - "$f" <<'PY'
 import json,sys
 try:
     d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])

@@ -931,9 +931,18 @@ struct Knobs {
     uint32_t level_mask = 0xffffffffu, diag = 0u;
     int blocks = 0;                            // -DNGP_BWD_DIAG: fewer persistent workgroups (contention experiment)
     bool deterministic = false;                // ngp_hash_bwd_sliced_deterministic(1): no sample-range replicas (no float atomics), see there
+    // ngp_hash_bwd_sliced_concentrated(1): the scene fills a small part of the box (multi-cascade scenes), so the COARSE HASHED levels
+    // behave like dense ones -- few hot cells carry most samples, and wherever their hash indices fall, a handful of slice owners get
+    // several times the mean (C3, profiles/r05_scatter_timeline_garden.txt: level 5's owners 374 us on average, the slowest ~1.3 ms; the
+    // XCDs busy 55 % of the launch).  Levels up to hashed_rep_res then get hashed_rep sample-range replicas per slice: C3's launch
+    // 2.49 -> 1.70-1.76 ms with the march beside it, the XCDs busy 75 % (profiles/r05_scatter_timeline_garden.txt, second half).
+    // merge_hashed: also the dense levels' run pre-summing up to merge_res -- measured, three A/B pairs, 0.6 % slower: off.
+    int hashed_rep_res = 0, hashed_rep = 1;
+    bool merge_hashed = false;
     bool operator==(const Knobs& o) const {
         return rep_target == o.rep_target && merge_res == o.merge_res && dense_min_rep == o.dense_min_rep && level_mask == o.level_mask &&
-               diag == o.diag && blocks == o.blocks && deterministic == o.deterministic;
+               diag == o.diag && blocks == o.blocks && deterministic == o.deterministic && hashed_rep_res == o.hashed_rep_res &&
+               hashed_rep == o.hashed_rep && merge_hashed == o.merge_hashed;
     }
 };
 static Knobs read_knobs() {
@@ -949,15 +958,26 @@ static Knobs read_knobs() {
     return k;
 }
 static thread_local bool g_bwd_deterministic = false;
+static thread_local bool g_bwd_concentrated = false;
+static void apply_modes(Knobs& k) {
+    k.deterministic = g_bwd_deterministic;
+    if (g_bwd_concentrated) {
+        // (NGP_BWD_HASHED_REP_RES / NGP_BWD_HASHED_REP / NGP_BWD_MERGE_HASHED: A/B overrides of what the mode switches on)
+        static const int res = [] { const char* e = getenv("NGP_BWD_HASHED_REP_RES"); return e ? atoi(e) : 256; }();
+        static const int rep = [] { const char* e = getenv("NGP_BWD_HASHED_REP"); return e && atoi(e) > 0 ? atoi(e) : 3; }();
+        static const bool mh = [] { const char* e = getenv("NGP_BWD_MERGE_HASHED"); return e ? atoi(e) != 0 : false; }();
+        k.hashed_rep_res = res; k.hashed_rep = rep; k.merge_hashed = mh;
+    } else { k.hashed_rep_res = 0; k.hashed_rep = 1; k.merge_hashed = false; }
+}
 static const Knobs& knobs() {
     static const bool dynamic = getenv("NGP_BWD_KNOBS_DYNAMIC") != nullptr;
     static const Knobs fixed = read_knobs();
     static thread_local Knobs k;
 #ifndef NGP_BWD_DIAG
-    if (!dynamic) { k = fixed; k.deterministic = g_bwd_deterministic; return k; }
+    if (!dynamic) { k = fixed; apply_modes(k); return k; }
 #endif
     k = read_knobs();
-    k.deterministic = g_bwd_deterministic;
+    apply_modes(k);
     return k;
 }
 
@@ -983,13 +1003,15 @@ static bool build_plan_with(const ngp_hash_levels& lv, BwdPlan& plan, uint32_t& 
         // sample ranges per dense slice, so the worst slice is bounded by S / dense_min_rep hits; the owners of the empty
         // slices cost ~3 us each
         if (l < lv.begin_fast_hash_level && ns > 1 && nrep < dense_min_rep) nrep = dense_min_rep;
+        // concentrated scenes: a coarse hashed level's hot cells land in a few slices -- sample-range replicas bound the worst owner
+        if (l >= lv.begin_fast_hash_level && (int)lv.resolution[l] <= K.hashed_rep_res && nrep < K.hashed_rep) nrep = K.hashed_rep;
         if (nrep < 1) nrep = 1;
         if (nrep > 63) nrep = 63;
         if (K.deterministic) nrep = 1;        // one owner per slice: its flush is a plain read-modify-write (or the optimizer), no float atomics
         lvls[l] = {l, ns, nrep, ((level_mask >> l) & 1u) ? ns * nrep : 0};
         plan.nrep[l] = (uint8_t)nrep;
         if (ns == 1) single_mask |= 1u << l;
-        if ((int)lv.resolution[l] <= merge_res && l < lv.begin_fast_hash_level) plan.merge_mask |= 1u << l;    // dense coarse levels
+        if ((int)lv.resolution[l] <= merge_res && (l < lv.begin_fast_hash_level || K.merge_hashed)) plan.merge_mask |= 1u << l;    // coarse levels: dense ones, hashed ones of a concentrated scene
     }
     for (int l = lv.n_levels; l < NGP_MAX_LEVELS; ++l) plan.nrep[l] = 1;
     plan.diag = K.diag;                   // timing experiments only (-DNGP_BWD_DIAG builds): wrong results
@@ -1132,6 +1154,14 @@ int ngp_hash_bwd_sliced_debug(void* device_buffer) { g_bwd_debug = (unsigned lon
 int ngp_hash_bwd_sliced_deterministic(int on) {
     const int was = g_bwd_deterministic ? 1 : 0;
     g_bwd_deterministic = on != 0;
+    return was;
+}
+
+// Concentrated-scene mode (per host thread; default off): the task plan treats the coarse hashed levels like dense ones (see Knobs).
+// Same result up to the float-atomic order of the replicas' flushes (as on the dense levels).  Returns the previous setting.
+int ngp_hash_bwd_sliced_concentrated(int on) {
+    const int was = g_bwd_concentrated ? 1 : 0;
+    g_bwd_concentrated = on != 0;
     return was;
 }
 

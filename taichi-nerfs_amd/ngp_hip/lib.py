@@ -148,6 +148,7 @@ SIGNATURES = {
     "ngp_hash_bwd_sliced_workspace": [_LV, _I],
     "ngp_hash_bwd_sliced_debug": [_P],
     "ngp_hash_bwd_sliced_deterministic": [_I],
+    "ngp_hash_bwd_sliced_concentrated": [_I],
     "ngp_hash_bwd_sliced_plan": [_LV, _P, _I, _P, _P, _P, _P, _P],
     "ngp_hash_bwd_sliced_prep": [_P, _LV, _I, _P, _P, _I, _F, _F, _P, ctypes.c_longlong, _P],
     "ngp_hash_bwd_sliced_main": [_P, _LV, _I, _P, _I, _P, _P, _P, ctypes.c_longlong, _P],

@@ -196,7 +196,10 @@ class FusedTrainer:
         # initialisation regime (2.1 M marched) 3.5 M against 4.0; 65 536 rays per step (2.8 M marched) 20.9 against 21.9.  So the
         # trainer ADAPTS: the side stream copies each prefetched march's sample count to pinned host memory (asynchronously: nothing
         # waits for it) and the next hooks read whatever has arrived -- at most a few steps old.  Up to _MARCH_NARROW_MAX marched
-        # samples: start of the step, 4-wave blocks, default priority; above: before the scatter-add, 16-wave blocks, low priority.
+        # samples: start of the step, 4-wave blocks, default priority; above: before the scatter-add at low priority -- as 16-wave
+        # blocks until the end of round 5, when 4-wave blocks measured better or equal in the three heavy cases (C3 with the
+        # concentrated-scene scatter-add 15.2-15.5 M rays/s against 14.6, 65 536 Lego rays 31.0-31.2 against 29.6, the initialisation
+        # regime 4.07 against 4.08: profiles/r05_bench_garden_c3_concentrated.txt, r05_heavy_march_placement.txt).
         # Any of NGP_PREFETCH_AT / NGP_MARCH_SHAPE / NGP_SIDE_PRIORITY pins the arrangement instead.
         self._one_gpu_flush = (self.world == 1 and not self.half and os.environ.get("NGP_FLUSH_ADAM", "1") != "0"
                                and self.hash_bwd == "sliced")
@@ -232,7 +235,7 @@ class FusedTrainer:
         import os as _os
         # (with world > 1 the default is 4: the march then runs underneath the gradient exchange -- RCCL's kernels occupy a few
         # workgroups and wait on xGMI -- instead of competing with the VALU-bound kernels of the step for issue slots)
-        self._prefetch_at = int(_os.environ.get("NGP_PREFETCH_AT", "3" if self.world == 1 else "4"))
+        self._prefetch_at = float(_os.environ.get("NGP_PREFETCH_AT", "3" if self.world == 1 else "4"))
         # Round 5: the SHAPE of the prefetched launch (ngp_march_train_fused_shaped): "waves per block, idle LDS bytes per block",
         # e.g. "4,82944" = 4-wave blocks, at most one per CU.  With the table's optimizer inside the scatter-add there is no
         # HBM-bound launch left to hide a 16-wave-per-CU march under; a narrow march asks every CU for one wave slot per SIMD and
@@ -279,6 +282,11 @@ class FusedTrainer:
         # occupancy update without its two order-dependent spots (ngp_hip/occupancy.py).  Same kernels, same arithmetic per sample;
         # what changes is the ORDER in which floating-point sums are formed, which is fixed.  Slower (~1.5 ms per step at C2).
         self.deterministic = False
+        # Multi-cascade / exponentially stepped scenes fill a small part of their box: the scatter-add's plan then treats the coarse
+        # hashed levels like dense ones (ngp_hash_bwd_sliced_concentrated; C3: the launch 2.5 -> 1.7 ms beside the march, which then no
+        # longer fits under it as 16-wave blocks: 4-wave blocks, profiles/r05_bench_garden_c3_concentrated.txt).  NGP_BWD_CONCENTRATED=0 / 1 overrides.
+        conc = os.environ.get("NGP_BWD_CONCENTRATED")
+        self._concentrated = (conc == "1") if conc is not None else (float(exp_step_factor) > 0 or int(model.cascades) > 1)
         self.set_deterministic(os.environ.get("NGP_DETERMINISTIC", "0") == "1")
         self._comm_stub = os.environ.get("NGP_COMM_STUB", "0") == "1"
         self._pending_comm = []
@@ -299,7 +307,11 @@ class FusedTrainer:
         if getattr(_lib_mod, "_det_state", 0) != want:
             self.L.ngp_hash_bwd_sliced_deterministic(want)
             _lib_mod._det_state = want
-        return want
+        conc = 1 if self._concentrated else 0
+        if getattr(_lib_mod, "_conc_state", 0) != conc:
+            self.L.ngp_hash_bwd_sliced_concentrated(conc)
+            _lib_mod._conc_state = conc
+        return want + 2 * conc
 
     def repack(self):
         """Rebuild the fp16 MFMA weight image from the fp32 master weights (call after loading a checkpoint into the
@@ -463,10 +475,11 @@ class FusedTrainer:
 
             at, shape, side = self._prefetch_at, self._march_shape, self._side
             if self._adaptive_prefetch:
-                if ctypes.c_int32.from_address(self._marched_host.value).value <= self._MARCH_NARROW_MAX:
+                marched = ctypes.c_int32.from_address(self._marched_host.value).value
+                if marched <= self._MARCH_NARROW_MAX:
                     at, shape, side = 0, (4, 0), self._side_default
                 else:
-                    at, shape, side = 3, None, self._side_low
+                    at, shape, side = 3, (4, 0), self._side_low
             self._hook_at = at
 
             def hook():
@@ -566,6 +579,8 @@ class FusedTrainer:
         # cross-stream join cost 23 us between the prepass's end and the scatter-add's start: in line it is 17 us per step faster
         sliced = self.hash_bwd == "sliced"          # (half2 encoder: same prepass, main pass with its fp16 arithmetic + fp16 table)
         det = self._scatter_mode()
+        if hook is not None and self._hook_at == 2.5:
+            hook(); hook = None                                             # position 2.5: under the prepass, the MLP backward and the scatter-add
         if sliced:
             ws = A.sliced_ws(cfg.levels)
             rc = L.ngp_hash_bwd_sliced_prep(_ptr(M.xyzs), ctypes.byref(cfg.levels), A.cap, _ptr(cnt), _ptr(live_idx), 1, cfg.lo, cfg.hi,
@@ -584,6 +599,8 @@ class FusedTrainer:
         # weight gradients leave the launch as per-block slabs (plain stores) instead of 256 x 9408 same-address float atomics (13 us
         # of the launch); the slabs are added up by the prologue launch below, or -- when the gradient is needed before that (an
         # exchange between ranks, compute_gradients) -- by a launch of its own right here
+        if hook is not None and self._hook_at == 2.75:
+            hook(); hook = None                                             # position 2.75: under the MLP backward and the scatter-add
         if self._dw_atomic:                                   # NGP_MLP_DW=atomic: round 3's flush, for A/B runs
             check(L.ngp_mlp_bwd_live(_ptr(A.enc), _ptr(M.dirs), _ptr(self.wpack), _ptr(A.d_sigmas), _ptr(A.d_rgbs), A.cap, _ptr(cnt),
                                      _ptr(live_idx), P, _ptr(A.d_enc), _ptr(self.mlp_grad), found, st), "ngp_mlp_bwd_live")

@@ -355,6 +355,43 @@ def test_hash_bwd_f32_sliced(oracle, hip_lib, max_res):
     np.testing.assert_allclose(got, dt3.cpu().numpy(), rtol=2e-5, atol=2e-5)
 
 
+def test_hash_bwd_f32_sliced_concentrated_plan(oracle, hip_lib):
+    """Round 5: ngp_hash_bwd_sliced_concentrated -- coarse hashed levels with sample-range replicas -- on the C3
+    table with points crowded into 2 % of the box (what a multi-cascade scene looks like to the coarse levels): same touched entries
+    and values as the oracle, as the default plan, and through the optimizer-in-the-flush entry's level split."""
+    L = ops._lib()
+    lv = ops.make_levels(2**19, 16, 16, 4096, 2)
+    rng = np.random.default_rng(3)
+    n_rays, per_ray = 700, 60
+    o = 0.5 + (rng.random((n_rays, 1, 3), dtype=np.float32) - 0.5) * 0.02
+    d = rng.standard_normal((n_rays, 1, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    t = (np.arange(per_ray, dtype=np.float32) * np.float32(0.0003))[None, :, None]
+    x = np.clip(o + d * t, 0.0, 1.0).reshape(-1, 3).astype(np.float32)
+    x = np.concatenate([x, rng.random((3001, 3), dtype=np.float32)])
+    dout = rng.standard_normal((x.shape[0], 32)).astype(np.float32)
+    ref = oracle.hash_bwd_f32(x, dout, lv)
+    nrep = (ctypes.c_uint8 * 16)()
+    mm = ctypes.c_uint32()
+    assert L.ngp_hash_bwd_sliced_concentrated(1) == 0
+    try:
+        assert L.ngp_hash_bwd_sliced_plan(ctypes.byref(lv), None, 0, None, None, nrep, ctypes.byref(mm), None) > 0
+        assert nrep[5] > 1 and nrep[7] > 1 and nrep[8] == 1 and nrep[15] == 1  # hashed levels up to res 256: sample-range replicas
+        prefix = int(L.ngp_hash_bwd_sliced_adam_prefix(ctypes.byref(lv)))
+        first = min(l for l in range(16) if nrep[l] == 1 and all(nrep[k] == 1 for k in range(l, 16)))
+        assert prefix == lv.offset[first] * 2
+        dt = torch.zeros(lv.total_entries * 2, device="cuda")
+        ops.hash_bwd_f32_sliced(dev(x), dev(dout), lv, dt)
+        got = dt.cpu().numpy()
+    finally:
+        assert L.ngp_hash_bwd_sliced_concentrated(0) == 1
+    assert support_matches(ref, got)
+    np.testing.assert_allclose(got, ref, rtol=2e-5, atol=2e-5 * float(np.abs(ref).max()))
+    dt0 = torch.zeros(lv.total_entries * 2, device="cuda")
+    ops.hash_bwd_f32_sliced(dev(x), dev(dout), lv, dt0)
+    np.testing.assert_allclose(got, dt0.cpu().numpy(), rtol=2e-5, atol=2e-5 * float(np.abs(ref).max()))
+
+
 @pytest.mark.parametrize("n", [1, 63, 65, 4097])
 def test_hash_bwd_f32_sliced_ragged_sizes(oracle, hip_lib, n):
     """Sample counts that are not multiples of the 64-sample bitmap word / the 4096-sample super-chunk, down to one sample."""

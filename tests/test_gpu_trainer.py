@@ -530,8 +530,8 @@ def test_prefetched_march_placement_adapts_to_the_march_it_follows(hip_lib, lego
     """Round 5: on one GPU with the optimizer in the scatter-add's flush the trainer places the next batch's march by the sample count
     of recent marches, reported asynchronously by the side stream (ngp_copy_to_host_async into ngp_host_alloc memory): a light march
     (trained-Lego occupancy: ~20 samples per ray) goes to the START of the step as 4-wave blocks, a heavy one (all cells occupied,
-    ~500 samples per ray) before the scatter-add as 16-wave blocks at low priority; with the result unchanged either way.  Setting
-    one of the three environment switches pins the arrangement."""
+    ~500 samples per ray) before the scatter-add at low priority, and back when the grid thins out; with the result unchanged
+    either way.  Setting one of the three environment switches pins the arrangement."""
     import ctypes
     from ngp_hip.trainer import FusedTrainer
     for k in ("NGP_PREFETCH_AT", "NGP_MARCH_SHAPE", "NGP_SIDE_PRIORITY"):
@@ -541,6 +541,7 @@ def test_prefetched_march_placement_adapts_to_the_march_it_follows(hip_lib, lego
     tr = FusedTrainer(m, init_scale=2.0**10)
     assert tr._adaptive_prefetch and tr._hook_at == 3
     old_max = FusedTrainer._MARCH_NARROW_MAX
+    sparse = m.density_bitfield.clone()
     try:
         FusedTrainer._MARCH_NARROW_MAX = 60 * n              # (the class threshold is in samples per step; scale it to this batch)
         hits0 = tr.prefetch_hits
@@ -555,6 +556,11 @@ def test_prefetched_march_placement_adapts_to_the_march_it_follows(hip_lib, lego
             torch.cuda.synchronize()
         heavy = ctypes.c_int32.from_address(tr._marched_host.value).value
         assert heavy > 60 * n and tr._hook_at == 3
+        m.density_bitfield.copy_(sparse)                     # the grid thins out: the counts say so, the next steps go back
+        for i in range(3):
+            tr.step(o, d, target, prefetch=(o, d))
+            torch.cuda.synchronize()
+        assert 0 < ctypes.c_int32.from_address(tr._marched_host.value).value < 60 * n and tr._hook_at == 0
     finally:
         FusedTrainer._MARCH_NARROW_MAX = old_max
     tr.close()
