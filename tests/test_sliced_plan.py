@@ -96,3 +96,35 @@ def test_flush_adam_prefix_and_deterministic_plan():
     assert plan_of(lv)[0] == n
     small = ops.make_levels(2**15, 16, 16, 512, 2)                  # no level of 64 slices: nothing for the flush to own
     assert L.ngp_hash_bwd_sliced_adam_prefix(ctypes.byref(small)) == -2
+
+
+def test_concentrated_scene_plan():
+    """Round 5: ngp_hash_bwd_sliced_concentrated(1) -- hashed levels up to resolution 256 get three sample-range replicas per slice (a
+    scene that fills a small part of its box loads a few of their owners with several times the mean), the plan still fits the
+    kernel argument, the flush-Adam set shrinks to the levels that keep one owner per slice, and switching the mode off restores the
+    default plan.  On the C2 table (levels up to resolution 256 are dense there or already replicated) the hashed levels it touches are
+    the first hashed ones only."""
+    L = lib.load()
+    c3 = ops.make_levels(2**19, 16, 16, 4096, 2)
+    bfhl = int(c3.begin_fast_hash_level)
+    n0, _, _, _, nrep0, mm0, _ = plan_of(c3)
+    pre0 = L.ngp_hash_bwd_sliced_adam_prefix(ctypes.byref(c3))
+    assert L.ngp_hash_bwd_sliced_concentrated(1) == 0
+    try:
+        n1, tasks, xoff, xlen, nrep1, mm1, _ = plan_of(c3)
+        assert 0 < n1 <= 1536 and int(xlen.sum()) == n1
+        hot = [l for l in range(bfhl, 16) if int(c3.resolution[l]) <= 256]
+        assert hot and all(int(nrep1[l]) == 3 for l in hot)
+        assert all(int(nrep1[l]) == 1 for l in range(bfhl, 16) if l not in hot)
+        assert all(int(nrep1[l]) >= 4 for l in range(bfhl) if int(c3.map_size[l]) > SLICE)       # dense levels keep >= 4 sample ranges
+        assert mm1 == mm0                                                                       # run pre-summing: dense levels only, as before
+        first = max(hot) + 1
+        assert L.ngp_hash_bwd_sliced_adam_prefix(ctypes.byref(c3)) == 2 * int(c3.offset[first]) > pre0
+        # every (level, slice, replica) exactly once
+        seen = set(int(t) for t in tasks[:n1])
+        assert len(seen) == n1
+    finally:
+        assert L.ngp_hash_bwd_sliced_concentrated(0) == 1
+    n2, _, _, _, nrep2, mm2, _ = plan_of(c3)
+    assert n2 == n0 and list(nrep2) == list(nrep0) and mm2 == mm0
+    assert L.ngp_hash_bwd_sliced_adam_prefix(ctypes.byref(c3)) == pre0
