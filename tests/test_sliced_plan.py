@@ -128,3 +128,38 @@ def test_concentrated_scene_plan():
     n2, _, _, _, nrep2, mm2, _ = plan_of(c3)
     assert n2 == n0 and list(nrep2) == list(nrep0) and mm2 == mm0
     assert L.ngp_hash_bwd_sliced_adam_prefix(ctypes.byref(c3)) == pre0
+
+
+def test_plan_sweep_over_level_tables_and_modes():
+    """Every level table the encoder can be built with, in every plan mode (default, deterministic, concentrated, both): the builder
+    either refuses (-2) or returns a plan of at most 1536 tasks (the kernel-argument bound) that names every (level, slice, replica)
+    once, with one owner per slice in deterministic mode, and a flush-Adam prefix that is exactly the start of the one-owner suffix."""
+    import itertools
+    L = lib.load()
+    n_plans = 0
+    try:
+        for det, conc in itertools.product((0, 1), (0, 1)):
+            L.ngp_hash_bwd_sliced_deterministic(det)
+            L.ngp_hash_bwd_sliced_concentrated(conc)
+            for log2_t, nl, base, max_res in itertools.product((12, 15, 17, 19, 20, 22), (1, 4, 8, 16), (4, 16, 64), (64, 512, 2048, 4096, 16384)):
+                lv = ops.make_levels(2**log2_t, nl, base, max_res, 2)
+                n, tasks, xoff, xlen, nrep, mm, sm = plan_of(lv)
+                if n < 0:
+                    assert n == -2
+                    continue
+                n_plans += 1
+                sizes = [int(lv.map_size[l]) for l in range(nl)]
+                assert 0 < n <= 1536 and int(xlen.sum()) == n and len(set(int(t) for t in tasks[:n])) == n
+                assert n == sum(((s + SLICE - 1) // SLICE) * int(nrep[l]) for l, s in enumerate(sizes))
+                if det:
+                    assert all(int(nrep[l]) == 1 for l in range(nl))
+                pre = L.ngp_hash_bwd_sliced_adam_prefix(ctypes.byref(lv))
+                if pre >= 0:
+                    first = min(l for l in range(nl) if all(int(nrep[k]) == 1 for k in range(l, nl)))
+                    assert pre == 2 * int(lv.offset[first])
+                else:
+                    assert pre == -2
+    finally:
+        L.ngp_hash_bwd_sliced_deterministic(0)
+        L.ngp_hash_bwd_sliced_concentrated(0)
+    assert n_plans > 500
