@@ -328,7 +328,7 @@ __global__ void __launch_bounds__(256) composite_test_kernel(const float* __rest
 // whose transmittance after the chunks shaded so far is at or below `thr_stop` gets no further chunk.  thr_stop = thr / 2: the
 // estimate here is exp(-sum sigma delta), the compositing kernels form the running product of (1 - a) -- equal up to rounding, so
 // every group they read has been shaded; what lies behind is never read, never contributes (its gradients are exact zeros in the
-// reference too).  One wave per ray, 16 rays per block, one returning atomic per block for the block's range of the list.
+// reference too).
 // Block shape of the two list builders below: 16 lanes per ray, 64 rays per 1024-thread block, ONE returning atomic per block on the
 // list's counter.  (First version: a wave per ray, 16 rays per block = 4096 same-address atomics per launch at 65 536 rays -- ~12 ns
 // each: 50 us of a launch that moves 12 MB; profiles/r05_rocprofv3_garden_timed_region.txt.)
