@@ -303,14 +303,12 @@ class FusedTrainer:
 
     def _scatter_mode(self):
         """Tell the library which task plan this trainer's scatter-add launches use (a per-thread switch of the library)."""
+        # (set on every step, not cached on the Python side: the flush-Adam prefix this trainer caches per mode must describe the plan
+        # the library will really build, whoever else flipped the switches on this thread in between -- two host calls, ~1 us)
         want = 1 if self.deterministic else 0
-        if getattr(_lib_mod, "_det_state", 0) != want:
-            self.L.ngp_hash_bwd_sliced_deterministic(want)
-            _lib_mod._det_state = want
         conc = 1 if self._concentrated else 0
-        if getattr(_lib_mod, "_conc_state", 0) != conc:
-            self.L.ngp_hash_bwd_sliced_concentrated(conc)
-            _lib_mod._conc_state = conc
+        self.L.ngp_hash_bwd_sliced_deterministic(want)
+        self.L.ngp_hash_bwd_sliced_concentrated(conc)
         return want + 2 * conc
 
     def repack(self):

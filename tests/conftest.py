@@ -41,12 +41,11 @@ def hip_lib():
 @pytest.fixture(autouse=True)
 def _default_scatter_plan():
     """The scatter-add's plan modes (deterministic / concentrated) are per-thread switches of the library that a FusedTrainer leaves
-    as it last needed them: every test starts from the defaults, whatever ran before it."""
+    as it last needed them (it sets them on every step): every test starts from the defaults, whatever ran before it."""
     from ngp_hip import lib
     if lib._lib is not None:
         lib._lib.ngp_hash_bwd_sliced_deterministic(0)
         lib._lib.ngp_hash_bwd_sliced_concentrated(0)
-        lib._det_state = lib._conc_state = 0
     yield
 
 

@@ -44,3 +44,24 @@ def test_comm_record_bus_bandwidth_and_model():
     o2 = dict(o, comm_bytes_per_rank_per_step={"all_reduce_flat_bucket": 45_717_904}, comm_breakdown_ms={"all_reduce_flat_bucket": 0.3})
     r2 = b._comm_record("n", "w", ["--no-shard"], {}, o2, 2)
     assert abs(r2["bus_bandwidth_GBs"] - 2 * 45_717_904 * 0.5 / 0.3e-3 / 1e9) < 1e-6
+
+
+def test_scatter_mode_sets_the_library_switches_every_time():
+    """FusedTrainer._scatter_mode: the key under which the trainer caches its flush-Adam prefix names the plan mode the library is
+    REALLY in afterwards -- it sets both per-thread switches on every call instead of trusting a Python-side copy of them (another
+    caller on the thread may have flipped them in between).  Host logic only: the C switches are plain thread-local flags."""
+    from types import SimpleNamespace
+    from ngp_hip import lib
+    from ngp_hip.trainer import FusedTrainer
+    L = lib.load()
+    try:
+        for det, conc in ((0, 0), (1, 0), (0, 1), (1, 1), (0, 0)):
+            stub = SimpleNamespace(L=L, deterministic=bool(det), _concentrated=bool(conc))
+            # somebody else leaves the opposite setting behind
+            L.ngp_hash_bwd_sliced_deterministic(1 - det)
+            L.ngp_hash_bwd_sliced_concentrated(1 - conc)
+            assert FusedTrainer._scatter_mode(stub) == det + 2 * conc
+            assert L.ngp_hash_bwd_sliced_deterministic(det) == det and L.ngp_hash_bwd_sliced_concentrated(conc) == conc
+    finally:
+        L.ngp_hash_bwd_sliced_deterministic(0)
+        L.ngp_hash_bwd_sliced_concentrated(0)
