@@ -26,7 +26,7 @@ extern "C" {
 #endif
 
 #define NGP_MAX_LEVELS 16
-#define NGP_ABI_VERSION 1
+#define NGP_ABI_VERSION 2
 
 /* Multiresolution level table.  Built ONCE on the host (ngp_hash_levels_init) in the arithmetic of
  * modules/hash_encoder.py:183-205 + modules/utils.py:19-42 (f64 sizes) and of the in-kernel
@@ -41,7 +41,24 @@ typedef struct ngp_hash_levels {
     uint32_t resolution[NGP_MAX_LEVELS]; /* ceil(scale)+1                                       */
     uint32_t map_size[NGP_MAX_LEVELS]; /* entries in level l                                    */
     uint32_t offset[NGP_MAX_LEVELS];   /* first entry of level l                                */
+    uint32_t bwd_plan;                 /* NGP_BWD_PLAN_* bits: task plan of the LDS-sliced scatter-add over this table
+                                          (ngp_hash_bwd_sliced_*); 0 after ngp_hash_levels_init; every other entry point ignores it */
 } ngp_hash_levels;
+
+/* Task-plan modes of the LDS-sliced scatter-add (ngp_hash_levels.bwd_plan).  They are part of the level table the caller hands to
+ * EVERY ngp_hash_bwd_sliced_* call of one step (prep, main*, adam_prefix, plan must see the same bits): the library keeps no mode
+ * state of its own (until ABI version 1 these were per-thread switches, ngp_hash_bwd_sliced_deterministic / _concentrated).
+ * DETERMINISTIC: the default plan replicates the coarse levels over sample ranges whose owners meet in dtable with float atomics
+ *   (order-dependent at ~1e-7) and pre-sums equal-cell runs in groups that depend on which wave took which piece of the sample list.
+ *   With this bit every slice has ONE owner (no float atomics; with _main_adam the optimizer runs in the flush of EVERY level,
+ *   _adam_prefix = 0) and a pre-summing group never spans two pieces: the result is a function of the inputs.  Slower on the coarse
+ *   levels; bench.py conditions its model in this mode so that two processes reach the same state.
+ * CONCENTRATED: for scenes that fill a small part of the box (multi-cascade scenes) the coarse hashed levels (resolution <= 256) get
+ *   sample-range replicas like the dense ones -- a few hot cells otherwise load a handful of slice owners with several times the mean
+ *   (C3: the launch 2.2 ms with the XCDs busy 55 % of it; 1.7 ms in this mode).  The levels that get replicas leave the set
+ *   ngp_hash_bwd_sliced_main_adam updates in its flush (ngp_hash_bwd_sliced_adam_prefix says where that set starts). */
+#define NGP_BWD_PLAN_DETERMINISTIC 1u
+#define NGP_BWD_PLAN_CONCENTRATED  2u
 
 int ngp_abi_version(void);
 
@@ -330,20 +347,6 @@ int ngp_hash_bwd_sliced_main_f16(const float* dout, const ngp_hash_levels* lv, i
  * tasks[xoff[x] .. xoff[x] + xlen[x]); returns the number of tasks or -2 when the level table cannot be expressed */
 int ngp_hash_bwd_sliced_plan(const ngp_hash_levels* lv, uint16_t* tasks, int max_tasks, uint16_t* xoff /*[8]*/, uint16_t* xlen /*[8]*/,
                              uint8_t* nrep /*[NGP_MAX_LEVELS]*/, uint32_t* merge_mask, uint32_t* single_mask);
-/* Deterministic mode of the sliced scatter-add, per host thread (default 0; returns the previous setting).  The default plan
- * replicates the coarse levels over sample ranges whose owners meet in dtable with float atomics (order-dependent at ~1e-7) and
- * pre-sums equal-cell runs in groups that depend on which wave took which piece of the sample list.  With on != 0 every slice has ONE
- * owner (no float atomics; with _main_adam the optimizer runs in the flush of EVERY level, _adam_prefix = 0) and a pre-summing
- * group never spans two pieces: the result is a function of the inputs.  Slower on the coarse levels; bench.py conditions its model
- * in this mode so that two processes reach the same state. */
-int ngp_hash_bwd_sliced_deterministic(int on);
-/* Concentrated-scene plan (per host thread, default off; returns the previous setting): for scenes that fill a small part of the
- * box (multi-cascade scenes) the coarse hashed levels (resolution <= 256) get sample-range replicas like the dense ones -- a few hot
- * cells otherwise load a handful of slice owners with several times the mean (C3: the launch 2.2 ms with the XCDs busy 55 % of it;
- * 1.7 ms in this mode).
- * The levels that get replicas leave the set ngp_hash_bwd_sliced_main_adam updates in its flush (ngp_hash_bwd_sliced_adam_prefix
- * says where that set starts). */
-int ngp_hash_bwd_sliced_concentrated(int on);
 /* diagnostics: per-TASK task word + wall-clock stamps into a device buffer of 8 * 1536 uint64 (one 8-word row per task of the
  * plan, at most 1536 tasks; NULL = off, the default) */
 int ngp_hash_bwd_sliced_debug(void* device_buffer);

@@ -60,11 +60,35 @@ class FusedAdam(torch.optim.Optimizer):
     def load_state_dict(self, state_dict):
         sd = dict(state_dict)
         gs = sd.pop("ngp_group_state", None)
+        if gs is not None:
+            # validated BEFORE anything is applied: a state of another optimizer layout must not be half-loaded
+            if len(gs) != len(self.param_groups):
+                raise ValueError("ngp_group_state has %d entries, this optimizer has %d parameter groups" % (len(gs), len(self.param_groups)))
+            for f, i in gs:
+                if f.numel() != 8 or i.numel() != 8:
+                    raise ValueError("ngp_group_state entries must hold 8 elements each (got %d / %d)" % (f.numel(), i.numel()))
         super().load_state_dict(sd)
         if gs is not None:
-            self._sf = [f.detach().clone() for f, _ in gs]
-            self._si = [i.detach().clone() for _, i in gs]
+            # torch's Optimizer.load_state_dict casts the per-parameter `state` entries to the parameters' device; these are ours, so
+            # the same has to happen here: a checkpoint read with map_location='cpu' would otherwise hand HOST pointers to the Adam
+            # kernels
+            sf, si = [], []
+            for (f, i), group in zip(gs, self.param_groups):
+                dev = self._group_device(group)
+                sf.append(f.detach().to(device=dev, dtype=torch.float32).clone().reshape(8))
+                si.append(i.detach().to(device=dev, dtype=torch.int32).clone().reshape(8))
+            self._sf, self._si = sf, si
         self._multi = {}
+
+    @staticmethod
+    def _group_device(group):
+        devs = {p.device for p in group["params"]}
+        if len(devs) != 1:
+            raise NotImplementedError("compat FusedAdam: the parameters of one group must live on one device (got %s)" % sorted(map(str, devs)))
+        dev = next(iter(devs))
+        if dev.type != "cuda":
+            raise NotImplementedError("compat FusedAdam: parameters must be CUDA tensors (libngp_hip has no CPU path)")
+        return dev
 
     def _check(self, p, g):
         if (not p.is_cuda or p.dtype != torch.float32 or g.dtype != torch.float32 or not p.is_contiguous() or not g.is_contiguous()
@@ -103,15 +127,29 @@ class FusedAdam(torch.optim.Optimizer):
             else:                                                  # scaler.unscale_(optimizer) ran: gradients are unscaled, flags recorded
                 scale = None
                 flags = list(state["found_inf_per_device"].values())
+                if not flags:
+                    raise RuntimeError("compat FusedAdam: GradScaler recorded no inf flag for this optimizer (unscale_ saw no gradients)")
                 found = flags[0] if len(flags) == 1 else sum(f.to(flags[0].device) for f in flags)
+        devices = {p.device for group in self.param_groups for p in group["params"] if p.grad is not None}
+        if len(devices) > 1:
+            # one skip decision per step needs one flag every group's prologue can read: parameters spread over devices would make the
+            # prologues of the other devices dereference a foreign pointer
+            raise NotImplementedError("compat FusedAdam: all parameters must live on one device (got %s)" % sorted(map(str, devices)))
+        self._pending.clear()                  # (a previous step() that raised half-way must not be replayed with stale pointers)
+        try:
+            return self._step(L, scale, found, own_check, grad_scaler, loss)
+        finally:
+            self._pending.clear()
+
+    def _step(self, L, scale, found, own_check, grad_scaler, loss):
         for gi, group in enumerate(self.param_groups):
             ps = [p for p in group["params"] if p.grad is not None]
             if not ps:
                 continue
             dev = ps[0].device
             if self._sf is None:
-                self._sf = [torch.zeros(8, device=dev, dtype=torch.float32) for _ in self.param_groups]
-                self._si = [torch.zeros(8, device=dev, dtype=torch.int32) for _ in self.param_groups]
+                self._sf = [torch.zeros(8, device=self._group_device(g), dtype=torch.float32) for g in self.param_groups]
+                self._si = [torch.zeros(8, device=self._group_device(g), dtype=torch.int32) for g in self.param_groups]
             sf, si = self._sf[gi], self._si[gi]
             b1, b2 = group["betas"]
             st = _stream()
@@ -151,16 +189,15 @@ class FusedAdam(torch.optim.Optimizer):
                     _lib.check(L.ngp_check_finite_multi(k, G, N, _ptr(found), st), "ngp_check_finite_multi")
             if scale is not None and (scale.dtype != torch.float32 or found is None or found.dtype != torch.float32):
                 raise TypeError("grad_scale / found_inf must be float32 device tensors (torch.cuda.amp.GradScaler's are)")
-            self._pending.append((gi, group, sf, si, b1, b2, chunks, st, ps))
+            self._pending.append((gi, group, sf, si, b1, b2, chunks, st, ps, scale, found))
         # every group's flag is complete before any group is updated: one overflow skips the whole step (GradScaler's semantics)
-        for gi, group, sf, si, b1, b2, chunks, st, ps in self._pending:
+        for gi, group, sf, si, b1, b2, chunks, st, ps, scale, found in self._pending:
             _lib.check(L.ngp_adam_amp_prologue(_ptr(sf), _ptr(si), _ptr(scale), _ptr(found), float(group["lr"]), float(b1), float(b2),
                                                st), "ngp_adam_amp_prologue")
             for k, P, G, M, V, N in chunks:
                 _lib.check(L.ngp_adam_multi(k, P, G, M, V, N, _ptr(sf), _ptr(si), float(b1), float(b2), float(group["eps"]), st),
                            "ngp_adam_multi")
             _touched(*ps, *[p.grad for p in ps])            # written through raw pointers: version-keyed caches (the encoders' 16-bit table copies) must see it
-        self._pending.clear()
         return loss
 
 

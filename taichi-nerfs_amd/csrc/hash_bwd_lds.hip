@@ -65,7 +65,7 @@ constexpr int BW_WAVES = BW_THREADS / 64;
 constexpr int BW_Q = 256;                                      // per-wave hit queue (entries)
 constexpr int BW_MAX_TASKS = 1536;
 constexpr int BW_PREP_BLOCKS = 2048;
-constexpr size_t BW_CTR_BYTES = 64;                           // 8 queue heads + the exit counter of the main kernel
+constexpr size_t BW_CTR_BYTES = 64;                           // 8 queue heads + the exit counter of the main kernel + [9]: a flush-Adam slice sum overflowed
 constexpr int BW_PERSISTENT_BLOCKS = 256;                     // one 1024-thread workgroup (147 KB of LDS) per CU
 
 struct BwdPlan {
@@ -864,6 +864,12 @@ __global__ void __launch_bounds__(BW_THREADS) hash_bwd_lds_kernel(const float* _
                 float2 mk = mi[k], vk = vi[k], pk = pi[k];
                 const bool in = !skip && h[k] < P.size;
                 if (!in || (gx == 0.f && gy == 0.f && mk.x == 0.f && mk.y == 0.f && vk.x == 0.f && vk.y == 0.f)) continue;   // exact fixed point
+                // The GradScaler decision of this step was taken on the per-sample d_enc values (MLP backward); a slice SUM that leaves the
+                // f32 range anyway must not reach the master table and the moments, where nothing could undo it: the entry is
+                // left alone and the overflow is recorded -- the last workgroup raises the inf flag in the state it publishes, so the NEXT
+                // step is skipped and the loss scale backs off (the two-launch path would have skipped THIS step: same scale trajectory
+                // one step later, no poisoned parameter).
+                if (!(isfinite(gx) && isfinite(gy))) { atomicOr(&ctr[9], 1u); continue; }
 #define NGP_ADAM1(c, g)                                                       \
                 {                                                             \
                     const float gr = (g) * inv_scale;                         \
@@ -912,9 +918,12 @@ __global__ void __launch_bounds__(BW_THREADS) hash_bwd_lds_kernel(const float* _
         if (atomicAdd(&ctr[8], 1u) == gridDim.x - 1u) {
             for (int x = 0; x < 8; ++x) ctr[x] = 0u;
             ctr[8] = 0u;
+            const uint32_t overflow = ADAM ? __atomic_load_n(&ctr[9], __ATOMIC_RELAXED) : 0u;      // a flush saw a non-finite slice sum
+            if (ADAM) ctr[9] = 0u;
             if (own_schedule) {
 #pragma unroll
                 for (int k = 0; k < 8; ++k) { sch.sf[k] = s_sf[k]; sch.si[k] = s_si[k]; }
+                if (overflow) sch.si[SI_FOUND_INF] = 1;
             }
         }
     }
@@ -930,8 +939,8 @@ struct Knobs {
     int rep_target = 48, merge_res = 128, dense_min_rep = 8;
     uint32_t level_mask = 0xffffffffu, diag = 0u;
     int blocks = 0;                            // -DNGP_BWD_DIAG: fewer persistent workgroups (contention experiment)
-    bool deterministic = false;                // ngp_hash_bwd_sliced_deterministic(1): no sample-range replicas (no float atomics), see there
-    // ngp_hash_bwd_sliced_concentrated(1): the scene fills a small part of the box (multi-cascade scenes), so the COARSE HASHED levels
+    bool deterministic = false;                // NGP_BWD_PLAN_DETERMINISTIC: no sample-range replicas (no float atomics), see include/ngp_hip.h
+    // NGP_BWD_PLAN_CONCENTRATED: the scene fills a small part of the box (multi-cascade scenes), so the COARSE HASHED levels
     // behave like dense ones -- few hot cells carry most samples, and wherever their hash indices fall, a handful of slice owners get
     // several times the mean (C3, profiles/r05_scatter_timeline_garden.txt: level 5's owners 374 us on average, the slowest ~1.3 ms; the
     // XCDs busy 55 % of the launch).  Levels up to hashed_rep_res then get hashed_rep sample-range replicas per slice: C3's launch
@@ -957,11 +966,10 @@ static Knobs read_knobs() {
 #endif
     return k;
 }
-static thread_local bool g_bwd_deterministic = false;
-static thread_local bool g_bwd_concentrated = false;
-static void apply_modes(Knobs& k) {
-    k.deterministic = g_bwd_deterministic;
-    if (g_bwd_concentrated) {
+// the plan modes travel with the level table (ngp_hash_levels.bwd_plan): no mode state in the library
+static void apply_modes(Knobs& k, uint32_t plan_bits) {
+    k.deterministic = (plan_bits & NGP_BWD_PLAN_DETERMINISTIC) != 0u;
+    if (plan_bits & NGP_BWD_PLAN_CONCENTRATED) {
         // (NGP_BWD_HASHED_REP_RES / NGP_BWD_HASHED_REP / NGP_BWD_MERGE_HASHED: A/B overrides of what the mode switches on)
         static const int res = [] { const char* e = getenv("NGP_BWD_HASHED_REP_RES"); return e ? atoi(e) : 256; }();
         static const int rep = [] { const char* e = getenv("NGP_BWD_HASHED_REP"); return e && atoi(e) > 0 ? atoi(e) : 3; }();
@@ -969,15 +977,15 @@ static void apply_modes(Knobs& k) {
         k.hashed_rep_res = res; k.hashed_rep = rep; k.merge_hashed = mh;
     } else { k.hashed_rep_res = 0; k.hashed_rep = 1; k.merge_hashed = false; }
 }
-static const Knobs& knobs() {
+static Knobs knobs(uint32_t plan_bits) {
     static const bool dynamic = getenv("NGP_BWD_KNOBS_DYNAMIC") != nullptr;
     static const Knobs fixed = read_knobs();
-    static thread_local Knobs k;
+    Knobs k;
 #ifndef NGP_BWD_DIAG
-    if (!dynamic) { k = fixed; apply_modes(k); return k; }
+    if (!dynamic) { k = fixed; apply_modes(k, plan_bits); return k; }
 #endif
     k = read_knobs();
-    apply_modes(k);
+    apply_modes(k, plan_bits);
     return k;
 }
 
@@ -1104,7 +1112,7 @@ struct PlanCache {
 static const BwdPlan* get_plan(const ngp_hash_levels& lv, uint32_t& single_mask, uint32_t level_mask = 0xffffffffu, int max_blocks = 0) {
     static thread_local PlanCache cache[8];                      // two tables alternate in a process that trains and evaluates,
     static thread_local int victim = 0;                          // each possibly split into a few level groups
-    Knobs K = knobs();
+    Knobs K = knobs(lv.bwd_plan);
     K.level_mask &= level_mask;
     if (max_blocks > 0 && (K.blocks <= 0 || max_blocks < K.blocks)) K.blocks = max_blocks;
     for (PlanCache& c : cache)
@@ -1143,27 +1151,6 @@ extern "C" {
 // diagnostics: when set to a device buffer of 8 * BW_MAX_TASKS (= 8 * 1536) u64, every task of the main kernel records its task
 // word, 100 MHz wall-clock stamps (begin, after LDS init, wave 0 done, all waves done, after flush), its XCC id and the sample count
 int ngp_hash_bwd_sliced_debug(void* device_buffer) { g_bwd_debug = (unsigned long long*)device_buffer; return 0; }
-
-// Deterministic mode (per host thread; default off).  The default plan replicates the coarse levels over sample ranges whose owners
-// meet in the gradient table with float atomics (order-dependent at ~1e-7), and pre-sums equal-cell runs in groups that depend on
-// which wave took which super-chunk.  With on != 0 every slice has ONE owner (plain read-modify-write / the optimizer in the flush
-// for every level) and a pre-summing group never spans two super-chunks: the result depends on the inputs only (up to the f64
-// slice sums, which are exact unless an entry's terms span more than 2^29).  Slower on the coarse levels (one workgroup sees every
-// sample of level 0); bench.py conditions its model in this mode so that two processes reach the same state, then switches it off
-// for the timed steps.  Returns the previous setting.
-int ngp_hash_bwd_sliced_deterministic(int on) {
-    const int was = g_bwd_deterministic ? 1 : 0;
-    g_bwd_deterministic = on != 0;
-    return was;
-}
-
-// Concentrated-scene mode (per host thread; default off): the task plan treats the coarse hashed levels like dense ones (see Knobs).
-// Same result up to the float-atomic order of the replicas' flushes (as on the dense levels).  Returns the previous setting.
-int ngp_hash_bwd_sliced_concentrated(int on) {
-    const int was = g_bwd_concentrated ? 1 : 0;
-    g_bwd_concentrated = on != 0;
-    return was;
-}
 
 // host-side introspection (no GPU needed; tests/test_sliced_plan.py): the task plan the main launch would use for this level
 // table.  tasks[k] = level | slice << 4 | replica << 10 for k < return value; XCD x owns tasks[xoff[x] .. xoff[x] + xlen[x]);

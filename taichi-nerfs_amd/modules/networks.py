@@ -207,7 +207,11 @@ class NGP(nn.Module):
                 self.density_grid[c, indices[i:i + chunk]] = torch.where(valid, 0., -1.)
 
     @torch.no_grad()
-    def update_density_grid(self, density_threshold, warmup=False, decay=0.95, erode=False):
+    def update_density_grid(self, density_threshold, warmup=False, decay=0.95, erode=False, jitter=None):
+        """Reference signature (:255-259) plus `jitter` (tests only): callable (cascade, n) -> [n, 3] uniforms that replace the
+        in-cell torch.rand_like draw of the warm-up form, row i belonging to the cell with Morton code i."""
+        if jitter is not None and not warmup:
+            raise ValueError("an explicit jitter is defined for the warm-up form (all cells) only")
         if (not erode and self.density_grid.is_cuda and self._fused_ok(self.density_grid)
                 and os.environ.get("NGP_FUSED_OCCUPANCY", "1") != "0"):
             # same algorithm, device-resident (no torch.nonzero / .item() host round trips): ngp_hip/occupancy.py
@@ -217,7 +221,7 @@ class NGP(nn.Module):
                 upd = self._occ_updater = OccupancyUpdater(self)
             if not self.density_grid.is_contiguous():
                 self.density_grid = self.density_grid.contiguous()
-            return upd.update(density_threshold, warmup=warmup, decay=decay)
+            return upd.update(density_threshold, warmup=warmup, decay=decay, jitter=jitter)
         fresh = torch.zeros_like(self.density_grid)
         cells = self.get_all_cells() if warmup else \
             self.sample_uniform_and_occupied_cells(self.grid_size**3 // 4, density_threshold)
@@ -226,7 +230,8 @@ class NGP(nn.Module):
             s = min(2**(c - 1), self.scale)
             half_grid = s / self.grid_size
             xyzs_w = (coords / (self.grid_size - 1) * 2 - 1) * (s - half_grid)
-            xyzs_w += (torch.rand_like(xyzs_w) * 2 - 1) * half_grid          # random point inside the cell
+            u = torch.rand_like(xyzs_w) if jitter is None else jitter(c, len(indices)).to(xyzs_w)   # (all cells: Morton-sorted rows)
+            xyzs_w += (u * 2 - 1) * half_grid                                # random point inside the cell
             fresh[c, indices] = self.density(xyzs_w).float()
         if erode:
             decay = torch.clamp(decay**(1 / self.count_grid), 0.1, 0.95)

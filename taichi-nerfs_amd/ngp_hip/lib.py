@@ -35,7 +35,25 @@ class HashLevels(ctypes.Structure):
         ("resolution", ctypes.c_uint32 * NGP_MAX_LEVELS),
         ("map_size", ctypes.c_uint32 * NGP_MAX_LEVELS),
         ("offset", ctypes.c_uint32 * NGP_MAX_LEVELS),
+        ("bwd_plan", ctypes.c_uint32),          # NGP_BWD_PLAN_* bits (task plan of the LDS-sliced scatter-add over this table)
     ]
+
+    def with_plan(self, bits):
+        """A copy of this level table whose LDS-sliced scatter-add runs on the task plan `bits` (BWD_PLAN_*); copies are cached."""
+        bits = int(bits)
+        if bits == self.bwd_plan:
+            return self
+        cache = self.__dict__.setdefault("_plans", {})
+        lv = cache.get(bits)
+        if lv is None:
+            lv = HashLevels()
+            ctypes.memmove(ctypes.byref(lv), ctypes.byref(self), ctypes.sizeof(HashLevels))
+            lv.bwd_plan = bits
+            cache[bits] = lv
+        return lv
+
+
+BWD_PLAN_DETERMINISTIC, BWD_PLAN_CONCENTRATED = 1, 2
 
 
 def _render_fields():
@@ -147,8 +165,6 @@ SIGNATURES = {
     "ngp_hash_bwd_f16_live": [_P, _P, _LV, _I, _P, _P, _I, _F, _F, _I, _P, _P, _P],
     "ngp_hash_bwd_sliced_workspace": [_LV, _I],
     "ngp_hash_bwd_sliced_debug": [_P],
-    "ngp_hash_bwd_sliced_deterministic": [_I],
-    "ngp_hash_bwd_sliced_concentrated": [_I],
     "ngp_hash_bwd_sliced_plan": [_LV, _P, _I, _P, _P, _P, _P, _P],
     "ngp_hash_bwd_sliced_prep": [_P, _LV, _I, _P, _P, _I, _F, _F, _P, ctypes.c_longlong, _P],
     "ngp_hash_bwd_sliced_main": [_P, _LV, _I, _P, _I, _P, _P, _P, ctypes.c_longlong, _P],

@@ -243,7 +243,6 @@ class FusedTrainer:
         # that on one GPU with the optimizer in the flush the trainer chooses per step (see _adaptive_prefetch above).
         shape = _os.environ.get("NGP_MARCH_SHAPE", "")
         self._march_shape = tuple(int(x) for x in shape.split(",")) if shape and shape != "16,0" else None
-        self._coarse_ver = None
         self.sync_occupancy = True            # world > 1: broadcast rank 0's occupancy after every update_density_grid()
         # bench.py: callable -> (record this step?, list); every collective of the step is then bracketed by two HIP events on the
         # step's stream and (name, e0, e1) is appended to the list
@@ -278,12 +277,12 @@ class FusedTrainer:
         self._adam_prefix = {}                # per scatter-add mode: floats of the table the flush does NOT update (-2: not expressible)
         # Deterministic mode (set_deterministic / NGP_DETERMINISTIC=1; bench.py conditions its model in it so that two processes
         # reach the same state): rays packed in ray order (count / scan / write chain), the live list in ray order
-        # (ngp_live_compact), every table slice owned by one workgroup (ngp_hash_bwd_sliced_deterministic: no float atomics), the
+        # (ngp_live_compact), every table slice owned by one workgroup (NGP_BWD_PLAN_DETERMINISTIC: no float atomics), the
         # occupancy update without its two order-dependent spots (ngp_hip/occupancy.py).  Same kernels, same arithmetic per sample;
         # what changes is the ORDER in which floating-point sums are formed, which is fixed.  Slower (~1.5 ms per step at C2).
         self.deterministic = False
         # Multi-cascade / exponentially stepped scenes fill a small part of their box: the scatter-add's plan then treats the coarse
-        # hashed levels like dense ones (ngp_hash_bwd_sliced_concentrated; C3: the launch 2.5 -> 1.7 ms beside the march, which then no
+        # hashed levels like dense ones (NGP_BWD_PLAN_CONCENTRATED; C3: the launch 2.5 -> 1.7 ms beside the march, which then no
         # longer fits under it as 16-wave blocks: 4-wave blocks, profiles/r05_bench_garden_c3_concentrated.txt).  NGP_BWD_CONCENTRATED=0 / 1 overrides.
         conc = os.environ.get("NGP_BWD_CONCENTRATED")
         self._concentrated = (conc == "1") if conc is not None else (float(exp_step_factor) > 0 or int(model.cascades) > 1)
@@ -297,19 +296,20 @@ class FusedTrainer:
         self.repack()
 
     def set_deterministic(self, on):
+        if getattr(self, "_graph", None) is not None and bool(on) != self.deterministic:
+            # the launch sequence (ray-ordered chain or one-launch march, which live list, which task plan) is baked into the captured
+            # graphs: flipping the mode afterwards would silently keep replaying the old one
+            raise RuntimeError("set_deterministic() after capture(): the captured graphs hold the previous mode's launches; "
+                               "set the mode before capture()")
         self.deterministic = bool(on)
         self.model._ngp_deterministic = self.deterministic          # read by ngp_hip/occupancy.py
         return self
 
     def _scatter_mode(self):
-        """Tell the library which task plan this trainer's scatter-add launches use (a per-thread switch of the library)."""
-        # (set on every step, not cached on the Python side: the flush-Adam prefix this trainer caches per mode must describe the plan
-        # the library will really build, whoever else flipped the switches on this thread in between -- two host calls, ~1 us)
-        want = 1 if self.deterministic else 0
-        conc = 1 if self._concentrated else 0
-        self.L.ngp_hash_bwd_sliced_deterministic(want)
-        self.L.ngp_hash_bwd_sliced_concentrated(conc)
-        return want + 2 * conc
+        """The task plan this trainer's scatter-add launches run on, as NGP_BWD_PLAN_* bits.  The bits travel inside the level table
+        handed to every ngp_hash_bwd_sliced_* call of the step (HashLevels.with_plan): the library holds no mode state."""
+        return ((_lib_mod.BWD_PLAN_DETERMINISTIC if self.deterministic else 0)
+                | (_lib_mod.BWD_PLAN_CONCENTRATED if self._concentrated else 0))
 
     def repack(self):
         """Rebuild the fp16 MFMA weight image from the fp32 master weights (call after loading a checkpoint into the
@@ -391,16 +391,13 @@ class FusedTrainer:
         return sets
 
     def _coarse_bits(self, cfg, A):
-        """The 8^3-block occupancy shortcut table, rebuilt only when the bitfield tensor was written to (its torch version
-        counter moves on every in-place op, e.g. packbits / copy_)."""
-        coarse = A.coarse_for(cfg)
-        # every writer of the bitfield moves its version counter: torch in-place ops by themselves, the raw-pointer kernels
-        # (ngp_occ_pack, ngp_packbits) through ops._touched; update_density_grid() additionally drops the cache outright
-        ver = (cfg.bitfield.data_ptr(), cfg.bitfield._version)
-        if self._coarse_ver != ver:
+        """The 8^3-block occupancy shortcut table, rebuilt only when the bitfield tensor was written to (its torch version counter
+        moves on every in-place op, e.g. packbits / copy_; the raw-pointer kernels move it through ops._touched).  The validity key
+        lives on the arena buffer, shared with the fused render() of the same (device, n_rays) (TrainArena.coarse_state)."""
+        coarse, stale = A.coarse_state(cfg)
+        if stale:
             check(self.L.ngp_bitfield_coarsen(_ptr(cfg.bitfield), cfg.cascades, cfg.grid_size, _ptr(coarse), _stream()),
                   "ngp_bitfield_coarsen")
-            self._coarse_ver = ver
         return coarse
 
     def _march(self, M, rays_o, rays_d, cfg, A, coarse=None, noise=None, shape=None):
@@ -577,11 +574,12 @@ class FusedTrainer:
         # cross-stream join cost 23 us between the prepass's end and the scatter-add's start: in line it is 17 us per step faster
         sliced = self.hash_bwd == "sliced"          # (half2 encoder: same prepass, main pass with its fp16 arithmetic + fp16 table)
         det = self._scatter_mode()
+        lvp = self._lvp = cfg.levels.with_plan(det)           # the level table + this step's plan bits: prep, main and adam_prefix see the same
         if hook is not None and self._hook_at == 2.5:
             hook(); hook = None                                             # position 2.5: under the prepass, the MLP backward and the scatter-add
         if sliced:
             ws = A.sliced_ws(cfg.levels)
-            rc = L.ngp_hash_bwd_sliced_prep(_ptr(M.xyzs), ctypes.byref(cfg.levels), A.cap, _ptr(cnt), _ptr(live_idx), 1, cfg.lo, cfg.hi,
+            rc = L.ngp_hash_bwd_sliced_prep(_ptr(M.xyzs), ctypes.byref(lvp), A.cap, _ptr(cnt), _ptr(live_idx), 1, cfg.lo, cfg.hi,
                                             _ptr(ws), ws.numel(), st)
             if rc == -2:
                 # level table not expressible as <= 64 LDS slices per level: the float-atomic kernel from here on.  The overlapped
@@ -621,7 +619,7 @@ class FusedTrainer:
         if reduce_in_scatter and self._flush_adam:
             npre = self._adam_prefix.get(det)
             if npre is None:
-                npre = int(L.ngp_hash_bwd_sliced_adam_prefix(ctypes.byref(cfg.levels)))
+                npre = int(L.ngp_hash_bwd_sliced_adam_prefix(ctypes.byref(lvp)))
                 npre = self._adam_prefix[det] = npre if npre % 4 == 0 else -2
             if npre >= 0:
                 return self._tail_flush_adam(A, M, cfg, cnt, P, ws, n_parts, st, hook, total, vr_per_ray, rgb, opacity, depth, sq_err, npre)
@@ -630,17 +628,17 @@ class FusedTrainer:
             return {"rm_samples": total, "vr_per_ray": vr_per_ray, "rgb": rgb, "opacity": opacity, "depth": depth, "rays_a": rays_a,
                     "deltas": M.deltas, "ts": M.ts, "sq_err": sq_err}
         if reduce_in_scatter:
-            check(L.ngp_hash_bwd_sliced_main_slabs(_ptr(A.d_enc), ctypes.byref(cfg.levels), A.cap, _ptr(cnt), P, _ptr(self.table_grad),
+            check(L.ngp_hash_bwd_sliced_main_slabs(_ptr(A.d_enc), ctypes.byref(lvp), A.cap, _ptr(cnt), P, _ptr(self.table_grad),
                                                    0, found, _ptr(ws), ws.numel(), _ptr(self.mlp_parts), n_parts,
                                                    _ptr(self.mlp_grad), st), "ngp_hash_bwd_sliced_main_slabs")
         elif self.half and sliced:
-            check(L.ngp_hash_bwd_sliced_main_f16(_ptr(A.d_enc), ctypes.byref(cfg.levels), A.cap, _ptr(cnt), P, _ptr(self.table_grad), found,
+            check(L.ngp_hash_bwd_sliced_main_f16(_ptr(A.d_enc), ctypes.byref(lvp), A.cap, _ptr(cnt), P, _ptr(self.table_grad), found,
                                                  _ptr(ws), ws.numel(), st), "ngp_hash_bwd_sliced_main_f16")
         elif self.half:
             check(L.ngp_hash_bwd_f16_live(_ptr(M.xyzs), _ptr(A.d_enc), ctypes.byref(cfg.levels), A.cap, _ptr(cnt), _ptr(live_idx), 1,
                                           cfg.lo, cfg.hi, P, _ptr(self.table_grad), found, st), "ngp_hash_bwd_f16_live")
         elif sliced:
-            check(L.ngp_hash_bwd_sliced_main(_ptr(A.d_enc), ctypes.byref(cfg.levels), A.cap, _ptr(cnt), P, _ptr(self.table_grad), found,
+            check(L.ngp_hash_bwd_sliced_main(_ptr(A.d_enc), ctypes.byref(lvp), A.cap, _ptr(cnt), P, _ptr(self.table_grad), found,
                                              _ptr(ws), ws.numel(), st), "ngp_hash_bwd_sliced_main")
         else:
             check(L.ngp_hash_bwd_f32_live(_ptr(M.xyzs), _ptr(A.d_enc), ctypes.byref(cfg.levels), A.cap, _ptr(cnt), _ptr(live_idx), 1,
@@ -716,11 +714,7 @@ class FusedTrainer:
         chunk_schedule_kernel).  Returns False when the level table does not fit the list encoder (the caller shades everything)."""
         L = self.L
         R = len(self._chunk_rounds)
-        if self._chunk_counts is None:
-            self._chunk_counts = torch.zeros(2, R, device=self.dev, dtype=torch.int32)
-        T_state = self._chunk_T.get(n)
-        if T_state is None:
-            T_state = self._chunk_T[n] = torch.empty(n, device=self.dev, dtype=torch.float32)
+        T_state = self._chunk_state(n)
         par = M.index
         c_cur = self._chunk_counts.data_ptr() + 4 * R * par             # this step's list lengths; the other parity's set is cleared
         c_oth = self._chunk_counts.data_ptr() + 4 * R * (1 - par)       # round by round for the next step
@@ -745,6 +739,16 @@ class FusedTrainer:
             hook(); hook = None
         return True, hook
 
+    def _chunk_state(self, n):
+        """Buffers of the chunked forward for n rays per step: [2, rounds] list counters (one set per step parity, all zero between
+        steps) and the per-ray transmittance carried from round to round.  Allocated on first use -- by capture() in graph mode."""
+        if self._chunk_counts is None:
+            self._chunk_counts = torch.zeros(2, len(self._chunk_rounds), device=self.dev, dtype=torch.int32)
+        T_state = self._chunk_T.get(n)
+        if T_state is None:
+            T_state = self._chunk_T[n] = torch.empty(n, device=self.dev, dtype=torch.float32)
+        return T_state
+
     def shaded_samples(self):
         """Samples the most recent step shaded (chunked forward; None when every marched sample is shaded).  One host read."""
         if not self.chunked or self._chunk_counts is None:
@@ -754,11 +758,11 @@ class FusedTrainer:
     def _tail_flush_adam(self, A, M, cfg, cnt, P, ws, n_parts, st, hook, total, vr_per_ray, rgb, opacity, depth, sq_err, npre):
         """Prologue -> scatter-add with the optimizer in its flush -> Adam on the replicated coarse levels + the MLP (one GPU, fp32
         master table with or without the bf16 copy; see __init__)."""
-        L, sf, si = self.L, self.state_f, self.state_i
+        L, sf, si, lvp = self.L, self.state_f, self.state_i, self._lvp
         copy16 = self.copy16_store[:self.nt] if self.copy16_store is not None else None
         if self._fold_prologue:
             # the GradScaler / schedule decision is evaluated inside the scatter-add launch (no one-thread launch in front of it)
-            check(L.ngp_hash_bwd_sliced_main_adam_step(_ptr(A.d_enc), ctypes.byref(cfg.levels), A.cap, _ptr(cnt), P, _ptr(self.table_grad),
+            check(L.ngp_hash_bwd_sliced_main_adam_step(_ptr(A.d_enc), ctypes.byref(lvp), A.cap, _ptr(cnt), P, _ptr(self.table_grad),
                                                        _ptr(ws), ws.numel(), _ptr(self.mlp_parts), n_parts, _ptr(self.mlp_grad),
                                                        _ptr(self.table), _ptr(self.table_m), _ptr(self.table_v), _ptr(copy16), _ptr(sf),
                                                        _ptr(si), self.lr0, self.eta_min, self.t_max, self.beta1, self.beta2, self.eps,
@@ -767,7 +771,7 @@ class FusedTrainer:
         else:
             check(L.ngp_train_prologue(_ptr(sf), _ptr(si), self.lr0, self.eta_min, self.t_max, self.beta1, self.beta2, self.growth,
                                        self.backoff, self.growth_interval, st), "ngp_train_prologue")
-            check(L.ngp_hash_bwd_sliced_main_adam(_ptr(A.d_enc), ctypes.byref(cfg.levels), A.cap, _ptr(cnt), P, _ptr(self.table_grad), _ptr(ws),
+            check(L.ngp_hash_bwd_sliced_main_adam(_ptr(A.d_enc), ctypes.byref(lvp), A.cap, _ptr(cnt), P, _ptr(self.table_grad), _ptr(ws),
                                                   ws.numel(), _ptr(self.mlp_parts), n_parts, _ptr(self.mlp_grad), _ptr(self.table),
                                                   _ptr(self.table_m), _ptr(self.table_v), _ptr(copy16), _ptr(sf), _ptr(si), self.beta1,
                                                   self.beta2, self.eps, st), "ngp_hash_bwd_sliced_main_adam")
@@ -854,11 +858,11 @@ class FusedTrainer:
 
     def _tail_overlapped(self, A, cfg, cnt, P, ws, found, st, hook, reduce_parts):
         """Scatter-add, gradient exchange and optimizer of one step with the exchange overlapped (see __init__)."""
-        L, sf, si = self.L, self.state_f, self.state_i
+        L, sf, si, lvp = self.L, self.state_f, self.state_i, self._lvp
         max_blocks = int(os.environ.get("NGP_COMM_SCATTER_BLOCKS", "240"))     # leave CUs for RCCL's workgroups beside the later launches
         fins = []
         for k, g in enumerate(self._groups):
-            check(L.ngp_hash_bwd_sliced_main_levels(_ptr(A.d_enc), ctypes.byref(cfg.levels), A.cap, _ptr(cnt), P, _ptr(self.table_grad),
+            check(L.ngp_hash_bwd_sliced_main_levels(_ptr(A.d_enc), ctypes.byref(lvp), A.cap, _ptr(cnt), P, _ptr(self.table_grad),
                                                     found, _ptr(ws), ws.numel(), g.mask, 0 if k == 0 else max_blocks, st),
                   "ngp_hash_bwd_sliced_main_levels")
             fins.append(self._rs_async(g))
@@ -1059,6 +1063,11 @@ class FusedTrainer:
             raise RuntimeError("graph capture is only wired for the single-GPU step")
         TrainArena.get(self.dev, n_rays, self.max_samples)                 # allocate the arena outside the graph pools
         self._march_sets(n_rays)
+        if self.chunked:
+            # the chunked forward's list counters and per-ray transmittance state: allocated HERE, not lazily inside the first captured
+            # step (they would come from graph 0's private pool, graph 1 would use memory it does not own, and the zero-fill would be
+            # replayed every other step: ADVICE r5)
+            self._chunk_state(n_rays)
         self._static_target = torch.zeros(n_rays, 3, device=self.dev, dtype=torch.float32)
         self._graph = {}                                                    # march-set parity -> (CUDAGraph, outputs)
         self._graph_n = n_rays
@@ -1075,7 +1084,7 @@ class FusedTrainer:
         if self.world > 1 and self.sync_occupancy:
             from .dist import broadcast_occupancy
             broadcast_occupancy(self.model, src=0, group=self.group)
-        self._coarse_ver = None              # the coarse 8^3-block table is rebuilt on the next march, whoever wrote the bitfield
+        TrainArena.invalidate_coarse()       # the coarse 8^3-block tables are rebuilt on the next march, whoever wrote the bitfield
         for sets in self._sets.values():     # a march prefetched against the old bitfield must not be consumed
             for M in sets:
                 M.src = None
@@ -1117,7 +1126,7 @@ class FusedTrainer:
             self.table_grad.zero_()
         if self.shard_grad is not None:
             self.shard_grad.zero_()
-        self._coarse_ver = None
+        TrainArena.invalidate_coarse()
         # the model's weights were loaded alongside: the fp32 master IS the checkpoint now, on every shard -- nothing left to gather
         self._master_stale = False
         self.repack()                          # refresh the fp16 MFMA image and the 16-bit table copy from the master

@@ -38,17 +38,6 @@ def hip_lib():
     return lib.load()
 
 
-@pytest.fixture(autouse=True)
-def _default_scatter_plan():
-    """The scatter-add's plan modes (deterministic / concentrated) are per-thread switches of the library that a FusedTrainer leaves
-    as it last needed them (it sets them on every step): every test starts from the defaults, whatever ran before it."""
-    from ngp_hip import lib
-    if lib._lib is not None:
-        lib._lib.ngp_hash_bwd_sliced_deterministic(0)
-        lib._lib.ngp_hash_bwd_sliced_concentrated(0)
-    yield
-
-
 def ray_order(rays_a):
     """Index array that brings per-sample arrays laid out as rays_a says (row = (ray, start, count), ranges in ANY order: the
     reference packs with atomic adds, ngp_march_train_fused in block-completion order) into ray order: x[ray_order(rays_a)] is

@@ -22,12 +22,28 @@ def test_header_symbols_exported(hip_lib):
     for n in names:
         assert hasattr(hip_lib, n), "libngp_hip.so does not export %s" % n
     assert sorted(lib.SIGNATURES) == names, "ngp_hip/lib.py binds a different symbol set than the header declares"
-    assert hip_lib.ngp_abi_version() == 1
+    assert hip_lib.ngp_abi_version() == 2
 
 
-def test_struct_layout_matches_header():
+def test_struct_layout_matches_header(tmp_path):
+    """ngp_hash_levels: the ctypes mirror has gcc's layout of include/ngp_hip.h, field by field (round 6: + bwd_plan, the scatter-add's
+    task-plan bits that used to be per-thread state of the library)."""
+    import subprocess
     from ngp_hip.lib import HashLevels
-    assert ctypes.sizeof(HashLevels) == 16 + 4 * 16 * 4
+    names = [f[0] for f in HashLevels._fields_]
+    assert names[-1] == "bwd_plan"
+    src = tmp_path / "lv.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "%s"\nint main(void) {\n  printf("%%zu\\n", sizeof(ngp_hash_levels));\n%s'
+                   '  printf("%%u %%u\\n", NGP_BWD_PLAN_DETERMINISTIC, NGP_BWD_PLAN_CONCENTRATED);\n  return 0;\n}\n'
+                   % (os.path.join(ROOT, "include", "ngp_hip.h"),
+                      "".join('  printf("%%zu\\n", offsetof(ngp_hash_levels, %s));\n' % n for n in names)))
+    exe = tmp_path / "lv"
+    subprocess.run(["gcc", "-o", str(exe), str(src)], check=True)
+    out = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    assert out[0] == ctypes.sizeof(HashLevels) == 16 + 4 * 16 * 4 + 4
+    assert out[1:-2] == [getattr(HashLevels, n).offset for n in names]
+    from ngp_hip import lib
+    assert out[-2:] == [lib.BWD_PLAN_DETERMINISTIC, lib.BWD_PLAN_CONCENTRATED]
 
 
 def test_render_args_layout_matches_header(tmp_path):

@@ -39,8 +39,22 @@ def test_fused_adam_matches_torch_adam_under_gradscaler(hip_lib):
         if step == 30:                 # the device-side step count travels with state_dict(): a resumed optimizer goes on
             sd = o_mine.state_dict()   # with the same bias corrections
             assert "ngp_group_state" in sd and int(sd["ngp_group_state"][0][1][1]) == 30
-            o_mine.load_state_dict(sd)
+            # ... also from a checkpoint that went through torch.save / torch.load(map_location='cpu') (the device-side
+            # counters used to stay HOST tensors after this, and the kernels were handed their host pointers)
+            import io
+            buf = io.BytesIO()
+            torch.save(sd, buf)
+            buf.seek(0)
+            sd_cpu = torch.load(buf, map_location="cpu")
+            assert not sd_cpu["ngp_group_state"][0][0].is_cuda
+            o_mine.load_state_dict(sd_cpu)
             assert int(o_mine._si[0][1]) == 30
+            assert all(t.is_cuda and t.device == mine[0].device for t in o_mine._sf + o_mine._si)
+            assert o_mine._sf[0].dtype == torch.float32 and o_mine._si[0].dtype == torch.int32
+            bad = dict(sd_cpu, ngp_group_state=sd_cpu["ngp_group_state"] * 2)
+            with pytest.raises(ValueError):
+                o_mine.load_state_dict(bad)
+            o_mine.load_state_dict(sd_cpu)
     assert s_ref.get_scale() == s_mine.get_scale()
     for a, b in zip(ref, mine):
         torch.testing.assert_close(b, a, rtol=2e-5, atol=2e-6)

@@ -356,7 +356,7 @@ def test_hash_bwd_f32_sliced(oracle, hip_lib, max_res):
 
 
 def test_hash_bwd_f32_sliced_concentrated_plan(oracle, hip_lib):
-    """Round 5: ngp_hash_bwd_sliced_concentrated -- coarse hashed levels with sample-range replicas -- on the C3
+    """Round 5: the concentrated plan (NGP_BWD_PLAN_CONCENTRATED in the level table) -- coarse hashed levels with sample-range replicas -- on the C3
     table with points crowded into 2 % of the box (what a multi-cascade scene looks like to the coarse levels): same touched entries
     and values as the oracle, as the default plan, and through the optimizer-in-the-flush entry's level split."""
     L = ops._lib()
@@ -373,18 +373,19 @@ def test_hash_bwd_f32_sliced_concentrated_plan(oracle, hip_lib):
     ref = oracle.hash_bwd_f32(x, dout, lv)
     nrep = (ctypes.c_uint8 * 16)()
     mm = ctypes.c_uint32()
-    assert L.ngp_hash_bwd_sliced_concentrated(1) == 0
+    from ngp_hip import lib as _libmod
+    lvc = lv.with_plan(_libmod.BWD_PLAN_CONCENTRATED)
     try:
-        assert L.ngp_hash_bwd_sliced_plan(ctypes.byref(lv), None, 0, None, None, nrep, ctypes.byref(mm), None) > 0
+        assert L.ngp_hash_bwd_sliced_plan(ctypes.byref(lvc), None, 0, None, None, nrep, ctypes.byref(mm), None) > 0
         assert nrep[5] > 1 and nrep[7] > 1 and nrep[8] == 1 and nrep[15] == 1  # hashed levels up to res 256: sample-range replicas
-        prefix = int(L.ngp_hash_bwd_sliced_adam_prefix(ctypes.byref(lv)))
+        prefix = int(L.ngp_hash_bwd_sliced_adam_prefix(ctypes.byref(lvc)))
         first = min(l for l in range(16) if nrep[l] == 1 and all(nrep[k] == 1 for k in range(l, 16)))
         assert prefix == lv.offset[first] * 2
         dt = torch.zeros(lv.total_entries * 2, device="cuda")
-        ops.hash_bwd_f32_sliced(dev(x), dev(dout), lv, dt)
+        ops.hash_bwd_f32_sliced(dev(x), dev(dout), lvc, dt)
         got = dt.cpu().numpy()
     finally:
-        assert L.ngp_hash_bwd_sliced_concentrated(0) == 1
+        pass
     assert support_matches(ref, got)
     np.testing.assert_allclose(got, ref, rtol=2e-5, atol=2e-5 * float(np.abs(ref).max()))
     dt0 = torch.zeros(lv.total_entries * 2, device="cuda")

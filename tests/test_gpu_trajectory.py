@@ -1,0 +1,192 @@
+"""K-step training TRAJECTORY of the HIP trainer against the CPU oracle loop.
+
+CPU side  = oracle/train_loop.py: the reference's iteration (train.py:168-201) restated on the oracle kernels -- march, hash encode,
+            SH16, compositing forward / backward, packbits from oracle/ngp_oracle.c; fp32 torch-CPU MLPs; torch.optim.Adam(eps=1e-15) +
+            CosineAnnealingLR; the occupancy update of networks.py:255-290 every 16 steps.
+GPU side  = FusedTrainer in deterministic mode (ray-ordered packing, fixed summation order): libngp_hip only.
+Both start from the same initialisation and see the same rays, targets, march jitter and in-cell jitter of the occupancy update; they
+never exchange state afterwards.  What is held:
+  * compaction: on the occupancy bitfield the GPU trainer holds at that step, the oracle march emits exactly the GPU's sample count
+    for every ray, every step (bit-exact indexing / compaction, north_star);
+  * the two INDEPENDENT occupancy grids differ in a handful of cells that sit on the threshold (mean density, networks.py:286), so
+    the two trajectories' sample totals agree to a stated fraction;
+  * per-step loss within a stated relative tolerance, and no further from the fp32 CPU curve than twice what the reference's own
+    arithmetic -- torch fp16 autocast Linear layers + torch Adam + GradScaler on the same HIP operators -- is (the yard-stick);
+  * final training-batch PSNR within 1e-3 relative (north_star's tolerance).
+"""
+import copy
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+N_RAYS, STEPS, UPDATE_EVERY = 1024, 48, 16
+THR = 0.01 * 1024 / 3**0.5                       # train.py:180
+NOISE_SEED = 5000
+INIT_SCALE = 2.0**10                             # a loss scale no step of these runs overflows at (asserted: skipped == 0)
+
+
+def _inputs():
+    from ngp_hip import synthetic
+    pool = []
+    for b in range(4):
+        o, d = synthetic.lego_rays(N_RAYS, seed=700 + b)
+        tgt = synthetic.procedural_render_gt(torch.from_numpy(o).cuda(), torch.from_numpy(d).cuda()).cpu().numpy()
+        pool.append((o, d, np.ascontiguousarray(tgt, np.float32)))
+    rng = np.random.default_rng(17)
+    noise = []
+    for s in range(STEPS):      # the march jitter render() draws first after torch.manual_seed(NOISE_SEED + s) (ray_march.py:138)
+        torch.manual_seed(NOISE_SEED + s)
+        noise.append(torch.rand(N_RAYS, device="cuda").cpu().numpy())
+    jit = {s: rng.random((128**3, 3), dtype=np.float32) for s in range(0, STEPS, UPDATE_EVERY)}
+    return pool, noise, jit
+
+
+def _model(kind, seed=11):
+    from modules.networks import NGP
+    torch.manual_seed(seed)
+    m = NGP(scale=0.5, max_res=1024, half_opt=kind == "half").cuda()
+    return m
+
+
+def _run_cpu(kind, state, pool, noise, jit):
+    from oracle.train_loop import OracleTrainer
+    otr = OracleTrainer(state["weights"], state["table"], lr=1e-2, max_steps=STEPS, kind=kind, loss_scale=INIT_SCALE)
+    recs, bits = [], {}
+    for s in range(STEPS):
+        if s % UPDATE_EVERY == 0:
+            otr.update_density_grid(THR, [jit[s]])
+            bits[s] = otr.bits.copy()
+        o, d, tgt = pool[s % len(pool)]
+        recs.append(otr.step(o, d, tgt, noise[s]))
+    return otr, recs, bits
+
+
+def _run_hip(kind, m, pool, noise, jit, oracle):
+    from ngp_hip.trainer import FusedTrainer
+    tr = FusedTrainer(m, lr=1e-2, max_steps=STEPS, init_scale=INIT_SCALE).set_deterministic(True)
+    dev = m.density_grid.device
+    gp = [tuple(torch.from_numpy(x).to(dev) for x in b) for b in pool]
+    recs, bits = [], {}
+    for s in range(STEPS):
+        if s % UPDATE_EVERY == 0:
+            tr.update_density_grid(THR, warmup=True, jitter=lambda c, n, u=jit[s]: torch.from_numpy(u).to(dev))
+            bits[s] = m.density_bitfield.cpu().numpy().copy()
+            cur_bits = bits[s]
+        o, d, tgt = gp[s % len(gp)]
+        st = tr.step(o, d, tgt, noise=torch.from_numpy(noise[s]).to(dev))
+        ra = st["rays_a"].cpu().numpy()
+        counts = ra[np.argsort(ra[:, 0], kind="stable"), 2]
+        # compaction, bit-exact: the oracle march on the bitfield this trainer holds right now
+        po, pd, _ = pool[s % len(pool)]
+        ref_ra, ref_total = oracle.march_train(po, pd, oracle.ray_aabb(po, pd, 0.5), cur_bits, noise[s], 1, 0.5, 0.0, 128, 1024,
+                                               count_only=True)
+        assert int(st["rm_samples"][0]) == ref_total, (s, int(st["rm_samples"][0]), ref_total)
+        assert np.array_equal(counts, ref_ra[np.argsort(ref_ra[:, 0], kind="stable"), 2]), s
+        loss = tr.last_loss()
+        recs.append({"loss": loss, "psnr": -10.0 * np.log10(loss), "rm_samples": int(st["rm_samples"][0]), "counts": counts,
+                     "vr": st["vr_per_ray"].cpu().numpy()})
+    c = tr.counters()
+    assert c["skipped"] == 0 and c["opt_steps"] == STEPS, c
+    return tr, recs, bits
+
+
+def _run_autocast(m, pool, noise, jit):
+    """The reference's own loop shape and arithmetic on the HIP operators: torch Linear layers under fp16 autocast, torch Adam,
+    torch GradScaler, CosineAnnealingLR (train.py:137-201) -- the yard-stick for what fp16 MLPs do to the fp32 trajectory."""
+    from modules.rendering import render
+    m.use_fused_mlp = False
+    dev = m.density_grid.device
+    gp = [tuple(torch.from_numpy(x).to(dev) for x in b) for b in pool]
+    opt = torch.optim.Adam(m.parameters(), 1e-2, eps=1e-15)
+    sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, STEPS, 1e-2 / 30)
+    scaler = torch.amp.GradScaler("cuda", init_scale=INIT_SCALE)
+    losses = []
+    old = os.environ.get("NGP_FUSED_RENDER")
+    os.environ["NGP_FUSED_RENDER"] = "0"
+    try:
+        for s in range(STEPS):
+            o, d, tgt = gp[s % len(gp)]
+            with torch.autocast("cuda", dtype=torch.float16):
+                if s % UPDATE_EVERY == 0:
+                    m.update_density_grid(THR, warmup=True, jitter=lambda c, n, u=jit[s]: torch.from_numpy(u).to(dev))
+                torch.manual_seed(NOISE_SEED + s)                 # -> the march draws noise[s]
+                res = render(m, o, d, exp_step_factor=0.0)
+                loss = F.mse_loss(res["rgb"], tgt)
+            opt.zero_grad()
+            scaler.scale(loss).backward()
+            scaler.step(opt)
+            scaler.update()
+            sched.step()
+            losses.append(float(loss))
+        assert scaler.get_scale() == INIT_SCALE          # no overflow, no skipped step on this side either
+    finally:
+        if old is None:
+            os.environ.pop("NGP_FUSED_RENDER", None)
+        else:
+            os.environ["NGP_FUSED_RENDER"] = old
+    return losses
+
+
+@pytest.mark.parametrize("kind", ["f32", "half"])
+def test_trajectory_matches_oracle_loop(oracle, hip_lib, kind):
+    pool, noise, jit = _inputs()
+    m = _model(kind)
+    state = {"weights": [w.detach().cpu().numpy().copy() for w in m._mlp_weights()],
+             "table": m.pos_encoder.hash_table.detach().float().reshape(-1).cpu().numpy().copy()}
+    m_auto = copy.deepcopy(m) if kind == "f32" else None
+    otr, cpu, cpu_bits = _run_cpu(kind, state, pool, noise, jit)
+    tr, hip, hip_bits = _run_hip(kind, m, pool, noise, jit, oracle)
+
+    lc, lh = np.array([r["loss"] for r in cpu]), np.array([r["loss"] for r in hip])
+    rel = np.abs(lh - lc) / lc
+    print("\ntrajectory [%s]: %d steps of %d rays, occupancy updates at %s" % (kind, STEPS, N_RAYS, sorted(jit)))
+    print(" step   loss CPU-fp32    loss HIP       rel      samples CPU / HIP")
+    for s in list(range(0, STEPS, 4)) + [STEPS - 1]:
+        print(" %4d   %.6f      %.6f    %.2e   %8d / %8d" % (s, lc[s], lh[s], rel[s], cpu[s]["rm_samples"], hip[s]["rm_samples"]))
+    # the two independent occupancy grids
+    for s in sorted(jit):
+        ham = np.unpackbits(cpu_bits[s] ^ hip_bits[s]).mean()
+        occ = np.unpackbits(cpu_bits[s]).mean()
+        print(" update at step %2d: occupied fraction %.3f, cells that differ between the two grids %.2e" % (s, occ, ham))
+        assert ham < 2e-3, (s, ham)
+    tot_c, tot_h = np.array([r["rm_samples"] for r in cpu]), np.array([r["rm_samples"] for r in hip])
+    assert np.abs(tot_c - tot_h).max() <= 5e-3 * tot_c.max(), np.abs(tot_c - tot_h).max()
+    first = slice(0, UPDATE_EVERY)                     # until the second update both sides march the step-0 grids: nearly all rays equal
+    same = np.mean([np.mean(c["counts"] == h["counts"]) for c, h in zip(cpu[first], hip[first])])
+    print(" rays with identical sample counts in the first %d steps: %.4f" % (UPDATE_EVERY, same))
+    assert same > 0.97
+    # early termination point per ray (compositing): where the rays' samples agree, the sample the ray stops at agrees to +-1
+    vr_ok = []
+    for c, h in zip(cpu, hip):
+        eq = c["counts"] == h["counts"]
+        vr_ok.append(np.mean(np.abs(c["vr"][eq].astype(np.int64) - h["vr"][eq].astype(np.int64)) <= 1))
+    print(" rays (same samples) whose early-termination point agrees to +-1 sample: min over steps %.4f" % min(vr_ok))
+    # loss curve
+    assert lh[-1] < 0.5 * lh[0] and lc[-1] < 0.5 * lc[0]                 # both learn
+    tol = 2e-2
+    print(" max relative loss deviation HIP vs CPU-fp32: %.3e (mean %.3e)" % (rel.max(), rel.mean()))
+    assert rel.max() <= tol, rel.max()
+    if m_auto is not None:
+        la = np.array(_run_autocast(m_auto, pool, noise, jit))
+        rel_a = np.abs(la - lc) / lc
+        print(" yard-stick (torch fp16 autocast + torch Adam on the HIP operators) vs CPU-fp32: max %.3e (mean %.3e)" % (rel_a.max(), rel_a.mean()))
+        assert rel.max() <= max(2.0 * rel_a.max(), 2e-3), (rel.max(), rel_a.max())
+        # ... and its growth: the deviation averaged over the last third is no more than twice the yard-stick's
+        third = slice(2 * STEPS // 3, STEPS)
+        assert rel[third].mean() <= max(2.0 * rel_a[third].mean(), 1e-3), (rel[third].mean(), rel_a[third].mean())
+    # final training-batch PSNR, north_star: within 1e-3 (relative)
+    p_c, p_h = cpu[-1]["psnr"], hip[-1]["psnr"]
+    print(" final training-batch PSNR: CPU-fp32 %.4f dB, HIP %.4f dB (relative difference %.2e)" % (p_c, p_h, abs(p_h - p_c) / p_c))
+    assert abs(p_h - p_c) <= 1e-3 * p_c
+    # parameters: the tables' touched entries stay close
+    t_c = otr.table.detach().numpy()
+    t_h = m.pos_encoder.hash_table.detach().float().reshape(-1).cpu().numpy()
+    moved = t_c != state["table"]
+    d_rel = np.linalg.norm((t_h - t_c)[moved]) / np.linalg.norm((t_c - state["table"])[moved])
+    print(" table: %d entries moved; |HIP - CPU| / |CPU - init| over them = %.3e" % (moved.sum(), d_rel))
+    assert moved.sum() > 10000 and d_rel < 0.25

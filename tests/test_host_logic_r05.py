@@ -46,22 +46,35 @@ def test_comm_record_bus_bandwidth_and_model():
     assert abs(r2["bus_bandwidth_GBs"] - 2 * 45_717_904 * 0.5 / 0.3e-3 / 1e9) < 1e-6
 
 
-def test_scatter_mode_sets_the_library_switches_every_time():
-    """FusedTrainer._scatter_mode: the key under which the trainer caches its flush-Adam prefix names the plan mode the library is
-    REALLY in afterwards -- it sets both per-thread switches on every call instead of trusting a Python-side copy of them (another
-    caller on the thread may have flipped them in between).  Host logic only: the C switches are plain thread-local flags."""
+def test_scatter_mode_travels_in_the_level_table():
+    """Round 6: the scatter-add's plan mode is no longer per-thread state of the library.  FusedTrainer._scatter_mode
+    returns NGP_BWD_PLAN_* bits, HashLevels.with_plan puts them into a (cached) copy of the level table, and the library's plan follows
+    the table it is handed -- two tables with different bits give their own plans in any call order.  Host logic only."""
+    import ctypes
     from types import SimpleNamespace
-    from ngp_hip import lib
+    from ngp_hip import lib, ops
     from ngp_hip.trainer import FusedTrainer
     L = lib.load()
-    try:
-        for det, conc in ((0, 0), (1, 0), (0, 1), (1, 1), (0, 0)):
-            stub = SimpleNamespace(L=L, deterministic=bool(det), _concentrated=bool(conc))
-            # somebody else leaves the opposite setting behind
-            L.ngp_hash_bwd_sliced_deterministic(1 - det)
-            L.ngp_hash_bwd_sliced_concentrated(1 - conc)
-            assert FusedTrainer._scatter_mode(stub) == det + 2 * conc
-            assert L.ngp_hash_bwd_sliced_deterministic(det) == det and L.ngp_hash_bwd_sliced_concentrated(conc) == conc
-    finally:
-        L.ngp_hash_bwd_sliced_deterministic(0)
-        L.ngp_hash_bwd_sliced_concentrated(0)
+    assert not hasattr(L, "ngp_hash_bwd_sliced_deterministic") and not hasattr(L, "ngp_hash_bwd_sliced_concentrated")
+    lv = ops.make_levels(2**19, 16, 16, 4096, 2)
+    assert lv.bwd_plan == 0 and lv.with_plan(0) is lv
+
+    def nrep_of(t):
+        nrep = (ctypes.c_uint8 * 16)()
+        assert L.ngp_hash_bwd_sliced_plan(ctypes.byref(t), None, 0, None, None, nrep, None, None) > 0
+        return list(nrep)
+    base = nrep_of(lv)
+    seen = {}
+    for det, conc in ((0, 0), (1, 0), (0, 1), (1, 1), (0, 0), (0, 1)):
+        stub = SimpleNamespace(deterministic=bool(det), _concentrated=bool(conc))
+        bits = FusedTrainer._scatter_mode(stub)
+        assert bits == det * lib.BWD_PLAN_DETERMINISTIC + conc * lib.BWD_PLAN_CONCENTRATED
+        t = lv.with_plan(bits)
+        assert t.bwd_plan == bits and lv.with_plan(bits) is t and lv.bwd_plan == 0           # cached copy, the original untouched
+        assert bytes(t)[:ctypes.sizeof(t) - 4] == bytes(lv)[:ctypes.sizeof(lv) - 4]
+        got = nrep_of(t)
+        assert seen.setdefault(bits, got) == got                                              # a function of the table, not of history
+        if det:
+            assert all(r == 1 for r in got)
+        assert nrep_of(lv) == base                                                            # the default table still gets the default plan
+    assert seen[lib.BWD_PLAN_CONCENTRATED] != base

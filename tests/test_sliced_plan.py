@@ -85,21 +85,21 @@ def test_flush_adam_prefix_and_deterministic_plan():
         first = min(l for l in range(16) if nrep[l] == 1)
         assert all(nrep[l] == 1 for l in range(first, 16)) and all(nrep[l] > 1 for l in range(first))
         assert L.ngp_hash_bwd_sliced_adam_prefix(ctypes.byref(lv)) == 2 * int(lv.offset[first])
-        assert L.ngp_hash_bwd_sliced_deterministic(1) == 0
-        n_d, tasks_d, _, xlen_d, nrep_d, mm_d, _ = plan_of(lv)
+        lv_d = lv.with_plan(lib.BWD_PLAN_DETERMINISTIC)
+        n_d, tasks_d, _, xlen_d, nrep_d, mm_d, _ = plan_of(lv_d)
         sizes = [int(lv.map_size[l]) for l in range(16)]
         assert all(int(r) == 1 for r in nrep_d) and n_d == sum((s + SLICE - 1) // SLICE for s in sizes) == int(xlen_d.sum())
         assert mm_d == mm                                           # run pre-summing stays (its grouping is what becomes order-free)
-        assert L.ngp_hash_bwd_sliced_adam_prefix(ctypes.byref(lv)) == 0
+        assert L.ngp_hash_bwd_sliced_adam_prefix(ctypes.byref(lv_d)) == 0
     finally:
-        assert L.ngp_hash_bwd_sliced_deterministic(0) in (0, 1)
+        pass
     assert plan_of(lv)[0] == n
     small = ops.make_levels(2**15, 16, 16, 512, 2)                  # no level of 64 slices: nothing for the flush to own
     assert L.ngp_hash_bwd_sliced_adam_prefix(ctypes.byref(small)) == -2
 
 
 def test_concentrated_scene_plan():
-    """Round 5: ngp_hash_bwd_sliced_concentrated(1) -- hashed levels up to resolution 256 get three sample-range replicas per slice (a
+    """Round 5 (round 6: the mode is the NGP_BWD_PLAN_CONCENTRATED bit of the level table) -- hashed levels up to resolution 256 get three sample-range replicas per slice (a
     scene that fills a small part of its box loads a few of their owners with several times the mean), the plan still fits the
     kernel argument, the flush-Adam set shrinks to the levels that keep one owner per slice, and switching the mode off restores the
     default plan.  On the C2 table (levels up to resolution 256 are dense there or already replicated) the hashed levels it touches are
@@ -109,9 +109,9 @@ def test_concentrated_scene_plan():
     bfhl = int(c3.begin_fast_hash_level)
     n0, _, _, _, nrep0, mm0, _ = plan_of(c3)
     pre0 = L.ngp_hash_bwd_sliced_adam_prefix(ctypes.byref(c3))
-    assert L.ngp_hash_bwd_sliced_concentrated(1) == 0
+    c3c = c3.with_plan(lib.BWD_PLAN_CONCENTRATED)
     try:
-        n1, tasks, xoff, xlen, nrep1, mm1, _ = plan_of(c3)
+        n1, tasks, xoff, xlen, nrep1, mm1, _ = plan_of(c3c)
         assert 0 < n1 <= 1536 and int(xlen.sum()) == n1
         hot = [l for l in range(bfhl, 16) if int(c3.resolution[l]) <= 256]
         assert hot and all(int(nrep1[l]) == 3 for l in hot)
@@ -119,12 +119,12 @@ def test_concentrated_scene_plan():
         assert all(int(nrep1[l]) >= 4 for l in range(bfhl) if int(c3.map_size[l]) > SLICE)       # dense levels keep >= 4 sample ranges
         assert mm1 == mm0                                                                       # run pre-summing: dense levels only, as before
         first = max(hot) + 1
-        assert L.ngp_hash_bwd_sliced_adam_prefix(ctypes.byref(c3)) == 2 * int(c3.offset[first]) > pre0
+        assert L.ngp_hash_bwd_sliced_adam_prefix(ctypes.byref(c3c)) == 2 * int(c3.offset[first]) > pre0
         # every (level, slice, replica) exactly once
         seen = set(int(t) for t in tasks[:n1])
         assert len(seen) == n1
     finally:
-        assert L.ngp_hash_bwd_sliced_concentrated(0) == 1
+        pass
     n2, _, _, _, nrep2, mm2, _ = plan_of(c3)
     assert n2 == n0 and list(nrep2) == list(nrep0) and mm2 == mm0
     assert L.ngp_hash_bwd_sliced_adam_prefix(ctypes.byref(c3)) == pre0
@@ -139,10 +139,9 @@ def test_plan_sweep_over_level_tables_and_modes():
     n_plans = 0
     try:
         for det, conc in itertools.product((0, 1), (0, 1)):
-            L.ngp_hash_bwd_sliced_deterministic(det)
-            L.ngp_hash_bwd_sliced_concentrated(conc)
+            bits = det * lib.BWD_PLAN_DETERMINISTIC + conc * lib.BWD_PLAN_CONCENTRATED
             for log2_t, nl, base, max_res in itertools.product((12, 15, 17, 19, 20, 22), (1, 4, 8, 16), (4, 16, 64), (64, 512, 2048, 4096, 16384)):
-                lv = ops.make_levels(2**log2_t, nl, base, max_res, 2)
+                lv = ops.make_levels(2**log2_t, nl, base, max_res, 2).with_plan(bits)
                 n, tasks, xoff, xlen, nrep, mm, sm = plan_of(lv)
                 if n < 0:
                     assert n == -2
@@ -160,6 +159,5 @@ def test_plan_sweep_over_level_tables_and_modes():
                 else:
                     assert pre == -2
     finally:
-        L.ngp_hash_bwd_sliced_deterministic(0)
-        L.ngp_hash_bwd_sliced_concentrated(0)
+        pass
     assert n_plans > 500
