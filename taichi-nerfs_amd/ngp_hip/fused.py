@@ -108,7 +108,9 @@ class TrainArena:
         Every writer of a bitfield moves its torch version counter (in-place torch ops by themselves, the raw-pointer kernels through
         ops._touched); the caller that gets stale == True must issue ngp_bitfield_coarsen (or set rebuild_coarse) on its stream."""
         buf = self.coarse_for(cfg)
-        key = (cfg.bitfield.data_ptr(), cfg.bitfield._version, cfg.cascades)
+        # (cfg.serial: a new model can be handed the freed bitfield's address with an equal version count -- the address alone would
+        # let its first march run against the previous model's table)
+        key = (cfg.serial, cfg.bitfield.data_ptr(), cfg.bitfield._version, cfg.cascades)
         stale = self._coarse_keys.get(buf.numel()) != key
         self._coarse_keys[buf.numel()] = key
         return buf, stale
@@ -234,7 +236,11 @@ class RenderConfig:
     """Scalars + handles the fused step needs from the model (captured once per call; plain Python values so a
     captured hipGraph bakes them in)."""
 
+    _serial = 0
+
     def __init__(self, model, exp_step_factor, T_threshold, max_samples):
+        RenderConfig._serial += 1
+        self.serial = RenderConfig._serial            # never reused (unlike id() / data_ptr()): names this configuration in cache keys
         self.scale = float(model.scale)
         self.cascades = int(model.cascades)
         self.grid_size = int(model.grid_size)

@@ -27,7 +27,8 @@ pytestmark = pytest.mark.gpu
 N_RAYS, STEPS, UPDATE_EVERY = 1024, 48, 16
 THR = 0.01 * 1024 / 3**0.5                       # train.py:180
 NOISE_SEED = 5000
-INIT_SCALE = 2.0**10                             # a loss scale no step of these runs overflows at (asserted: skipped == 0)
+INIT_SCALE = 2.0**15                             # a loss scale no step of these runs overflows at (asserted: skipped == 0); torch's fp16
+                                                 # autocast backward (the yard-stick) underflows visibly below ~2^14 (train.py:137-141 uses 2^19)
 
 
 def _inputs():
@@ -122,7 +123,7 @@ def _run_autocast(m, pool, noise, jit):
             scaler.step(opt)
             scaler.update()
             sched.step()
-            losses.append(float(loss))
+            losses.append(float(loss.detach()))
         assert scaler.get_scale() == INIT_SCALE          # no overflow, no skipped step on this side either
     finally:
         if old is None:
@@ -153,13 +154,15 @@ def test_trajectory_matches_oracle_loop(oracle, hip_lib, kind):
         ham = np.unpackbits(cpu_bits[s] ^ hip_bits[s]).mean()
         occ = np.unpackbits(cpu_bits[s]).mean()
         print(" update at step %2d: occupied fraction %.3f, cells that differ between the two grids %.2e" % (s, occ, ham))
-        assert ham < 2e-3, (s, ham)
+        # (half2 encoder: its table starts at U(+-1e-4), every density is 1 +- 1e-4 and the threshold is their mean -- the cells' order
+        # around it is decided in the last bits of an fp16 logit)
+        assert ham < (1e-2 if kind == "half" else 2e-3), (s, ham)
     tot_c, tot_h = np.array([r["rm_samples"] for r in cpu]), np.array([r["rm_samples"] for r in hip])
-    assert np.abs(tot_c - tot_h).max() <= 5e-3 * tot_c.max(), np.abs(tot_c - tot_h).max()
+    assert np.abs(tot_c - tot_h).max() <= (1e-2 if kind == "half" else 5e-3) * tot_c.max(), np.abs(tot_c - tot_h).max()
     first = slice(0, UPDATE_EVERY)                     # until the second update both sides march the step-0 grids: nearly all rays equal
     same = np.mean([np.mean(c["counts"] == h["counts"]) for c, h in zip(cpu[first], hip[first])])
     print(" rays with identical sample counts in the first %d steps: %.4f" % (UPDATE_EVERY, same))
-    assert same > 0.97
+    assert same > (0.5 if kind == "half" else 0.99)
     # early termination point per ray (compositing): where the rays' samples agree, the sample the ray stops at agrees to +-1
     vr_ok = []
     for c, h in zip(cpu, hip):
@@ -168,7 +171,7 @@ def test_trajectory_matches_oracle_loop(oracle, hip_lib, kind):
     print(" rays (same samples) whose early-termination point agrees to +-1 sample: min over steps %.4f" % min(vr_ok))
     # loss curve
     assert lh[-1] < 0.5 * lh[0] and lc[-1] < 0.5 * lc[0]                 # both learn
-    tol = 2e-2
+    tol = 2e-2 if kind == "half" else 5e-3
     print(" max relative loss deviation HIP vs CPU-fp32: %.3e (mean %.3e)" % (rel.max(), rel.mean()))
     assert rel.max() <= tol, rel.max()
     if m_auto is not None:

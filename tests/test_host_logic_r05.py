@@ -78,3 +78,41 @@ def test_scatter_mode_travels_in_the_level_table():
             assert all(r == 1 for r in got)
         assert nrep_of(lv) == base                                                            # the default table still gets the default plan
     assert seen[lib.BWD_PLAN_CONCENTRATED] != base
+
+
+def test_coarse_table_validity_key_is_shared_and_never_aliases():
+    """Round 6: the 8^3-block occupancy shortcut table of an arena has ONE validity key, kept on the arena, that both
+    FusedTrainer and the fused render() consult -- and the key names the render configuration by a serial that is never reused, so a
+    new model whose bitfield lands on a freed bitfield's address with an equal version count still rebuilds (the first cut of this
+    change keyed on the address alone and marched a fresh model against the previous model's table)."""
+    import torch
+    from types import SimpleNamespace
+    from ngp_hip.fused import RenderConfig, TrainArena
+    A = TrainArena(torch.device("cpu"), 4, 4)
+    bits = torch.zeros(128**3 // 8, dtype=torch.uint8)
+
+    def cfg_for(serial):
+        return SimpleNamespace(serial=serial, bitfield=bits, cascades=1, grid_size=128)
+    c1 = cfg_for(1)
+    buf, stale = A.coarse_state(c1)
+    assert stale and buf.numel() == 128**3 // 512 // 32
+    assert not A.coarse_state(c1)[1]                                                # second consumer of the same configuration: valid
+    bits.add_(1)                                                                    # an in-place write moves the version counter
+    assert A.coarse_state(c1)[1] and not A.coarse_state(c1)[1]
+    c2 = cfg_for(2)                                                                 # another model, same address, same version
+    assert A.coarse_state(c2)[1] and not A.coarse_state(c2)[1]
+    assert A.coarse_state(c1)[1]                                                    # ... and back: the buffer now holds c2's table
+    TrainArena._cache[("test", 4, 4)] = A
+    try:
+        TrainArena.invalidate_coarse()
+        assert A.coarse_state(c1)[1]
+    finally:
+        del TrainArena._cache[("test", 4, 4)]
+    # RenderConfig hands out fresh serials
+    m = SimpleNamespace(scale=0.5, cascades=1, grid_size=128, density_bitfield=bits, half_opt=False,
+                        pos_encoder=SimpleNamespace(levels_struct=__import__("ngp_hip.ops", fromlist=["x"]).make_levels(2**19, 16, 16, 1024, 2)))
+    a, b = RenderConfig(m, 0.0, 1e-4, 1024), RenderConfig(m, 0.0, 1e-4, 1024)
+    assert a.serial != b.serial and a.levels.bwd_plan == 0
+    m3 = SimpleNamespace(**{**m.__dict__, "scale": 16.0, "cascades": 6})
+    from ngp_hip import lib
+    assert RenderConfig(m3, 1.0 / 256, 1e-4, 1024).levels.bwd_plan == lib.BWD_PLAN_CONCENTRATED     # multi-cascade scene: concentrated plan on the drop-in path too
