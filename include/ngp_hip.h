@@ -485,14 +485,6 @@ int ngp_adam_all_ex(float* table, void* table_g, int grad_is_f16, float* table_m
                     uint16_t* table_16, int copy_kind, float* mlp, float* mlp_g, float* mlp_m, float* mlp_v,
                     const float* state_f, const int32_t* state_i, float beta1, float beta2, float eps, int enc_pairs,
                     uint16_t* wpack, void* stream);
-/* The same pass with the launch SHAPE as an argument: block_threads = 1024 (what ngp_adam_all_ex launches) or 256.  A 16-wave
- * workgroup needs four free wave slots on every SIMD of a CU at once; beside another kernel's stream of 4-wave workgroups (the
- * next batch's march under a multi-cascade step) that moment does not come until that kernel has drained -- 256-thread workgroups
- * take the same holes its workgroups do.  Same arithmetic, same results. */
-int ngp_adam_all_shaped(float* table, void* table_g, int grad_is_f16, float* table_m, float* table_v, long long n,
-                        uint16_t* table_16, int copy_kind, float* mlp, float* mlp_g, float* mlp_m, float* mlp_v,
-                        const float* state_f, const int32_t* state_i, float beta1, float beta2, float eps, int enc_pairs,
-                        uint16_t* wpack, int block_threads, void* stream);
 /* Adam on the 9 408 flat MLP weights (W1|W2|W3|W4|W5) + the fp16 fragment repack for the next step, one launch. */
 int ngp_adam_mlp_pack(float* p, float* g, float* m, float* v, const float* state_f, const int32_t* state_i,
                       float beta1, float beta2, float eps, int enc_pairs, uint16_t* wpack, void* stream);

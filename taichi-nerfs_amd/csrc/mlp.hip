@@ -123,11 +123,6 @@ __global__ void __launch_bounds__(256) mlp_pack_kernel(const float* __restrict__
 // Round 5: the block is the whole launch once the table's optimizer rides in the scatter-add's flush (hash_bwd_lds.hip), so its
 // latency counts: every thread requests its ten weights' p / g / m / v at once (one round trip instead of ten dependent ones), the
 // updated weights are also kept in LDS, and the repack reads them from there instead of from memory the block has just written.
-// THREADS = 1024: every thread owns ceil(9408 / 1024) = 10 weights and requests p / g / m / v of all of them before it touches
-// anything (40 loads in flight: the block is ONE round trip + the repack).  THREADS = 256 (round 6: the narrow launch shape, see
-// ngp_adam_all_shaped): 4 weights per thread and trip, 10 trips -- a few microseconds more, in a launch that no longer needs a whole
-// CU's wave slots at once.
-template <int THREADS>
 __device__ __forceinline__ void adam_mlp_pack_block(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, const float* __restrict__ sf,
                                                     const int32_t* __restrict__ si, float beta1, float beta2, float eps,
@@ -135,29 +130,27 @@ __device__ __forceinline__ void adam_mlp_pack_block(float* __restrict__ p, float
     __shared__ float wl[9408];
     const bool skip = si[SI_SKIP] != 0;
     const float inv_scale = sf[SF_INV_SCALE], step_size = sf[SF_LR] / sf[SF_BC1], bc2_sqrt = sf[SF_BC2_SQRT];
-    constexpr int PER = THREADS >= 1024 ? (9408 + THREADS - 1) / THREADS : 4;
-    for (int base = 0; base < 9408; base += PER * THREADS) {
-        float pi[PER], gi[PER], mi[PER], vi[PER];
+    constexpr int PER = (9408 + 1023) / 1024;
+    float pi[PER], gi[PER], mi[PER], vi[PER];
 #pragma unroll
-        for (int k = 0; k < PER; ++k) {
-            const int i = base + (int)threadIdx.x + THREADS * k, ic = i < 9408 ? i : 0;
-            pi[k] = p[ic]; gi[k] = g[ic]; mi[k] = m[ic]; vi[k] = v[ic];
-        }
+    for (int k = 0; k < PER; ++k) {
+        const int i = (int)threadIdx.x + 1024 * k, ic = i < 9408 ? i : 0;
+        pi[k] = p[ic]; gi[k] = g[ic]; mi[k] = m[ic]; vi[k] = v[ic];
+    }
 #pragma unroll
-        for (int k = 0; k < PER; ++k) {
-            const int i = base + (int)threadIdx.x + THREADS * k;
-            if (i >= 9408) continue;
-            if (!skip) {
-                const float gr = gi[k] * inv_scale;
-                const float mk = mi[k] + (gr - mi[k]) * (1.0f - beta1);
-                const float vk = vi[k] * beta2 + gr * gr * (1.0f - beta2);
-                const float denom = sqrtf(vk) / bc2_sqrt + eps;
-                pi[k] = pi[k] - step_size * (mk / denom);
-                p[i] = pi[k]; m[i] = mk; v[i] = vk;
-            }
-            g[i] = 0.0f;
-            wl[i] = pi[k];
+    for (int k = 0; k < PER; ++k) {
+        const int i = (int)threadIdx.x + 1024 * k;
+        if (i >= 9408) continue;
+        if (!skip) {
+            const float gr = gi[k] * inv_scale;
+            const float mk = mi[k] + (gr - mi[k]) * (1.0f - beta1);
+            const float vk = vi[k] * beta2 + gr * gr * (1.0f - beta2);
+            const float denom = sqrtf(vk) / bc2_sqrt + eps;
+            pi[k] = pi[k] - step_size * (mk / denom);
+            p[i] = pi[k]; m[i] = mk; v[i] = vk;
         }
+        g[i] = 0.0f;
+        wl[i] = pi[k];
     }
     __syncthreads();
     // one 16-byte fragment slot (8 halfs) per work item
@@ -171,19 +164,19 @@ __global__ void __launch_bounds__(1024) adam_mlp_pack_kernel(float* __restrict__
                                                              float* __restrict__ v, const float* __restrict__ sf,
                                                              const int32_t* __restrict__ si, float beta1, float beta2, float eps,
                                                              int pairs, half_t* __restrict__ wpack) {
-    adam_mlp_pack_block<1024>(p, g, m, v, sf, si, beta1, beta2, eps, pairs, wpack);
+    adam_mlp_pack_block(p, g, m, v, sf, si, beta1, beta2, eps, pairs, wpack);
 }
 
 // The whole optimizer pass in ONE launch: block 0 (dispatched first) does the MLP weights + repack while blocks 1.. stream the
 // hash table -- the 16 us small-kernel tail of the step disappears under the 46 us table pass.
-template <int SHADOW, bool GRAD16, int THREADS>
-__global__ void __launch_bounds__(THREADS) adam_all_kernel(float4* __restrict__ tp, void* __restrict__ tg, float4* __restrict__ tm,
-                                                           float4* __restrict__ tv, long n4, uint2* __restrict__ shadow,
-                                                           float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
-                                                           float* __restrict__ v, const float* __restrict__ sf,
-                                                           const int32_t* __restrict__ si, float beta1, float beta2, float eps,
-                                                           int pairs, half_t* __restrict__ wpack) {
-    if (blockIdx.x == 0) { if (p) adam_mlp_pack_block<THREADS>(p, g, m, v, sf, si, beta1, beta2, eps, pairs, wpack); }     // (mlp == NULL: table range only)
+template <int SHADOW, bool GRAD16>
+__global__ void __launch_bounds__(1024) adam_all_kernel(float4* __restrict__ tp, void* __restrict__ tg, float4* __restrict__ tm,
+                                                        float4* __restrict__ tv, long n4, uint2* __restrict__ shadow,
+                                                        float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                        float* __restrict__ v, const float* __restrict__ sf,
+                                                        const int32_t* __restrict__ si, float beta1, float beta2, float eps,
+                                                        int pairs, half_t* __restrict__ wpack) {
+    if (blockIdx.x == 0) { if (p) adam_mlp_pack_block(p, g, m, v, sf, si, beta1, beta2, eps, pairs, wpack); }     // (mlp == NULL: table range only)
     else adam_table_pass<SHADOW, GRAD16>(tp, tg, tm, tv, n4, sf, si, beta1, beta2, eps, shadow, (long)blockIdx.x - 1, (long)gridDim.x - 1);
 }
 
@@ -804,45 +797,29 @@ int ngp_adam_mlp_pack(float* p, float* g, float* m, float* v, const float* state
     return 0;
 }
 
-#define NGP_ADAM_ALL(SH, G16, TH)                                                                                                 \
-    hipLaunchKernelGGL((adam_all_kernel<SH, G16, TH>), grid, block, 0, (hipStream_t)stream, (float4*)table, table_g, (float4*)table_m, \
+#define NGP_ADAM_ALL(SH, G16)                                                                                                     \
+    hipLaunchKernelGGL((adam_all_kernel<SH, G16>), grid, block, 0, (hipStream_t)stream, (float4*)table, table_g, (float4*)table_m,    \
                        (float4*)table_v, n4, (uint2*)table_16, mlp, mlp_g, mlp_m, mlp_v, state_f, state_i, beta1, beta2, eps,         \
                        enc_pairs, (half_t*)wpack)
-#define NGP_ADAM_ALL_TH(SH, G16) do { if (block_threads == 256) NGP_ADAM_ALL(SH, G16, 256); else NGP_ADAM_ALL(SH, G16, 1024); } while (0)
-
-// block_threads: 1024 (the default shape: 16-wave workgroups, 4 per CU) or 256.  Why a caller would want 256: a 16-wave workgroup
-// is only dispatched where a CU has four free wave slots on EVERY SIMD at the same moment; beside a stream of small (4-wave)
-// workgroups of another kernel -- FusedTrainer's next-batch march under a multi-cascade scene's step -- such a moment does not come
-// until that kernel has drained, whatever the streams' priorities say, and this launch sits on the step's critical path
-// (BENCH_r05 C3: 314 us in the step, 18 us alone).  4-wave workgroups take the same holes the other kernel's do.
-int ngp_adam_all_shaped(float* table, void* table_g, int grad_is_f16, float* table_m, float* table_v, long long n, uint16_t* table_16,
-                        int copy_kind, float* mlp, float* mlp_g, float* mlp_m, float* mlp_v, const float* state_f, const int32_t* state_i,
-                        float beta1, float beta2, float eps, int enc_pairs, uint16_t* wpack, int block_threads, void* stream) {
-    if (n <= 0 || n % 4 != 0) return -1;
-    if ((copy_kind != 0) != (table_16 != nullptr) || copy_kind < 0 || copy_kind > 2) return -1;
-    if (block_threads != 256 && block_threads != 1024) return -1;
-    const long n4 = (long)(n / 4);
-    long blocks = (n4 + block_threads - 1) / block_threads;
-    const long cap = 256L * 4 * (1024 / block_threads);      // 4096 resident threads per CU, grid-stride beyond
-    if (blocks > cap) blocks = cap;
-    const dim3 grid((unsigned)blocks + 1), block((unsigned)block_threads);
-    if (grad_is_f16) {
-        if (copy_kind == 2) NGP_ADAM_ALL_TH(2, true); else if (copy_kind == 1) NGP_ADAM_ALL_TH(1, true); else NGP_ADAM_ALL_TH(0, true);
-    } else {
-        if (copy_kind == 2) NGP_ADAM_ALL_TH(2, false); else if (copy_kind == 1) NGP_ADAM_ALL_TH(1, false); else NGP_ADAM_ALL_TH(0, false);
-    }
-    NGP_LAUNCH_CHECK();
-    return 0;
-}
-#undef NGP_ADAM_ALL_TH
-#undef NGP_ADAM_ALL
 
 int ngp_adam_all_ex(float* table, void* table_g, int grad_is_f16, float* table_m, float* table_v, long long n, uint16_t* table_16,
                     int copy_kind, float* mlp, float* mlp_g, float* mlp_m, float* mlp_v, const float* state_f, const int32_t* state_i,
                     float beta1, float beta2, float eps, int enc_pairs, uint16_t* wpack, void* stream) {
-    return ngp_adam_all_shaped(table, table_g, grad_is_f16, table_m, table_v, n, table_16, copy_kind, mlp, mlp_g, mlp_m, mlp_v, state_f,
-                               state_i, beta1, beta2, eps, enc_pairs, wpack, 1024, stream);
+    if (n <= 0 || n % 4 != 0) return -1;
+    if ((copy_kind != 0) != (table_16 != nullptr) || copy_kind < 0 || copy_kind > 2) return -1;
+    const long n4 = (long)(n / 4);
+    long blocks = (n4 + 1023) / 1024;
+    if (blocks > 256L * 4) blocks = 256L * 4;                 // 4 x 1024-thread blocks per CU, grid-stride beyond
+    const dim3 grid((unsigned)blocks + 1), block(1024);
+    if (grad_is_f16) {
+        if (copy_kind == 2) NGP_ADAM_ALL(2, true); else if (copy_kind == 1) NGP_ADAM_ALL(1, true); else NGP_ADAM_ALL(0, true);
+    } else {
+        if (copy_kind == 2) NGP_ADAM_ALL(2, false); else if (copy_kind == 1) NGP_ADAM_ALL(1, false); else NGP_ADAM_ALL(0, false);
+    }
+    NGP_LAUNCH_CHECK();
+    return 0;
 }
+#undef NGP_ADAM_ALL
 
 int ngp_adam_all(float* table, float* table_g, float* table_m, float* table_v, long long n, uint16_t* table_bf16, float* mlp,
                  float* mlp_g, float* mlp_m, float* mlp_v, const float* state_f, const int32_t* state_i, float beta1, float beta2,

@@ -211,7 +211,6 @@ SIGNATURES = {
     "ngp_cast_f32_bf16": [_P, _P, ctypes.c_longlong, _P],
     "ngp_adam_all": [_P, _P, _P, _P, ctypes.c_longlong, _P, _P, _P, _P, _P, _P, _P, _F, _F, _F, _I, _P, _P],
     "ngp_adam_all_ex": [_P, _P, _I, _P, _P, ctypes.c_longlong, _P, _I, _P, _P, _P, _P, _P, _P, _F, _F, _F, _I, _P, _P],
-    "ngp_adam_all_shaped": [_P, _P, _I, _P, _P, ctypes.c_longlong, _P, _I, _P, _P, _P, _P, _P, _P, _F, _F, _F, _I, _P, _I, _P],
     "ngp_adam_mlp_pack": [_P, _P, _P, _P, _P, _P, _F, _F, _F, _I, _P, _P],
     "ngp_distortion_fwd": [_P, _P, _P, _P, _I, _P, _P, _P, _P],
     "ngp_distortion_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P],

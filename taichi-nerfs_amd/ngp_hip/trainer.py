@@ -215,7 +215,6 @@ class FusedTrainer:
             self._side_prio = (lo.value, hi.value)
             self._side = self._side_low
         self._hook_at = 3
-        self._adam_block = int(os.environ.get("NGP_ADAM_BLOCK", "0")) or None
         self._marched_host = None              # pinned host int32 (ngp_host_alloc): sample count of a recent prefetched march
         if self._adaptive_prefetch:
             h = ctypes.c_void_p()
@@ -780,14 +779,9 @@ class FusedTrainer:
             hook()                                                          # position 4
         kind = 1 if copy16 is not None else 0
         if npre > 0:
-            # launch shape: 16-wave workgroups by default; 4-wave ones while the next batch's (heavy) march runs beside the step -- its
-            # stream of 4-wave workgroups otherwise keeps this launch out of the CUs until it has drained (C3: 220-314 us in the step
-            # against 18 alone; ngp_adam_all_shaped).  NGP_ADAM_BLOCK=256 / 1024 pins it.
-            blk = self._adam_block or (256 if (self._adaptive_prefetch and self._hook_at == 3) else 1024)
-            check(L.ngp_adam_all_shaped(_ptr(self.table), _ptr(self.table_grad), 0, _ptr(self.table_m), _ptr(self.table_v), npre,
-                                        _ptr(copy16), kind, _ptr(self.mlp_flat), _ptr(self.mlp_grad), _ptr(self.mlp_m), _ptr(self.mlp_v),
-                                        _ptr(sf), _ptr(si), self.beta1, self.beta2, self.eps, P, _ptr(self.wpack), blk, st),
-                  "ngp_adam_all_shaped")
+            check(L.ngp_adam_all_ex(_ptr(self.table), _ptr(self.table_grad), 0, _ptr(self.table_m), _ptr(self.table_v), npre,
+                                    _ptr(copy16), kind, _ptr(self.mlp_flat), _ptr(self.mlp_grad), _ptr(self.mlp_m), _ptr(self.mlp_v),
+                                    _ptr(sf), _ptr(si), self.beta1, self.beta2, self.eps, P, _ptr(self.wpack), st), "ngp_adam_all_ex")
         else:
             check(L.ngp_adam_mlp_pack(_ptr(self.mlp_flat), _ptr(self.mlp_grad), _ptr(self.mlp_m), _ptr(self.mlp_v), _ptr(sf), _ptr(si),
                                       self.beta1, self.beta2, self.eps, P, _ptr(self.wpack), st), "ngp_adam_mlp_pack")

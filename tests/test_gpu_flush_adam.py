@@ -270,39 +270,3 @@ def test_trainer_deterministic_mode_reproduces_itself(hip_lib, lego_bitfield):
     for k in res[0]:
         assert _same(res[0][k], res[1][k]), k
     assert abs(live[0] - live[1]) <= 0.005 * max(live) + 2, live
-
-
-@pytest.mark.parametrize("copy", [False, True], ids=["f32", "bf16copy"])
-def test_adam_all_shaped_256_equals_1024(hip_lib, copy):
-    """Round 6: ngp_adam_all_shaped with 4-wave workgroups (the shape FusedTrainer launches beside a heavy next-batch march, where a
-    16-wave workgroup waits for that kernel to drain) -- bit-identical to the 16-wave launch on table, moments, 16-bit copy, MLP
-    weights and the fp16 fragment image, on a step and on a skipped step."""
-    from ngp_hip.ops import _ptr, _stream
-    L = ops._lib()
-    lv = ops.make_levels(2**19, 16, 16, 1024, 2)
-    gen = torch.Generator(device="cuda").manual_seed(11)
-    base = _State(lv, copy, gen)
-    n = 934304                                     # a prefix of the table, as the flush path leaves to this launch (multiple of 4)
-    base.g[:n] = torch.randn(n, generator=gen, device="cuda") * (torch.rand(n, generator=gen, device="cuda") < 0.3)
-    base.mlp_g.copy_(torch.randn(N_MLP, generator=gen, device="cuda"))
-    base.m[:n] = torch.randn(n, generator=gen, device="cuda") * 1e-3
-    base.v[:n] = torch.rand(n, generator=gen, device="cuda") * 1e-6
-    for skip in (0, 1):
-        outs = []
-        for blk in (1024, 256):
-            s = base.clone()
-            s.sf[1], s.sf[2], s.sf[3], s.sf[4] = 1.0 / 1024.0, 1e-2, 0.1, 0.0316              # inv scale, lr, bias corrections
-            s.si[4] = skip
-            rc = L.ngp_adam_all_shaped(_ptr(s.table), _ptr(s.g), 0, _ptr(s.m), _ptr(s.v), n, _ptr(s.copy), 1 if copy else 0, _ptr(s.mlp),
-                                       _ptr(s.mlp_g), _ptr(s.mlp_m), _ptr(s.mlp_v), _ptr(s.sf), _ptr(s.si), B1, B2, EPS, 1, _ptr(s.wpack),
-                                       blk, _stream())
-            assert rc == 0
-            torch.cuda.synchronize()
-            outs.append(s)
-        a, b = outs
-        for k in ("table", "m", "v", "g", "mlp", "mlp_m", "mlp_v", "mlp_g", "wpack") + (("copy",) if copy else ()):
-            assert torch.equal(getattr(a, k).view(torch.uint8), getattr(b, k).view(torch.uint8)), (skip, k)
-        assert float(a.g[:n].abs().max()) == 0.0 and float(a.mlp_g.abs().max()) == 0.0        # gradients cleared either way
-        assert (not torch.equal(a.table, base.table)) == (skip == 0)
-    assert L.ngp_adam_all_shaped(_ptr(base.table), _ptr(base.g), 0, _ptr(base.m), _ptr(base.v), n, _ptr(None), 0, _ptr(None), _ptr(None),
-                                 _ptr(None), _ptr(None), _ptr(base.sf), _ptr(base.si), B1, B2, EPS, 1, _ptr(None), 512, _stream()) == -1
