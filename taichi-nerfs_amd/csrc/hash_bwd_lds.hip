@@ -351,9 +351,11 @@ enum { KIND_GENERIC = 0, KIND_HASHED = 1, KIND_MERGE = 2, KIND_MERGE0 = 3,      
                           // the subtract, every w * g product rounded to f16; the owner's f64 sum is rounded to f16 once, at the flush
 
 // One batch of <= 64 hits (one per lane): accumulate this level's contributions that fall into slice `sl`.
+// Hashed levels (round 6): `preset` != 0 restricts the lane's hit to those (y, z) combinations (a re-queued hit, see below); the return
+// value is the mask of combinations of this lane that are in the slice but were NOT processed (`defer`), 0 otherwise.
 template <int KIND>
-__device__ __forceinline__ void accumulate(const LevelParams P, const uint32_t sl, const bool single, const Hit H, const bool valid,
-                                           double* __restrict__ slice) {
+__device__ __forceinline__ uint32_t accumulate(const LevelParams P, const uint32_t sl, const bool single, const Hit H, const bool valid,
+                                               double* __restrict__ slice, const uint32_t preset = 0u, const bool defer = false) {
     constexpr bool HALF = (KIND & KIND_HALF) != 0;
     constexpr int K = KIND & 3;
     const int lane = threadIdx.x & 63;
@@ -374,22 +376,35 @@ __device__ __forceinline__ void accumulate(const LevelParams P, const uint32_t s
         if (act) {
             m = (uint32_t)(((A0 & msk) >> BW_SLICE_LOG2) == sl) | ((uint32_t)(((A1 & msk) >> BW_SLICE_LOG2) == sl) << 1) |
                 ((uint32_t)(((A2 & msk) >> BW_SLICE_LOG2) == sl) << 2) | ((uint32_t)(((A3 & msk) >> BW_SLICE_LOG2) == sl) << 3);
+            if (preset) m &= preset;
         }
         const float wx0 = 1.0f * (1.0f - fx), wx1 = 1.0f * fx;                               // same product order as the forward
+        auto body = [&](const int k) {
+            const uint32_t A = (k & 2) ? ((k & 1) ? A3 : A2) : ((k & 1) ? A1 : A0);
+            const float wy = (k & 1) ? fy : 1.0f - fy, wz = (k & 2) ? fz : 1.0f - fz;
+            const float w0 = (wx0 * wy) * wz, w1 = (wx1 * wy) * wz;
+            double* p0 = slice + 2 * (((cx ^ A) & msk) & (BW_SLICE_ENTRIES - 1));
+            double* p1 = slice + 2 * ((((cx + 1u) ^ A) & msk) & (BW_SLICE_ENTRIES - 1));
+            LDS_ADD(p0, R(w0 * g0)); LDS_ADD(p0 + 1, R(w0 * g1));
+            LDS_ADD(p1, R(w1 * g0)); LDS_ADD(p1 + 1, R(w1 * g1));
+        };
+        // Round 6.  A hit has (almost always) ONE combination in this slice; a second one with probability 3/64 per lane -- which is
+        // 95 % per 64-lane batch, so the former `while (any lane has a combination left)` loop ran its ~45-instruction body twice (2.05
+        // times on average) for 1.05 combinations per lane.  Now every lane does its first combination straight-line, and a lane with
+        // more hands the rest back (`defer`): the caller re-queues the hit with the leftover mask, and the ~5 % extra hits fill later
+        // batches with all lanes busy.
+        if (m != 0u) {
+            body(__builtin_ctz(m));
+            m &= m - 1u;
+        }
+        if (defer) return m;
         while (__any(m != 0u)) {
             if (m != 0u) {
-                const int k = __builtin_ctz(m);
+                body(__builtin_ctz(m));
                 m &= m - 1u;
-                const uint32_t A = (k & 2) ? ((k & 1) ? A3 : A2) : ((k & 1) ? A1 : A0);
-                const float wy = (k & 1) ? fy : 1.0f - fy, wz = (k & 2) ? fz : 1.0f - fz;
-                const float w0 = (wx0 * wy) * wz, w1 = (wx1 * wy) * wz;
-                double* p0 = slice + 2 * (((cx ^ A) & msk) & (BW_SLICE_ENTRIES - 1));
-                double* p1 = slice + 2 * ((((cx + 1u) ^ A) & msk) & (BW_SLICE_ENTRIES - 1));
-                LDS_ADD(p0, R(w0 * g0)); LDS_ADD(p0 + 1, R(w0 * g1));
-                LDS_ADD(p1, R(w1 * g0)); LDS_ADD(p1 + 1, R(w1 * g1));
             }
         }
-        return;
+        return 0u;
     }
     if (K == KIND_GENERIC) {
         if (act) {
@@ -410,7 +425,7 @@ __device__ __forceinline__ void accumulate(const LevelParams P, const uint32_t s
                 }
             }
         }
-        return;
+        return 0u;
     }
     // KIND_MERGE / KIND_MERGE0: consecutive hits are consecutive samples of a ray; on a coarse level they sit in the same cell for many steps.
     // Sum each equal-cell run (in f32, fixed lane order) with a segmented scan inside 16-lane rows (DPP row shifts: one VALU
@@ -443,13 +458,16 @@ __device__ __forceinline__ void accumulate(const LevelParams P, const uint32_t s
             }
         }
     }
+    return 0u;
 }
 
 // A pair of batches (lane holds hits i0 and i1): the four gathers of a lane are issued together.
 struct Batch {
     Hit h0, h1;
     bool v0, v1;
+    uint32_t e0, e1;      // queue entries the hits came from: sample index | (y, z)-combination mask << 28 (0 = all; hashed levels)
 };
+constexpr uint32_t BW_IDX_MASK = 0x0fffffffu;
 
 __device__ __forceinline__ Batch load_batch(const int level, const int i0, const bool v0, const int i1, const bool v1,
                                             const float* __restrict__ xyzc, const float* __restrict__ dout, const size_t plane,
@@ -457,22 +475,25 @@ __device__ __forceinline__ Batch load_batch(const int level, const int i0, const
                                             const bool half) {
     Batch b;
     b.v0 = v0; b.v1 = v1;
-    b.h0 = load_hit(level, i0, v0, xyzc, dout, plane, enc_pairs, nl, found_inf, diag, half);
-    b.h1 = load_hit(level, i1, v1, xyzc, dout, plane, enc_pairs, nl, found_inf, diag, half);
+    b.e0 = (uint32_t)i0; b.e1 = (uint32_t)i1;
+    b.h0 = load_hit(level, (int)((uint32_t)i0 & BW_IDX_MASK), v0, xyzc, dout, plane, enc_pairs, nl, found_inf, diag, half);
+    b.h1 = load_hit(level, (int)((uint32_t)i1 & BW_IDX_MASK), v1, xyzc, dout, plane, enc_pairs, nl, found_inf, diag, half);
     return b;
 }
 
 template <int KIND>
 __device__ __forceinline__ void accumulate_batch(const LevelParams P, const uint32_t sl, const bool single, const Batch& b,
-                                                 double* __restrict__ slice, int32_t* __restrict__ found_inf) {
+                                                 double* __restrict__ slice, int32_t* __restrict__ found_inf, uint32_t& rest0,
+                                                 uint32_t& rest1, const bool defer) {
+    rest0 = rest1 = 0u;
     // GradScaler's inf/nan check, where the data passes -- here, not at the load: testing a value the moment it is requested
     // would make the wave wait for the gather it has just issued
     if (found_inf && !(isfinite(b.h0.g0) && isfinite(b.h0.g1) && isfinite(b.h1.g0) && isfinite(b.h1.g1))) *found_inf = 1;
 #ifdef NGP_BWD_DIAG
     if (P.diag & 4u) { asm volatile("" :: "v"(b.h0.x), "v"(b.h0.g0), "v"(b.h1.x), "v"(b.h1.g0)); return; }
 #endif
-    accumulate<KIND>(P, sl, single, b.h0, b.v0, slice);
-    accumulate<KIND>(P, sl, single, b.h1, b.v1, slice);
+    rest0 = accumulate<KIND>(P, sl, single, b.h0, b.v0, slice, b.e0 >> 28, defer);
+    rest1 = accumulate<KIND>(P, sl, single, b.h1, b.v1, slice, b.e1 >> 28, defer);
 }
 
 // One task: software-pipelined.  The wave's share of the hit bitmap is fetched 64 words (4096 samples) per vector load, one
