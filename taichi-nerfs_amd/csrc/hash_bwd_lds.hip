@@ -379,31 +379,37 @@ __device__ __forceinline__ uint32_t accumulate(const LevelParams P, const uint32
             if (preset) m &= preset;
         }
         const float wx0 = 1.0f * (1.0f - fx), wx1 = 1.0f * fx;                               // same product order as the forward
-        auto body = [&](const int k) {
-            const uint32_t A = (k & 2) ? ((k & 1) ? A3 : A2) : ((k & 1) ? A1 : A0);
-            const float wy = (k & 1) ? fy : 1.0f - fy, wz = (k & 2) ? fz : 1.0f - fz;
-            const float w0 = (wx0 * wy) * wz, w1 = (wx1 * wy) * wz;
-            double* p0 = slice + 2 * (((cx ^ A) & msk) & (BW_SLICE_ENTRIES - 1));
-            double* p1 = slice + 2 * ((((cx + 1u) ^ A) & msk) & (BW_SLICE_ENTRIES - 1));
-            LDS_ADD(p0, R(w0 * g0)); LDS_ADD(p0 + 1, R(w0 * g1));
-            LDS_ADD(p1, R(w1 * g0)); LDS_ADD(p1 + 1, R(w1 * g1));
-        };
+        // one (y, z) combination k = (z bit, y bit).  A is rebuilt from b0 / c0 (a select + an add each) instead of being picked out
+        // of A0..A3: as a by-reference lambda over those four the compiler turned them into an indexed SCRATCH array
+#define NGP_HASHED_COMBO(k)                                                                                     \
+        {                                                                                                       \
+            const uint32_t A = (b0 + (((k) & 1) ? 2654435761u : 0u)) ^ (c0 + (((k) & 2) ? 805459861u : 0u));     \
+            const float wy = ((k) & 1) ? fy : 1.0f - fy, wz = ((k) & 2) ? fz : 1.0f - fz;                        \
+            const float w0 = (wx0 * wy) * wz, w1 = (wx1 * wy) * wz;                                              \
+            double* p0 = slice + 2 * (((cx ^ A) & msk) & (BW_SLICE_ENTRIES - 1));                               \
+            double* p1 = slice + 2 * ((((cx + 1u) ^ A) & msk) & (BW_SLICE_ENTRIES - 1));                        \
+            LDS_ADD(p0, R(w0 * g0)); LDS_ADD(p0 + 1, R(w0 * g1));                                               \
+            LDS_ADD(p1, R(w1 * g0)); LDS_ADD(p1 + 1, R(w1 * g1));                                               \
+        }
         // Round 6.  A hit has (almost always) ONE combination in this slice; a second one with probability 3/64 per lane -- which is
         // 95 % per 64-lane batch, so the former `while (any lane has a combination left)` loop ran its ~45-instruction body twice (2.05
         // times on average) for 1.05 combinations per lane.  Now every lane does its first combination straight-line, and a lane with
         // more hands the rest back (`defer`): the caller re-queues the hit with the leftover mask, and the ~5 % extra hits fill later
         // batches with all lanes busy.
         if (m != 0u) {
-            body(__builtin_ctz(m));
+            const int k = __builtin_ctz(m);
             m &= m - 1u;
+            NGP_HASHED_COMBO(k)
         }
         if (defer) return m;
         while (__any(m != 0u)) {
             if (m != 0u) {
-                body(__builtin_ctz(m));
+                const int k = __builtin_ctz(m);
                 m &= m - 1u;
+                NGP_HASHED_COMBO(k)
             }
         }
+#undef NGP_HASHED_COMBO
         return 0u;
     }
     if (K == KIND_GENERIC) {
@@ -515,18 +521,33 @@ __device__ __forceinline__ void bwd_task(const LevelParams P, const int level, c
     const int lo_w = rep * chunk, hi_w = min(n_words, lo_w + chunk);
     Batch pend;
     pend.v0 = pend.v1 = false;
+    pend.e0 = pend.e1 = 0u;
     pend.h0 = pend.h1 = Hit{0.f, 0.f, 0.f, 0.f, 0.f};
+    uint32_t rest0 = 0u, rest1 = 0u;
     if (single) {
         for (int w0 = lo_w + 2 * wave; w0 < hi_w; w0 += 2 * BW_WAVES) {
             const int i0 = w0 * 64 + lane, i1 = i0 + 64;
             const Batch nxt = load_batch(level, i0, i0 < n, i1, (w0 + 1 < hi_w) && i1 < n, xyzc, dout, plane, enc_pairs, nl, found_inf, P.diag, HALF);
-            accumulate_batch<KIND>(P, sl, true, pend, slice, found_inf);
+            accumulate_batch<KIND>(P, sl, true, pend, slice, found_inf, rest0, rest1, false);
             pend = nxt;
         }
-        accumulate_batch<KIND>(P, sl, true, pend, slice, found_inf);
+        accumulate_batch<KIND>(P, sl, true, pend, slice, found_inf, rest0, rest1, false);
         return;
     }
     int qhead = 0, qlen = 0;
+    // Hashed levels: a hit whose lane has further (y, z) combinations in this slice after the first goes back to the END of this wave's
+    // queue as (sample | leftover mask << 28) and is gathered again with a later batch (see accumulate).  Room: the queue holds at
+    // most 127 + 64 entries when a drain starts, the drain takes 128 of them BEFORE it accumulates, and one batch hands back at most
+    // 128 -- never more than 191 of the ring's 256.
+    constexpr bool DEFER = K == KIND_HASHED;
+    auto requeue = [&](const uint32_t rest, const uint32_t entry) {
+        const unsigned long long need = __ballot(rest != 0u);
+        if (need) {
+            const int pos = qlen + __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0));
+            if (rest != 0u) q[(qhead + pos) & (BW_Q - 1)] = (entry & BW_IDX_MASK) | (rest << 28);
+            qlen += __popcll(need);
+        }
+    };
     // super-chunk c = words [lo_w + SCW c, + SCW): lane l < SCW holds word l.  Waves take super-chunks from a shared LDS counter
     // (hit density varies along the sample list; a static deal left the slowest wave 15-30 % behind), one ahead of the one in
     // work.  SCW = 64 words (4096 samples, ~256 hits) where ~6 % of the samples hit (hashed levels); fewer where a larger share
@@ -549,10 +570,11 @@ __device__ __forceinline__ void bwd_task(const LevelParams P, const int level, c
         __builtin_amdgcn_wave_barrier();
         const int i0 = (int)q[(qhead + lane) & (BW_Q - 1)], i1 = (int)q[(qhead + 64 + lane) & (BW_Q - 1)];
         const Batch nxt = load_batch(level, i0, true, i1, true, xyzc, dout, plane, enc_pairs, nl, found_inf, P.diag, HALF);
-        accumulate_batch<KIND>(P, sl, false, pend, slice, found_inf);
-        pend = nxt;
         __builtin_amdgcn_wave_barrier();
-        qhead = (qhead + 128) & (BW_Q - 1); qlen -= 128;
+        qhead = (qhead + 128) & (BW_Q - 1); qlen -= 128;               // consumed BEFORE the accumulate below hands leftovers back
+        accumulate_batch<KIND>(P, sl, false, pend, slice, found_inf, rest0, rest1, DEFER);
+        if (DEFER) { requeue(rest0, pend.e0); requeue(rest1, pend.e1); }
+        pend = nxt;
     };
     int sc = grab();
     unsigned long long cur = load_words(sc);
@@ -618,7 +640,7 @@ __device__ __forceinline__ void bwd_task(const LevelParams P, const int level, c
                             bits &= bits - 1u;
                         }
                         qlen += __popcll(live);
-                        if (qlen >= 128) drain();
+                        while (qlen >= 128) drain();                     // (a drain may hand back leftovers: see requeue)
                         live = __ballot(bits != 0u);
                     }
                     ++pass;
@@ -633,23 +655,34 @@ __device__ __forceinline__ void bwd_task(const LevelParams P, const int level, c
             const bool v0 = lane < qlen, v1 = lane + 64 < qlen;
             const int i0 = v0 ? (int)q[(qhead + lane) & (BW_Q - 1)] : 0, i1 = v1 ? (int)q[(qhead + 64 + lane) & (BW_Q - 1)] : 0;
             const Batch nxt = load_batch(level, i0, v0, i1, v1, xyzc, dout, plane, enc_pairs, nl, found_inf, P.diag, HALF);
-            accumulate_batch<KIND>(P, sl, false, pend, slice, found_inf);
+            accumulate_batch<KIND>(P, sl, false, pend, slice, found_inf, rest0, rest1, false);
             pend = nxt;
             __builtin_amdgcn_wave_barrier();
             qhead = (qhead + 128) & (BW_Q - 1); qlen = 0;
         }
         cur = nxtw; sc = sc_next;
     }
-    if (qlen > 0) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const bool v0 = lane < qlen, v1 = lane + 64 < qlen;
-        const int i0 = v0 ? (int)q[(qhead + lane) & (BW_Q - 1)] : 0, i1 = v1 ? (int)q[(qhead + 64 + lane) & (BW_Q - 1)] : 0;
-        const Batch nxt = load_batch(level, i0, v0, i1, v1, xyzc, dout, plane, enc_pairs, nl, found_inf, P.diag, HALF);
-        accumulate_batch<KIND>(P, sl, false, pend, slice, found_inf);
+    // the tail: what is still queued (< 128 hits) and the batch in flight -- and, on hashed levels, whatever those hand back
+    for (;;) {
+        const int take = qlen < 128 ? qlen : 128;
+        Batch nxt;
+        nxt.v0 = nxt.v1 = false;
+        nxt.e0 = nxt.e1 = 0u;
+        nxt.h0 = nxt.h1 = Hit{0.f, 0.f, 0.f, 0.f, 0.f};
+        if (take > 0) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const bool v0 = lane < take, v1 = lane + 64 < take;
+            const int i0 = v0 ? (int)q[(qhead + lane) & (BW_Q - 1)] : 0, i1 = v1 ? (int)q[(qhead + 64 + lane) & (BW_Q - 1)] : 0;
+            nxt = load_batch(level, i0, v0, i1, v1, xyzc, dout, plane, enc_pairs, nl, found_inf, P.diag, HALF);
+            __builtin_amdgcn_wave_barrier();
+            qhead = (qhead + take) & (BW_Q - 1); qlen -= take;
+        }
+        accumulate_batch<KIND>(P, sl, false, pend, slice, found_inf, rest0, rest1, DEFER);
+        if (DEFER) { requeue(rest0, pend.e0); requeue(rest1, pend.e1); }
         pend = nxt;
+        if (take == 0 && qlen == 0) break;              // nothing in flight (pend = the empty batch), nothing queued
     }
-    accumulate_batch<KIND>(P, sl, false, pend, slice, found_inf);
 }
 
 // Queue heads: ctr[x] = tasks taken from the front of XCD x's queue (low 16 bits, by its own workgroups) and from the back (high
