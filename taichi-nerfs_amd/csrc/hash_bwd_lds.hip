@@ -351,11 +351,9 @@ enum { KIND_GENERIC = 0, KIND_HASHED = 1, KIND_MERGE = 2, KIND_MERGE0 = 3,      
                           // the subtract, every w * g product rounded to f16; the owner's f64 sum is rounded to f16 once, at the flush
 
 // One batch of <= 64 hits (one per lane): accumulate this level's contributions that fall into slice `sl`.
-// Hashed levels (round 6): `preset` != 0 restricts the lane's hit to those (y, z) combinations (a re-queued hit, see below); the return
-// value is the mask of combinations of this lane that are in the slice but were NOT processed (`defer`), 0 otherwise.
 template <int KIND>
-__device__ __forceinline__ uint32_t accumulate(const LevelParams P, const uint32_t sl, const bool single, const Hit H, const bool valid,
-                                               double* __restrict__ slice, const uint32_t preset = 0u, const bool defer = false) {
+__device__ __forceinline__ void accumulate(const LevelParams P, const uint32_t sl, const bool single, const Hit H, const bool valid,
+                                           double* __restrict__ slice) {
     constexpr bool HALF = (KIND & KIND_HALF) != 0;
     constexpr int K = KIND & 3;
     const int lane = threadIdx.x & 63;
@@ -376,41 +374,22 @@ __device__ __forceinline__ uint32_t accumulate(const LevelParams P, const uint32
         if (act) {
             m = (uint32_t)(((A0 & msk) >> BW_SLICE_LOG2) == sl) | ((uint32_t)(((A1 & msk) >> BW_SLICE_LOG2) == sl) << 1) |
                 ((uint32_t)(((A2 & msk) >> BW_SLICE_LOG2) == sl) << 2) | ((uint32_t)(((A3 & msk) >> BW_SLICE_LOG2) == sl) << 3);
-            if (preset) m &= preset;
         }
         const float wx0 = 1.0f * (1.0f - fx), wx1 = 1.0f * fx;                               // same product order as the forward
-        // one (y, z) combination k = (z bit, y bit).  A is rebuilt from b0 / c0 (a select + an add each) instead of being picked out
-        // of A0..A3: as a by-reference lambda over those four the compiler turned them into an indexed SCRATCH array
-#define NGP_HASHED_COMBO(k)                                                                                     \
-        {                                                                                                       \
-            const uint32_t A = (b0 + (((k) & 1) ? 2654435761u : 0u)) ^ (c0 + (((k) & 2) ? 805459861u : 0u));     \
-            const float wy = ((k) & 1) ? fy : 1.0f - fy, wz = ((k) & 2) ? fz : 1.0f - fz;                        \
-            const float w0 = (wx0 * wy) * wz, w1 = (wx1 * wy) * wz;                                              \
-            double* p0 = slice + 2 * (((cx ^ A) & msk) & (BW_SLICE_ENTRIES - 1));                               \
-            double* p1 = slice + 2 * ((((cx + 1u) ^ A) & msk) & (BW_SLICE_ENTRIES - 1));                        \
-            LDS_ADD(p0, R(w0 * g0)); LDS_ADD(p0 + 1, R(w0 * g1));                                               \
-            LDS_ADD(p1, R(w1 * g0)); LDS_ADD(p1 + 1, R(w1 * g1));                                               \
-        }
-        // Round 6.  A hit has (almost always) ONE combination in this slice; a second one with probability 3/64 per lane -- which is
-        // 95 % per 64-lane batch, so the former `while (any lane has a combination left)` loop ran its ~45-instruction body twice (2.05
-        // times on average) for 1.05 combinations per lane.  Now every lane does its first combination straight-line, and a lane with
-        // more hands the rest back (`defer`): the caller re-queues the hit with the leftover mask, and the ~5 % extra hits fill later
-        // batches with all lanes busy.
-        if (m != 0u) {
-            const int k = __builtin_ctz(m);
-            m &= m - 1u;
-            NGP_HASHED_COMBO(k)
-        }
-        if (defer) return m;
         while (__any(m != 0u)) {
             if (m != 0u) {
                 const int k = __builtin_ctz(m);
                 m &= m - 1u;
-                NGP_HASHED_COMBO(k)
+                const uint32_t A = (k & 2) ? ((k & 1) ? A3 : A2) : ((k & 1) ? A1 : A0);
+                const float wy = (k & 1) ? fy : 1.0f - fy, wz = (k & 2) ? fz : 1.0f - fz;
+                const float w0 = (wx0 * wy) * wz, w1 = (wx1 * wy) * wz;
+                double* p0 = slice + 2 * (((cx ^ A) & msk) & (BW_SLICE_ENTRIES - 1));
+                double* p1 = slice + 2 * ((((cx + 1u) ^ A) & msk) & (BW_SLICE_ENTRIES - 1));
+                LDS_ADD(p0, R(w0 * g0)); LDS_ADD(p0 + 1, R(w0 * g1));
+                LDS_ADD(p1, R(w1 * g0)); LDS_ADD(p1 + 1, R(w1 * g1));
             }
         }
-#undef NGP_HASHED_COMBO
-        return 0u;
+        return;
     }
     if (K == KIND_GENERIC) {
         if (act) {
@@ -431,7 +410,7 @@ __device__ __forceinline__ uint32_t accumulate(const LevelParams P, const uint32
                 }
             }
         }
-        return 0u;
+        return;
     }
     // KIND_MERGE / KIND_MERGE0: consecutive hits are consecutive samples of a ray; on a coarse level they sit in the same cell for many steps.
     // Sum each equal-cell run (in f32, fixed lane order) with a segmented scan inside 16-lane rows (DPP row shifts: one VALU
@@ -464,16 +443,13 @@ __device__ __forceinline__ uint32_t accumulate(const LevelParams P, const uint32
             }
         }
     }
-    return 0u;
 }
 
 // A pair of batches (lane holds hits i0 and i1): the four gathers of a lane are issued together.
 struct Batch {
     Hit h0, h1;
     bool v0, v1;
-    uint32_t e0, e1;      // queue entries the hits came from: sample index | (y, z)-combination mask << 28 (0 = all; hashed levels)
 };
-constexpr uint32_t BW_IDX_MASK = 0x0fffffffu;
 
 __device__ __forceinline__ Batch load_batch(const int level, const int i0, const bool v0, const int i1, const bool v1,
                                             const float* __restrict__ xyzc, const float* __restrict__ dout, const size_t plane,
@@ -481,25 +457,22 @@ __device__ __forceinline__ Batch load_batch(const int level, const int i0, const
                                             const bool half) {
     Batch b;
     b.v0 = v0; b.v1 = v1;
-    b.e0 = (uint32_t)i0; b.e1 = (uint32_t)i1;
-    b.h0 = load_hit(level, (int)((uint32_t)i0 & BW_IDX_MASK), v0, xyzc, dout, plane, enc_pairs, nl, found_inf, diag, half);
-    b.h1 = load_hit(level, (int)((uint32_t)i1 & BW_IDX_MASK), v1, xyzc, dout, plane, enc_pairs, nl, found_inf, diag, half);
+    b.h0 = load_hit(level, i0, v0, xyzc, dout, plane, enc_pairs, nl, found_inf, diag, half);
+    b.h1 = load_hit(level, i1, v1, xyzc, dout, plane, enc_pairs, nl, found_inf, diag, half);
     return b;
 }
 
 template <int KIND>
 __device__ __forceinline__ void accumulate_batch(const LevelParams P, const uint32_t sl, const bool single, const Batch& b,
-                                                 double* __restrict__ slice, int32_t* __restrict__ found_inf, uint32_t& rest0,
-                                                 uint32_t& rest1, const bool defer) {
-    rest0 = rest1 = 0u;
+                                                 double* __restrict__ slice, int32_t* __restrict__ found_inf) {
     // GradScaler's inf/nan check, where the data passes -- here, not at the load: testing a value the moment it is requested
     // would make the wave wait for the gather it has just issued
     if (found_inf && !(isfinite(b.h0.g0) && isfinite(b.h0.g1) && isfinite(b.h1.g0) && isfinite(b.h1.g1))) *found_inf = 1;
 #ifdef NGP_BWD_DIAG
     if (P.diag & 4u) { asm volatile("" :: "v"(b.h0.x), "v"(b.h0.g0), "v"(b.h1.x), "v"(b.h1.g0)); return; }
 #endif
-    rest0 = accumulate<KIND>(P, sl, single, b.h0, b.v0, slice, b.e0 >> 28, defer);
-    rest1 = accumulate<KIND>(P, sl, single, b.h1, b.v1, slice, b.e1 >> 28, defer);
+    accumulate<KIND>(P, sl, single, b.h0, b.v0, slice);
+    accumulate<KIND>(P, sl, single, b.h1, b.v1, slice);
 }
 
 // One task: software-pipelined.  The wave's share of the hit bitmap is fetched 64 words (4096 samples) per vector load, one
@@ -521,33 +494,18 @@ __device__ __forceinline__ void bwd_task(const LevelParams P, const int level, c
     const int lo_w = rep * chunk, hi_w = min(n_words, lo_w + chunk);
     Batch pend;
     pend.v0 = pend.v1 = false;
-    pend.e0 = pend.e1 = 0u;
     pend.h0 = pend.h1 = Hit{0.f, 0.f, 0.f, 0.f, 0.f};
-    uint32_t rest0 = 0u, rest1 = 0u;
     if (single) {
         for (int w0 = lo_w + 2 * wave; w0 < hi_w; w0 += 2 * BW_WAVES) {
             const int i0 = w0 * 64 + lane, i1 = i0 + 64;
             const Batch nxt = load_batch(level, i0, i0 < n, i1, (w0 + 1 < hi_w) && i1 < n, xyzc, dout, plane, enc_pairs, nl, found_inf, P.diag, HALF);
-            accumulate_batch<KIND>(P, sl, true, pend, slice, found_inf, rest0, rest1, false);
+            accumulate_batch<KIND>(P, sl, true, pend, slice, found_inf);
             pend = nxt;
         }
-        accumulate_batch<KIND>(P, sl, true, pend, slice, found_inf, rest0, rest1, false);
+        accumulate_batch<KIND>(P, sl, true, pend, slice, found_inf);
         return;
     }
     int qhead = 0, qlen = 0;
-    // Hashed levels: a hit whose lane has further (y, z) combinations in this slice after the first goes back to the END of this wave's
-    // queue as (sample | leftover mask << 28) and is gathered again with a later batch (see accumulate).  Room: the queue holds at
-    // most 127 + 64 entries when a drain starts, the drain takes 128 of them BEFORE it accumulates, and one batch hands back at most
-    // 128 -- never more than 191 of the ring's 256.
-    constexpr bool DEFER = K == KIND_HASHED;
-    auto requeue = [&](const uint32_t rest, const uint32_t entry) {
-        const unsigned long long need = __ballot(rest != 0u);
-        if (need) {
-            const int pos = qlen + __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0));
-            if (rest != 0u) q[(qhead + pos) & (BW_Q - 1)] = (entry & BW_IDX_MASK) | (rest << 28);
-            qlen += __popcll(need);
-        }
-    };
     // super-chunk c = words [lo_w + SCW c, + SCW): lane l < SCW holds word l.  Waves take super-chunks from a shared LDS counter
     // (hit density varies along the sample list; a static deal left the slowest wave 15-30 % behind), one ahead of the one in
     // work.  SCW = 64 words (4096 samples, ~256 hits) where ~6 % of the samples hit (hashed levels); fewer where a larger share
@@ -570,11 +528,10 @@ __device__ __forceinline__ void bwd_task(const LevelParams P, const int level, c
         __builtin_amdgcn_wave_barrier();
         const int i0 = (int)q[(qhead + lane) & (BW_Q - 1)], i1 = (int)q[(qhead + 64 + lane) & (BW_Q - 1)];
         const Batch nxt = load_batch(level, i0, true, i1, true, xyzc, dout, plane, enc_pairs, nl, found_inf, P.diag, HALF);
-        __builtin_amdgcn_wave_barrier();
-        qhead = (qhead + 128) & (BW_Q - 1); qlen -= 128;               // consumed BEFORE the accumulate below hands leftovers back
-        accumulate_batch<KIND>(P, sl, false, pend, slice, found_inf, rest0, rest1, DEFER);
-        if (DEFER) { requeue(rest0, pend.e0); requeue(rest1, pend.e1); }
+        accumulate_batch<KIND>(P, sl, false, pend, slice, found_inf);
         pend = nxt;
+        __builtin_amdgcn_wave_barrier();
+        qhead = (qhead + 128) & (BW_Q - 1); qlen -= 128;
     };
     int sc = grab();
     unsigned long long cur = load_words(sc);
@@ -640,7 +597,7 @@ __device__ __forceinline__ void bwd_task(const LevelParams P, const int level, c
                             bits &= bits - 1u;
                         }
                         qlen += __popcll(live);
-                        while (qlen >= 128) drain();                     // (a drain may hand back leftovers: see requeue)
+                        if (qlen >= 128) drain();
                         live = __ballot(bits != 0u);
                     }
                     ++pass;
@@ -655,34 +612,23 @@ __device__ __forceinline__ void bwd_task(const LevelParams P, const int level, c
             const bool v0 = lane < qlen, v1 = lane + 64 < qlen;
             const int i0 = v0 ? (int)q[(qhead + lane) & (BW_Q - 1)] : 0, i1 = v1 ? (int)q[(qhead + 64 + lane) & (BW_Q - 1)] : 0;
             const Batch nxt = load_batch(level, i0, v0, i1, v1, xyzc, dout, plane, enc_pairs, nl, found_inf, P.diag, HALF);
-            accumulate_batch<KIND>(P, sl, false, pend, slice, found_inf, rest0, rest1, false);
+            accumulate_batch<KIND>(P, sl, false, pend, slice, found_inf);
             pend = nxt;
             __builtin_amdgcn_wave_barrier();
             qhead = (qhead + 128) & (BW_Q - 1); qlen = 0;
         }
         cur = nxtw; sc = sc_next;
     }
-    // the tail: what is still queued (< 128 hits) and the batch in flight -- and, on hashed levels, whatever those hand back
-    for (;;) {
-        const int take = qlen < 128 ? qlen : 128;
-        Batch nxt;
-        nxt.v0 = nxt.v1 = false;
-        nxt.e0 = nxt.e1 = 0u;
-        nxt.h0 = nxt.h1 = Hit{0.f, 0.f, 0.f, 0.f, 0.f};
-        if (take > 0) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            const bool v0 = lane < take, v1 = lane + 64 < take;
-            const int i0 = v0 ? (int)q[(qhead + lane) & (BW_Q - 1)] : 0, i1 = v1 ? (int)q[(qhead + 64 + lane) & (BW_Q - 1)] : 0;
-            nxt = load_batch(level, i0, v0, i1, v1, xyzc, dout, plane, enc_pairs, nl, found_inf, P.diag, HALF);
-            __builtin_amdgcn_wave_barrier();
-            qhead = (qhead + take) & (BW_Q - 1); qlen -= take;
-        }
-        accumulate_batch<KIND>(P, sl, false, pend, slice, found_inf, rest0, rest1, DEFER);
-        if (DEFER) { requeue(rest0, pend.e0); requeue(rest1, pend.e1); }
+    if (qlen > 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const bool v0 = lane < qlen, v1 = lane + 64 < qlen;
+        const int i0 = v0 ? (int)q[(qhead + lane) & (BW_Q - 1)] : 0, i1 = v1 ? (int)q[(qhead + 64 + lane) & (BW_Q - 1)] : 0;
+        const Batch nxt = load_batch(level, i0, v0, i1, v1, xyzc, dout, plane, enc_pairs, nl, found_inf, P.diag, HALF);
+        accumulate_batch<KIND>(P, sl, false, pend, slice, found_inf);
         pend = nxt;
-        if (take == 0 && qlen == 0) break;              // nothing in flight (pend = the empty batch), nothing queued
     }
+    accumulate_batch<KIND>(P, sl, false, pend, slice, found_inf);
 }
 
 // Queue heads: ctr[x] = tasks taken from the front of XCD x's queue (low 16 bits, by its own workgroups) and from the back (high
