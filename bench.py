@@ -110,8 +110,9 @@ def parse(argv=None):
     ap.add_argument("--graph", action="store_true", help="replay the trainer step from a captured hipGraph (1 GPU)")
     ap.add_argument("--no-prefetch", dest="prefetch", action="store_false",
                     help="do not march the next batch on a side stream underneath the current step")
-    ap.add_argument("--comm", default="f32", choices=["f32", "bf16"],
-                    help="N>1: dtype the gradient bucket travels in (f32 = exact mean, the default; bf16 halves xGMI bytes)")
+    ap.add_argument("--comm", default="auto", choices=["auto", "f32", "bf16"],
+                    help="N>1: dtype the gradient bucket travels in (auto, the default: bf16 when the model reads a bf16 table copy [--table bf16], "
+                         "else f32 = the exact mean; bf16 halves xGMI bytes)")
     ap.add_argument("--no-shard", dest="shard", action="store_false",
                     help="N>1: round 1's exchange (ONE all-reduce of the flat gradient bucket + replicated Adam) instead of the default "
                          "reduce-scatter -> Adam on the own 1/N of the table -> all-gather")
@@ -312,7 +313,7 @@ def main():
     out = measure(args, ctx)
     if rank == 0 and world == 1 and args.configs and _is_headline(args):
         out["configs"] = other_configs(args, ctx)
-    if world > 1 and args.configs and _is_headline(args) and args.comm == "f32" and args.shard and not os.environ.get("NGP_COMM_OVERLAP"):
+    if world > 1 and args.configs and _is_headline(args) and args.comm in ("auto", "f32") and args.shard and "comm_overlap" not in os.environ.get("NGP_EXPERIMENT", ""):
         # ONE invocation decides the multi-GPU defaults: the other exchange variants run in the same process group, behind the headline
         # The variants have never met a real multi-GPU node (no SCALE run in five rounds): the headline must survive one of them
         # hanging.  Every rank arms a watchdog for the variants phase (NGP_BENCH_VARIANT_TIMEOUT seconds, default 240): when it fires,
@@ -380,8 +381,8 @@ COMM_VARIANTS = [
                              "forward reads (half the bytes both ways)", ["--comm", "bf16", "--table", "bf16"], {}),
     ("no-shard-all-reduce", "--no-shard: SURVEY 8(e)'s single all-reduce of one flat fp32 bucket + replicated Adam (north_star's wording)",
      ["--no-shard"], {}),
-    ("overlap-8,0", "NGP_COMM_OVERLAP=1: the scatter-add issued per level group (8-15, then 0-7), a group's reduce-scatter in flight under "
-                    "the next group's launch, all-gathers waited for at the next step's forward", [], {"NGP_COMM_OVERLAP": "1", "NGP_COMM_GROUPS": "8,0"}),
+    ("overlap-8,0", "NGP_EXPERIMENT comm_overlap=1: the scatter-add issued per level group (8-15, then 0-7), a group's reduce-scatter in flight under "
+                    "the next group's launch, all-gathers waited for at the next step's forward", [], {"NGP_EXPERIMENT": "comm_overlap=1;comm_groups=8,0"}),
 ]
 COMM_MODEL_BW_GBS = (150.0, 300.0, 450.0)                      # DESIGN.md section 7's bus-bandwidth rows
 
@@ -475,15 +476,16 @@ def comm_fields(trainer, ctx, args):
         ver = ".".join(str(x) for x in torch.cuda.nccl.version())
     except Exception:
         ver = None
+    from ngp_hip import experiment as _exp
     overlap = trainer is not None and getattr(trainer, "_groups", None) is not None
     stub_ms = getattr(_Probe, "stub_ms", None)
     return {"comm_ms": comm_ms,
             "exposed_comm_ms": None if (stub_ms is None or ctx.get("ms_per_step") is None) else ctx["ms_per_step"] - stub_ms,
             "ms_per_step_comm_stubbed": stub_ms,
-            "comm_overlap": {"enabled": overlap, "level_groups": os.environ.get("NGP_COMM_GROUPS", "8,0") if overlap else None},
+            "comm_overlap": {"enabled": overlap, "level_groups": _exp.get("comm_groups", "8,0") if overlap else None},
             "comm_breakdown_ms": {k: float(np.mean(v)) for k, v in per.items()},
             "comm_note": "comm_ms = per step, HIP events on the step's stream around each collective (sampled steps) -- in line: the "
-                         "transfer; with NGP_COMM_OVERLAP=1: what the step's stream WAITS for the collective issued earlier.  "
+                         "transfer; with NGP_EXPERIMENT comm_overlap=1: what the step's stream WAITS for the collective issued earlier.  "
                          "exposed_comm_ms = ms_per_step minus the same K steps re-run with every collective replaced by its local "
                          "part (ms_per_step_comm_stubbed): measured, not assumed",
             "comm_bytes_per_rank_per_step": None if trainer is None else trainer.comm_bytes_per_step(),
@@ -556,7 +558,7 @@ def _measure(args, ctx, brief):
         from ngp_hip.trainer import FusedTrainer
         trainer = FusedTrainer(model, lr=1e-2, max_steps=20000, init_scale=2.0**16 if args.half else 2.0**19, world_size=world,
                                exp_step_factor=esf, distortion_loss_w=w_dist,
-                               grad_comm_dtype=torch.bfloat16 if args.comm == "bf16" else torch.float32,
+                               grad_comm_dtype={"bf16": torch.bfloat16, "f32": torch.float32, "auto": None}[args.comm],
                                shard_optimizer=args.shard if world > 1 else None)
     else:
         # train.py:143-156 picks apex.optimizers.FusedAdam when `import apex` works and torch.optim.Adam otherwise.  With this package's
@@ -1004,15 +1006,16 @@ def _measure(args, ctx, brief):
                         ("analytic-scene targets, model conditioned for %d steps, marching its own occupancy grid" % args.condition)
                         if scene else ("random target colours, fixed occupancy=%s (diagnostic state)" % args.regime),
                         rm / total_rays * world, vr / total_rays * world))
+        comm_name = args.comm if args.comm != "auto" else ("bf16" if (use_trainer and trainer.grad_comm_dtype == torch.bfloat16) else "f32")
         if world == 1:
             parallelism = "single GPU"
         elif use_trainer and args.shard:
             parallelism = ("ray-sharded dp%d, RCCL reduce-scatter of the %s table gradient -> Adam on the own 1/%d of the table -> all-gather of "
                            "the updated %s, + one 37.6 KB all-reduce [MLP gradient | inf flag]" % (
-                               world, "f16" if args.half else args.comm, world,
+                               world, "f16" if args.half else comm_name, world,
                                "f16 table copy" if args.half else ("bf16 table copy" if args.table == "bf16" else "f32 table")))
         else:
-            parallelism = "ray-sharded dp%d, RCCL all-reduce of one flat %s gradient bucket per step" % (world, args.comm)
+            parallelism = "ray-sharded dp%d, RCCL all-reduce of one flat %s gradient bucket per step" % (world, comm_name)
         out = {
             "metric": "training rays/sec", "value": total_rays / elapsed, "unit": "rays/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,

@@ -62,6 +62,9 @@ typedef struct ngp_hash_levels {
 
 int ngp_abi_version(void);
 
+/* Entry points that NO default path of the package calls (earlier rounds' forms kept for A/B runs, the overlapped-exchange experiment, host-side
+ * introspection and diagnostics) are declared in ngp_hip_experimental.h; the library exports both sets. */
+
 /* Host-only helper: fills `lv` like HashEncoder.__init__ (hash_encoder.py:183-205). Returns 0. */
 int ngp_hash_levels_init(ngp_hash_levels* lv, double max_params, int levels, double base_res,
                          double max_res, int features);
@@ -78,12 +81,6 @@ int ngp_ray_aabb(const float* rays_o, const float* rays_d, float scale, int n_ra
  *   scan  : exclusive prefix sum over counts -> rays_a[r] = (r, start, count) IN RAY ORDER and
  *           total[0] = number of samples (replaces counter[0]/counter[1] atomics, ray_march.py:76-81);
  *   write : sample-parallel expansion of the staged (t,dt) into xyzs/dirs/deltas/ts.            */
-int ngp_march_train_count(const float* rays_o, const float* rays_d, const float* hits_t,
-                          const uint8_t* density_bitfield, const float* noise,
-                          int cascades, int grid_size, float scale, float exp_step_factor,
-                          int max_samples, int n_rays,
-                          float* stage /*[n*max_samples,2] (t,dt)*/, int32_t* counts /*[n]*/,
-                          void* stream);
 /* (hits_t may be NULL in the _ex form below: the slab test of ngp_ray_aabb is then evaluated inline.) */
 /* Optional acceleration of `count`: coarse[k] bit = any occupied cell among the 512 Morton codes of 8^3-cell block k
  * (built by ngp_bitfield_coarsen whenever the bitfield changes; cascades*grid^3/512 bits).  Purely a shortcut for
@@ -173,9 +170,6 @@ int ngp_hash_fwd_list(const float* xyzs, const void* table, int table_kind, cons
                       void* stream);
 /* found_inf (nullable): set to 1 when a non-finite incoming gradient is seen -- GradScaler's inf/nan check
  * (train.py:199) done where the data passes instead of in an extra pass over the 45.7 MB gradient. */
-int ngp_hash_bwd_f32_ex(const float* xyzs, const float* dout, const ngp_hash_levels* lv, int n_max,
-                        const int32_t* n_dev, int normalize, float lo, float hi, int enc_pairs, float* dtable,
-                        int32_t* found_inf, void* stream);
 
 /* ---- a-5  half2 encoder fwd / explicit bwd (modules/hash_encoder_half.py:112-161,164-213) ----
  * table/out/dout/dtable are IEEE binary16 pairs (uint16_t storage). */
@@ -192,9 +186,6 @@ int ngp_hash_bwd_f16(const float* xyzs, const uint16_t* dout, const ngp_hash_lev
 int ngp_hash_fwd_f16_ex(const float* xyzs, const uint16_t* table, const ngp_hash_levels* lv, int n_max,
                         const int32_t* n_dev, int normalize, float lo, float hi, int enc_pairs, float* out,
                         void* stream);
-int ngp_hash_bwd_f16_ex(const float* xyzs, const float* dout, const ngp_hash_levels* lv, int n_max,
-                        const int32_t* n_dev, int normalize, float lo, float hi, int enc_pairs, uint16_t* dtable,
-                        int32_t* found_inf, void* stream);
 int ngp_check_finite_f16(const uint16_t* g, long long n, int32_t* found_inf, void* stream);
 
 /* ---- a-6  dir_encoder (modules/spherical_harmonics.py:7-42) + analytic backward -------------- */
@@ -218,14 +209,6 @@ int ngp_composite_train_bwd(const float* dL_dopacity, const float* dL_ddepth, co
                             const float* rgb, const float* ws, float T_threshold, int n_rays,
                             float* dL_dsigmas, void* dL_drgbs, void* stream);
 
-/* Trainer fusion of composite forward + MSE gradient (train.py:193, white/black background blend of
- * rendering.py:219-226) + composite backward: one wave per ray, two passes.  loss_scale points at state_f[0]; the
- * per-ray squared error sum_c (rgb_final - target)^2 is written to sq_err[ray] (nullable) for logging. */
-int ngp_composite_train_fused(const float* sigmas, const void* rgbs, int rgbs_is_half, const float* deltas,
-                              const float* ts, const int32_t* rays_a, const float* target, float bg,
-                              const float* loss_scale, float T_threshold, int n_rays, int32_t* vr_per_ray,
-                              float* opacity, float* depth, float* rgb, float* ws, float* d_sigmas, void* d_rgbs,
-                              float* sq_err, void* stream);
 /* Round 5 -- chunked forward: do not shade what compositing will never read.  The reference shades every marched sample and then
  * ignores those behind T <= T_threshold (volume_train.py:38); its evaluation loop (rendering.py:62-158) already shades in rounds
  * and drops finished rays.  One call per round: samples [begin, begin + len) of every ray still alive are appended to `list`
@@ -303,13 +286,6 @@ int ngp_hash_bwd_sliced_main(const float* dout, const ngp_hash_levels* lv, int n
 int ngp_hash_bwd_sliced_main_slabs(const float* dout, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev, int enc_pairs,
                                    void* dtable, int table_is_f16, int32_t* found_inf, const void* workspace,
                                    long long workspace_bytes, const float* mlp_dw_parts, int n_parts, float* mlp_dw, void* stream);
-/* ngp_hash_bwd_sliced_main restricted to the levels in `level_mask` (bit l = level l), optionally on at most max_blocks persistent
- * workgroups (0 = as many as CUs): a caller that exchanges the gradient between ranks launches the fine levels first and sends
- * their part of dtable while the coarse levels are still being accumulated.  Launches over disjoint masks add up to the full
- * scatter-add; they share the prepass's workspace and must run one after the other on one stream. */
-int ngp_hash_bwd_sliced_main_levels(const float* dout, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev, int enc_pairs,
-                                    float* dtable, int32_t* found_inf, const void* workspace, long long workspace_bytes,
-                                    unsigned int level_mask, int max_blocks, void* stream);
 /* Round 5 -- scatter-add WITH the optimizer (replaces train.py:197-201 on the path modules/hash_encoder.py:269 feeds; one GPU).
  * The owner of a slice that is not replicated over sample ranges (every level of 64 slices = 2^19 entries: the hashed levels)
  * holds that slice's complete gradient in LDS when its task ends; instead of adding it to dtable for ngp_adam_all_ex to read
@@ -323,11 +299,6 @@ int ngp_hash_bwd_sliced_main_levels(const float* dout, const ngp_hash_levels* lv
  * mlp_dw_parts / n_parts / mlp_dw: the optional slab sum of ngp_hash_bwd_sliced_main_slabs (NULL / 0: none).
  * _adam_prefix returns -2 (and _main_adam -2) when the level table has no non-replicated levels. */
 long long ngp_hash_bwd_sliced_adam_prefix(const ngp_hash_levels* lv);
-int ngp_hash_bwd_sliced_main_adam(const float* dout, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev, int enc_pairs,
-                                  float* dtable, const void* workspace, long long workspace_bytes, const float* mlp_dw_parts,
-                                  int n_parts, float* mlp_dw, float* table, float* table_m, float* table_v, uint16_t* table_bf16,
-                                  const float* state_f, const int32_t* state_i, float beta1, float beta2, float eps,
-                                  void* stream);
 /* The same launch with the step's scalar bookkeeping inside it (ngp_train_prologue's arguments; train.py:197-201): every workgroup
  * evaluates the GradScaler / schedule decision on a private copy of state_f / state_i when it starts (as the previous step left
  * them + this step's inf flag from the MLP backward), its flushes use that copy, and the last workgroup out stores it -- after the
@@ -343,13 +314,6 @@ int ngp_hash_bwd_sliced_main_adam_step(const float* dout, const ngp_hash_levels*
 int ngp_hash_bwd_sliced_main_f16(const float* dout, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev, int enc_pairs,
                                  uint16_t* dtable_f16, int32_t* found_inf, const void* workspace, long long workspace_bytes,
                                  void* stream);
-/* host-side introspection of the task plan (no GPU): tasks[k] = level | slice << 4 | replica << 10; XCD x owns
- * tasks[xoff[x] .. xoff[x] + xlen[x]); returns the number of tasks or -2 when the level table cannot be expressed */
-int ngp_hash_bwd_sliced_plan(const ngp_hash_levels* lv, uint16_t* tasks, int max_tasks, uint16_t* xoff /*[8]*/, uint16_t* xlen /*[8]*/,
-                             uint8_t* nrep /*[NGP_MAX_LEVELS]*/, uint32_t* merge_mask, uint32_t* single_mask);
-/* diagnostics: per-TASK task word + wall-clock stamps into a device buffer of 8 * 1536 uint64 (one 8-word row per task of the
- * plan, at most 1536 tasks; NULL = off, the default) */
-int ngp_hash_bwd_sliced_debug(void* device_buffer);
 int ngp_hash_bwd_f32_sliced(const float* xyzs, const float* dout, const ngp_hash_levels* lv, int n_max, const int32_t* n_dev,
                             const int32_t* live_idx, int normalize, float lo, float hi, int enc_pairs, float* dtable,
                             int32_t* found_inf, void* workspace, long long workspace_bytes, void* stream);
@@ -378,9 +342,6 @@ int ngp_mlp_bwd(const float* enc, const float* dirs, const uint16_t* wpack, cons
 
 int ngp_mlp_fwd_ex(const float* enc, const float* dirs, const uint16_t* wpack, int n_max, const int32_t* n_dev,
                    int enc_pairs, float* sigmas, uint16_t* rgbs, void* stream);
-int ngp_mlp_bwd_ex(const float* enc, const float* dirs, const uint16_t* wpack, const float* dsigmas,
-                   const uint16_t* drgbs, int n_max, const int32_t* n_dev, int enc_pairs, float* d_enc, float* dW,
-                   int32_t* found_inf, void* stream);
 /* Round 5 -- the forward over a LIST of samples: position j < *n_list shades sample list[j] (reads its enc row and direction, writes
  * its sigma / rgb; networks.py:136-166).  Bit-identical per sample to ngp_mlp_fwd_ex. */
 int ngp_mlp_fwd_list(const float* enc, const float* dirs, const uint16_t* wpack, int n_max, const int32_t* n_list,
@@ -456,8 +417,6 @@ int ngp_train_prologue_reduce(float* state_f, int32_t* state_i, float lr0, float
 int ngp_adam_amp_prologue(float* state_f, int32_t* state_i, const float* grad_scale, const float* found_inf, float lr,
                           float beta1, float beta2, void* stream);
 /* p, g, m, v: n floats each (n % 4 == 0, 16-byte aligned); g is unscaled on the fly and zero-filled. */
-int ngp_adam_step(float* p, float* g, float* m, float* v, long long n, const float* state_f,
-                  const int32_t* state_i, float beta1, float beta2, float eps, void* stream);
 /* The same pass over up to NGP_ADAM_MULTI_MAX tensors in ONE launch (host arrays of device pointers and element counts, read at
  * call time): what an optimizer over model.parameters() -- the table and the five weight matrices, train.py:143-149 -- needs per
  * step instead of one launch per tensor. */
@@ -467,18 +426,8 @@ int ngp_adam_multi(int n_tensors, float* const* p, float* const* g, float* const
 /* GradScaler's inf / nan check (train.py:199, torch.amp.GradScaler._check_inf_per_device) over the same tensor list, read-only:
  * found_inf[0] (a float32 device scalar, cleared by the caller) becomes 1.0f when any gradient value is not finite. */
 int ngp_check_finite_multi(int n_tensors, const float* const* g, const long long* n, float* found_inf, void* stream);
-/* Same pass, additionally refreshing p_bf16 (n bf16, round-to-nearest-even) -- the table ngp_hash_fwd_bf16_ex gathers from.
- * BASELINE config 2 names a bf16 hash grid; the reference itself has fp32 (hash_encoder.py) and fp16 (hash_encoder_half.py)
- * tables only, so the semantics here are "fp32 master + 16-bit storage copy", as hash_encoder_half.py:367 does for fp16. */
-int ngp_adam_step_bf16(float* p, float* g, float* m, float* v, long long n, const float* state_f,
-                       const int32_t* state_i, float beta1, float beta2, float eps, uint16_t* p_bf16, void* stream);
 /* dst[i] = bf16(src[i]), round-to-nearest-even; n % 4 == 0 (the per-forward cast of hash_encoder_half.py:367, in bf16). */
 int ngp_cast_f32_bf16(const float* src, uint16_t* dst, long long n, void* stream);
-/* The whole optimizer pass in one launch: ngp_adam_step (or ngp_adam_step_bf16 when table_bf16 != NULL) on the table and
- * ngp_adam_mlp_pack on the MLP weights, the latter in the first workgroup while the others stream the table. */
-int ngp_adam_all(float* table, float* table_g, float* table_m, float* table_v, long long n, uint16_t* table_bf16,
-                 float* mlp, float* mlp_g, float* mlp_m, float* mlp_v, const float* state_f, const int32_t* state_i,
-                 float beta1, float beta2, float eps, int enc_pairs, uint16_t* wpack, void* stream);
 /* General form: table_g is fp32 or (grad_is_f16) the half2 encoder's f16 gradient buffer, widened to fp32 on the fly;
  * copy_kind 0 = no storage copy, 1 = bf16, 2 = f16 (the table the f16 forward gathers from, hash_encoder_half.py:367). */
 int ngp_adam_all_ex(float* table, void* table_g, int grad_is_f16, float* table_m, float* table_v, long long n,

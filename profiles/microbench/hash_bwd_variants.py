@@ -18,6 +18,16 @@ for p in (ROOT, os.path.join(ROOT, "taichi-nerfs_amd")):
 import torch  # noqa: E402
 
 
+
+_KNOBS = {"bwd_knobs_dynamic": "1"}
+
+
+def _knob(**kw):
+    """(round 6) the plan / diagnostic knobs live behind NGP_EXPERIMENT; bwd_knobs_dynamic makes the library re-read them per call."""
+    _KNOBS.update({k: str(v) for k, v in kw.items()})
+    os.environ["NGP_EXPERIMENT"] = ";".join("%s=%s" % kv for kv in _KNOBS.items())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--condition", type=int, default=1024)
@@ -83,7 +93,7 @@ def main():
     med, best = timeit(atomic, args.reps)
     out["variants"]["atomic (round 1)"] = {"median_us": med, "min_us": best}
     print("atomic: median %.1f us  min %.1f us" % (med, best))
-    os.environ["NGP_BWD_REP_TARGET"] = "64"; os.environ["NGP_BWD_MERGE_RES"] = "128"
+    _knob(bwd_rep_target=64, bwd_merge_res=128)
     # per-block timeline of one full launch
     dbg = torch.zeros(8 * 1536, device=dev, dtype=torch.int64)
     L.ngp_hash_bwd_sliced_debug(_ptr(dbg))
@@ -114,15 +124,15 @@ def main():
         return
     # where the time goes: the same launch with pieces switched off (results are wrong with these flags: timing only)
     for diag, what in ((0, "full"), (1, "no LDS adds"), (2, "no gathers"), (3, "no adds, no gathers"), (4, "no accumulate"), (6, "no accumulate, no gathers")):
-        os.environ["NGP_BWD_DIAG"] = str(diag)
+        _knob(bwd_diag=diag)
         med, best = timeit(sliced, 5)
         print("sliced, %-12s: median %.1f us" % (what, med))
-    os.environ["NGP_BWD_DIAG"] = "0"
+    _knob(bwd_diag=0)
     for l in []:
-        os.environ["NGP_BWD_LEVELS"] = hex(1 << l)
+        _knob(bwd_levels=hex(1 << l))
         med, best = timeit(sliced, 5)
         print("sliced level %2d only: median %.1f us" % (l, med))
-    os.environ["NGP_BWD_LEVELS"] = "0xffffffff"
+    _knob(bwd_levels="0xffffffff")
     sweep = os.environ.get("NGP_VARIANTS_SWEEP")           # plan knobs: "rep=32,64;merge=64,128;dmin=2,4"
     knobs = {"rep": [64], "merge": [128], "dmin": [4]}
     if sweep:
@@ -132,8 +142,8 @@ def main():
     for rep_t in knobs["rep"]:
         for merge in knobs["merge"]:
             for dmin in knobs["dmin"]:
-                os.environ["NGP_BWD_REP_TARGET"] = str(rep_t); os.environ["NGP_BWD_MERGE_RES"] = str(merge)
-                os.environ["NGP_BWD_DENSE_MIN_REP"] = str(dmin)
+                _knob(bwd_rep_target=rep_t, bwd_merge_res=merge)
+                _knob(bwd_dense_min_rep=dmin)
                 grad.zero_()
                 if sliced() != 0:
                     print("sliced rep_target=%2d merge_res=%3d dense_min_rep=%d: plan not expressible" % (rep_t, merge, dmin))

@@ -931,9 +931,9 @@ __global__ void __launch_bounds__(BW_THREADS) hash_bwd_lds_kernel(const float* _
 
 // ---- host: the task plan -------------------------------------------------------------------------------------------------
 // Returns false when the level table does not fit the formulation (F != 2, or a level of more than 64 slices).
-// Plan knobs.  Release builds read the environment ONCE (NGP_BWD_REP_TARGET / NGP_BWD_MERGE_RES / NGP_BWD_DENSE_MIN_REP tune the
-// replication of the dense levels); NGP_BWD_KNOBS_DYNAMIC=1 makes them re-read on every call so that one process can A/B them on
-// the same inputs (profiles/microbench).  The diagnostic knobs that change RESULTS (NGP_BWD_LEVELS drops levels, NGP_BWD_DIAG
+// Plan knobs.  Release builds read the environment ONCE (NGP_EXPERIMENT bwd_rep_target / NGP_EXPERIMENT bwd_merge_res / NGP_EXPERIMENT bwd_dense_min_rep tune the
+// replication of the dense levels); NGP_EXPERIMENT bwd_knobs_dynamic=1 makes them re-read on every call so that one process can A/B them on
+// the same inputs (profiles/microbench).  The diagnostic knobs that change RESULTS (NGP_EXPERIMENT bwd_levels drops levels, NGP_BWD_DIAG
 // switches pieces of the kernel off) exist only in -DNGP_BWD_DIAG builds (they used to be honoured by every build).
 struct Knobs {
     int rep_target = 48, merge_res = 128, dense_min_rep = 8;
@@ -956,13 +956,13 @@ struct Knobs {
 };
 static Knobs read_knobs() {
     Knobs k;
-    if (const char* e = getenv("NGP_BWD_REP_TARGET")) k.rep_target = atoi(e) > 0 ? atoi(e) : k.rep_target;
-    if (const char* e = getenv("NGP_BWD_MERGE_RES")) k.merge_res = atoi(e);
-    if (const char* e = getenv("NGP_BWD_DENSE_MIN_REP")) k.dense_min_rep = atoi(e) > 0 ? atoi(e) : k.dense_min_rep;
+    if (const char* e = ngp_experiment("bwd_rep_target")) k.rep_target = atoi(e) > 0 ? atoi(e) : k.rep_target;
+    if (const char* e = ngp_experiment("bwd_merge_res")) k.merge_res = atoi(e);
+    if (const char* e = ngp_experiment("bwd_dense_min_rep")) k.dense_min_rep = atoi(e) > 0 ? atoi(e) : k.dense_min_rep;
 #ifdef NGP_BWD_DIAG
-    if (const char* e = getenv("NGP_BWD_LEVELS")) k.level_mask = (uint32_t)strtoul(e, nullptr, 0);
-    if (const char* e = getenv("NGP_BWD_DIAG")) k.diag = (uint32_t)atoi(e);
-    if (const char* e = getenv("NGP_BWD_BLOCKS")) k.blocks = atoi(e);
+    if (const char* e = ngp_experiment("bwd_levels")) k.level_mask = (uint32_t)strtoul(e, nullptr, 0);
+    if (const char* e = ngp_experiment("bwd_diag")) k.diag = (uint32_t)atoi(e);
+    if (const char* e = ngp_experiment("bwd_blocks")) k.blocks = atoi(e);
 #endif
     return k;
 }
@@ -970,15 +970,15 @@ static Knobs read_knobs() {
 static void apply_modes(Knobs& k, uint32_t plan_bits) {
     k.deterministic = (plan_bits & NGP_BWD_PLAN_DETERMINISTIC) != 0u;
     if (plan_bits & NGP_BWD_PLAN_CONCENTRATED) {
-        // (NGP_BWD_HASHED_REP_RES / NGP_BWD_HASHED_REP / NGP_BWD_MERGE_HASHED: A/B overrides of what the mode switches on)
-        static const int res = [] { const char* e = getenv("NGP_BWD_HASHED_REP_RES"); return e ? atoi(e) : 256; }();
-        static const int rep = [] { const char* e = getenv("NGP_BWD_HASHED_REP"); return e && atoi(e) > 0 ? atoi(e) : 3; }();
-        static const bool mh = [] { const char* e = getenv("NGP_BWD_MERGE_HASHED"); return e ? atoi(e) != 0 : false; }();
+        // (NGP_EXPERIMENT bwd_hashed_rep_res / NGP_EXPERIMENT bwd_hashed_rep / NGP_EXPERIMENT bwd_merge_hashed: A/B overrides of what the mode switches on)
+        static const int res = [] { const char* e = ngp_experiment("bwd_hashed_rep_res"); return e ? atoi(e) : 256; }();
+        static const int rep = [] { const char* e = ngp_experiment("bwd_hashed_rep"); return e && atoi(e) > 0 ? atoi(e) : 3; }();
+        static const bool mh = [] { const char* e = ngp_experiment("bwd_merge_hashed"); return e ? atoi(e) != 0 : false; }();
         k.hashed_rep_res = res; k.hashed_rep = rep; k.merge_hashed = mh;
     } else { k.hashed_rep_res = 0; k.hashed_rep = 1; k.merge_hashed = false; }
 }
 static Knobs knobs(uint32_t plan_bits) {
-    static const bool dynamic = getenv("NGP_BWD_KNOBS_DYNAMIC") != nullptr;
+    static const bool dynamic = ngp_experiment("bwd_knobs_dynamic") != nullptr;
     static const Knobs fixed = read_knobs();
     Knobs k;
 #ifndef NGP_BWD_DIAG
@@ -1199,7 +1199,7 @@ int ngp_hash_bwd_sliced_prep(const float* xyzs, const ngp_hash_levels* lv, int n
     while (lds_begin < lv->n_levels && pl.l[lds_begin].map.ns <= 8u) ++lds_begin;
     for (int l = lds_begin; l < lv->n_levels; ++l)
         if (pl.l[l].map.ns <= 8u) return -2;                              // (sizes grow with the level in every table ngp_hash_levels_init makes)
-    static const int batch = [] { const char* e = getenv("NGP_PREP_BATCH"); return e ? atoi(e) : 1; }();
+    static const int batch = [] { const char* e = ngp_experiment("prep_batch"); return e ? atoi(e) : 1; }();
 #define NGP_PREP(B) hipLaunchKernelGGL(hash_bwd_prep_kernel<B>, dim3(BW_PREP_BLOCKS), dim3(256), 0, (hipStream_t)stream, xyzs, live_idx, pl, \
                                        lv->n_levels, lv->begin_fast_hash_level, lds_begin, n_max, n_dev, nm, W.words, single_mask, xyzc, bitmap, ctr)
     if (batch == 3) NGP_PREP(3); else if (batch == 6) NGP_PREP(6); else if (batch == 12) NGP_PREP(12); else NGP_PREP(1);

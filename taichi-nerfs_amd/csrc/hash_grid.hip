@@ -179,7 +179,7 @@ __global__ void __launch_bounds__(256) hash_fwd_f32_kernel(const float* __restri
 // Round 4: the loop body is one basic block.  The position of the NEXT iteration is requested (index clamped, so the request is
 // unconditional) before this iteration's index arithmetic, the level's constants live in registers, and the corners come from
 // corners_flat: an iteration used to be four dependent memory round trips (x, y, z each behind a branch of norm01, then the
-// gathers) and ~60 scalar branches; it is now the gathers' round trip alone.  V1 = the round-1..3 loop (NGP_HASH_FWD_V1=1), kept
+// gathers) and ~60 scalar branches; it is now the gathers' round trip alone.  V1 = the round-1..3 loop (NGP_EXPERIMENT hash_fwd_v1=1), kept
 // for the A/B in profiles/r04_hash_fwd_loop_experiment.txt.
 // LIST (round 5, the chunked forward of FusedTrainer on scenes whose rays terminate long before their marched samples end): the
 // launch encodes the samples list[0 .. *n_dev) -- position j reads xyzs[list[j]] and writes row list[j] of `out` -- instead of
@@ -286,7 +286,7 @@ __global__ void __launch_bounds__(256) hash_fwd_f32_xcd_kernel(const float* __re
                 for (int ci = 0; ci < 8; ++ci) c.idx[ci] = h_raw[ci] % lr.size;
             }
 #ifdef NGP_HASH_FWD_DIAG
-            // timing experiment (profiles/microbench/encoder_ab.py NGP_HASH_FWD_FREE_LEVELS): the gathers of the levels in the mask
+            // timing experiment (profiles/microbench/encoder_ab.py NGP_EXPERIMENT hash_fwd_free_levels): the gathers of the levels in the mask
             // all read entry 0 of the level -- one line, always in the vector L1 -- i.e. what staging those levels' tables in LDS
             // could at best buy; results are wrong by construction
             if ((nm.enabled >> (8 + level)) & 1) {
@@ -586,15 +586,15 @@ __global__ void __launch_bounds__(256) check_finite_f16_kernel(const uint4* __re
 }
 
 // The round-4 loop of hash_fwd_f32_xcd_kernel addresses the table with 32-bit byte offsets: tables of 4 GB and more (and
-// NGP_HASH_FWD_V1=1, for A/B timing) take the round-1..3 loop.
+// NGP_EXPERIMENT hash_fwd_v1=1, for A/B timing) take the round-1..3 loop.
 inline bool xcd_v1(const ngp_hash_levels& lv, unsigned entry_bytes) {
-    static const bool forced = [] { const char* e = getenv("NGP_HASH_FWD_V1"); return e && e[0] == '1'; }();
+    static const bool forced = [] { const char* e = ngp_experiment("hash_fwd_v1"); return e && e[0] == '1'; }();
     return forced || (unsigned long long)(unsigned)lv.total_entries * entry_bytes >= 0xffffff00ull;
 }
 
-// tiles of 128 samples per level pair in one launch of hash_fwd_f32_xcd_kernel (8 workgroups per tile); NGP_HASH_FWD_TILES for A/B runs
+// tiles of 128 samples per level pair in one launch of hash_fwd_f32_xcd_kernel (8 workgroups per tile); NGP_EXPERIMENT hash_fwd_tiles for A/B runs
 inline int xcd_tiles_cap() {
-    static const int cap = [] { const char* e = getenv("NGP_HASH_FWD_TILES"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 512; }();
+    static const int cap = [] { const char* e = ngp_experiment("hash_fwd_tiles"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 512; }();
     return cap;
 }
 
@@ -620,7 +620,7 @@ int ngp_hash_fwd_f32_ex(const float* xyzs, const float* table, const ngp_hash_le
     hipStream_t s = (hipStream_t)stream;
     XyzNorm nm = {normalize, lo, hi};
 #ifdef NGP_HASH_FWD_DIAG
-    if (const char* e = getenv("NGP_HASH_FWD_FREE_LEVELS")) nm.enabled |= (int)(strtoul(e, nullptr, 0) & 0xffffu) << 8;
+    if (const char* e = ngp_experiment("hash_fwd_free_levels")) nm.enabled |= (int)(strtoul(e, nullptr, 0) & 0xffffu) << 8;
 #endif
     if (enc_pairs && !(lv->n_features == 2 && lv->n_levels == 16)) return -1;
     if (lv->n_features == 2 && lv->n_levels == 16 && (n_max >= 4096 || enc_pairs)) {

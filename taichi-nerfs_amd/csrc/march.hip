@@ -613,8 +613,8 @@ int ngp_march_train_count_ex(const float* rays_o, const float* rays_d, const flo
     if (n_rays <= 0) return 0;
     MarchParams p = make_march_params(cascades, grid_size, scale, exp_step_factor);
     // lanes per ray: more lanes = more resident waves for this latency-bound kernel, at the price of a longer replay when
-    // a batch contains occupied cells or real skips.  NGP_MARCH_GROUP overrides (16 / 32 / 64) for experiments.
-    const char* ge = getenv("NGP_MARCH_GROUP");
+    // a batch contains occupied cells or real skips.  NGP_EXPERIMENT march_group overrides (16 / 32 / 64) for experiments.
+    const char* ge = ngp_experiment("march_group");
     const int group = ge ? atoi(ge) : MARCH_GROUP;
     hipStream_t s = (hipStream_t)stream;
 #define NGP_LAUNCH_MARCH(CD, GG, C1)                                                                                           \

@@ -833,7 +833,7 @@ int ngp_adam_all(float* table, float* table_g, float* table_m, float* table_v, l
 // capacity (the live count is on the device), and with the former 2048 blocks a training step's ~370 k samples were 1.4 trips per
 // wave in 2.7 rounds of block residency, each block reloading the 20 KB weight image for 4-8 tiles.
 static inline int mlp_grid(int S) {
-    static const int cap = [] { const char* e = getenv("NGP_MLP_FWD_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 768; }();
+    static const int cap = [] { const char* e = ngp_experiment("mlp_fwd_blocks"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 768; }();
     const int iters = (S + 31) / 32;
     int blocks = (iters + 3) / 4;
     if (blocks > cap) blocks = cap;
@@ -876,10 +876,10 @@ static int mlp_bwd_launch(const float* enc, const float* dirs, const uint16_t* w
                           int n_max, const int32_t* n_dev, const int32_t* live_idx, int enc_pairs, float* d_enc, float* dW,
                           float* parts, int32_t* found_inf, void* stream) {
     // the LDS-image form (12-wave blocks).  -DNGP_MLP_BWD_REG builds also carry round 4's register-resident form (a recorded
-    // negative: profiles/microbench/mlp_bwd_reg_kernel.inc), selected per call with NGP_MLP_BWD=reg
+    // negative: profiles/microbench/mlp_bwd_reg_kernel.inc), selected per call with NGP_EXPERIMENT mlp_bwd=reg
     int blocks;
 #ifdef NGP_MLP_BWD_REG
-    const char* form = getenv("NGP_MLP_BWD");
+    const char* form = ngp_experiment("mlp_bwd");
     if (form && form[0] == 'r') {
         if ((long long)n_max * 128 > 0xffffffffLL) return -1;   // (d_enc is addressed through a 32-bit buffer descriptor)
         blocks = ((n_max + 31) / 32 + RW - 1) / RW;

@@ -9,6 +9,35 @@
 #include <hip/hip_fp16.h>
 #include <stdint.h>
 #include "../../include/ngp_hip.h"
+#include "../../include/ngp_hip_experimental.h"
+#include <stdlib.h>
+#include <string.h>
+
+// NGP_EXPERIMENT="key=value;key=value": the ONE environment variable behind which every launch-shape / A-B knob of the library lives
+// (round 6; until round 5 each had an NGP_* variable of its own).  Returns the value of `key` in a thread-local buffer, or NULL.
+// The keys are listed, with what they do, in ngp_hip/experiment.py (KEYS) and INTEGRATION.md section 5; none is needed -- every default
+// is the measured-fastest form.
+static inline const char* ngp_experiment(const char* key) {
+    const char* e = getenv("NGP_EXPERIMENT");
+    if (!e || !key) return nullptr;
+    static thread_local char buf[64];
+    const size_t kl = strlen(key);
+    while (*e) {
+        while (*e == ';' || *e == ' ') ++e;
+        const char* end = strchr(e, ';');
+        const size_t len = end ? (size_t)(end - e) : strlen(e);
+        if (len > kl && strncmp(e, key, kl) == 0 && e[kl] == '=') {
+            size_t vl = len - kl - 1;
+            if (vl >= sizeof(buf)) vl = sizeof(buf) - 1;
+            memcpy(buf, e + kl + 1, vl);
+            buf[vl] = 0;
+            return buf;
+        }
+        e += len;
+    }
+    return nullptr;
+}
+
 
 #define NGP_WAVE 64
 

@@ -89,7 +89,7 @@ def needs_build():
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    deps = _sources() + [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(INCLUDE, "ngp_hip.h")]
+    deps = _sources() + [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(INCLUDE, "ngp_hip.h"), os.path.join(INCLUDE, "ngp_hip_experimental.h")]
     if any(os.path.getmtime(d) > t for d in deps if os.path.exists(d)):
         return True
     # a library built with other flags (a -D... diagnostic build left in the tree) is stale too; no stamp = a prebuilt library that
@@ -124,7 +124,7 @@ _I = ctypes.c_int
 _F = ctypes.c_float
 _LV = ctypes.POINTER(HashLevels)
 
-# name -> argtypes (restype is always int); must list every symbol include/ngp_hip.h declares
+# name -> argtypes (restype is always int); must list every symbol include/ngp_hip.h and include/ngp_hip_experimental.h declare
 SIGNATURES = {
     "ngp_abi_version": [],
     "ngp_hash_levels_init": [_LV, ctypes.c_double, _I, ctypes.c_double, ctypes.c_double, _I],
@@ -231,6 +231,10 @@ SIGNATURES = {
     "ngp_packbits": [_P, _F, _I, _P, _P],
 }
 
+# declared in include/ngp_hip_experimental.h: exported and typed like the rest, called by no default path of the package
+EXPERIMENTAL = {"ngp_adam_all", "ngp_adam_step", "ngp_adam_step_bf16", "ngp_composite_train_fused", "ngp_hash_bwd_f16_ex", "ngp_hash_bwd_f32_ex",
+                "ngp_hash_bwd_sliced_debug", "ngp_hash_bwd_sliced_plan", "ngp_march_train_count", "ngp_mlp_bwd_ex",
+                "ngp_hash_bwd_sliced_main_adam", "ngp_hash_bwd_sliced_main_levels"}
 _LONGLONG_RESULT = {"ngp_hash_bwd_sliced_workspace", "ngp_hash_bwd_sliced_adam_prefix"}       # byte counts; every other entry point returns an int status
 _lib = None
 

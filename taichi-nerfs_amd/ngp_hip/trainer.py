@@ -25,6 +25,7 @@ import os
 import torch
 import torch.distributed as dist
 
+from . import experiment as _exp
 from . import lib as _lib_mod
 from .fused import RenderConfig, TrainArena
 from .lib import check
@@ -51,7 +52,7 @@ class FusedTrainer:
 
     def __init__(self, model, lr=1e-2, betas=(0.9, 0.999), eps=1e-15, max_steps=20000, eta_min=None, init_scale=2.0**19,
                  growth_factor=2.0, backoff_factor=0.5, growth_interval=2000, exp_step_factor=0.0, T_threshold=1e-4,
-                 max_samples=1024, process_group=None, world_size=None, grad_comm_dtype=torch.float32,
+                 max_samples=1024, process_group=None, world_size=None, grad_comm_dtype=None,
                  distortion_loss_w=0.0, shard_optimizer=None, chunked_forward=None):
         if not model.use_fused_mlp:
             raise ValueError("FusedTrainer needs the default architecture (L=16, F=2 hash grid, 64-wide MLPs)")
@@ -75,8 +76,8 @@ class FusedTrainer:
         # ray and all gradients are unchanged (tests/test_gpu_chunked.py); `rm_samples` stays the MARCHED count, shaded_samples()
         # reports what was shaded.  Default: on for multi-cascade / exponentially stepped scenes (where rays run far past their
         # surfaces), off for the bounded synthetic ones (C2: 45 marched vs 43 composited samples per ray -- five rounds of three
-        # launches would cost more than they save); chunked_forward=True / False or NGP_CHUNKED_FWD=1 / 0 override.
-        ck = os.environ.get("NGP_CHUNKED_FWD")
+        # launches would cost more than they save); chunked_forward=True / False or NGP_EXPERIMENT chunked_fwd=1 / 0 override.
+        ck = _exp.get("chunked_fwd")
         if chunked_forward is None and ck is not None:
             chunked_forward = ck == "1"
         if chunked_forward is None:
@@ -85,10 +86,10 @@ class FusedTrainer:
         self._chunk_rounds = self.chunk_rounds(int(max_samples)) if self.chunked else []
         self._chunk_counts = None                      # [2, rounds] int32: list lengths per round, one set per step parity
         self._chunk_T = {}
-        # backward over the samples in front of each ray's early-termination point only (NGP_LIVE_BACKWARD=0: over all of them)
-        self.live_backward = os.environ.get("NGP_LIVE_BACKWARD", "1") != "0"
-        self.march_fused = os.environ.get("NGP_MARCH_FUSED", "1") != "0"
-        self._march_rng = os.environ.get("NGP_MARCH_RNG", "kernel") != "torch"     # torch: a torch.rand vector per march (rounds 1-3)
+        # backward over the samples in front of each ray's early-termination point only (NGP_EXPERIMENT live_backward=0: over all of them)
+        self.live_backward = _exp.get("live_backward", "1") != "0"
+        self.march_fused = _exp.get("march_fused", "1") != "0"
+        self._march_rng = _exp.get("march_rng", "kernel") != "torch"     # torch: a torch.rand vector per march (rounds 1-3)
         # table gradient (fp32, or fp16 for the half2 encoder): "sliced" = LDS-owned table slices, no global float atomics
         # (csrc/hash_bwd_lds.hip; the default whenever the level table fits: F = 2, levels of <= 2^19 entries), "atomic" = round
         # 1's float-atomic / packed-f16-atomic kernels
@@ -149,6 +150,14 @@ class FusedTrainer:
             self.small_bucket = self.grad_flat[self.nt_pad:]
         self.shard_grad = (torch.zeros(self.shard_len, device=dev, dtype=self.table_grad_store.dtype) if self.shard else None)
         # optional 16-bit gradient transport: halves the bytes on xGMI; fp32 (exact mean) is the default
+        # gradient transport between ranks.  None (default, round 6): bf16 when the model ALREADY reads a bf16 storage copy of its table
+        # (NGP(table_dtype=torch.bfloat16): its forward sees 8 bits of mantissa per parameter anyway, and the updated parameters
+        # travel back as that copy) -- half the bytes in both directions of the exchange, 83 % against 68 % modelled scaling efficiency
+        # at 300 GB/s; fp32 (the exact mean) otherwise.  Pass torch.float32 / torch.bfloat16 to pin it.
+        if grad_comm_dtype is None:
+            enc_dt = getattr(model.pos_encoder, "table_dtype", torch.float32)
+            grad_comm_dtype = torch.bfloat16 if (enc_dt == torch.bfloat16 and not self.half) else torch.float32
+        self.grad_comm_dtype = grad_comm_dtype
         if grad_comm_dtype not in (torch.float32, torch.bfloat16):
             raise ValueError("grad_comm_dtype must be torch.float32 or torch.bfloat16")
         self._comm = self._comm_shard = None
@@ -160,7 +169,7 @@ class FusedTrainer:
                 self._comm = torch.empty_like(self.grad_flat, dtype=grad_comm_dtype)
         # per-block slabs of the MLP backward's weight gradients (ngp_mlp_bwd_live_parts), summed by the prologue launch
         self.mlp_parts = torch.empty(self.L.ngp_mlp_dw_parts_max() * MLP_N_WEIGHTS, **f32)
-        self._dw_atomic = os.environ.get("NGP_MLP_DW", "") == "atomic"
+        self._dw_atomic = _exp.get("mlp_dw", "") == "atomic"
         self.table_m, self.table_v = torch.zeros(self.nt_pad, **f32), torch.zeros(self.nt_pad, **f32)
         self.mlp_m, self.mlp_v = torch.zeros(MLP_N_WEIGHTS, **f32), torch.zeros(MLP_N_WEIGHTS, **f32)
         self.state_f = torch.zeros(8, **f32)
@@ -176,7 +185,7 @@ class FusedTrainer:
         self._sets = {}
         self._cur = 0
         self._side = torch.cuda.Stream(device=dev)
-        # The side stream runs at the device's LOWEST priority (NGP_SIDE_PRIORITY=default: torch's): since the march draws its jitter
+        # The side stream runs at the device's LOWEST priority (NGP_EXPERIMENT side_priority=default: torch's): since the march draws its jitter
         # itself (no torch uniform_ kernel in front of it any more) it is ready the moment the scatter-add is launched, and at equal
         # priority its blocks were dispatched in front of the scatter-add's persistent workgroups and ran beside them for the whole
         # launch (scatter-add 190 -> 210 us, march 235 us: profiles/r04_rocprofv3_timed_region_equal_priority.txt); at low priority
@@ -200,15 +209,15 @@ class FusedTrainer:
         # blocks until the end of round 5, when 4-wave blocks measured better or equal in the three heavy cases (C3 with the
         # concentrated-scene scatter-add 15.2-15.5 M rays/s against 14.6, 65 536 Lego rays 31.0-31.2 against 29.6, the initialisation
         # regime 4.07 against 4.08: profiles/r05_bench_garden_c3_concentrated.txt, r05_heavy_march_placement.txt).
-        # Any of NGP_PREFETCH_AT / NGP_MARCH_SHAPE / NGP_SIDE_PRIORITY pins the arrangement instead.
-        self._one_gpu_flush = (self.world == 1 and not self.half and os.environ.get("NGP_FLUSH_ADAM", "1") != "0"
+        # Any of NGP_EXPERIMENT prefetch_at / NGP_EXPERIMENT march_shape / NGP_EXPERIMENT side_priority pins the arrangement instead.
+        self._one_gpu_flush = (self.world == 1 and not self.half and _exp.get("flush_adam", "1") != "0"
                                and self.hash_bwd == "sliced")
-        pinned = any(k in os.environ for k in ("NGP_PREFETCH_AT", "NGP_MARCH_SHAPE", "NGP_SIDE_PRIORITY"))
+        pinned = any(_exp.has(k) for k in ("prefetch_at", "march_shape", "side_priority"))
         self._adaptive_prefetch = self._one_gpu_flush and not pinned
         self._side_prio = None
         self._side_default = self._side
         self._side_low = None
-        if self._adaptive_prefetch or os.environ.get("NGP_SIDE_PRIORITY", "low") == "low":
+        if self._adaptive_prefetch or _exp.get("side_priority", "low") == "low":
             h, lo, hi = ctypes.c_void_p(), ctypes.c_int(), ctypes.c_int()
             check(self.L.ngp_stream_create_low_priority(ctypes.byref(h), ctypes.byref(lo), ctypes.byref(hi)), "ngp_stream_create_low_priority")
             self._side_low = torch.cuda.ExternalStream(h.value, device=dev)
@@ -235,13 +244,13 @@ class FusedTrainer:
         import os as _os
         # (with world > 1 the default is 4: the march then runs underneath the gradient exchange -- RCCL's kernels occupy a few
         # workgroups and wait on xGMI -- instead of competing with the VALU-bound kernels of the step for issue slots)
-        self._prefetch_at = float(_os.environ.get("NGP_PREFETCH_AT", "3" if self.world == 1 else "4"))
+        self._prefetch_at = float(_exp.get("prefetch_at", "3" if self.world == 1 else "4"))
         # Round 5: the SHAPE of the prefetched launch (ngp_march_train_fused_shaped): "waves per block, idle LDS bytes per block",
         # e.g. "4,82944" = 4-wave blocks, at most one per CU.  With the table's optimizer inside the scatter-add there is no
         # HBM-bound launch left to hide a 16-wave-per-CU march under; a narrow march asks every CU for one wave slot per SIMD and
         # runs beside whatever the step is doing.  Unset (and "16,0"): the 16-wave block every other march launch uses -- except
         # that on one GPU with the optimizer in the flush the trainer chooses per step (see _adaptive_prefetch above).
-        shape = _os.environ.get("NGP_MARCH_SHAPE", "")
+        shape = _exp.get("march_shape", "")
         self._march_shape = tuple(int(x) for x in shape.split(",")) if shape and shape != "16,0" else None
         self.sync_occupancy = True            # world > 1: broadcast rank 0's occupancy after every update_density_grid()
         # bench.py: callable -> (record this step?, list); every collective of the step is then bracketed by two HIP events on the
@@ -262,17 +271,17 @@ class FusedTrainer:
             enc._f16, enc._f16_ver = self.copy16_store[:nt].view(enc.hash_table.shape), None
             self.table_f16 = enc.table_f16().view(-1)
         self._master_stale = False            # sharded + 16-bit copy: the fp32 master of the other ranks' shards is gathered lazily
-        # NGP_COMM_OVERLAP=1 (sharded exchange, fp32 gradient, LDS-sliced scatter-add): the scatter-add is issued as one launch per
-        # LEVEL GROUP (NGP_COMM_GROUPS = first level of each group in launch order, default "8,0": levels 8-15, then 0-7) and a
+        # NGP_EXPERIMENT comm_overlap=1 (sharded exchange, fp32 gradient, LDS-sliced scatter-add): the scatter-add is issued as one launch per
+        # LEVEL GROUP (NGP_EXPERIMENT comm_groups = first level of each group in launch order, default "8,0": levels 8-15, then 0-7) and a
         # group's reduce-scatter travels while the next group is still being accumulated; every rank owns the rank-th 1/world of
-        # EACH group.  Default off until a multi-GPU run has decided.  NGP_COMM_STUB=1 replaces every collective
+        # EACH group.  Default off until a multi-GPU run has decided.  NGP_EXPERIMENT comm_stub=1 replaces every collective
         # by its local part (bench.py: the step without communication, i.e. what of comm_ms is exposed).
         # Round 5, one GPU: the table's optimizer rides in the scatter-add's flush (ngp_hash_bwd_sliced_main_adam: the owner of a
         # non-replicated slice applies Adam to its 8192 entries instead of writing their gradient out for another launch to read
         # back); the optimizer launch shrinks to the replicated coarse levels [0, _adam_prefix) + the MLP.  The GradScaler decision
         # then has to exist before the scatter-add: the prologue moves in front of it (the MLP backward raises the inf flag on the
-        # same d_enc values the scatter-add would).  NGP_FLUSH_ADAM=0: the two-launch path (bit-identical results).
-        self._flush_adam = os.environ.get("NGP_FLUSH_ADAM", "1") != "0"
+        # same d_enc values the scatter-add would).  NGP_EXPERIMENT flush_adam=0: the two-launch path (bit-identical results).
+        self._flush_adam = _exp.get("flush_adam", "1") != "0"
         self._fold_prologue = True            # ... and the step's scalar bookkeeping inside that launch (ngp_hash_bwd_sliced_main_adam_step)
         self._adam_prefix = {}                # per scatter-add mode: floats of the table the flush does NOT update (-2: not expressible)
         # Deterministic mode (set_deterministic / NGP_DETERMINISTIC=1; bench.py conditions its model in it so that two processes
@@ -283,16 +292,16 @@ class FusedTrainer:
         self.deterministic = False
         # Multi-cascade / exponentially stepped scenes fill a small part of their box: the scatter-add's plan then treats the coarse
         # hashed levels like dense ones (NGP_BWD_PLAN_CONCENTRATED; C3: the launch 2.5 -> 1.7 ms beside the march, which then no
-        # longer fits under it as 16-wave blocks: 4-wave blocks, profiles/r05_bench_garden_c3_concentrated.txt).  NGP_BWD_CONCENTRATED=0 / 1 overrides.
-        conc = os.environ.get("NGP_BWD_CONCENTRATED")
+        # longer fits under it as 16-wave blocks: 4-wave blocks, profiles/r05_bench_garden_c3_concentrated.txt).  NGP_EXPERIMENT bwd_concentrated=0 / 1 overrides.
+        conc = _exp.get("bwd_concentrated")
         self._concentrated = (conc == "1") if conc is not None else (float(exp_step_factor) > 0 or int(model.cascades) > 1)
         self.set_deterministic(os.environ.get("NGP_DETERMINISTIC", "0") == "1")
-        self._comm_stub = os.environ.get("NGP_COMM_STUB", "0") == "1"
+        self._comm_stub = _exp.get("comm_stub", "0") == "1"
         self._pending_comm = []
         self._groups = None
-        if (self.shard and os.environ.get("NGP_COMM_OVERLAP", "0") == "1" and not self.half and self.hash_bwd == "sliced"
+        if (self.shard and _exp.get("comm_overlap", "0") == "1" and not self.half and self.hash_bwd == "sliced"
                 and lvs.n_features == 2):
-            self._groups = self._make_groups(lvs, os.environ.get("NGP_COMM_GROUPS", "8,0"))
+            self._groups = self._make_groups(lvs, _exp.get("comm_groups", "8,0"))
         self.repack()
 
     def set_deterministic(self, on):
@@ -430,7 +439,7 @@ class FusedTrainer:
             noise = torch.rand(n, device=self.dev, dtype=torch.float32)                     # ray_march.py:138
         if self.march_fused and not self.deterministic:
             # one launch: count, block-wise allocation of the output ranges (rays in block-completion order, like the reference's
-            # atomic packing), expansion.  NGP_MARCH_FUSED=0: the count / scan / write chain (rays packed in ray order)
+            # atomic packing), expansion.  NGP_EXPERIMENT march_fused=0: the count / scan / write chain (rays packed in ray order)
             check(L.ngp_march_train_fused(_ptr(rays_o), _ptr(rays_d), _ptr(None), _ptr(cfg.bitfield), _ptr(coarse), _ptr(noise),
                                           cfg.cascades, cfg.grid_size, cfg.scale, cfg.exp_step_factor, cfg.max_samples, n,
                                           _ptr(M.stage), _ptr(M.ctr), _ptr(M.rays_a), _ptr(M.total), _ptr(M.xyzs), _ptr(M.dirs),
@@ -587,8 +596,8 @@ class FusedTrainer:
                 # through to the contiguous shard layout with the group layout still recorded would make state_dict() /
                 # sync_master() gather the wrong ranges -- a trainer configured that way cannot continue
                 if self._groups is not None:
-                    raise RuntimeError("NGP_COMM_OVERLAP=1 needs the LDS-sliced scatter-add, which this level table does not fit "
-                                       "(ngp_hash_bwd_sliced_prep returned -2); unset NGP_COMM_OVERLAP")
+                    raise RuntimeError("NGP_EXPERIMENT comm_overlap=1 needs the LDS-sliced scatter-add, which this level table does not fit "
+                                       "(ngp_hash_bwd_sliced_prep returned -2); unset NGP_EXPERIMENT comm_overlap")
                 self.hash_bwd, sliced = "atomic", False
             else:
                 check(rc, "ngp_hash_bwd_sliced_prep")
@@ -597,7 +606,7 @@ class FusedTrainer:
         # exchange between ranks, compute_gradients) -- by a launch of its own right here
         if hook is not None and self._hook_at == 2.75:
             hook(); hook = None                                             # position 2.75: under the MLP backward and the scatter-add
-        if self._dw_atomic:                                   # NGP_MLP_DW=atomic: round 3's flush, for A/B runs
+        if self._dw_atomic:                                   # NGP_EXPERIMENT mlp_dw=atomic: round 3's flush, for A/B runs
             check(L.ngp_mlp_bwd_live(_ptr(A.enc), _ptr(M.dirs), _ptr(self.wpack), _ptr(A.d_sigmas), _ptr(A.d_rgbs), A.cap, _ptr(cnt),
                                      _ptr(live_idx), P, _ptr(A.d_enc), _ptr(self.mlp_grad), found, st), "ngp_mlp_bwd_live")
             n_parts = 0
@@ -610,7 +619,7 @@ class FusedTrainer:
         # the LDS-sliced scatter-add; by the prologue launch when the scatter-add is another kernel; by a launch of its own when the
         # gradient is needed earlier (an exchange between ranks, compute_gradients)
         single = self.world == 1 and not self._grads_only and n_parts > 0 and self._groups is None   # (overlapped tail: no slab hand-over)
-        reduce_in_scatter = single and sliced and not self.half and os.environ.get("NGP_MLP_DW_REDUCE", "scatter") == "scatter"
+        reduce_in_scatter = single and sliced and not self.half and _exp.get("mlp_dw_reduce", "scatter") == "scatter"
         reduce_in_prologue = single and not reduce_in_scatter
         if n_parts > 0 and not single:
             check(L.ngp_mlp_dw_reduce(_ptr(self.mlp_parts), n_parts, _ptr(self.mlp_grad), st), "ngp_mlp_dw_reduce")
@@ -859,7 +868,7 @@ class FusedTrainer:
     def _tail_overlapped(self, A, cfg, cnt, P, ws, found, st, hook, reduce_parts):
         """Scatter-add, gradient exchange and optimizer of one step with the exchange overlapped (see __init__)."""
         L, sf, si, lvp = self.L, self.state_f, self.state_i, self._lvp
-        max_blocks = int(os.environ.get("NGP_COMM_SCATTER_BLOCKS", "240"))     # leave CUs for RCCL's workgroups beside the later launches
+        max_blocks = int(_exp.get("comm_scatter_blocks", "240"))     # leave CUs for RCCL's workgroups beside the later launches
         fins = []
         for k, g in enumerate(self._groups):
             check(L.ngp_hash_bwd_sliced_main_levels(_ptr(A.d_enc), ctypes.byref(lvp), A.cap, _ptr(cnt), P, _ptr(self.table_grad),

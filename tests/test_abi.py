@@ -9,20 +9,40 @@ import pytest
 from conftest import ROOT
 
 
-def _declared():
-    hdr = open(os.path.join(ROOT, "include", "ngp_hip.h")).read()
+def _declared(name="ngp_hip.h"):
+    hdr = open(os.path.join(ROOT, "include", name)).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
     return sorted(set(re.findall(r"\b(?:int|long long)\s+(ngp_[a-z0-9_]+)\s*\(", hdr)))
 
 
 def test_header_symbols_exported(hip_lib):
+    """The boundary header and the experimental header are disjoint, together they are exactly what the ctypes table binds, and the
+    library exports every one of them."""
     from ngp_hip import lib
-    names = _declared()
-    assert len(names) >= 19
-    for n in names:
+    names, extra = _declared(), _declared("ngp_hip_experimental.h")
+    assert len(names) >= 19 and not set(names) & set(extra)
+    for n in names + extra:
         assert hasattr(hip_lib, n), "libngp_hip.so does not export %s" % n
-    assert sorted(lib.SIGNATURES) == names, "ngp_hip/lib.py binds a different symbol set than the header declares"
+    assert sorted(lib.SIGNATURES) == sorted(names + extra), "ngp_hip/lib.py binds a different symbol set than the headers declare"
+    assert sorted(lib.EXPERIMENTAL) == extra
     assert hip_lib.ngp_abi_version() == 2
+
+
+def test_no_default_path_calls_an_experimental_entry_point():
+    """Round 6: what include/ngp_hip_experimental.h declares is reached only through a non-default switch, a test or a
+    diagnostic.  The drop-in surface (modules/, compat/), the operator layer and the fused render never name one; FusedTrainer names exactly
+    the two that sit behind switches that are off by default (NGP_EXPERIMENT comm_overlap=1, `_fold_prologue = False`)."""
+    from ngp_hip import lib
+    pkg = os.path.join(ROOT, "taichi-nerfs_amd")
+    hits = {}
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py") and f != "lib.py" or f == "render.hip":
+                src = open(os.path.join(dp, f)).read()
+                for n in lib.EXPERIMENTAL:
+                    if re.search(r"\b%s\b" % n, src):
+                        hits.setdefault(os.path.relpath(os.path.join(dp, f), pkg), set()).add(n)
+    assert hits == {os.path.join("ngp_hip", "trainer.py"): {"ngp_hash_bwd_sliced_main_adam", "ngp_hash_bwd_sliced_main_levels"}}, hits
 
 
 def test_struct_layout_matches_header(tmp_path):

@@ -121,12 +121,12 @@ def test_bench_two_ranks_watchdog_keeps_the_headline(hip_lib):
 
 
 def test_bench_two_ranks_overlapped_exchange(hip_lib):
-    """NGP_COMM_OVERLAP=1: the scatter-add in one launch per level group, each group's reduce-scatter in flight under the next
+    """NGP_EXPERIMENT comm_overlap=1: the scatter-add in one launch per level group, each group's reduce-scatter in flight under the next
     group's launch (functional run over gloo on one GPU; the line names the grouping and what the step waited for)."""
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--condition", "32",
            "--kernel-events-every", "2"]
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    env.update(NGP_BENCH_BACKEND="gloo", NGP_BENCH_ONE_DEVICE="1", NGP_COMM_OVERLAP="1", NGP_COMM_GROUPS="12,8,0")
+    env.update(NGP_BENCH_BACKEND="gloo", NGP_BENCH_ONE_DEVICE="1", NGP_EXPERIMENT="comm_overlap=1;comm_groups=12,8,0")
     out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.strip().startswith("{")][0])

@@ -119,3 +119,17 @@ def test_trainer_bf16_table(hip_lib, lego_bitfield):
     tr.update_density_grid(0.01 * 1024 / 3**0.5, warmup=True)
     torch.cuda.synchronize()
     assert torch.isfinite(m.density_grid).all()
+
+
+def test_gradient_transport_defaults_to_the_table_copys_width(hip_lib):
+    """Round 6: a trainer whose model already reads a bf16 storage copy of the table exchanges its gradient as
+    bf16 by default (the parameters come back as that copy too); an fp32 table keeps the exact fp32 mean; explicit values pin it."""
+    from modules.networks import NGP
+    from ngp_hip.trainer import FusedTrainer
+    for table_dtype, want in ((torch.bfloat16, torch.bfloat16), (None, torch.float32)):
+        tr = FusedTrainer(NGP(scale=0.5, max_res=1024, table_dtype=table_dtype).cuda())
+        assert tr.grad_comm_dtype == want
+        tr.close()
+    tr = FusedTrainer(NGP(scale=0.5, max_res=1024, table_dtype=torch.bfloat16).cuda(), grad_comm_dtype=torch.float32)
+    assert tr.grad_comm_dtype == torch.float32
+    tr.close()

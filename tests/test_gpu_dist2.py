@@ -22,7 +22,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _worker(rank, world, port, kind, shard_opt, bits_np, out_dir, overlap=None):
     try:
         if overlap:                          # round 4: the exchange overlapped with the scatter-add, one launch per level group
-            os.environ["NGP_COMM_OVERLAP"], os.environ["NGP_COMM_GROUPS"] = "1", overlap
+            os.environ["NGP_EXPERIMENT"] = "comm_overlap=1;comm_groups=%s" % overlap
         for p in (ROOT, os.path.join(ROOT, "taichi-nerfs_amd")):
             if p not in sys.path:
                 sys.path.insert(0, p)

@@ -233,7 +233,7 @@ def _same(a, b):
 
 @pytest.mark.parametrize("table_dtype", [None, torch.bfloat16], ids=["f32", "bf16copy"])
 def test_trainer_flush_adam_equals_two_launch_path(hip_lib, lego_bitfield, table_dtype):
-    """FusedTrainer with the optimizer in the scatter-add's flush (the default) against the same trainer with NGP_FLUSH_ADAM=0
+    """FusedTrainer with the optimizer in the scatter-add's flush (the default) against the same trainer with NGP_EXPERIMENT flush_adam=0
     semantics, 56 steps on a scene: one forced overflow step, an all-cell and a sampled occupancy update.  Both run in deterministic
     mode, so the comparison is bit for bit on everything the step writes (table, both moments, 16-bit copy, MLP, occupancy grid,
     GradScaler / schedule state)."""

@@ -178,7 +178,7 @@ def test_pair_major_layout_equals_natural_layout(hip_lib):
 @pytest.mark.parametrize("form", ["lds"])       # ("reg": round 4's register-resident form, only in -DNGP_MLP_BWD_REG builds now)
 @pytest.mark.parametrize("n", [1, 47, 20000])
 def test_backward_forms_and_slab_reduction(hip_lib, monkeypatch, form, n):
-    """The backward kernel (the LDS-image form; a -DNGP_MLP_BWD_REG build also answers NGP_MLP_BWD=reg) and both
+    """The backward kernel (the LDS-image form; a -DNGP_MLP_BWD_REG build also answers NGP_EXPERIMENT mlp_bwd=reg) and both
     ways the weight gradients leave it -- float atomics on dW, or per-block slabs + ngp_mlp_dw_reduce (what the trainer
     uses) -- give the same d_enc bit for bit and the same dW up to the summation order; a live list in reverse order too."""
     import ctypes
@@ -191,9 +191,9 @@ def test_backward_forms_and_slab_reduction(hip_lib, monkeypatch, form, n):
     g_sig = (torch.randn(n, generator=g) * 64).cuda()
     g_rgb = (torch.randn(n, 3, generator=g) * 64).half().cuda()
     wpack = ops.mlp_pack(m._mlp_weights())
-    monkeypatch.setenv("NGP_MLP_BWD", "lds")
+    monkeypatch.setenv("NGP_EXPERIMENT", "mlp_bwd=lds")
     de_ref, dw_ref = ops.mlp_bwd(enc, dirs, wpack, g_sig, g_rgb)
-    monkeypatch.setenv("NGP_MLP_BWD", form)
+    monkeypatch.setenv("NGP_EXPERIMENT", "mlp_bwd=%s" % form)
     de, dw = ops.mlp_bwd(enc, dirs, wpack, g_sig, g_rgb)
     assert torch.equal(de, de_ref)
     scale = dw_ref.abs().max().item() + 1e-30

@@ -95,7 +95,7 @@ def test_march_train_replay_stress(oracle, lego_batch, group, monkeypatch):
     """The count kernel resolves a batch of G orbit points in parallel (chain of examined points by pointer doubling): hold it to
     the serial oracle on sparse .. nearly full grids (short and long skips, chains of every length), with max_samples reached in
     the middle of a batch, for every lanes-per-ray variant."""
-    monkeypatch.setenv("NGP_MARCH_GROUP", str(group))
+    monkeypatch.setenv("NGP_EXPERIMENT", "march_group=%d" % group)
     o, d, noise, _ = lego_batch
     n = 1024
     o, d, noise = o[:n].copy(), d[:n].copy(), noise[:n]

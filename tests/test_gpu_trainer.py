@@ -165,13 +165,12 @@ def test_sharded_optimizer_on_rccl_world1(hip_lib, lego_bitfield, kind, monkeypa
     """reduce-scatter -> Adam on the own shard -> all-gather (the N > 1 default) on the real `nccl` backend with a 1-rank group:
     the shard is the whole table, so three steps must land where the plain single-GPU trainer lands (same kernels; only the
     float-atomic flush order of the replicated coarse levels differs run to run).  "f32-overlap": the same with the exchange
-    split by level group and issued async under the scatter-add (NGP_COMM_OVERLAP=1), i.e. RCCL's async reduce-scatter /
+    split by level group and issued async under the scatter-add (NGP_EXPERIMENT comm_overlap=1), i.e. RCCL's async reduce-scatter /
     all-gather on the group staging buffers."""
     import os
     overlap = kind == "f32-overlap"
     if overlap:
-        monkeypatch.setenv("NGP_COMM_OVERLAP", "1")
-        monkeypatch.setenv("NGP_COMM_GROUPS", "12,8,0")
+        monkeypatch.setenv("NGP_EXPERIMENT", "comm_overlap=1;comm_groups=12,8,0")
     import socket
     import torch.distributed as dist
     from modules.networks import NGP
@@ -192,7 +191,7 @@ def test_sharded_optimizer_on_rccl_world1(hip_lib, lego_bitfield, kind, monkeypa
         o, d = [torch.from_numpy(a).cuda() for a in synthetic.lego_rays(2048, seed=9)]
         target = torch.rand(2048, 3, device="cuda")
         tr_a = FusedTrainer(make(), world_size=1, shard_optimizer=True, init_scale=2.0**15)
-        monkeypatch.delenv("NGP_COMM_OVERLAP", raising=False)
+        monkeypatch.delenv("NGP_EXPERIMENT", raising=False)
         tr_b = FusedTrainer(make(), world_size=1, init_scale=2.0**15)
         assert tr_a.shard and not tr_b.shard and tr_a.shard_len == tr_a.nt_pad
         assert (tr_a._groups is not None) == overlap and tr_b._groups is None
@@ -505,15 +504,12 @@ def test_train_results_mapping_protocol(hip_lib, lego_bitfield):
 
 def test_mlp_slab_sum_in_scatter_launch_equals_other_paths(hip_lib, lego_bitfield, monkeypatch):
     """Round 4: the MLP backward's per-block weight-gradient slabs are summed by the head of the scatter-add launch
-    (ngp_hash_bwd_sliced_main_slabs), by the prologue launch (NGP_MLP_DW_REDUCE=prologue), or not used at all (NGP_MLP_DW=atomic:
+    (ngp_hash_bwd_sliced_main_slabs), by the prologue launch (NGP_EXPERIMENT mlp_dw_reduce=prologue), or not used at all (mlp_dw=atomic:
     round 3's float atomics): three trainers from the same model and jitter take the same first steps."""
     from ngp_hip.trainer import FusedTrainer
     outs = []
-    for env in ({"NGP_MLP_DW_REDUCE": "scatter"}, {"NGP_MLP_DW_REDUCE": "prologue"}, {"NGP_MLP_DW": "atomic"}):
-        for k in ("NGP_MLP_DW_REDUCE", "NGP_MLP_DW"):
-            monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
+    for env in ("mlp_dw_reduce=scatter", "mlp_dw_reduce=prologue", "mlp_dw=atomic"):
+        monkeypatch.setenv("NGP_EXPERIMENT", env)
         m, o, d, target = _make(lego_bitfield, n=2048)
         tr = FusedTrainer(m, init_scale=2.0**12)
         g = torch.Generator(device="cuda").manual_seed(9)
@@ -531,11 +527,10 @@ def test_prefetched_march_placement_adapts_to_the_march_it_follows(hip_lib, lego
     of recent marches, reported asynchronously by the side stream (ngp_copy_to_host_async into ngp_host_alloc memory): a light march
     (trained-Lego occupancy: ~20 samples per ray) goes to the START of the step as 4-wave blocks, a heavy one (all cells occupied,
     ~500 samples per ray) before the scatter-add at low priority, and back when the grid thins out; with the result unchanged
-    either way.  Setting one of the three environment switches pins the arrangement."""
+    either way.  Setting one of the three NGP_EXPERIMENT keys (prefetch_at / march_shape / side_priority) pins the arrangement."""
     import ctypes
     from ngp_hip.trainer import FusedTrainer
-    for k in ("NGP_PREFETCH_AT", "NGP_MARCH_SHAPE", "NGP_SIDE_PRIORITY"):
-        monkeypatch.delenv(k, raising=False)
+    monkeypatch.delenv("NGP_EXPERIMENT", raising=False)
     n = 4096
     m, o, d, target = _make(lego_bitfield, n=n)
     tr = FusedTrainer(m, init_scale=2.0**10)
@@ -565,7 +560,7 @@ def test_prefetched_march_placement_adapts_to_the_march_it_follows(hip_lib, lego
         FusedTrainer._MARCH_NARROW_MAX = old_max
     tr.close()
     assert tr._marched_host is None and tr._side_low is None
-    monkeypatch.setenv("NGP_PREFETCH_AT", "2")
+    monkeypatch.setenv("NGP_EXPERIMENT", "prefetch_at=2")
     tr2 = FusedTrainer(_make(lego_bitfield, n=n)[0])
     assert not tr2._adaptive_prefetch and tr2._prefetch_at == 2 and tr2._marched_host is None
 
