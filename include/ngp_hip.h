@@ -389,6 +389,12 @@ typedef struct ngp_render_args {
     float* d_sigmas; uint16_t* d_rgbs; float* d_enc; int32_t* live_off; int32_t* live_idx; int32_t* live_total;
     void* workspace; long long workspace_bytes;      /* ngp_hash_bwd_sliced_workspace(levels, cap) bytes */
     int32_t force_atomic, reserved;
+    /* round 6 (both nullable: NULL = round 5's launches).  dW_parts: ngp_mlp_dw_parts_max() * 9408 floats -- the MLP backward leaves its
+     * weight gradients as per-block slabs and the head of the scatter-add launch adds them to dW (ngp_hash_bwd_sliced_main_slabs) instead of
+     * 256 x 9408 same-address float atomics.  live_zero: a second counter that is 0 at launch; the live list is then built by ngp_live_list
+     * (one atomic per 64 rays, block-completion order) into live_total -- WHICH MUST BE 0 AT LAUNCH -- and live_zero is what the launch clears
+     * for the next call (a caller alternating the two never clears one itself). */
+    float* dW_parts; int32_t* live_zero;
     float* dW /*[9408], cleared by the caller*/; void* dtable /*f32 [entries * 2]; table_kind 2: f16; cleared by the caller*/; long long dtable_bytes;
 } ngp_render_args;
 int ngp_render_train_fwd(const ngp_render_args* args, void* stream);

@@ -3,7 +3,8 @@
 // Replaces, for modules.rendering.render (train path, reference rendering.py:161-228 + networks.py:152-166), the ~9 ctypes launches and
 // ~90 pointer marshals per step of the Python autograd node: the forward entry issues [coarse occupancy table] -> one-launch march ->
 // hash-grid encode -> MFMA weight repack -> fused MLP forward -> compositing forward, the backward entry compositing backward ->
-// live-sample list -> fused MLP backward -> LDS-sliced scatter-add (float-atomic kernel where the level table does not fit it), on one
+// live-sample list -> fused MLP backward (weight gradients as per-block slabs) -> LDS-sliced scatter-add whose head sums the slabs (float-atomic
+// kernels where the level table does not fit it), on one
 // stream, through the same extern "C" entry points the operator path uses.  No new arithmetic lives here: only the launch sequence.
 // The argument block is a plain C struct (include/ngp_hip.h: ngp_render_args) the caller keeps per sample arena and patches per call.
 #include "ngp_device.h"
@@ -42,27 +43,40 @@ int ngp_render_train_bwd(const ngp_render_args* a, void* stream) {
     if ((rc = ngp_composite_train_bwd(a->g_opacity, a->g_depth, a->g_rgb, a->g_ws, a->sigmas, a->rgbs, 1, a->deltas, a->ts, a->rays_a,
                                       a->opacity, a->depth, a->rgb, a->ws, a->T_threshold, a->n_rays, a->d_sigmas, a->d_rgbs, stream)) != 0)
         return rc;
-    if ((rc = ngp_live_compact(a->rays_a, a->vr_per_ray, a->n_rays, a->live_off, a->live_idx, a->live_total, stream)) != 0) return rc;
+    // the live-sample list: ngp_live_list (one atomic per 64 rays, block-completion order) when the caller alternates two counters,
+    // round 5's ray-ordered ngp_live_compact otherwise -- the *_live kernels do not depend on the order
+    if (a->live_zero) rc = ngp_live_list(a->rays_a, a->vr_per_ray, a->n_rays, a->live_idx, a->live_total, a->live_zero, stream);
+    else rc = ngp_live_compact(a->rays_a, a->vr_per_ray, a->n_rays, a->live_off, a->live_idx, a->live_total, stream);
+    if (rc != 0) return rc;
     const int cap = (int)a->cap;
-    if ((rc = ngp_mlp_bwd_live(a->enc, a->dirs, a->wpack, a->d_sigmas, a->d_rgbs, cap, a->live_total, a->live_idx, a->enc_pairs, a->d_enc,
-                               a->dW, nullptr, stream)) != 0) return rc;
-    if (a->table_kind == 2) {
-        // half2 encoder: the scatter-add with the encoder's fp16 arithmetic into an fp16 gradient table (hash_encoder_half.py:300-306)
-        rc = a->force_atomic ? -2 : ngp_hash_bwd_sliced_prep(a->xyzs, a->levels, cap, a->live_total, a->live_idx, 1, a->lo, a->hi, a->workspace,
-                                                             a->workspace_bytes, stream);
-        if (rc == -2)
-            return ngp_hash_bwd_f16_live(a->xyzs, a->d_enc, a->levels, cap, a->live_total, a->live_idx, 1, a->lo, a->hi, a->enc_pairs,
-                                         (uint16_t*)a->dtable, nullptr, stream);
-        if (rc != 0) return rc;
-        return ngp_hash_bwd_sliced_main_f16(a->d_enc, a->levels, cap, a->live_total, a->enc_pairs, (uint16_t*)a->dtable, nullptr, a->workspace,
-                                            a->workspace_bytes, stream);
+    // weight gradients: per-block slabs (plain stores) summed by the head of the scatter-add launch, or round 3's float atomics on dW
+    int n_parts = 0;
+    if (a->dW_parts && !a->force_atomic) {
+        n_parts = ngp_mlp_bwd_live_parts(a->enc, a->dirs, a->wpack, a->d_sigmas, a->d_rgbs, cap, a->live_total, a->live_idx, a->enc_pairs,
+                                         a->d_enc, a->dW_parts, nullptr, stream);
+        if (n_parts <= 0) return n_parts < 0 ? n_parts : -1;
+    } else if ((rc = ngp_mlp_bwd_live(a->enc, a->dirs, a->wpack, a->d_sigmas, a->d_rgbs, cap, a->live_total, a->live_idx, a->enc_pairs,
+                                      a->d_enc, a->dW, nullptr, stream)) != 0) return rc;
+    const bool half = a->table_kind == 2;
+    // scatter-add in its LDS-sliced form (half2 encoder: its fp16 arithmetic into an fp16 gradient table, hash_encoder_half.py:300-306);
+    // the float-atomic kernels where the level table does not fit it (-2) or the caller forces them
+    rc = a->force_atomic ? -2 : ngp_hash_bwd_sliced_prep(a->xyzs, a->levels, cap, a->live_total, a->live_idx, 1, a->lo, a->hi, a->workspace,
+                                                         a->workspace_bytes, stream);
+    if (rc == 0) {
+        if (n_parts > 0)
+            return ngp_hash_bwd_sliced_main_slabs(a->d_enc, a->levels, cap, a->live_total, a->enc_pairs, a->dtable, half ? 1 : 0, nullptr,
+                                                  a->workspace, a->workspace_bytes, a->dW_parts, n_parts, a->dW, stream);
+        return half ? ngp_hash_bwd_sliced_main_f16(a->d_enc, a->levels, cap, a->live_total, a->enc_pairs, (uint16_t*)a->dtable, nullptr,
+                                                   a->workspace, a->workspace_bytes, stream)
+                    : ngp_hash_bwd_sliced_main(a->d_enc, a->levels, cap, a->live_total, a->enc_pairs, (float*)a->dtable, nullptr,
+                                               a->workspace, a->workspace_bytes, stream);
     }
-    rc = a->force_atomic ? -2 : ngp_hash_bwd_f32_sliced(a->xyzs, a->d_enc, a->levels, cap, a->live_total, a->live_idx, 1, a->lo, a->hi,
-                                                        a->enc_pairs, (float*)a->dtable, nullptr, a->workspace, a->workspace_bytes, stream);
-    if (rc == -2)            // level table not expressible as <= 64 LDS slices per level (or NGP_HASH_BWD=atomic)
-        rc = ngp_hash_bwd_f32_live(a->xyzs, a->d_enc, a->levels, cap, a->live_total, a->live_idx, 1, a->lo, a->hi, a->enc_pairs,
-                                   (float*)a->dtable, nullptr, stream);
-    return rc;
+    if (rc != -2) return rc;
+    if (n_parts > 0 && (rc = ngp_mlp_dw_reduce(a->dW_parts, n_parts, a->dW, stream)) != 0) return rc;
+    return half ? ngp_hash_bwd_f16_live(a->xyzs, a->d_enc, a->levels, cap, a->live_total, a->live_idx, 1, a->lo, a->hi, a->enc_pairs,
+                                        (uint16_t*)a->dtable, nullptr, stream)
+                : ngp_hash_bwd_f32_live(a->xyzs, a->d_enc, a->levels, cap, a->live_total, a->live_idx, 1, a->lo, a->hi, a->enc_pairs,
+                                        (float*)a->dtable, nullptr, stream);
 }
 
 }  // extern "C"

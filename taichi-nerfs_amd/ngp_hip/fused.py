@@ -49,6 +49,12 @@ class TrainArena:
         self._scratch = {}
         self.live_idx = torch.empty(cap, device=device, dtype=torch.int32)     # compacted backward: indices of the live samples
         self._live_off = torch.empty(n_rays, device=device, dtype=torch.int32)
+        # the fused render's backward (round 6): two live-list counters used alternately -- ngp_live_list needs its counter at 0 and
+        # clears the OTHER one for the next call, so no memset launch sits in the backward -- and the MLP backward's weight-gradient
+        # slabs (9.6 MB, allocated with the first backward)
+        self._live_pair = torch.zeros(2, device=device, dtype=torch.int32)
+        self._live_parity = 0
+        self._live_dirty = False           # a backward that raised may have left its counter non-zero: cleared before the next one
         # bumped by every FusedTrainRender.forward that overwrites the per-sample buffers; a backward whose forward is not the
         # latest one would silently differentiate the WRONG batch's activations, so it checks this stamp and raises instead
         self.generation = 0
@@ -209,15 +215,22 @@ class FusedTrainRender(torch.autograd.Function):
             g_bg = g_rgb.sum(1) * (-cfg.bg)
             g_opacity = g_bg if g_opacity is None else g_opacity + g_bg
         # ONE call (csrc/render.hip): compositing backward -> live-sample list (the first vr_per_ray[r] samples of ray r: everything
-        # behind the early-termination point has exact-zero gradients) -> MLP backward over that list -> scatter-add in its
-        # LDS-sliced form (no global float atomics) when the level table fits it -- the same kernels FusedTrainer runs.  dW and the
+        # behind the early-termination point has exact-zero gradients; one atomic per 64 rays) -> MLP backward over that list, its
+        # weight gradients as per-block slabs -> scatter-add in its LDS-sliced form (no global float atomics; its head sums the slabs)
+        # when the level table fits it -- the same kernels FusedTrainer runs.  dW and the
         # table gradient are accumulated into: cleared here.  half2 encoder: fp16 arithmetic into an fp16 gradient table (the reference's
         # hash_grad, hash_encoder_half.py:300-306,350-352), handed to autograd widened to the fp32 parameter's dtype.
         a = A.render_args(cfg)
         half = cfg.table_f16 is not None
         dW = torch.zeros(MLP_N_WEIGHTS, device=dev, dtype=torch.float32)
         dtable = torch.zeros(ctx.table_numel, device=dev, dtype=torch.float16 if half else torch.float32)
-        live_total = torch.empty(1, device=dev, dtype=torch.int32)
+        if A._live_dirty:
+            A._live_pair.zero_()
+        par, A._live_parity, A._live_dirty = A._live_parity, 1 - A._live_parity, True
+        live_total, live_zero = A._live_pair[par:par + 1], A._live_pair[1 - par:2 - par]
+        parts = A._scratch.get("mlp_parts")
+        if parts is None:
+            parts = A._scratch["mlp_parts"] = torch.empty(L.ngp_mlp_dw_parts_max() * MLP_N_WEIGHTS, device=dev, dtype=torch.float32)
         a.table_kind = 2 if half else (1 if cfg.table_bf16 is not None else 0)
         a.rays_a, a.vr_per_ray = rays_a.data_ptr(), vr_per_ray.data_ptr()
         a.opacity, a.depth, a.rgb = opacity.data_ptr(), depth.data_ptr(), rgb.data_ptr()
@@ -225,9 +238,10 @@ class FusedTrainRender(torch.autograd.Function):
         a.g_depth = None if g_depth is None else g_depth.data_ptr()
         a.g_ws = None if g_ws is None else g_ws.data_ptr()
         a.g_rgb = g_rgb.data_ptr()
-        a.live_total = live_total.data_ptr()
+        a.live_total, a.live_zero, a.dW_parts = live_total.data_ptr(), live_zero.data_ptr(), parts.data_ptr()
         a.dW, a.dtable, a.dtable_bytes = dW.data_ptr(), dtable.data_ptr(), dtable.numel() * dtable.element_size()
         check(L.ngp_render_train_bwd(ctypes.byref(a), st), "ngp_render_train_bwd")
+        A._live_dirty = False
         grads = [g.view(shape) for g, shape in zip(dW.split(MLP_SPLITS), MLP_SHAPES)]
         return (None, None, None, (dtable.float() if half else dtable).view(ctx.table_shape), *grads, None)
 

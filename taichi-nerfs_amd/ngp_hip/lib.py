@@ -69,6 +69,7 @@ def _render_fields():
             + ptrs("g_opacity", "g_depth", "g_rgb", "g_ws")
             + ptrs("d_sigmas", "d_rgbs", "d_enc", "live_off", "live_idx", "live_total")
             + [("workspace", P), ("workspace_bytes", LL), ("force_atomic", I), ("reserved", I)]
+            + ptrs("dW_parts", "live_zero")
             + [("dW", P), ("dtable", P), ("dtable_bytes", LL)])
 
 
