@@ -113,6 +113,9 @@ def parse(argv=None):
     ap.add_argument("--comm", default="auto", choices=["auto", "f32", "bf16"],
                     help="N>1: dtype the gradient bucket travels in (auto, the default: bf16 when the model reads a bf16 table copy [--table bf16], "
                          "else f32 = the exact mean; bf16 halves xGMI bytes)")
+    ap.add_argument("--comm-path", default="rccl", choices=["rccl", "p2p"],
+                    help="N>1: how the table's reduce-scatter / all-gather travel: RCCL collectives (default) or round 6's prototype of the "
+                         "DIRECT exchange -- one push into the peers' memory (hipIpc) + flags per phase (ngp_hip/p2p.py; needs --comm f32)")
     ap.add_argument("--no-shard", dest="shard", action="store_false",
                     help="N>1: round 1's exchange (ONE all-reduce of the flat gradient bucket + replicated Adam) instead of the default "
                          "reduce-scatter -> Adam on the own 1/N of the table -> all-gather")
@@ -381,6 +384,9 @@ COMM_VARIANTS = [
                              "forward reads (half the bytes both ways)", ["--comm", "bf16", "--table", "bf16"], {}),
     ("no-shard-all-reduce", "--no-shard: SURVEY 8(e)'s single all-reduce of one flat fp32 bucket + replicated Adam (north_star's wording)",
      ["--no-shard"], {}),
+    ("p2p-direct", "--comm-path p2p --comm f32: round 6's prototype of SURVEY 8(e)'s direct exchange -- every rank writes slice p of its gradient "
+                   "straight into rank p's inbox (peer memory through hipIpc, all links at once, one hop), flags, a local reduce; the updated shards "
+                   "travel back the same way.  UNMEASURED on xGMI until this line exists on a multi-GPU node", ["--comm-path", "p2p", "--comm", "f32"], {}),
     ("overlap-8,0", "NGP_EXPERIMENT comm_overlap=1: the scatter-add issued per level group (8-15, then 0-7), a group's reduce-scatter in flight under "
                     "the next group's launch, all-gathers waited for at the next step's forward", [], {"NGP_EXPERIMENT": "comm_overlap=1;comm_groups=8,0"}),
 ]
@@ -559,7 +565,7 @@ def _measure(args, ctx, brief):
         trainer = FusedTrainer(model, lr=1e-2, max_steps=20000, init_scale=2.0**16 if args.half else 2.0**19, world_size=world,
                                exp_step_factor=esf, distortion_loss_w=w_dist,
                                grad_comm_dtype={"bf16": torch.bfloat16, "f32": torch.float32, "auto": None}[args.comm],
-                               shard_optimizer=args.shard if world > 1 else None)
+                               shard_optimizer=args.shard if world > 1 else None, exchange=args.comm_path)
     else:
         # train.py:143-156 picks apex.optimizers.FusedAdam when `import apex` works and torch.optim.Adam otherwise.  With this package's
         # compat/ directory on the path (how scripts/run_reference_train.py runs the unchanged driver) the import resolves to

@@ -89,6 +89,19 @@ int ngp_hash_bwd_sliced_main_levels(const float* dout, const ngp_hash_levels* lv
                                     float* dtable, int32_t* found_inf, const void* workspace, long long workspace_bytes,
                                     unsigned int level_mask, int max_blocks, void* stream);
 
+/* ---- direct gradient exchange over peer memory (csrc/exchange.hip; round 6 prototype, SURVEY section 8e: "use the direct (all-links) reduce-scatter
+ * + all-gather form rather than ring").  peer_dst / peer_flags are HOST arrays of `world` device pointers into the peers' allocations (this rank's own
+ * entry included), mapped with hipIpc by the caller (ngp_hip/p2p.py).  Functional on one device only so far -- see the file header.
+ * ngp_p2p_push: slice k of src (n_per_peer elements of elem_bytes = 4 or 2; broadcast != 0: the same n_per_peer elements for everybody) goes to
+ *   peer_dst[k] + dst_offset, then peer_flags[k][rank] = step with system-scope release.  done: one uint32 of local memory, 0 between launches.
+ * ngp_p2p_wait: bounded wait (max_spins polls per block; on expiry err[0] = 1 and nothing is written) for flags[0 .. world) >= step; reduce != 0:
+ *   out[0 .. n) = scale * (sum of the `world` rows of inbox [world, n] f32). */
+int ngp_p2p_max_peers(void);
+int ngp_p2p_push(const void* src, long long n_per_peer, int elem_bytes, int world, void* const* peer_dst, int32_t* const* peer_flags,
+                 long long dst_offset, int broadcast, int rank, int step, uint32_t* done, void* stream);
+int ngp_p2p_wait(const int32_t* flags, int world, int step, long long max_spins, const float* inbox, long long n, float scale, int reduce,
+                 float* out, int32_t* err, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

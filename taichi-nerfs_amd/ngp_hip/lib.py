@@ -16,7 +16,7 @@ CSRC = os.path.join(PKG_ROOT, "csrc")
 INCLUDE = os.path.join(os.path.dirname(PKG_ROOT), "include")
 LIB_PATH = os.path.join(CSRC, "libngp_hip.so")
 SOURCES = ["march.hip", "hash_grid.hip", "hash_bwd_lds.hip", "composite.hip", "sh_grid.hip", "mlp.hip", "optim.hip", "distortion.hip", "occupancy.hip", "rays.hip",
-           "render.hip"]
+           "render.hip", "exchange.hip"]
 HEADERS = ["ngp_device.h", "hash_common.h"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
 FLAGS_STAMP = LIB_PATH + ".flags"      # the flags the in-tree .so was built with: a flag change rebuilds
@@ -227,6 +227,9 @@ SIGNATURES = {
     "ngp_occ_stats_floats": [],
     "ngp_occ_merge": [_P, _P, _F, _I, _P, _P],
     "ngp_occ_pack": [_P, _P, _F, _I, _P, _P],
+    "ngp_p2p_max_peers": [],
+    "ngp_p2p_push": [_P, ctypes.c_longlong, _I, _I, _P, _P, ctypes.c_longlong, _I, _I, _I, _P, _P],
+    "ngp_p2p_wait": [_P, _I, _I, ctypes.c_longlong, _P, ctypes.c_longlong, _F, _I, _P, _P, _P],
     "ngp_morton3d": [_P, _I, _P, _P],
     "ngp_morton3d_invert": [_P, _I, _P, _P],
     "ngp_packbits": [_P, _F, _I, _P, _P],
@@ -235,7 +238,7 @@ SIGNATURES = {
 # declared in include/ngp_hip_experimental.h: exported and typed like the rest, called by no default path of the package
 EXPERIMENTAL = {"ngp_adam_all", "ngp_adam_step", "ngp_adam_step_bf16", "ngp_composite_train_fused", "ngp_hash_bwd_f16_ex", "ngp_hash_bwd_f32_ex",
                 "ngp_hash_bwd_sliced_debug", "ngp_hash_bwd_sliced_plan", "ngp_march_train_count", "ngp_mlp_bwd_ex",
-                "ngp_hash_bwd_sliced_main_adam", "ngp_hash_bwd_sliced_main_levels"}
+                "ngp_hash_bwd_sliced_main_adam", "ngp_hash_bwd_sliced_main_levels", "ngp_p2p_max_peers", "ngp_p2p_push", "ngp_p2p_wait"}
 _LONGLONG_RESULT = {"ngp_hash_bwd_sliced_workspace", "ngp_hash_bwd_sliced_adam_prefix"}       # byte counts; every other entry point returns an int status
 _lib = None
 

@@ -53,7 +53,7 @@ class FusedTrainer:
     def __init__(self, model, lr=1e-2, betas=(0.9, 0.999), eps=1e-15, max_steps=20000, eta_min=None, init_scale=2.0**19,
                  growth_factor=2.0, backoff_factor=0.5, growth_interval=2000, exp_step_factor=0.0, T_threshold=1e-4,
                  max_samples=1024, process_group=None, world_size=None, grad_comm_dtype=None,
-                 distortion_loss_w=0.0, shard_optimizer=None, chunked_forward=None):
+                 distortion_loss_w=0.0, shard_optimizer=None, chunked_forward=None, exchange="rccl"):
         if not model.use_fused_mlp:
             raise ValueError("FusedTrainer needs the default architecture (L=16, F=2 hash grid, 64-wide MLPs)")
         self.half = bool(model.half_opt)              # half2 encoder (hash_encoder_half.py): f16 table copy, f16 gradient buffer
@@ -297,6 +297,20 @@ class FusedTrainer:
         self._concentrated = (conc == "1") if conc is not None else (float(exp_step_factor) > 0 or int(model.cascades) > 1)
         self.set_deterministic(os.environ.get("NGP_DETERMINISTIC", "0") == "1")
         self._comm_stub = _exp.get("comm_stub", "0") == "1"
+        # exchange="p2p" (round 6 prototype, ngp_hip/p2p.py): the table's reduce-scatter and all-gather as direct writes into the peers'
+        # memory (hipIpc mappings) + flags instead of RCCL collectives -- one hop per phase on every xGMI link at once.  Needs the
+        # sharded optimizer and the fp32 gradient; the 37.6 KB [MLP gradient | inf flag] all-reduce stays a collective.
+        self._p2p = None
+        if exchange not in ("rccl", "p2p"):
+            raise ValueError("exchange must be 'rccl' or 'p2p'")
+        if exchange == "p2p" and self.world > 1:
+            if not self.shard or self.half or self._comm is not None:
+                raise ValueError("exchange='p2p' needs the sharded optimizer, the fp32 encoder and fp32 gradient transport")
+            from .p2p import PeerExchange
+            stores = {"table": self.table_store}
+            if self.copy16_store is not None:
+                stores["copy16"] = self.copy16_store
+            self._p2p = PeerExchange(self.rank, self.world, dev, self.shard_len, stores, group=self.group)
         self._pending_comm = []
         self._groups = None
         if (self.shard and _exp.get("comm_overlap", "0") == "1" and not self.half and self.hash_bwd == "sliced"
@@ -974,12 +988,18 @@ class FusedTrainer:
         from .dist import reduce_scatter_avg
         if self._comm_stub:
             return out.copy_(inp[self.rank * out.numel():(self.rank + 1) * out.numel()])
+        if self._p2p is not None and inp.dtype == torch.float32:
+            return self._timed("p2p_reduce_scatter_table_grad", lambda: self._p2p.reduce_scatter_avg(out, inp))
         self._timed("reduce_scatter_table_grad", lambda: reduce_scatter_avg(out, inp, self.rank, self.world, self.group))
 
     def _all_gather(self, store, sl):
         from .dist import all_gather_shards
         if self._comm_stub:
             return store
+        if self._p2p is not None:
+            name = "table" if store is self.table_store else ("copy16" if store is self.copy16_store else None)
+            if name is not None:
+                return self._timed("p2p_all_gather_table", lambda: self._p2p.all_gather(name, sl))
         self._timed("all_gather_table", lambda: all_gather_shards(store, self.rank, self.shard_len, self.world, self.group))
 
     def sync_master(self):

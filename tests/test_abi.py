@@ -31,7 +31,8 @@ def test_header_symbols_exported(hip_lib):
 def test_no_default_path_calls_an_experimental_entry_point():
     """Round 6: what include/ngp_hip_experimental.h declares is reached only through a non-default switch, a test or a
     diagnostic.  The drop-in surface (modules/, compat/), the operator layer and the fused render never name one; FusedTrainer names exactly
-    the two that sit behind switches that are off by default (NGP_EXPERIMENT comm_overlap=1, `_fold_prologue = False`)."""
+    the two that sit behind switches that are off by default (NGP_EXPERIMENT comm_overlap=1, `_fold_prologue = False`);
+    ngp_hip/p2p.py (reached only through FusedTrainer(exchange="p2p")) names the three of the direct exchange."""
     from ngp_hip import lib
     pkg = os.path.join(ROOT, "taichi-nerfs_amd")
     hits = {}
@@ -42,7 +43,9 @@ def test_no_default_path_calls_an_experimental_entry_point():
                 for n in lib.EXPERIMENTAL:
                     if re.search(r"\b%s\b" % n, src):
                         hits.setdefault(os.path.relpath(os.path.join(dp, f), pkg), set()).add(n)
-    assert hits == {os.path.join("ngp_hip", "trainer.py"): {"ngp_hash_bwd_sliced_main_adam", "ngp_hash_bwd_sliced_main_levels"}}, hits
+    assert hits == {os.path.join("ngp_hip", "trainer.py"): {"ngp_hash_bwd_sliced_main_adam", "ngp_hash_bwd_sliced_main_levels"},
+                    # the direct peer-memory exchange (FusedTrainer(exchange="p2p"), a prototype: default "rccl")
+                    os.path.join("ngp_hip", "p2p.py"): {"ngp_p2p_max_peers", "ngp_p2p_push", "ngp_p2p_wait"}}, hits
 
 
 def test_struct_layout_matches_header(tmp_path):

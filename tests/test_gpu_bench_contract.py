@@ -91,14 +91,16 @@ def test_bench_self_launches_two_ranks(hip_lib):
     # its communication time, the measured exposed part, the bus bandwidth they imply and DESIGN 7's model beside it
     cfgs = d["configs"]
     # (the overlapped exchange runs last: it is the one variant a real node could hang in, and the watchdog keeps what came before)
-    assert [c["name"] for c in cfgs] == ["inline-f32 (headline)", "bf16-comm+bf16-table", "no-shard-all-reduce", "overlap-8,0"]
+    assert [c["name"] for c in cfgs] == ["inline-f32 (headline)", "bf16-comm+bf16-table", "no-shard-all-reduce", "p2p-direct", "overlap-8,0"]
     assert "configs_incomplete" not in d
     for c in cfgs:
         assert "error" not in c, c
         assert c["comm_ms"] > 0 and c["ms_per_step_comm_stubbed"] > 0 and c["exposed_comm_ms"] is not None and c["bus_bandwidth_GBs"] > 0
         assert set(c["design7_model_at_bus_bandwidth"]) == {"150_GBs", "300_GBs", "450_GBs"}
     assert cfgs[0]["ms_per_step"] == d["ms_per_step"]
-    assert any(k.startswith("wait_reduce_scatter_group") for k in cfgs[3]["comm_breakdown_ms"])
+    assert any(k.startswith("wait_reduce_scatter_group") for k in cfgs[4]["comm_breakdown_ms"])
+    # round 6: the direct peer-memory exchange (two processes on this one GPU: real hipIpc mappings, no xGMI)
+    assert {"p2p_reduce_scatter_table_grad", "p2p_all_gather_table", "all_reduce_mlp_grad_and_flag"} <= set(cfgs[3]["comm_breakdown_ms"])
     b_f32 = sum(cfgs[0]["comm_bytes_per_rank_per_step"].values()); b_16 = sum(cfgs[1]["comm_bytes_per_rank_per_step"].values())
     assert 0.45 < b_16 / b_f32 < 0.55
     assert set(cfgs[2]["comm_breakdown_ms"]) == {"all_reduce_flat_bucket"} or "all_reduce" in " ".join(cfgs[2]["comm_breakdown_ms"])
@@ -117,7 +119,7 @@ def test_bench_two_ranks_watchdog_keeps_the_headline(hip_lib):
     assert len(lines) == 1, out.stdout[-2000:] + out.stderr[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["comm_ms"] > 0 and "did not finish" in d["configs_incomplete"]
-    assert d["configs"][0]["name"] == "inline-f32 (headline)" and len(d["configs"]) < 4
+    assert d["configs"][0]["name"] == "inline-f32 (headline)" and len(d["configs"]) < 5
 
 
 def test_bench_two_ranks_overlapped_exchange(hip_lib):
