@@ -930,7 +930,7 @@ def _measure(args, ctx, brief):
         # which records the workload state it was taken in); it is attached only if that state matches this run within 15 %
         # (two runs of the same command end their conditioning 5-12 % apart in live samples per step: float-atomic order in the
         # MLP weight gradients), otherwise traffic stays null -- a counter value from another state says nothing about this one
-        pmc_path = next((q for q in (os.path.join(ROOT, "profiles", f) for f in ("r05_pmc.json", "r04_pmc.json", "r03_pmc.json", "r02_pmc.json")) if os.path.exists(q)),
+        pmc_path = next((q for q in (os.path.join(ROOT, "profiles", f) for f in ("r06_pmc.json", "r05_pmc.json", "r04_pmc.json", "r03_pmc.json", "r02_pmc.json")) if os.path.exists(q)),
                         os.path.join(ROOT, "profiles", "r05_pmc.json"))
         pmc_name = "profiles/" + os.path.basename(pmc_path)
         traffic_src = None
