@@ -11,6 +11,7 @@ What one `step()` restates, statement by statement:
                                                                     rgb_net 32 -> 64 ReLU -> 64 ReLU -> 3 Sigmoid
     TruncExp                       modules/networks.py:18-30       exp forward, backward exponent clamped to [-15, 15]
     F.mse_loss(results['rgb'], data['rgb'])                         train.py:191
+    + distortion_loss_w * distortion_loss(results).mean()           train.py:194-195, modules/distortion.py:8-119 (optional)
     Adam(eps=1e-15) + CosineAnnealingLR(max_steps, lr / 30)         train.py:143-160, :197-201  (torch's own CPU implementations)
     model.update_density_grid(thr, warmup=True)                     modules/networks.py:255-290 (all cells, :168-179; decay / max merge
                                                                     :281-284; threshold = min(mean positive density, thr) :286-290)
@@ -45,13 +46,14 @@ class OracleTrainer:
     rgb_net hidden 0, hidden 1, output); `table`: flat fp32 hash table; kind: 'f32' (hash_encoder.py) or 'half' (hash_encoder_half.py)."""
 
     def __init__(self, weights, table, scale=0.5, max_res=1024, exp_step_factor=0.0, lr=1e-2, max_steps=20000, kind="f32",
-                 loss_scale=1.0, grid_size=128, max_samples=1024, T_threshold=1e-4):
+                 loss_scale=1.0, grid_size=128, max_samples=1024, T_threshold=1e-4, distortion_loss_w=0.0):
         assert kind in ("f32", "half")
         self.kind, self.scale, self.esf = kind, float(scale), float(exp_step_factor)
         self.cascades = max(1 + int(np.ceil(np.log2(2 * scale))), 1)                         # networks.py:63
         self.G, self.max_samples, self.T_threshold = int(grid_size), int(max_samples), float(T_threshold)
         self.bg = 1.0 if exp_step_factor == 0 else 0.0                                        # rendering.py:219-226
         self.loss_scale = float(loss_scale)
+        self.distortion_loss_w = float(distortion_loss_w)                                     # train.py:194-195 (0 = off, the default)
         self.lv = ora.make_levels(2**19, 16, 16, max_res, 2)
         self.table = torch.from_numpy(np.ascontiguousarray(table, dtype=np.float32).reshape(-1).copy()).requires_grad_(True)
         self.w = [torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32).copy()).requires_grad_(True) for a in weights]
@@ -125,10 +127,16 @@ class OracleTrainer:
         vr, op, dep, rgb, ws = ora.composite_train_fwd(sg, cl, deltas, ts, rays_a, self.T_threshold)
         rgb_f = rgb + np.float32(self.bg) * (1.0 - op)[:, None]                               # rendering.py:219-226
         diff = (rgb_f - target).astype(np.float32)
-        loss = float((diff.astype(np.float64)**2).mean())                                     # train.py:191
+        loss = mse = float((diff.astype(np.float64)**2).mean())                               # train.py:191
         g_rgb = (2.0 / (3 * n) * diff).astype(np.float32)
         g_op = (-self.bg * g_rgb.sum(1)).astype(np.float32)
-        ds, dc = ora.composite_train_bwd(g_op, None, g_rgb, None, sg, cl, deltas, ts, rays_a, self.T_threshold)
+        g_ws = None
+        if self.distortion_loss_w > 0:                                                        # loss += w * distortion_loss(results).mean()
+            dl, ws_inc, wts_inc = ora.distortion_fwd(ws, deltas, ts, rays_a)                  # distortion.py:15-66
+            loss += self.distortion_loss_w * float(dl.astype(np.float64).mean())
+            g_dl = np.full(n, self.distortion_loss_w / n, np.float32)
+            g_ws = ora.distortion_bwd(g_dl, deltas, ws, ts, ws_inc, wts_inc, rays_a)          # distortion.py:69-119
+        ds, dc = ora.composite_train_bwd(g_op, None, g_rgb, g_ws, sg, cl, deltas, ts, rays_a, self.T_threshold)
         for p in [self.table] + self.w:
             p.grad = None
         if S > 0:
@@ -145,7 +153,7 @@ class OracleTrainer:
             for p in self.w:
                 p.grad = torch.zeros_like(p)
         order = np.argsort(rays_a[:, 0], kind="stable")
-        return {"loss": loss, "psnr": -10.0 * math.log10(max(loss, 1e-30)), "rm_samples": int(S), "counts": rays_a[order, 2].copy(),
+        return {"loss": loss, "mse": mse, "psnr": -10.0 * math.log10(max(mse, 1e-30)), "rm_samples": int(S), "counts": rays_a[order, 2].copy(),
                 "vr": vr.copy(), "rgb": rgb_f, "opacity": op}
 
     def step(self, o, d, target, noise, bits=None):

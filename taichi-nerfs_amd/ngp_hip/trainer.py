@@ -70,6 +70,16 @@ class FusedTrainer:
         self.exp_step_factor, self.T_threshold, self.max_samples = float(exp_step_factor), float(T_threshold), int(max_samples)
         self.bg = 1.0 if exp_step_factor == 0 else 0.0                    # rendering.py:219-226
         self.distortion_loss_w = float(distortion_loss_w)                # train.py:194-195 (0 = off, the reference default)
+        self._init_options(model, exp_step_factor, max_samples, chunked_forward, process_group, world_size)
+        self._init_buffers(model, dev, init_scale, grad_comm_dtype, shard_optimizer, process_group)
+        self._init_prefetch(dev)
+        self._init_table_copies(model, dev, exp_step_factor)
+        self._init_exchange(model, dev, exchange)
+        self.repack()
+
+    # ---- construction, piece by piece (round 6: __init__ was one 260-line body) ------------------------------------------------
+    def _init_options(self, model, exp_step_factor, max_samples, chunked_forward, process_group, world_size):
+        """Launch-sequence options: chunked forward, live backward, which march, which scatter-add; the process group."""
         # Round 5 -- chunked forward: shade a ray's samples in growing chunks (64, 64, 128, 256, ...) and stop at the chunk in which
         # its transmittance falls to the compositing threshold, instead of shading everything the march emitted (the reference shades
         # all of it and ignores what lies behind T <= 1e-4, volume_train.py:38; on the C3 shape that is 3 of 4 samples).  Results per
@@ -96,6 +106,9 @@ class FusedTrainer:
         self.hash_bwd = os.environ.get("NGP_HASH_BWD", "sliced")
         self.group = process_group
         self.world = world_size if world_size is not None else (dist.get_world_size(process_group) if dist.is_initialized() else 1)
+
+    def _init_buffers(self, model, dev, init_scale, grad_comm_dtype, shard_optimizer, process_group):
+        """Parameters as views of flat / padded storage, gradient buckets, Adam moments, the device-side step state."""
 
         # the five MLP weights become views of one flat buffer so their gradient is the kernel's flat dW
         ws = list(model._mlp_weights())
@@ -184,6 +197,9 @@ class FusedTrainer:
         self.stats = {}
         self._sets = {}
         self._cur = 0
+
+    def _init_prefetch(self, dev):
+        """The side stream(s) the next batch's march runs on, and where in the step it is issued."""
         self._side = torch.cuda.Stream(device=dev)
         # The side stream runs at the device's LOWEST priority (NGP_EXPERIMENT side_priority=default: torch's): since the march draws its jitter
         # itself (no torch uniform_ kernel in front of it any more) it is ready the moment the scatter-add is launched, and at equal
@@ -256,6 +272,10 @@ class FusedTrainer:
         # bench.py: callable -> (record this step?, list); every collective of the step is then bracketed by two HIP events on the
         # step's stream and (name, e0, e1) is appended to the list
         self.comm_probe = None
+
+    def _init_table_copies(self, model, dev, exp_step_factor):
+        """The fp16 MFMA weight image, the 16-bit storage copy of the table (bf16 copy / half2 encoder), the scatter-add's plan modes."""
+        nt = self.nt
         lvs = model.pos_encoder.levels_struct
         self.enc_pairs = 1 if (lvs.n_levels == 16 and lvs.n_features == 2) else 0
         self.wpack = torch.empty(self.L.ngp_mlp_wpack_halfs(), device=dev, dtype=torch.float16)
@@ -296,6 +316,10 @@ class FusedTrainer:
         conc = _exp.get("bwd_concentrated")
         self._concentrated = (conc == "1") if conc is not None else (float(exp_step_factor) > 0 or int(model.cascades) > 1)
         self.set_deterministic(os.environ.get("NGP_DETERMINISTIC", "0") == "1")
+
+    def _init_exchange(self, model, dev, exchange):
+        """world > 1: how the table's gradient and parameters travel (collectives, per-level-group overlap, direct peer memory)."""
+        lvs = model.pos_encoder.levels_struct
         self._comm_stub = _exp.get("comm_stub", "0") == "1"
         # exchange="p2p" (round 6 prototype, ngp_hip/p2p.py): the table's reduce-scatter and all-gather as direct writes into the peers'
         # memory (hipIpc mappings) + flags instead of RCCL collectives -- one hop per phase on every xGMI link at once.  Needs the
@@ -316,7 +340,6 @@ class FusedTrainer:
         if (self.shard and _exp.get("comm_overlap", "0") == "1" and not self.half and self.hash_bwd == "sliced"
                 and lvs.n_features == 2):
             self._groups = self._make_groups(lvs, _exp.get("comm_groups", "8,0"))
-        self.repack()
 
     def set_deterministic(self, on):
         if getattr(self, "_graph", None) is not None and bool(on) != self.deterministic:

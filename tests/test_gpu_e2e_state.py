@@ -300,3 +300,8 @@ def test_end_to_end_gradients_vs_fp32_cpu_chain(oracle, conditioned):
     assert bad.mean() < 4e-3 and worst <= 1e-4 * np.abs(r_table).max()      # (fp16 underflow of tiny output gradients: ~1e-5 of the largest)
     for nm, e1, e3 in zip(names, hip, auto):
         assert e1 <= max(1.5 * e3, 2e-3), (nm, e1, e3)      # no worse than torch's own fp16 autocast (plus a small floor)
+        # ... and an ABSOLUTE bound beside the relative yard-stick: against the fp32 chain the fp16-autocast arithmetic
+        # the reference itself runs loses 5e-4 .. 5e-3 on these gradients (both columns above, run after run: the fp16 forward, not the
+        # backward, sets it); north_star's 1e-3 is stated for rendered radiance and PSNR (held in the tests above and in
+        # test_gpu_trajectory.py), not for gradients
+        assert e1 <= 8e-3, (nm, e1)

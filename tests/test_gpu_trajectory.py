@@ -27,40 +27,55 @@ pytestmark = pytest.mark.gpu
 N_RAYS, STEPS, UPDATE_EVERY = 1024, 48, 16
 THR = 0.01 * 1024 / 3**0.5                       # train.py:180
 NOISE_SEED = 5000
+# kind -> workload.  "c3" = BASELINE config 3's shape (scale 16 -> 6 cascades, max_res 4096, exp_step_factor 1/256, black background,
+# distortion loss 1e-3: train.py:54,105,194-195 with scripts/train_360_v2_garden.sh's weight), through the trainer's chunked forward
+CFG = {"f32": dict(scale=0.5, max_res=1024, esf=0.0, n_rays=1024, steps=48, w_dist=0.0),
+       "half": dict(scale=0.5, max_res=1024, esf=0.0, n_rays=1024, steps=48, w_dist=0.0),
+       "c3": dict(scale=16.0, max_res=4096, esf=1.0 / 256, n_rays=512, steps=24, w_dist=1e-3)}
 INIT_SCALE = 2.0**15                             # a loss scale no step of these runs overflows at (asserted: skipped == 0); torch's fp16
                                                  # autocast backward (the yard-stick) underflows visibly below ~2^14 (train.py:137-141 uses 2^19)
 
 
-def _inputs():
+def _inputs(kind):
     from ngp_hip import synthetic
+    c = CFG[kind]
+    n, steps = c["n_rays"], c["steps"]
+    cascades = max(1 + int(np.ceil(np.log2(2 * c["scale"]))), 1)
     pool = []
     for b in range(4):
-        o, d = synthetic.lego_rays(N_RAYS, seed=700 + b)
-        tgt = synthetic.procedural_render_gt(torch.from_numpy(o).cuda(), torch.from_numpy(d).cuda()).cpu().numpy()
+        if kind == "c3":
+            o, d = synthetic.garden_rays(n, seed=700 + b)
+            tgt = synthetic.garden_render_gt(torch.from_numpy(o).cuda(), torch.from_numpy(d).cuda(), scale=c["scale"]).cpu().numpy()
+        else:
+            o, d = synthetic.lego_rays(n, seed=700 + b)
+            tgt = synthetic.procedural_render_gt(torch.from_numpy(o).cuda(), torch.from_numpy(d).cuda()).cpu().numpy()
         pool.append((o, d, np.ascontiguousarray(tgt, np.float32)))
     rng = np.random.default_rng(17)
     noise = []
-    for s in range(STEPS):      # the march jitter render() draws first after torch.manual_seed(NOISE_SEED + s) (ray_march.py:138)
+    for s in range(steps):      # the march jitter render() draws first after torch.manual_seed(NOISE_SEED + s) (ray_march.py:138)
         torch.manual_seed(NOISE_SEED + s)
-        noise.append(torch.rand(N_RAYS, device="cuda").cpu().numpy())
-    jit = {s: rng.random((128**3, 3), dtype=np.float32) for s in range(0, STEPS, UPDATE_EVERY)}
+        noise.append(torch.rand(n, device="cuda").cpu().numpy())
+    jit = {s: [rng.random((128**3, 3), dtype=np.float32) for _ in range(cascades)] for s in range(0, steps, UPDATE_EVERY)}
     return pool, noise, jit
 
 
 def _model(kind, seed=11):
     from modules.networks import NGP
     torch.manual_seed(seed)
-    m = NGP(scale=0.5, max_res=1024, half_opt=kind == "half").cuda()
+    c = CFG[kind]
+    m = NGP(scale=c["scale"], max_res=c["max_res"], half_opt=kind == "half").cuda()
     return m
 
 
 def _run_cpu(kind, state, pool, noise, jit):
     from oracle.train_loop import OracleTrainer
-    otr = OracleTrainer(state["weights"], state["table"], lr=1e-2, max_steps=STEPS, kind=kind, loss_scale=INIT_SCALE)
+    c = CFG[kind]
+    otr = OracleTrainer(state["weights"], state["table"], scale=c["scale"], max_res=c["max_res"], exp_step_factor=c["esf"], lr=1e-2,
+                        max_steps=c["steps"], kind="half" if kind == "half" else "f32", loss_scale=INIT_SCALE, distortion_loss_w=c["w_dist"])
     recs, bits = [], {}
-    for s in range(STEPS):
+    for s in range(c["steps"]):
         if s % UPDATE_EVERY == 0:
-            otr.update_density_grid(THR, [jit[s]])
+            otr.update_density_grid(THR, jit[s])
             bits[s] = otr.bits.copy()
         o, d, tgt = pool[s % len(pool)]
         recs.append(otr.step(o, d, tgt, noise[s]))
@@ -69,13 +84,17 @@ def _run_cpu(kind, state, pool, noise, jit):
 
 def _run_hip(kind, m, pool, noise, jit, oracle):
     from ngp_hip.trainer import FusedTrainer
-    tr = FusedTrainer(m, lr=1e-2, max_steps=STEPS, init_scale=INIT_SCALE).set_deterministic(True)
+    c = CFG[kind]
+    tr = FusedTrainer(m, lr=1e-2, max_steps=c["steps"], init_scale=INIT_SCALE, exp_step_factor=c["esf"],
+                      distortion_loss_w=c["w_dist"]).set_deterministic(True)
+    assert tr.chunked == (kind == "c3")             # multi-cascade scenes take the chunked forward (bit-identical results by construction)
     dev = m.density_grid.device
     gp = [tuple(torch.from_numpy(x).to(dev) for x in b) for b in pool]
     recs, bits = [], {}
-    for s in range(STEPS):
+    casc = m.cascades
+    for s in range(c["steps"]):
         if s % UPDATE_EVERY == 0:
-            tr.update_density_grid(THR, warmup=True, jitter=lambda c, n, u=jit[s]: torch.from_numpy(u).to(dev))
+            tr.update_density_grid(THR, warmup=True, jitter=lambda ci, n, u=jit[s]: torch.from_numpy(u[ci]).to(dev))
             bits[s] = m.density_bitfield.cpu().numpy().copy()
             cur_bits = bits[s]
         o, d, tgt = gp[s % len(gp)]
@@ -84,15 +103,15 @@ def _run_hip(kind, m, pool, noise, jit, oracle):
         counts = ra[np.argsort(ra[:, 0], kind="stable"), 2]
         # compaction, bit-exact: the oracle march on the bitfield this trainer holds right now
         po, pd, _ = pool[s % len(pool)]
-        ref_ra, ref_total = oracle.march_train(po, pd, oracle.ray_aabb(po, pd, 0.5), cur_bits, noise[s], 1, 0.5, 0.0, 128, 1024,
-                                               count_only=True)
+        ref_ra, ref_total = oracle.march_train(po, pd, oracle.ray_aabb(po, pd, c["scale"]), cur_bits, noise[s], casc, c["scale"], c["esf"],
+                                               128, 1024, count_only=True)
         assert int(st["rm_samples"][0]) == ref_total, (s, int(st["rm_samples"][0]), ref_total)
         assert np.array_equal(counts, ref_ra[np.argsort(ref_ra[:, 0], kind="stable"), 2]), s
         loss = tr.last_loss()
         recs.append({"loss": loss, "psnr": -10.0 * np.log10(loss), "rm_samples": int(st["rm_samples"][0]), "counts": counts,
                      "vr": st["vr_per_ray"].cpu().numpy()})
-    c = tr.counters()
-    assert c["skipped"] == 0 and c["opt_steps"] == STEPS, c
+    cnt = tr.counters()
+    assert cnt["skipped"] == 0 and cnt["opt_steps"] == c["steps"], cnt
     return tr, recs, bits
 
 
@@ -104,6 +123,7 @@ def _run_autocast(m, pool, noise, jit):
     dev = m.density_grid.device
     gp = [tuple(torch.from_numpy(x).to(dev) for x in b) for b in pool]
     opt = torch.optim.Adam(m.parameters(), 1e-2, eps=1e-15)
+    STEPS = CFG["f32"]["steps"]
     sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, STEPS, 1e-2 / 30)
     scaler = torch.amp.GradScaler("cuda", init_scale=INIT_SCALE)
     losses = []
@@ -114,7 +134,7 @@ def _run_autocast(m, pool, noise, jit):
             o, d, tgt = gp[s % len(gp)]
             with torch.autocast("cuda", dtype=torch.float16):
                 if s % UPDATE_EVERY == 0:
-                    m.update_density_grid(THR, warmup=True, jitter=lambda c, n, u=jit[s]: torch.from_numpy(u).to(dev))
+                    m.update_density_grid(THR, warmup=True, jitter=lambda c, n, u=jit[s]: torch.from_numpy(u[c]).to(dev))
                 torch.manual_seed(NOISE_SEED + s)                 # -> the march draws noise[s]
                 res = render(m, o, d, exp_step_factor=0.0)
                 loss = F.mse_loss(res["rgb"], tgt)
@@ -133,9 +153,10 @@ def _run_autocast(m, pool, noise, jit):
     return losses
 
 
-@pytest.mark.parametrize("kind", ["f32", "half"])
+@pytest.mark.parametrize("kind", ["f32", "half", "c3"])
 def test_trajectory_matches_oracle_loop(oracle, hip_lib, kind):
-    pool, noise, jit = _inputs()
+    STEPS, N_RAYS = CFG[kind]["steps"], CFG[kind]["n_rays"]
+    pool, noise, jit = _inputs(kind)
     m = _model(kind)
     state = {"weights": [w.detach().cpu().numpy().copy() for w in m._mlp_weights()],
              "table": m.pos_encoder.hash_table.detach().float().reshape(-1).cpu().numpy().copy()}
@@ -143,7 +164,7 @@ def test_trajectory_matches_oracle_loop(oracle, hip_lib, kind):
     otr, cpu, cpu_bits = _run_cpu(kind, state, pool, noise, jit)
     tr, hip, hip_bits = _run_hip(kind, m, pool, noise, jit, oracle)
 
-    lc, lh = np.array([r["loss"] for r in cpu]), np.array([r["loss"] for r in hip])
+    lc, lh = np.array([r["mse"] for r in cpu]), np.array([r["loss"] for r in hip])      # (the MSE part: what FusedTrainer.last_loss() reports)
     rel = np.abs(lh - lc) / lc
     print("\ntrajectory [%s]: %d steps of %d rays, occupancy updates at %s" % (kind, STEPS, N_RAYS, sorted(jit)))
     print(" step   loss CPU-fp32    loss HIP       rel      samples CPU / HIP")
@@ -156,13 +177,18 @@ def test_trajectory_matches_oracle_loop(oracle, hip_lib, kind):
         print(" update at step %2d: occupied fraction %.3f, cells that differ between the two grids %.2e" % (s, occ, ham))
         # (half2 encoder: its table starts at U(+-1e-4), every density is 1 +- 1e-4 and the threshold is their mean -- the cells' order
         # around it is decided in the last bits of an fp16 logit)
-        assert ham < (1e-2 if kind == "half" else 2e-3), (s, ham)
+        # (c3, second update: five of the six cascades lie outside the scene, their cells still hold the initial density to ~1e-3 and the
+        # threshold is the mean density -- which side of it such a cell falls on is an fp16 rounding; the marched sample totals below
+        # still agree to 0.5 %)
+        assert ham < {"f32": 2e-3, "half": 1e-2, "c3": 5e-2 if s else 2e-3}[kind], (s, ham)
+    if kind == "c3":
+        assert cpu_bits[0].size == 6 * 128**3 // 8
     tot_c, tot_h = np.array([r["rm_samples"] for r in cpu]), np.array([r["rm_samples"] for r in hip])
     assert np.abs(tot_c - tot_h).max() <= (1e-2 if kind == "half" else 5e-3) * tot_c.max(), np.abs(tot_c - tot_h).max()
     first = slice(0, UPDATE_EVERY)                     # until the second update both sides march the step-0 grids: nearly all rays equal
     same = np.mean([np.mean(c["counts"] == h["counts"]) for c, h in zip(cpu[first], hip[first])])
     print(" rays with identical sample counts in the first %d steps: %.4f" % (UPDATE_EVERY, same))
-    assert same > (0.5 if kind == "half" else 0.99)
+    assert same > (0.5 if kind == "half" else 0.98)
     # early termination point per ray (compositing): where the rays' samples agree, the sample the ray stops at agrees to +-1
     vr_ok = []
     for c, h in zip(cpu, hip):
@@ -170,8 +196,9 @@ def test_trajectory_matches_oracle_loop(oracle, hip_lib, kind):
         vr_ok.append(np.mean(np.abs(c["vr"][eq].astype(np.int64) - h["vr"][eq].astype(np.int64)) <= 1))
     print(" rays (same samples) whose early-termination point agrees to +-1 sample: min over steps %.4f" % min(vr_ok))
     # loss curve
-    assert lh[-1] < 0.5 * lh[0] and lc[-1] < 0.5 * lc[0]                 # both learn
-    tol = 2e-2 if kind == "half" else 5e-3
+    learn = 0.9 if kind == "c3" else 0.5                                # (24 steps of the unbounded scene: the loss has only started to fall)
+    assert lh[-1] < learn * lh[0] and lc[-1] < learn * lc[0]             # both learn
+    tol = {"f32": 5e-3, "half": 2e-2, "c3": 1e-2}[kind]
     print(" max relative loss deviation HIP vs CPU-fp32: %.3e (mean %.3e)" % (rel.max(), rel.mean()))
     assert rel.max() <= tol, rel.max()
     if m_auto is not None:
