@@ -684,8 +684,13 @@ def _measure(args, ctx, brief):
         scaler.step(opt)
         scaler.update()
         sched.step()
-        state["rm"] += res["rm_samples"]
-        state["vr"] += res["vr_samples"]
+        # train.py:203-221 reads rm_samples / vr_samples in its log line only (every 1000th step); reading them on every step would
+        # put two reductions + two adds on the step's stream that the reference's loop does not have.  Sampled like the trainer path.
+        k = state["k"]
+        if log and k % STAT_EVERY == 0 and k // STAT_EVERY < stat_log.shape[0]:
+            stat_log[k // STAT_EVERY, 0] = res["rm_samples"]
+            vr_log[k // STAT_EVERY, 0] = res["vr_samples"]
+        state["k"] = k + 1
 
     def fence():
         if world > 1:
@@ -824,7 +829,7 @@ def _measure(args, ctx, brief):
         elapsed_stub = float(tt.item())
     _Probe.stub_ms = None if elapsed_stub is None else elapsed_stub / args.steps * 1e3
 
-    if use_trainer:
+    if True:
         n_st = (k_timed + STAT_EVERY - 1) // STAT_EVERY
         state["rm"] = stat_log[:n_st].sum(dtype=torch.int64) * k_timed // max(n_st, 1)
         state["vr"] = vr_log[:n_st].sum(dtype=torch.int64) * k_timed // max(n_st, 1)

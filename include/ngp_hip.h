@@ -26,7 +26,7 @@ extern "C" {
 #endif
 
 #define NGP_MAX_LEVELS 16
-#define NGP_ABI_VERSION 2
+#define NGP_ABI_VERSION 3
 
 /* Multiresolution level table.  Built ONCE on the host (ngp_hash_levels_init) in the arithmetic of
  * modules/hash_encoder.py:183-205 + modules/utils.py:19-42 (f64 sizes) and of the in-kernel
@@ -208,6 +208,17 @@ int ngp_composite_train_bwd(const float* dL_dopacity, const float* dL_ddepth, co
                             const int32_t* rays_a, const float* opacity, const float* depth,
                             const float* rgb, const float* ws, float T_threshold, int n_rays,
                             float* dL_dsigmas, void* dL_drgbs, void* stream);
+/* ... with the background blend of rendering.py:219-226 (results['rgb'] = rgb + rgb_bg * (1 - opacity), rgb_bg = ones behind
+ * synthetic scenes) inside the two launches: _fwd_bg also writes rgb_out[n,3] = rgb + bg (1 - opacity) (nullable; `rgb` stays the
+ * unblended colour the backward reads); _bwd_bg takes dL_drgb as the gradient of the BLENDED colour and adds the blend's share,
+ * -bg sum_c dL_drgb, to d opacity.  bg == 0: the two entries above. */
+int ngp_composite_train_fwd_bg(const float* sigmas, const void* rgbs, int rgbs_is_half, const float* deltas, const float* ts,
+                               const int32_t* rays_a, float T_threshold, int n_rays, int32_t* total_samples, float* opacity,
+                               float* depth, float* rgb, float* ws, float* rgb_out, float bg, void* stream);
+int ngp_composite_train_bwd_bg(const float* dL_dopacity, const float* dL_ddepth, const float* dL_drgb, const float* dL_dws,
+                               const float* sigmas, const void* rgbs, int rgbs_is_half, const float* deltas, const float* ts,
+                               const int32_t* rays_a, const float* opacity, const float* depth, const float* rgb, const float* ws,
+                               float T_threshold, int n_rays, float* dL_dsigmas, void* dL_drgbs, float bg, void* stream);
 
 /* Round 5 -- chunked forward: do not shade what compositing will never read.  The reference shades every marched sample and then
  * ignores those behind T <= T_threshold (volume_train.py:38); its evaluation loop (rendering.py:62-158) already shades in rounds
@@ -396,6 +407,12 @@ typedef struct ngp_render_args {
      * for the next call (a caller alternating the two never clears one itself). */
     float* dW_parts; int32_t* live_zero;
     float* dW /*[9408], cleared by the caller*/; void* dtable /*f32 [entries * 2]; table_kind 2: f16; cleared by the caller*/; long long dtable_bytes;
+    /* ABI 3.  bg: the background the composited colour is blended over (rendering.py:219-226: 1 behind synthetic scenes, 0 behind real
+     * ones).  rgb_out (nullable, [n_rays,3]): _fwd also writes rgb + bg (1 - opacity) there -- what the loss sees; `rgb` stays the
+     * unblended colour the backward reads.  _bwd takes g_rgb as the gradient of the BLENDED colour when bg != 0 (adds -bg sum_c g_rgb to
+     * d opacity).  clear_grads != 0: _bwd clears dW and dtable itself (one fill launch behind the compositing backward; dtable_bytes % 16
+     * == 0) instead of expecting them cleared. */
+    float bg; int32_t clear_grads; float* rgb_out;
 } ngp_render_args;
 int ngp_render_train_fwd(const ngp_render_args* args, void* stream);
 int ngp_render_train_bwd(const ngp_render_args* args, void* stream);
@@ -432,6 +449,13 @@ int ngp_adam_multi(int n_tensors, float* const* p, float* const* g, float* const
 /* GradScaler's inf / nan check (train.py:199, torch.amp.GradScaler._check_inf_per_device) over the same tensor list, read-only:
  * found_inf[0] (a float32 device scalar, cleared by the caller) becomes 1.0f when any gradient value is not finite. */
 int ngp_check_finite_multi(int n_tensors, const float* const* g, const long long* n, float* found_inf, void* stream);
+/* ... and ngp_adam_amp_prologue in the same launch (one parameter group of <= NGP_ADAM_MULTI_MAX tensors): the last block out runs the
+ * prologue on the finished flag.  found_inf must be 0 at launch; clear_next (nullable) is a second flag this launch clears for the
+ * caller's NEXT step -- GradScaler.update() (train.py:200) reads found_inf after step() returns, so a caller alternating two flags never
+ * issues a fill.  done: 17 x 32 uint32 of device memory (arrival counters 128 bytes apart), 0 between launches. */
+int ngp_adam_amp_check_prologue(int n_tensors, const float* const* g, const long long* n, float* found_inf, float* clear_next,
+                                uint32_t* done, float* state_f, int32_t* state_i, const float* grad_scale, float lr, float beta1,
+                                float beta2, void* stream);
 /* dst[i] = bf16(src[i]), round-to-nearest-even; n % 4 == 0 (the per-forward cast of hash_encoder_half.py:367, in bf16). */
 int ngp_cast_f32_bf16(const float* src, uint16_t* dst, long long n, void* stream);
 /* General form: table_g is fp32 or (grad_is_f16) the half2 encoder's f16 gradient buffer, widened to fp32 on the fly;

@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--rays", type=int, default=8192)
     args = ap.parse_args()
+    _knob()                                                 # before the library's first plan: it latches bwd_knobs_dynamic then
     from ngp_hip import lib, synthetic
     from ngp_hip.fused import RenderConfig, TrainArena
     from ngp_hip.ops import _ptr, _stream

@@ -35,6 +35,7 @@ class FusedAdam(torch.optim.Optimizer):
         self._sf = self._si = None
         self._multi = {}                     # group index -> (parameter identities, ctypes pointer / count arrays)
         self._found = {}                     # device -> float32 [1]: this optimizer's own inf flag (step(grad_scaler=...))
+        self._found2 = {}                    # device -> [float32 [2] flags used alternately, uint32 arrival counter, parity] (one-launch check + prologue)
         self._pending = []
         # GradScaler.step() looks for the `grad_scaler` keyword with inspect.signature(optimizer.step) on EVERY call (~35 us of
         # Python through torch's hook wrapper around step); a function that carries __signature__ answers from it
@@ -142,6 +143,7 @@ class FusedAdam(torch.optim.Optimizer):
             self._pending.clear()
 
     def _step(self, L, scale, found, own_check, grad_scaler, loss):
+        n_active = sum(1 for group in self.param_groups if any(p.grad is not None for p in group["params"]))
         for gi, group in enumerate(self.param_groups):
             ps = [p for p in group["params"] if p.grad is not None]
             if not ps:
@@ -177,7 +179,22 @@ class FusedAdam(torch.optim.Optimizer):
                         self._check(p, g)
                     G[j] = g.data_ptr()
                 chunks.append((len(chunk), P, G, M, V, N))
-            if own_check:
+            merged = False
+            if own_check and n_active == 1 and len(chunks) == 1 and scale is not None and scale.dtype == torch.float32:
+                # the usual case (train.py:143-149: one group, six tensors): inf check and prologue in ONE launch, and no fill -- two flags
+                # used alternately, each cleared by the launch of the step after the one GradScaler.update() read it in
+                ent = self._found2.get(dev)
+                if ent is None:
+                    ent = self._found2[dev] = [torch.zeros(2, device=dev, dtype=torch.float32), torch.zeros(17 * 32, device=dev, dtype=torch.int32), 0]
+                pair, done, par = ent
+                found, nxt = pair[par:par + 1], pair[1 - par:2 - par]
+                ent[2] = 1 - par
+                grad_scaler._per_optimizer_states[id(self)]["found_inf_per_device"][dev] = found
+                k, P, G, M, V, N = chunks[0]
+                _lib.check(L.ngp_adam_amp_check_prologue(k, G, N, _ptr(found), _ptr(nxt), _ptr(done), _ptr(sf), _ptr(si), _ptr(scale),
+                                                         float(group["lr"]), float(b1), float(b2), st), "ngp_adam_amp_check_prologue")
+                merged = True
+            elif own_check:
                 if gi == 0 or found is None or found.device != dev:
                     found = self._found.get(dev)
                     if found is None:
@@ -189,11 +206,12 @@ class FusedAdam(torch.optim.Optimizer):
                     _lib.check(L.ngp_check_finite_multi(k, G, N, _ptr(found), st), "ngp_check_finite_multi")
             if scale is not None and (scale.dtype != torch.float32 or found is None or found.dtype != torch.float32):
                 raise TypeError("grad_scale / found_inf must be float32 device tensors (torch.cuda.amp.GradScaler's are)")
-            self._pending.append((gi, group, sf, si, b1, b2, chunks, st, ps, scale, found))
+            self._pending.append((gi, group, sf, si, b1, b2, chunks, st, ps, scale, found, merged))
         # every group's flag is complete before any group is updated: one overflow skips the whole step (GradScaler's semantics)
-        for gi, group, sf, si, b1, b2, chunks, st, ps, scale, found in self._pending:
-            _lib.check(L.ngp_adam_amp_prologue(_ptr(sf), _ptr(si), _ptr(scale), _ptr(found), float(group["lr"]), float(b1), float(b2),
-                                               st), "ngp_adam_amp_prologue")
+        for gi, group, sf, si, b1, b2, chunks, st, ps, scale, found, merged in self._pending:
+            if not merged:
+                _lib.check(L.ngp_adam_amp_prologue(_ptr(sf), _ptr(si), _ptr(scale), _ptr(found), float(group["lr"]), float(b1), float(b2),
+                                                   st), "ngp_adam_amp_prologue")
             for k, P, G, M, V, N in chunks:
                 _lib.check(L.ngp_adam_multi(k, P, G, M, V, N, _ptr(sf), _ptr(si), float(b1), float(b2), float(group["eps"]), st),
                            "ngp_adam_multi")

@@ -31,7 +31,7 @@ __global__ void __launch_bounds__(256) composite_fwd_kernel(const float* __restr
                                                             const int32_t* __restrict__ rays_a, float thr, int n_rays,
                                                             int32_t* __restrict__ total_samples, float* __restrict__ opacity,
                                                             float* __restrict__ depth, float* __restrict__ rgb,
-                                                            float* __restrict__ ws) {
+                                                            float* __restrict__ ws, float* __restrict__ rgb_out, float bg) {
     const int n = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (n >= n_rays) return;
     const int lane = lane_id();
@@ -73,6 +73,10 @@ __global__ void __launch_bounds__(256) composite_fwd_kernel(const float* __restr
     if (lane == 0) {
         rgb[3 * ray_idx] = r0; rgb[3 * ray_idx + 1] = r1; rgb[3 * ray_idx + 2] = r2;
         depth[ray_idx] = dep; opacity[ray_idx] = op; total_samples[ray_idx] = cnt;
+        if (rgb_out) {                     // rendering.py:219-226: rgb + rgb_bg * (1 - opacity), the colour the loss sees
+            const float b = bg * (1.0f - op);
+            rgb_out[3 * ray_idx] = r0 + b; rgb_out[3 * ray_idx + 1] = r1 + b; rgb_out[3 * ray_idx + 2] = r2 + b;
+        }
     }
 }
 
@@ -89,14 +93,15 @@ __global__ void __launch_bounds__(256) composite_bwd_kernel(const float* __restr
                                                             const int32_t* __restrict__ rays_a, const float* __restrict__ opacity,
                                                             const float* __restrict__ depth, const float* __restrict__ rgb,
                                                             const float* __restrict__ ws, float thr, int n_rays,
-                                                            float* __restrict__ d_sigmas, void* __restrict__ d_rgbs) {
+                                                            float* __restrict__ d_sigmas, void* __restrict__ d_rgbs, float bg) {
     const int n = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (n >= n_rays) return;
     const int lane = lane_id();
     const int ray_idx = rays_a[3 * n], start = rays_a[3 * n + 1], N = rays_a[3 * n + 2];
     if (N == 0) return;
     const float gr0 = g_rgb[3 * ray_idx], gr1 = g_rgb[3 * ray_idx + 1], gr2 = g_rgb[3 * ray_idx + 2];
-    const float gd = g_dep ? g_dep[ray_idx] : 0.0f, go = g_op ? g_op[ray_idx] : 0.0f;
+    // g_rgb is the gradient of the BLENDED colour rgb + bg (1 - opacity) when bg != 0: the blend's share of d opacity is -bg sum_c g_rgb
+    const float gd = g_dep ? g_dep[ray_idx] : 0.0f, go = (g_op ? g_op[ray_idx] : 0.0f) + (bg != 0.0f ? -bg * (gr0 + gr1 + gr2) : 0.0f);
     const float R0 = rgb[3 * ray_idx], R1 = rgb[3 * ray_idx + 1], R2 = rgb[3 * ray_idx + 2];
     const float D = depth[ray_idx], O = opacity[ray_idx];
     float W = 0.0f;
@@ -406,17 +411,42 @@ using namespace ngp;
 
 extern "C" {
 
-int ngp_composite_train_fwd(const float* sigmas, const void* rgbs, int rgbs_is_half, const float* deltas, const float* ts,
-                            const int32_t* rays_a, float T_threshold, int n_rays, int32_t* total_samples, float* opacity,
-                            float* depth, float* rgb, float* ws, void* stream) {
+int ngp_composite_train_fwd_bg(const float* sigmas, const void* rgbs, int rgbs_is_half, const float* deltas, const float* ts,
+                               const int32_t* rays_a, float T_threshold, int n_rays, int32_t* total_samples, float* opacity,
+                               float* depth, float* rgb, float* ws, float* rgb_out, float bg, void* stream) {
     if (n_rays <= 0) return 0;
     dim3 grid((n_rays + 3) / 4), block(256);
     if (rgbs_is_half)
         hipLaunchKernelGGL(composite_fwd_kernel<true>, grid, block, 0, (hipStream_t)stream, sigmas, rgbs, deltas, ts, rays_a,
-                           T_threshold, n_rays, total_samples, opacity, depth, rgb, ws);
+                           T_threshold, n_rays, total_samples, opacity, depth, rgb, ws, rgb_out, bg);
     else
         hipLaunchKernelGGL(composite_fwd_kernel<false>, grid, block, 0, (hipStream_t)stream, sigmas, rgbs, deltas, ts, rays_a,
-                           T_threshold, n_rays, total_samples, opacity, depth, rgb, ws);
+                           T_threshold, n_rays, total_samples, opacity, depth, rgb, ws, rgb_out, bg);
+    NGP_LAUNCH_CHECK();
+    return 0;
+}
+
+int ngp_composite_train_fwd(const float* sigmas, const void* rgbs, int rgbs_is_half, const float* deltas, const float* ts,
+                            const int32_t* rays_a, float T_threshold, int n_rays, int32_t* total_samples, float* opacity,
+                            float* depth, float* rgb, float* ws, void* stream) {
+    return ngp_composite_train_fwd_bg(sigmas, rgbs, rgbs_is_half, deltas, ts, rays_a, T_threshold, n_rays, total_samples, opacity, depth,
+                                      rgb, ws, nullptr, 0.0f, stream);
+}
+
+int ngp_composite_train_bwd_bg(const float* dL_dopacity, const float* dL_ddepth, const float* dL_drgb, const float* dL_dws,
+                               const float* sigmas, const void* rgbs, int rgbs_is_half, const float* deltas, const float* ts,
+                               const int32_t* rays_a, const float* opacity, const float* depth, const float* rgb, const float* ws,
+                               float T_threshold, int n_rays, float* dL_dsigmas, void* dL_drgbs, float bg, void* stream) {
+    if (n_rays <= 0) return 0;
+    dim3 grid((n_rays + 3) / 4), block(256);
+    if (rgbs_is_half)
+        hipLaunchKernelGGL(composite_bwd_kernel<true>, grid, block, 0, (hipStream_t)stream, dL_dopacity, dL_ddepth, dL_drgb,
+                           dL_dws, sigmas, rgbs, deltas, ts, rays_a, opacity, depth, rgb, ws, T_threshold, n_rays, dL_dsigmas,
+                           dL_drgbs, bg);
+    else
+        hipLaunchKernelGGL(composite_bwd_kernel<false>, grid, block, 0, (hipStream_t)stream, dL_dopacity, dL_ddepth, dL_drgb,
+                           dL_dws, sigmas, rgbs, deltas, ts, rays_a, opacity, depth, rgb, ws, T_threshold, n_rays, dL_dsigmas,
+                           dL_drgbs, bg);
     NGP_LAUNCH_CHECK();
     return 0;
 }
@@ -425,18 +455,8 @@ int ngp_composite_train_bwd(const float* dL_dopacity, const float* dL_ddepth, co
                             const float* sigmas, const void* rgbs, int rgbs_is_half, const float* deltas, const float* ts,
                             const int32_t* rays_a, const float* opacity, const float* depth, const float* rgb, const float* ws,
                             float T_threshold, int n_rays, float* dL_dsigmas, void* dL_drgbs, void* stream) {
-    if (n_rays <= 0) return 0;
-    dim3 grid((n_rays + 3) / 4), block(256);
-    if (rgbs_is_half)
-        hipLaunchKernelGGL(composite_bwd_kernel<true>, grid, block, 0, (hipStream_t)stream, dL_dopacity, dL_ddepth, dL_drgb,
-                           dL_dws, sigmas, rgbs, deltas, ts, rays_a, opacity, depth, rgb, ws, T_threshold, n_rays, dL_dsigmas,
-                           dL_drgbs);
-    else
-        hipLaunchKernelGGL(composite_bwd_kernel<false>, grid, block, 0, (hipStream_t)stream, dL_dopacity, dL_ddepth, dL_drgb,
-                           dL_dws, sigmas, rgbs, deltas, ts, rays_a, opacity, depth, rgb, ws, T_threshold, n_rays, dL_dsigmas,
-                           dL_drgbs);
-    NGP_LAUNCH_CHECK();
-    return 0;
+    return ngp_composite_train_bwd_bg(dL_dopacity, dL_ddepth, dL_drgb, dL_dws, sigmas, rgbs, rgbs_is_half, deltas, ts, rays_a, opacity, depth,
+                                      rgb, ws, T_threshold, n_rays, dL_dsigmas, dL_drgbs, 0.0f, stream);
 }
 
 int ngp_composite_train_fused_live(const float* sigmas, const void* rgbs, int rgbs_is_half, const float* deltas, const float* ts,

@@ -25,10 +25,8 @@ __global__ void train_prologue_kernel(float* __restrict__ sf, int32_t* __restric
 // Prologue of an optimizer step driven by torch.cuda.amp.GradScaler (compat/apex FusedAdam under the reference's unchanged
 // train.py:143-149,198-201): the scale and the inf flag are the scaler's own device tensors, the learning rate comes from
 // torch's scheduler on the host; the step counter of the bias corrections advances only when the step is not skipped.
-__global__ void adam_amp_prologue_kernel(float* __restrict__ sf, int32_t* __restrict__ si, const float* __restrict__ grad_scale,
-                                         const float* __restrict__ found_inf, float lr, float beta1, float beta2) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const bool skip = found_inf && *found_inf != 0.0f;
+__device__ __forceinline__ void adam_amp_prologue_thread(float* __restrict__ sf, int32_t* __restrict__ si, const float* __restrict__ grad_scale,
+                                                         const bool skip, float lr, float beta1, float beta2) {
     sf[SF_INV_SCALE] = grad_scale ? 1.0f / *grad_scale : 1.0f;
     sf[SF_LR] = lr;
     si[SI_SKIP] = skip ? 1 : 0;
@@ -40,6 +38,11 @@ __global__ void adam_amp_prologue_kernel(float* __restrict__ sf, int32_t* __rest
     } else {
         si[SI_SKIPPED_TOTAL] += 1;
     }
+}
+__global__ void adam_amp_prologue_kernel(float* __restrict__ sf, int32_t* __restrict__ si, const float* __restrict__ grad_scale,
+                                         const float* __restrict__ found_inf, float lr, float beta1, float beta2) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    adam_amp_prologue_thread(sf, si, grad_scale, found_inf && *found_inf != 0.0f, lr, beta1, beta2);
 }
 
 // The same launch also finishes the MLP backward: blocks 0..146 add up the per-block weight-gradient slabs (ngp_device.h); the
@@ -101,6 +104,52 @@ __global__ void __launch_bounds__(256) check_finite_multi_kernel(FiniteMulti T, 
             bad |= !(((a.x - a.x) + (a.y - a.y)) + ((a.z - a.z) + (a.w - a.w)) == 0.0f);
         }
     if (__any(bad) && (threadIdx.x & 63) == 0) *found = 1.0f;
+}
+
+// Round 6: the check and the prologue in ONE launch (the reference-shaped loop's optimizer step was fill + check + prologue + Adam: three
+// ~5-10 us launches in front of the sweep, profiles/r06_modules_path_timeline.txt).  Every block reports with ONE relaxed atomic that
+// carries both its arrival (low 16 bits; the grid has <= 4096 blocks) and whether it saw a non-finite value (high bits), so the last block
+// out knows the verdict from the value the atomic returns -- no fence anywhere: a first version with __threadfence() in front of the
+// arrival count took 260 us, 4096 agent-scope releases each writing back and invalidating an L2 full of the gradients just produced.
+// And not one counter: 4096 same-address atomics are ~10 ns each, 54 us (measured).  Two levels: block b reports to counter b % 16 (128
+// bytes apart), the last arrival of each reports that counter's sum to the top one (done[0]; the sub-counters are done[32 (1 + k)]).
+// The last block stores the flag (GradScaler.update() reads it after step()), runs the one-thread prologue and rearms the counter;
+// block 0 clears `clear_next`, the flag the caller hands to the NEXT step (two flags used alternately: this step's cannot be cleared
+// here, and a fill launch per step is what this removes).
+__global__ void __launch_bounds__(256) check_finite_prologue_kernel(FiniteMulti T, float* __restrict__ found, float* __restrict__ clear_next,
+                                                                    uint32_t* __restrict__ done, float* __restrict__ sf,
+                                                                    int32_t* __restrict__ si, const float* __restrict__ grad_scale, float lr,
+                                                                    float beta1, float beta2) {
+    __shared__ int s_bad;
+    if (threadIdx.x == 0) s_bad = 0;
+    __syncthreads();
+    bool bad = false;
+    for (int t = 0; t < T.count; ++t)
+        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < T.n4[t]; i += (long)gridDim.x * blockDim.x) {
+            const float4 a = T.g[t][i];
+            bad |= !(((a.x - a.x) + (a.y - a.y)) + ((a.z - a.z) + (a.w - a.w)) == 0.0f);
+        }
+    if (__any(bad) && (threadIdx.x & 63) == 0) s_bad = 1;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (blockIdx.x == 0 && clear_next) *clear_next = 0.0f;
+        const uint32_t k = blockIdx.x & 15u, members = (gridDim.x + 15u - k) >> 4;           // blocks b with b % 16 == k
+        uint32_t* sub = done + 32u * (1u + k);
+        const uint32_t mine = 1u + (s_bad ? 0x10000u : 0u);
+        const uint32_t old = __hip_atomic_fetch_add(sub, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((old & 0xffffu) == members - 1u) {
+            __hip_atomic_store(sub, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t groups = gridDim.x < 16u ? gridDim.x : 16u;
+            const uint32_t up = 1u + (((old + mine) >> 16) ? 0x10000u : 0u);
+            const uint32_t top = __hip_atomic_fetch_add(done, up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((top & 0xffffu) == groups - 1u) {
+                const bool skip = ((top + up) >> 16) != 0u;
+                __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (skip) *found = 1.0f;
+                adam_amp_prologue_thread(sf, si, grad_scale, skip, lr, beta1, beta2);
+            }
+        }
+    }
 }
 
 __global__ void __launch_bounds__(256) cast_bf16_kernel(const float4* __restrict__ src, uint2* __restrict__ dst, long n4) {
@@ -270,6 +319,27 @@ int ngp_check_finite_multi(int n_tensors, const float* const* g, const long long
     long blocks = (most + 255) / 256;
     if (blocks > 256L * 16) blocks = 256L * 16;
     hipLaunchKernelGGL(check_finite_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, T, found_inf);
+    NGP_LAUNCH_CHECK();
+    return 0;
+}
+
+int ngp_adam_amp_check_prologue(int n_tensors, const float* const* g, const long long* n, float* found_inf, float* clear_next,
+                                uint32_t* done, float* state_f, int32_t* state_i, const float* grad_scale, float lr, float beta1,
+                                float beta2, void* stream) {
+    if (n_tensors <= 0 || n_tensors > NGP_ADAM_MULTI_MAX || !g || !n || !found_inf || !done || !state_f || !state_i) return -1;
+    FiniteMulti T;
+    long most = 0;
+    T.count = n_tensors;
+    for (int t = 0; t < n_tensors; ++t) {
+        if (n[t] <= 0 || n[t] % 4 != 0 || !g[t]) return -1;
+        T.g[t] = (const float4*)g[t];
+        T.n4[t] = (long)(n[t] / 4);
+        if (T.n4[t] > most) most = T.n4[t];
+    }
+    long blocks = (most + 255) / 256;
+    if (blocks > 256L * 16) blocks = 256L * 16;          // (< 2^16: the arrival count shares its word with the verdict)
+    hipLaunchKernelGGL(check_finite_prologue_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, T, found_inf, clear_next, done,
+                       state_f, state_i, grad_scale, lr, beta1, beta2);
     NGP_LAUNCH_CHECK();
     return 0;
 }

@@ -10,6 +10,16 @@
 #include "ngp_device.h"
 #include "../../include/ngp_hip.h"
 
+namespace ngp {
+// zero two 16-byte-granular buffers in one launch (the table gradient and the 9408 weight gradients)
+__global__ void __launch_bounds__(256) clear2_kernel(uint4* __restrict__ a, long na, uint4* __restrict__ b, long nb) {
+    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+    const long stride = (long)gridDim.x * blockDim.x, i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (long i = i0; i < na; i += stride) a[i] = z;
+    for (long i = i0; i < nb; i += stride) b[i] = z;
+}
+}  // namespace ngp
+
 extern "C" {
 
 int ngp_render_train_fwd(const ngp_render_args* a, void* stream) {
@@ -30,19 +40,29 @@ int ngp_render_train_fwd(const ngp_render_args* a, void* stream) {
     if (rc != 0) return rc;
     if ((rc = ngp_mlp_pack(a->w[0], a->w[1], a->w[2], a->w[3], a->w[4], a->enc_pairs, a->wpack, stream)) != 0) return rc;
     if ((rc = ngp_mlp_fwd_ex(a->enc, a->dirs, a->wpack, cap, a->total, a->enc_pairs, a->sigmas, a->rgbs, stream)) != 0) return rc;
-    return ngp_composite_train_fwd(a->sigmas, a->rgbs, 1, a->deltas, a->ts, a->rays_a, a->T_threshold, a->n_rays, a->vr_per_ray, a->opacity,
-                                   a->depth, a->rgb, a->ws, stream);
+    // (round 6: rgb_out = rgb + bg (1 - opacity), the blend of rendering.py:219-226, written by the compositing launch itself)
+    return ngp_composite_train_fwd_bg(a->sigmas, a->rgbs, 1, a->deltas, a->ts, a->rays_a, a->T_threshold, a->n_rays, a->vr_per_ray, a->opacity,
+                                      a->depth, a->rgb, a->ws, a->rgb_out, a->rgb_out ? a->bg : 0.0f, stream);
 }
 
-// dW [9408] and dtable are ACCUMULATED into: the caller hands them over cleared (torch.zeros: a cached allocation + one fill kernel;
-// two hipMemsetAsync calls in here cost the host ~15 us each -- measured, profiles/r05_train_py_cprofile.txt -- more than the
-// consolidation of the launches saves).
+// dW [9408] and dtable are ACCUMULATED into.  Round 5: the caller hands them over cleared (torch.zeros: a cached allocation + one fill
+// kernel each; two hipMemsetAsync calls in here cost the host ~15 us each -- measured, profiles/r05_train_py_cprofile.txt).  Round 6,
+// clear_grads != 0: ONE fill launch of this library clears both, issued BEHIND the compositing backward -- the autograd node's prelude
+// (profiles/r06_modules_path_timeline.txt: 74 us between the loss's backward kernel and the compositing backward, 17 us of them kernels)
+// loses its two torch fills and, with bg in the argument block, the two torch kernels of the blend's gradient.
 int ngp_render_train_bwd(const ngp_render_args* a, void* stream) {
     if (!a || a->n_rays <= 0 || !a->levels || !a->dW || !a->dtable || !a->live_idx || !a->live_total || !a->live_off) return -1;
     int rc = 0;
-    if ((rc = ngp_composite_train_bwd(a->g_opacity, a->g_depth, a->g_rgb, a->g_ws, a->sigmas, a->rgbs, 1, a->deltas, a->ts, a->rays_a,
-                                      a->opacity, a->depth, a->rgb, a->ws, a->T_threshold, a->n_rays, a->d_sigmas, a->d_rgbs, stream)) != 0)
+    if ((rc = ngp_composite_train_bwd_bg(a->g_opacity, a->g_depth, a->g_rgb, a->g_ws, a->sigmas, a->rgbs, 1, a->deltas, a->ts, a->rays_a,
+                                         a->opacity, a->depth, a->rgb, a->ws, a->T_threshold, a->n_rays, a->d_sigmas, a->d_rgbs, a->bg,
+                                         stream)) != 0)
         return rc;
+    if (a->clear_grads) {
+        if (a->dtable_bytes % 16 != 0) return -1;
+        hipLaunchKernelGGL(ngp::clear2_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, (uint4*)a->dtable, (long)(a->dtable_bytes / 16),
+                           (uint4*)a->dW, (long)(ngp::NGP_MLP_NW * 4 / 16));
+        NGP_LAUNCH_CHECK();
+    }
     // the live-sample list: ngp_live_list (one atomic per 64 rays, block-completion order) when the caller alternates two counters,
     // round 5's ray-ordered ngp_live_compact otherwise -- the *_live kernels do not depend on the order
     if (a->live_zero) rc = ngp_live_list(a->rays_a, a->vr_per_ray, a->n_rays, a->live_idx, a->live_total, a->live_zero, stream);

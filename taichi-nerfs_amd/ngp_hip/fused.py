@@ -176,17 +176,21 @@ class FusedTrainRender(torch.autograd.Function):
         a.w[0], a.w[1], a.w[2], a.w[3], a.w[4] = w1.data_ptr(), w2.data_ptr(), w3.data_ptr(), w4.data_ptr(), w5.data_ptr()
         a.rays_a, a.total, a.vr_per_ray = rays_a.data_ptr(), total.data_ptr(), vr_per_ray.data_ptr()
         a.opacity, a.depth, a.rgb = opacity.data_ptr(), depth.data_ptr(), rgb.data_ptr()
+        # the background blend of rendering.py:219-226 (white behind synthetic scenes, black behind real ones) is written by the compositing
+        # launch itself into a second per-ray colour (the backward kernel wants the unblended one); its gradient -- d opacity -= bg * sum_c
+        # g_rgb -- is formed inside the compositing backward (round 6: three torch kernels forward and two backward until then)
+        rgb_out = rgb
+        a.bg = cfg.bg
+        if cfg.bg != 0.0:
+            rgb_out = torch.empty(n, 3, **f32)
+            a.rgb_out = rgb_out.data_ptr()
+        else:
+            a.rgb_out = None
         check(L.ngp_render_train_fwd(ctypes.byref(a), st), "ngp_render_train_fwd")
         A.generation += 1
         ctx.cfg, ctx.arena, ctx.table_numel, ctx.table_shape, ctx.generation = cfg, A, table.numel(), table.shape, A.generation
         ctx.save_for_backward(rays_a, total, opacity, depth, rgb, vr_per_ray)
         ctx.set_materialize_grads(False)
-        # the background blend of rendering.py:219-226 (white behind synthetic scenes, black behind real ones) happens HERE, on a copy
-        # of the composited colour (the backward kernel wants the unblended one): three small torch kernels and their three autograd
-        # nodes per step otherwise; its gradient -- d opacity -= bg * sum_c g_rgb -- is folded into backward() below
-        rgb_out = rgb
-        if cfg.bg != 0.0:
-            rgb_out = torch.addcmul(rgb, (1.0 - opacity).unsqueeze(1), cfg.bg_vec(dev))
         ctx.mark_non_differentiable(total, vr_per_ray, rays_a)
         return rgb_out, opacity, depth, A.ws, total, vr_per_ray, rays_a
 
@@ -211,19 +215,18 @@ class FusedTrainRender(torch.autograd.Function):
         if g_rgb is None:
             g_rgb = torch.zeros(n, 3, device=dev, dtype=torch.float32)
         g_opacity, g_depth, g_ws = f32(g_opacity), f32(g_depth), f32(g_ws)
-        if cfg.bg != 0.0:                                                 # rgb_out = rgb + bg (1 - opacity): the blend's share of d opacity
-            g_bg = g_rgb.sum(1) * (-cfg.bg)
-            g_opacity = g_bg if g_opacity is None else g_opacity + g_bg
         # ONE call (csrc/render.hip): compositing backward -> live-sample list (the first vr_per_ray[r] samples of ray r: everything
         # behind the early-termination point has exact-zero gradients; one atomic per 64 rays) -> MLP backward over that list, its
         # weight gradients as per-block slabs -> scatter-add in its LDS-sliced form (no global float atomics; its head sums the slabs)
         # when the level table fits it -- the same kernels FusedTrainer runs.  dW and the
-        # table gradient are accumulated into: cleared here.  half2 encoder: fp16 arithmetic into an fp16 gradient table (the reference's
+        # table gradient are accumulated into: cleared by one fill launch of the entry itself, behind the compositing backward (round 6:
+        # no torch op between the loss's backward kernel and this node's first launch).  half2 encoder: fp16 arithmetic into an fp16 gradient table (the reference's
         # hash_grad, hash_encoder_half.py:300-306,350-352), handed to autograd widened to the fp32 parameter's dtype.
         a = A.render_args(cfg)
         half = cfg.table_f16 is not None
-        dW = torch.zeros(MLP_N_WEIGHTS, device=dev, dtype=torch.float32)
-        dtable = torch.zeros(ctx.table_numel, device=dev, dtype=torch.float16 if half else torch.float32)
+        dW = torch.empty(MLP_N_WEIGHTS, device=dev, dtype=torch.float32)
+        dtable = torch.empty(ctx.table_numel, device=dev, dtype=torch.float16 if half else torch.float32)
+        a.clear_grads, a.bg = 1, cfg.bg
         if A._live_dirty:
             A._live_pair.zero_()
         par, A._live_parity, A._live_dirty = A._live_parity, 1 - A._live_parity, True

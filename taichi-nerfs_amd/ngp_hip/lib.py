@@ -70,7 +70,8 @@ def _render_fields():
             + ptrs("d_sigmas", "d_rgbs", "d_enc", "live_off", "live_idx", "live_total")
             + [("workspace", P), ("workspace_bytes", LL), ("force_atomic", I), ("reserved", I)]
             + ptrs("dW_parts", "live_zero")
-            + [("dW", P), ("dtable", P), ("dtable_bytes", LL)])
+            + [("dW", P), ("dtable", P), ("dtable_bytes", LL)]
+            + [("bg", F), ("clear_grads", I), ("rgb_out", P)])
 
 
 class RenderArgs(ctypes.Structure):
@@ -181,6 +182,8 @@ SIGNATURES = {
     "ngp_sh16_bwd": [_P, _P, _I, _P, _P],
     "ngp_composite_train_fwd": [_P, _P, _I, _P, _P, _P, _F, _I, _P, _P, _P, _P, _P, _P],
     "ngp_composite_train_bwd": [_P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _F, _I, _P, _P, _P],
+    "ngp_composite_train_fwd_bg": [_P, _P, _I, _P, _P, _P, _F, _I, _P, _P, _P, _P, _P, _P, _F, _P],
+    "ngp_composite_train_bwd_bg": [_P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _F, _I, _P, _P, _F, _P],
     "ngp_composite_train_fused": [_P, _P, _I, _P, _P, _P, _P, _F, _P, _F, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "ngp_composite_train_fused_live": [_P, _P, _I, _P, _P, _P, _P, _F, _P, _F, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "ngp_composite_test": [_P, _P, _I, _P, _P, _P, _P, _F, _I, _P, _P, _P, _P],
@@ -208,6 +211,7 @@ SIGNATURES = {
     "ngp_adam_step": [_P, _P, _P, _P, ctypes.c_longlong, _P, _P, _F, _F, _F, _P],
     "ngp_adam_multi": [_I, _P, _P, _P, _P, _P, _P, _P, _F, _F, _F, _P],
     "ngp_check_finite_multi": [_I, _P, _P, _P, _P],
+    "ngp_adam_amp_check_prologue": [_I, _P, _P, _P, _P, _P, _P, _P, _P, _F, _F, _F, _P],
     "ngp_adam_step_bf16": [_P, _P, _P, _P, ctypes.c_longlong, _P, _P, _F, _F, _F, _P, _P],
     "ngp_cast_f32_bf16": [_P, _P, ctypes.c_longlong, _P],
     "ngp_adam_all": [_P, _P, _P, _P, ctypes.c_longlong, _P, _P, _P, _P, _P, _P, _P, _F, _F, _F, _I, _P, _P],

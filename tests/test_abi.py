@@ -25,7 +25,7 @@ def test_header_symbols_exported(hip_lib):
         assert hasattr(hip_lib, n), "libngp_hip.so does not export %s" % n
     assert sorted(lib.SIGNATURES) == sorted(names + extra), "ngp_hip/lib.py binds a different symbol set than the headers declare"
     assert sorted(lib.EXPERIMENTAL) == extra
-    assert hip_lib.ngp_abi_version() == 2
+    assert hip_lib.ngp_abi_version() == 3
 
 
 def test_no_default_path_calls_an_experimental_entry_point():

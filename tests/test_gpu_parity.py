@@ -596,6 +596,42 @@ def test_composite_train_fwd_bwd(oracle, hip_lib, half, dense):
         np.testing.assert_allclose(got_dc.float().cpu().numpy(), dc, rtol=2e-3 if half else 1e-4, atol=1e-6)
 
 
+@pytest.mark.parametrize("bg", [1.0, 0.5])
+def test_composite_train_background_blend_entries(oracle, hip_lib, bg):
+    """Round 6: the blend of rendering.py:219-226 (rgb + bg (1 - opacity)) inside the compositing launches (ngp_composite_train_fwd_bg /
+    _bwd_bg, what the fused render() calls).  Forward: the blended colour against the oracle's composite + the blend on the host, the
+    unblended outputs bit-equal to the plain entry's.  Backward: against the oracle handed the blend's share of d opacity."""
+    from ngp_hip.ops import _ptr, _stream
+    rng = np.random.default_rng(14)
+    rays_a, sig, rgbs, deltas, ts = _composite_case(rng, 2000, 200, True)
+    rgbs16 = rgbs.astype(np.float16)
+    n, S = rays_a.shape[0], sig.shape[0]
+    tot, op, dep, rgb, ws = oracle.composite_train_fwd(sig, rgbs16.astype(np.float32), deltas, ts, rays_a, 1e-4)
+    plain = ops.composite_train_fwd(dev(sig), dev(rgbs16), dev(deltas), dev(ts), dev(rays_a), 1e-4)
+    d_sig, d_rgbs, d_del, d_ts, d_ra = dev(sig), dev(rgbs16), dev(deltas), dev(ts), dev(rays_a)
+    f32 = dict(device="cuda", dtype=torch.float32)
+    g_tot = torch.empty(n, device="cuda", dtype=torch.int32)
+    g_op, g_dep, g_rgb, g_out, g_ws = torch.empty(n, **f32), torch.empty(n, **f32), torch.empty(n, 3, **f32), torch.empty(n, 3, **f32), torch.empty(S, **f32)
+    assert hip_lib.ngp_composite_train_fwd_bg(_ptr(d_sig), _ptr(d_rgbs), 1, _ptr(d_del), _ptr(d_ts), _ptr(d_ra), 1e-4, n, _ptr(g_tot), _ptr(g_op),
+                                              _ptr(g_dep), _ptr(g_rgb), _ptr(g_ws), _ptr(g_out), bg, _stream()) == 0
+    torch.cuda.synchronize()
+    for a, b in zip(plain, (g_tot, g_op, g_dep, g_rgb, g_ws)):
+        assert torch.equal(a, b)
+    # (fp32 on both sides: one rounding of bg (1 - O), one of the sum; the host may contract differently by an ulp of the colour)
+    np.testing.assert_allclose(g_out.cpu().numpy(), rgb + np.float32(bg) * (1 - op)[:, None], rtol=1e-5, atol=2e-6)
+    assert torch.equal(g_out, g_rgb + bg * (1 - g_op)[:, None]) or bg != 1.0
+    go = rng.standard_normal(n).astype(np.float32)
+    gr = rng.standard_normal((n, 3)).astype(np.float32)
+    ds, dc = oracle.composite_train_bwd(go - np.float32(bg) * gr.sum(1), np.zeros(n, np.float32), gr, None, sig, rgbs16.astype(np.float32), deltas, ts, rays_a, 1e-4)
+    o_ds, o_dc = torch.empty(S, **f32), torch.empty(S, 3, device="cuda", dtype=torch.float16)
+    assert hip_lib.ngp_composite_train_bwd_bg(_ptr(dev(go)), _ptr(None), _ptr(dev(gr)), _ptr(None), _ptr(d_sig), _ptr(d_rgbs), 1, _ptr(d_del),
+                                              _ptr(d_ts), _ptr(d_ra), _ptr(g_op), _ptr(g_dep), _ptr(g_rgb), _ptr(g_ws), 1e-4, n, _ptr(o_ds),
+                                              _ptr(o_dc), bg, _stream()) == 0
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(o_ds.cpu().numpy(), ds, rtol=1e-3, atol=2e-5 * np.abs(ds).max())
+    np.testing.assert_allclose(o_dc.float().cpu().numpy(), dc, rtol=2e-3, atol=1e-6)
+
+
 def test_composite_test_kernel(oracle, hip_lib):
     rng = np.random.default_rng(6)
     n_rays, n_alive = 5000, 1700
