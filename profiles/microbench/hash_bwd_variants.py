@@ -135,7 +135,7 @@ def main():
         print("sliced level %2d only: median %.1f us" % (l, med))
     _knob(bwd_levels="0xffffffff")
     sweep = os.environ.get("NGP_VARIANTS_SWEEP")           # plan knobs: "rep=32,64;merge=64,128;dmin=2,4"
-    knobs = {"rep": [64], "merge": [128], "dmin": [4]}
+    knobs = {"rep": [48], "merge": [128], "dmin": [8]}
     if sweep:
         for part in sweep.split(";"):
             k, v = part.split("=")
@@ -143,18 +143,17 @@ def main():
     for rep_t in knobs["rep"]:
         for merge in knobs["merge"]:
             for dmin in knobs["dmin"]:
-                _knob(bwd_rep_target=rep_t, bwd_merge_res=merge)
-                _knob(bwd_dense_min_rep=dmin)
-                grad.zero_()
-                if sliced() != 0:
-                    print("sliced rep_target=%2d merge_res=%3d dense_min_rep=%d: plan not expressible" % (rep_t, merge, dmin))
-                    continue
-                err = float((grad - ref).abs().max() / ref.abs().max())
-                med, best = timeit(sliced, args.reps)
-                out["variants"]["sliced rep_target=%d merge_res=%d dense_min_rep=%d" % (rep_t, merge, dmin)] = {
-                    "median_us": med, "min_us": best, "max_rel_err_vs_atomic": err}
-                print("sliced rep_target=%2d merge_res=%3d dense_min_rep=%d: median %.1f us  min %.1f us   max|d|/max|ref| %.2e" % (
-                    rep_t, merge, dmin, med, best, err))
+                if True:
+                    _knob(bwd_rep_target=rep_t, bwd_merge_res=merge, bwd_dense_min_rep=dmin)
+                    grad.zero_()
+                    name = "sliced rep_target=%d merge_res=%d dense_min_rep=%d" % (rep_t, merge, dmin)
+                    if sliced() != 0:
+                        print(name + ": plan not expressible")
+                        continue
+                    err = float((grad - ref).abs().max() / ref.abs().max())
+                    med, best = timeit(sliced, args.reps)
+                    out["variants"][name] = {"median_us": med, "min_us": best, "max_rel_err_vs_atomic": err}
+                    print("%s: median %.1f us  min %.1f us   max|d|/max|ref| %.2e" % (name, med, best, err))
     print(json.dumps(out))
 
 
