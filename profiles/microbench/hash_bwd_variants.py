@@ -94,7 +94,7 @@ def main():
     med, best = timeit(atomic, args.reps)
     out["variants"]["atomic (round 1)"] = {"median_us": med, "min_us": best}
     print("atomic: median %.1f us  min %.1f us" % (med, best))
-    _knob(bwd_rep_target=64, bwd_merge_res=128)
+    _knob(bwd_rep_target=48, bwd_merge_res=128, bwd_dense_min_rep=8, bwd_merge_chunks=32)      # the shipped plan
     # per-block timeline of one full launch
     dbg = torch.zeros(8 * 1536, device=dev, dtype=torch.int64)
     L.ngp_hash_bwd_sliced_debug(_ptr(dbg))
@@ -135,7 +135,7 @@ def main():
         print("sliced level %2d only: median %.1f us" % (l, med))
     _knob(bwd_levels="0xffffffff")
     sweep = os.environ.get("NGP_VARIANTS_SWEEP")           # plan knobs: "rep=32,64;merge=64,128;dmin=2,4"
-    knobs = {"rep": [48], "merge": [128], "dmin": [8]}
+    knobs = {"rep": [48], "merge": [128], "dmin": [8], "mchunks": [32]}
     if sweep:
         for part in sweep.split(";"):
             k, v = part.split("=")
@@ -143,10 +143,10 @@ def main():
     for rep_t in knobs["rep"]:
         for merge in knobs["merge"]:
             for dmin in knobs["dmin"]:
-                if True:
-                    _knob(bwd_rep_target=rep_t, bwd_merge_res=merge, bwd_dense_min_rep=dmin)
+                for mc in knobs["mchunks"]:
+                    _knob(bwd_rep_target=rep_t, bwd_merge_res=merge, bwd_dense_min_rep=dmin, bwd_merge_chunks=mc)
                     grad.zero_()
-                    name = "sliced rep_target=%d merge_res=%d dense_min_rep=%d" % (rep_t, merge, dmin)
+                    name = "sliced rep_target=%d merge_res=%d dense_min_rep=%d merge_chunks=%d" % (rep_t, merge, dmin, mc)
                     if sliced() != 0:
                         print(name + ": plan not expressible")
                         continue

@@ -73,6 +73,7 @@ struct BwdPlan {
     uint32_t merge_mask;                  // bit l: pre-sum equal-cell runs on level l
     uint32_t diag;                        // timing experiments (-DNGP_BWD_DIAG builds): 1 no LDS adds, 2 no gathers, 4 no accumulate
     uint32_t det;                         // ngp_hash_bwd_sliced_deterministic: run pre-summing groups hits per super-chunk (see bwd_task)
+    int32_t merge_chunks;                 // see LevelParams
     uint8_t nrep[NGP_MAX_LEVELS];         // replicas (sample ranges) per slice of level l
     uint16_t task[BW_MAX_TASKS];          // level | slice << 4 | rep << 10; XCD x owns task[xoff[x] .. xoff[x] + xlen[x])
     uint16_t xoff[8], xlen[8];
@@ -286,6 +287,7 @@ struct LevelParams {
     SliceMap map;
     uint32_t diag;           // diagnostics only (NGP_BWD_DIAG): bit 0 = skip the LDS adds, bit 1 = skip the gathers
     uint32_t det;
+    int merge_chunks;        // run-pre-summing levels: at least this many super-chunks per task (0: the slice-count rule alone)
 };
 struct Hit {
     float x, y, z, g0, g1;
@@ -512,7 +514,12 @@ __device__ __forceinline__ void bwd_task(const LevelParams P, const int level, c
     // hits (dense levels: ~2 of ns slices per sample, replicated over short sample ranges -- a 4096-sample chunk would leave
     // most of the 16 waves idle there, a 256-sample chunk of a 32-slice level would be one exposed load latency per 25 hits).
     int SCW = 64;
-    if (K == KIND_MERGE || K == KIND_MERGE0) { SCW = 4; while (SCW < 64 && SCW < 2 * (int)P.map.ns) SCW <<= 1; }
+    if (K == KIND_MERGE || K == KIND_MERGE0) {
+        SCW = 4; while (SCW < 64 && SCW < 2 * (int)P.map.ns) SCW <<= 1;
+        // ... and never so wide that the range has fewer pieces than `merge_chunks` (round 6: with 8 sample ranges per slice a 32-slice
+        // level's task held 13 pieces of 64 words for its 16 waves)
+        if (P.merge_chunks > 0) while (SCW > 4 && (hi_w - lo_w) < P.merge_chunks * SCW) SCW >>= 1;
+    }
     const int n_sc = (hi_w - lo_w + SCW - 1) / SCW;
     auto load_words = [&](int c) -> unsigned long long {
         const int w = lo_w + c * SCW + lane;
@@ -786,6 +793,7 @@ __global__ void __launch_bounds__(BW_THREADS) hash_bwd_lds_kernel(const float* _
     P.map = slice_map(P.size, P.res, P.dense);
     P.diag = plan.diag;
     P.det = plan.det;
+    P.merge_chunks = plan.merge_chunks;
     const bool single = P.size <= (uint32_t)BW_SLICE_ENTRIES;           // one slice: every sample is a hit, no bitmap
     const bool merge = (plan.merge_mask >> level) & 1u;
     const bool hashed = !P.dense && P.mode == 1u && P.res < (1u << BW_SLICE_LOG2) && !single;
@@ -948,8 +956,9 @@ struct Knobs {
     // merge_hashed: also the dense levels' run pre-summing up to merge_res -- measured, three A/B pairs, 0.6 % slower: off.
     int hashed_rep_res = 0, hashed_rep = 1;
     bool merge_hashed = false;
+    int merge_chunks = 32;                     // NGP_EXPERIMENT bwd_merge_chunks (0: round 5's rule; 16 / 32 / 64 measured alike: -8 us of 253)
     bool operator==(const Knobs& o) const {
-        return rep_target == o.rep_target && merge_res == o.merge_res && dense_min_rep == o.dense_min_rep && level_mask == o.level_mask &&
+        return merge_chunks == o.merge_chunks && rep_target == o.rep_target && merge_res == o.merge_res && dense_min_rep == o.dense_min_rep && level_mask == o.level_mask &&
                diag == o.diag && blocks == o.blocks && deterministic == o.deterministic && hashed_rep_res == o.hashed_rep_res &&
                hashed_rep == o.hashed_rep && merge_hashed == o.merge_hashed;
     }
@@ -959,6 +968,7 @@ static Knobs read_knobs() {
     if (const char* e = ngp_experiment("bwd_rep_target")) k.rep_target = atoi(e) > 0 ? atoi(e) : k.rep_target;
     if (const char* e = ngp_experiment("bwd_merge_res")) k.merge_res = atoi(e);
     if (const char* e = ngp_experiment("bwd_dense_min_rep")) k.dense_min_rep = atoi(e) > 0 ? atoi(e) : k.dense_min_rep;
+    if (const char* e = ngp_experiment("bwd_merge_chunks")) k.merge_chunks = atoi(e) >= 0 ? atoi(e) : k.merge_chunks;
 #ifdef NGP_BWD_DIAG
     if (const char* e = ngp_experiment("bwd_levels")) k.level_mask = (uint32_t)strtoul(e, nullptr, 0);
     if (const char* e = ngp_experiment("bwd_diag")) k.diag = (uint32_t)atoi(e);
@@ -1024,6 +1034,7 @@ static bool build_plan_with(const ngp_hash_levels& lv, BwdPlan& plan, uint32_t& 
     for (int l = lv.n_levels; l < NGP_MAX_LEVELS; ++l) plan.nrep[l] = 1;
     plan.diag = K.diag;                   // timing experiments only (-DNGP_BWD_DIAG builds): wrong results
     plan.det = K.deterministic ? 1u : 0u;
+    plan.merge_chunks = K.merge_chunks;
     // XCD-aware order (block b runs on XCD b % 8, one 1024-thread block per CU): the owners of one level read the same
     // position / gradient lines, and they only find them in L2 if they run on the same XCD at about the same time (measured:
     // a hashed level's owners take 52 us when the level has an XCD to itself, 115 us when its 64 owners are spread over all

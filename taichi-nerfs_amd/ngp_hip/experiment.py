@@ -31,6 +31,7 @@ KEYS = {
     "bwd_rep_target": "[C] tasks a replicated level of the scatter-add gets (48)",
     "bwd_merge_res": "[C] run pre-summing on levels up to this resolution (128)",
     "bwd_dense_min_rep": "[C] sample ranges per dense slice, at least (8)",
+    "bwd_merge_chunks": "[C] run-pre-summing levels: at least this many super-chunks per task (32; 0: round 5's slice-count rule alone)",
     "bwd_hashed_rep_res": "[C] concentrated plan: hashed levels up to this resolution get replicas (256)",
     "bwd_hashed_rep": "[C] ... this many (3)",
     "bwd_merge_hashed": "[C] concentrated plan: run pre-summing on those levels too (0)",
