@@ -98,7 +98,10 @@ int ngp_p2p_push(const void* src, long long n_per_peer, int elem_bytes, int worl
     for (int k = 0; k < world; ++k) { pp.p[k] = peer_dst[k]; pp.flag[k] = peer_flags[k]; if (!pp.p[k] || !pp.flag[k]) return -1; }
     const long n16 = (long)(n_per_peer * elem_bytes / 16);
     long blocks = (n16 * world + 255) / 256;
-    if (blocks > 1024) blocks = 1024;
+    // one workgroup per CU at most: every block ends in a system-scope release, and this round measured what many of those cost on this
+    // part (csrc/optim.hip, check_finite_prologue_kernel: 4096 agent-scope fences behind a kernel that left the L2s dirty = 260 us);
+    // 256 blocks of 16-byte stores are more than seven xGMI links take
+    if (blocks > 256) blocks = 256;
     hipLaunchKernelGGL(p2p_push_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)src, n16, world, pp,
                        (long)(dst_offset * elem_bytes / 16), broadcast, rank, step, done);
     NGP_LAUNCH_CHECK();

@@ -921,8 +921,12 @@ __global__ void __launch_bounds__(BW_THREADS) hash_bwd_lds_kernel(const float* _
     claim = s_claim;
   }
     // the last workgroup to leave resets the queue heads for the next launch
+    // (Round 6: no __threadfence() in front of the arrival count.  Nothing the last workgroup READS here was written by plain stores of the
+    // others -- the queue heads and the overflow word are only ever touched by device-scope atomics, each of them complete before its
+    // workgroup got here (the claims' return values were consumed; the flush's atomicOr sits behind the end-of-task barrier's s_waitcnt) --
+    // and what it WRITES is for the next launch, behind this launch's end-of-kernel release.  The fence was an L2 write-back per workgroup
+    // of the parameters / moments the flushes had just stored: launch -3.5 us, alternating builds on one box.)
     if (tid == 0) {
-        __threadfence();
         if (atomicAdd(&ctr[8], 1u) == gridDim.x - 1u) {
             for (int x = 0; x < 8; ++x) ctr[x] = 0u;
             ctr[8] = 0u;
