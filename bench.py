@@ -829,10 +829,10 @@ def _measure(args, ctx, brief):
         elapsed_stub = float(tt.item())
     _Probe.stub_ms = None if elapsed_stub is None else elapsed_stub / args.steps * 1e3
 
-    if True:
-        n_st = (k_timed + STAT_EVERY - 1) // STAT_EVERY
-        state["rm"] = stat_log[:n_st].sum(dtype=torch.int64) * k_timed // max(n_st, 1)
-        state["vr"] = vr_log[:n_st].sum(dtype=torch.int64) * k_timed // max(n_st, 1)
+    # both paths sample the counts on every STAT_EVERY-th step: scaled back to the K timed steps
+    n_st = (k_timed + STAT_EVERY - 1) // STAT_EVERY
+    state["rm"] = stat_log[:n_st].sum(dtype=torch.int64) * k_timed // max(n_st, 1)
+    state["vr"] = vr_log[:n_st].sum(dtype=torch.int64) * k_timed // max(n_st, 1)
     rm = int(state["rm"]); vr = int(state["vr"])
     total_rays = args.rays * world * args.steps
     out = None
