@@ -313,6 +313,8 @@ def main():
     lib.build()
     lib.load()
     ctx = {"world": world, "rank": rank, "dev": dev, "backend": backend}
+    if os.environ.get("NGP_BENCH_CHILD") == "1" and os.environ.get("NGP_BENCH_CHILD_CRASH") == "1":
+        os.abort()                                  # (tests: an isolated leg that dies like a device fault would make it die)
     out = measure(args, ctx)
     if rank == 0 and world == 1 and args.configs and _is_headline(args):
         out["configs"] = other_configs(args, ctx)
@@ -384,11 +386,14 @@ COMM_VARIANTS = [
                              "forward reads (half the bytes both ways)", ["--comm", "bf16", "--table", "bf16"], {}),
     ("no-shard-all-reduce", "--no-shard: SURVEY 8(e)'s single all-reduce of one flat fp32 bucket + replicated Adam (north_star's wording)",
      ["--no-shard"], {}),
-    ("p2p-direct", "--comm-path p2p --comm f32: round 6's prototype of SURVEY 8(e)'s direct exchange -- every rank writes slice p of its gradient "
-                   "straight into rank p's inbox (peer memory through hipIpc, all links at once, one hop), flags, a local reduce; the updated shards "
-                   "travel back the same way.  UNMEASURED on xGMI until this line exists on a multi-GPU node", ["--comm-path", "p2p", "--comm", "f32"], {}),
     ("overlap-8,0", "NGP_EXPERIMENT comm_overlap=1: the scatter-add issued per level group (8-15, then 0-7), a group's reduce-scatter in flight under "
                     "the next group's launch, all-gathers waited for at the next step's forward", [], {"NGP_EXPERIMENT": "comm_overlap=1;comm_groups=8,0"}),
+    # LAST and in CHILD processes (one per rank, their own process group one port up): kernels that write into other devices' memory have
+    # never run across xGMI here -- a device fault there must not take the line (headline + the collective variants) with it
+    ("p2p-direct", "--comm-path p2p --comm f32: round 6's prototype of SURVEY 8(e)'s direct exchange -- every rank writes slice p of its gradient "
+                   "straight into rank p's inbox (peer memory through hipIpc, all links at once, one hop), flags, a local reduce; the updated shards "
+                   "travel back the same way.  Runs in child processes of the ranks (isolated: its own conditioning, same state recipe).  UNMEASURED "
+                   "on xGMI until this line exists on a multi-GPU node", ["--comm-path", "p2p", "--comm", "f32"], {"NGP_BENCH_ISOLATE": "1"}),
 ]
 COMM_MODEL_BW_GBS = (150.0, 300.0, 450.0)                      # DESIGN.md section 7's bus-bandwidth rows
 
@@ -438,6 +443,28 @@ def _variant_watchdog(timeout_s, rank, out, progress):
     threading.Thread(target=run, daemon=True).start()
 
 
+def _isolated_leg(args, ctx, extra, timeout_s):
+    """One exchange variant in CHILD processes: every rank starts `python bench.py --gpus N <extra>` with its own RANK / LOCAL_RANK and a
+    rendezvous one port above the parents'; rank 0 returns its child's line (or raises with the child's exit code and stderr tail)."""
+    import subprocess
+    world, rank = ctx["world"], ctx["rank"]
+    env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC") and k != "NGP_BENCH_ISOLATE"}
+    env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 17)      # (rank 0's child hosts this store itself)
+    env["NGP_BENCH_CHILD"] = "1"
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(world), "--steps", str(args.steps), "--warmup", str(args.warmup),
+           "--condition", str(args.condition), "--kernel-events-every", str(args.kernel_events_every), "--no-cpu-baseline", "--no-configs"] + extra
+    try:
+        res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        raise RuntimeError("isolated leg: the child of rank %d did not finish within %.0f s" % (rank, timeout_s))
+    if rank != 0:
+        return None
+    lines = [l for l in res.stdout.splitlines() if l.strip().startswith("{")]
+    if res.returncode != 0 or not lines:
+        raise RuntimeError("isolated leg: child exit code %s; stderr tail: %s" % (res.returncode, res.stderr[-600:]))
+    return json.loads(lines[-1])
+
+
 def comm_variants(args, ctx, headline, progress=None):
     world, rank = ctx["world"], ctx["rank"]
     res = progress["configs"] if progress is not None else []
@@ -452,7 +479,16 @@ def comm_variants(args, ctx, headline, progress=None):
         if progress is not None:
             progress["current"] = name
         try:
-            o = measure(sub, ctx)
+            if env.get("NGP_BENCH_ISOLATE") == "1":
+                err = None
+                try:
+                    o = _isolated_leg(sub, ctx, extra, float(os.environ.get("NGP_BENCH_ISOLATED_TIMEOUT", "150")))
+                except RuntimeError as e:              # (per rank: the parents stay in step through the barrier below)
+                    o, err = None, e
+                if rank == 0 and err is not None:
+                    raise err
+            else:
+                o = measure(sub, ctx)
             if rank == 0:
                 res.append(_comm_record(name, what, extra, env, o, world))
         except Exception as e:                       # (raised on every rank alike: argument / setup errors)

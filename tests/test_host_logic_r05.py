@@ -29,7 +29,7 @@ def test_comm_record_bus_bandwidth_and_model():
     all-gather payload, twice that of an all-reduce), the bandwidth comm_ms implies, and DESIGN section 7's model on the measured
     communication-free step."""
     b = _bench()
-    assert [v[0] for v in b.COMM_VARIANTS] == ["bf16-comm+bf16-table", "no-shard-all-reduce", "p2p-direct", "overlap-8,0"]
+    assert [v[0] for v in b.COMM_VARIANTS] == ["bf16-comm+bf16-table", "no-shard-all-reduce", "overlap-8,0", "p2p-direct"]
     o = {"value": 1e8, "ms_per_step": 0.8, "steps": 20, "comm_ms": 0.3, "exposed_comm_ms": 0.25, "ms_per_step_comm_stubbed": 0.55,
          "comm_breakdown_ms": {"reduce_scatter_table_grad": 0.14, "all_gather_table": 0.15, "all_reduce_mlp_grad_and_flag": 0.01},
          "comm_bytes_per_rank_per_step": {"reduce_scatter_table_grad": 45_680_256, "all_gather_table": 45_680_256,
