@@ -592,9 +592,11 @@ inline bool xcd_v1(const ngp_hash_levels& lv, unsigned entry_bytes) {
     return forced || (unsigned long long)(unsigned)lv.total_entries * entry_bytes >= 0xffffff00ull;
 }
 
-// tiles of 128 samples per level pair in one launch of hash_fwd_f32_xcd_kernel (8 workgroups per tile); NGP_EXPERIMENT hash_fwd_tiles for A/B runs
+// tiles of 128 samples per level pair in one launch of hash_fwd_f32_xcd_kernel (8 workgroups per tile); NGP_EXPERIMENT hash_fwd_tiles for A/B runs.
+// 768 since round 6 (512 before): three instead of two residency rounds of workgroups per CU at C2 -- gather 84.6-86.8 -> 79.8-84.2 us in
+// four alternating pairs on one box (step 0.4696 -> 0.4631 ms); 1024 / 1536 no better; 65 536 rays and the C3 chunks unchanged.
 inline int xcd_tiles_cap() {
-    static const int cap = [] { const char* e = ngp_experiment("hash_fwd_tiles"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 512; }();
+    static const int cap = [] { const char* e = ngp_experiment("hash_fwd_tiles"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 768; }();
     return cap;
 }
 

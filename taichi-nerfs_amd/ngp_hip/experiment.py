@@ -41,7 +41,7 @@ KEYS = {
     "bwd_blocks": "[C] -DNGP_BWD_DIAG builds only: fewer persistent workgroups",
     "prep_batch": "[C] 3 / 6 / 12: LDS-form levels per fence in the scatter-add's prepass (1)",
     "hash_fwd_v1": "[C] 1: the round-1..3 loop of the forward hash gather",
-    "hash_fwd_tiles": "[C] tile cap of the forward hash gather's persistent grid (512)",
+    "hash_fwd_tiles": "[C] tile cap of the forward hash gather's persistent grid (768)",
     "hash_fwd_free_levels": "[C] -DNGP_HASH_FWD_DIAG builds only: levels whose gathers all read one line",
     "march_group": "[C] 16 / 32 / 64 lanes per ray of the march's count pass (32)",
     "mlp_fwd_blocks": "[C] persistent grid of the MLP forward (768)",
