@@ -67,7 +67,16 @@ def _model(kind, seed=11):
     return m
 
 
+_CPU_RUNS = {}          # kind -> the CPU loop's result: a function of (kind, seeds) only, shared by the trainer test and the drop-in-loop test
+
+
 def _run_cpu(kind, state, pool, noise, jit):
+    if kind not in _CPU_RUNS:
+        _CPU_RUNS[kind] = _run_cpu_loop(kind, state, pool, noise, jit)
+    return _CPU_RUNS[kind]
+
+
+def _run_cpu_loop(kind, state, pool, noise, jit):
     from oracle.train_loop import OracleTrainer
     c = CFG[kind]
     otr = OracleTrainer(state["weights"], state["table"], scale=c["scale"], max_res=c["max_res"], exp_step_factor=c["esf"], lr=1e-2,
@@ -151,6 +160,80 @@ def _run_autocast(m, pool, noise, jit):
         else:
             os.environ["NGP_FUSED_RENDER"] = old
     return losses
+
+
+def _run_dropin(kind, m, pool, noise, jit):
+    """The DROP-IN surface: the reference's loop (train.py:137-201) on this package as it ships -- modules.rendering.render (fused render
+    node, fused MLP), modules.distortion, compat apex FusedAdam under torch's GradScaler, CosineAnnealingLR."""
+    import sys
+    compat = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "taichi-nerfs_amd", "compat")
+    if compat not in sys.path:
+        sys.path.insert(0, compat)
+    from apex.optimizers import FusedAdam
+    from modules.distortion import distortion_loss
+    from modules.rendering import render
+    c = CFG[kind]
+    dev = m.density_grid.device
+    gp = [tuple(torch.from_numpy(x).to(dev) for x in b) for b in pool]
+    opt = FusedAdam(m.parameters(), 1e-2, eps=1e-15)
+    sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, c["steps"], 1e-2 / 30)
+    scaler = torch.amp.GradScaler("cuda", init_scale=INIT_SCALE)
+    recs, bits = [], {}
+    for s in range(c["steps"]):
+        o, d, tgt = gp[s % len(gp)]
+        with torch.autocast("cuda", dtype=torch.float16):
+            if s % UPDATE_EVERY == 0:
+                m.update_density_grid(THR, warmup=True, jitter=lambda ci, n, u=jit[s]: torch.from_numpy(u[ci]).to(dev))
+                bits[s] = m.density_bitfield.cpu().numpy().copy()
+            torch.manual_seed(NOISE_SEED + s)                 # -> the march draws noise[s]
+            res = render(m, o, d, exp_step_factor=c["esf"])
+            mse = F.mse_loss(res["rgb"], tgt)
+            loss = mse
+            if c["w_dist"] > 0:
+                loss = loss + c["w_dist"] * distortion_loss(res).mean()
+        opt.zero_grad()
+        scaler.scale(loss).backward()
+        scaler.step(opt)
+        scaler.update()
+        sched.step()
+        recs.append({"loss": float(mse.detach()), "rm_samples": int(res["rm_samples"])})
+    assert scaler.get_scale() == INIT_SCALE          # no overflow, no skipped step
+    return recs, bits
+
+
+@pytest.mark.parametrize("kind", ["f32", "c3"])
+def test_dropin_loop_trajectory_matches_oracle_loop(oracle, hip_lib, kind):
+    """The same comparison for the surface north_star names: the reference's training loop, as train.py:137-201 writes it, on `modules` +
+    compat FusedAdam + torch GradScaler / CosineAnnealingLR -- against the CPU oracle loop on the same rays, jitter and initialisation.
+    (FusedTrainer above is the faster caller of the same kernels; this is the caller the reference has.)"""
+    pool, noise, jit = _inputs(kind)
+    m = _model(kind)
+    state = {"weights": [w.detach().cpu().numpy().copy() for w in m._mlp_weights()],
+             "table": m.pos_encoder.hash_table.detach().float().reshape(-1).cpu().numpy().copy()}
+    otr, cpu, cpu_bits = _run_cpu(kind, state, pool, noise, jit)
+    got, got_bits = _run_dropin(kind, m, pool, noise, jit)
+    lc, lh = np.array([r["mse"] for r in cpu]), np.array([r["loss"] for r in got])
+    rel = np.abs(lh - lc) / lc
+    tot_c, tot_h = np.array([r["rm_samples"] for r in cpu]), np.array([r["rm_samples"] for r in got])
+    print("\ndrop-in loop [%s]: max relative loss deviation vs CPU-fp32 %.3e (mean %.3e); marched totals differ by at most %d of %d"
+          % (kind, rel.max(), rel.mean(), np.abs(tot_c - tot_h).max(), tot_c.max()))
+    for s in sorted(jit):
+        ham = np.unpackbits(cpu_bits[s] ^ got_bits[s]).mean()
+        print(" update at step %2d: cells that differ between the two grids %.2e" % (s, ham))
+        assert ham < {"f32": 2e-3, "c3": 5e-2 if s else 2e-3}[kind], (s, ham)
+    assert np.abs(tot_c - tot_h).max() <= 5e-3 * tot_c.max()
+    # until the second update both sides march the step-0 grids, which differ in a handful of cells (~1e-6): the same samples up to those
+    assert np.abs(tot_c - tot_h)[:UPDATE_EVERY].max() <= 1e-4 * tot_c.max()
+    assert rel.max() <= {"f32": 5e-3, "c3": 1e-2}[kind], rel.max()
+    p_c, p_h = -10.0 * np.log10(lc[-1]), -10.0 * np.log10(lh[-1])
+    print(" final training-batch PSNR: CPU-fp32 %.4f dB, drop-in loop %.4f dB (relative difference %.2e)" % (p_c, p_h, abs(p_h - p_c) / p_c))
+    assert abs(p_h - p_c) <= 1e-3 * p_c
+    t_c = otr.table.detach().numpy()
+    t_h = m.pos_encoder.hash_table.detach().float().reshape(-1).cpu().numpy()
+    moved = t_c != state["table"]
+    d_rel = np.linalg.norm((t_h - t_c)[moved]) / np.linalg.norm((t_c - state["table"])[moved])
+    print(" table: |drop-in - CPU| / |CPU - init| over the %d entries that moved = %.3e" % (moved.sum(), d_rel))
+    assert d_rel < 0.25
 
 
 @pytest.mark.parametrize("kind", ["f32", "half", "c3"])
