@@ -214,6 +214,8 @@ int ngp_stream_wait_event(void* stream, void* event) {
     return hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0) == hipSuccess ? 0 : -1;
 }
 int ngp_event_destroy(void* event) { return hipEventDestroy((hipEvent_t)event) == hipSuccess ? 0 : -1; }
+// the HOST waits until the work recorded in front of the event has completed (completion only: no host-visible data is implied)
+int ngp_event_synchronize(void* event) { return hipEventSynchronize((hipEvent_t)event) == hipSuccess ? 0 : -1; }
 
 // A non-blocking stream of the LOWEST priority the device offers, for work that should only take the CUs the step's own kernels
 // leave free (FusedTrainer's prefetched march: launched at equal priority it is dispatched in front of the scatter-add's persistent

@@ -198,6 +198,7 @@ SIGNATURES = {
     "ngp_event_record": [_P, _P],
     "ngp_stream_wait_event": [_P, _P],
     "ngp_event_destroy": [_P],
+    "ngp_event_synchronize": [_P],
     "ngp_stream_create_low_priority": [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)],
     "ngp_stream_destroy": [_P],
     "ngp_render_train_fwd": [_P, _P],

@@ -230,6 +230,7 @@ class FusedTrainer:
                                and self.hash_bwd == "sliced")
         pinned = any(_exp.has(k) for k in ("prefetch_at", "march_shape", "side_priority"))
         self._adaptive_prefetch = self._one_gpu_flush and not pinned
+        self._host_wait_ok = _exp.get("prefetch_host_wait", "1") != "0"
         self._side_prio = None
         self._side_default = self._side
         self._side_low = None
@@ -386,6 +387,9 @@ class FusedTrainer:
         def wait(self, stream):
             check(self.L.ngp_stream_wait_event(ctypes.c_void_p(stream.cuda_stream), self.h), "ngp_stream_wait_event")
 
+        def synchronize(self):
+            check(self.L.ngp_event_synchronize(self.h), "ngp_event_synchronize")
+
         def __del__(self):
             try:
                 self.L.ngp_event_destroy(self.h)
@@ -409,6 +413,7 @@ class FusedTrainer:
             self.xyzs, self.dirs = torch.empty(cap, 3, **f32), torch.empty(cap, 3, **f32)
             self.deltas, self.ts = torch.empty(cap, **f32), torch.empty(cap, **f32)
             self.ready = None               # event recorded on the side stream when a prefetched march has finished
+            self.issued_early = False       # ... and that march was issued at the START of the previous step (see step())
             self.src = None                 # the caller's (rays_o, rays_d) tensor OBJECTS + their versions the set was marched for
             self.held = None                # the (possibly converted) tensors the side-stream march reads: kept alive until reuse
 
@@ -500,8 +505,17 @@ class FusedTrainer:
         self.prefetch_hits += int(hit)
         if M.ready is not None:
             # whatever the side stream did to this set has to be finished before the main stream reads OR rewrites it (a stale
-            # prefetch for other rays would otherwise race with the re-march below on M.stage / counts / xyzs)
-            M.ready.wait(torch.cuda.current_stream())
+            # prefetch for other rays would otherwise race with the re-march below on M.stage / counts / xyzs).
+            # Round 6: a stream-side wait for an event of ANOTHER queue is a barrier packet that costs the main stream ~10 us even when
+            # the event completed long ago (measured: 0.4745 -> 0.4635 ms per step without it).  Where the march was issued at the START of
+            # the previous step (narrow marches: it is done ~100 us into that step) the HOST waits for the event instead and no packet is
+            # queued: the host then runs at most one step ahead of the device, with ~130 us of launches to issue against ~370 us of that
+            # step still to run.  Marches placed late in the step (heavy ones) keep the stream-side wait: the host would stall for a
+            # whole step.  NGP_EXPERIMENT prefetch_host_wait=0: the stream-side wait always.
+            if self._host_wait_ok and M.issued_early and self._graph is None:
+                M.ready.synchronize()
+            else:
+                M.ready.wait(torch.cuda.current_stream())
         if not hit:
             self._march(M, rays_o, rays_d, cfg, A, noise=noise)
         M.ready, M.src, M.held = None, None, None
@@ -533,6 +547,7 @@ class FusedTrainer:
                     self._march(nxt, prefetch[0], prefetch[1], cfg, A, shape=shape)
                     nxt.ready = nxt.ev_ready
                     nxt.ready.record(side)
+                    nxt.issued_early = at == 0
                     if self._marched_host is not None:                    # behind the march, on the side stream: nobody waits
                         check(self.L.ngp_copy_to_host_async(self._marched_host, _ptr(nxt.total), 4, ctypes.c_void_p(side.cuda_stream)),
                               "ngp_copy_to_host_async")
