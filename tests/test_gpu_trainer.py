@@ -565,6 +565,36 @@ def test_prefetched_march_placement_adapts_to_the_march_it_follows(hip_lib, lego
     assert not tr2._adaptive_prefetch and tr2._prefetch_at == 2 and tr2._marched_host is None
 
 
+def test_host_side_wait_for_the_prefetched_march_changes_nothing(hip_lib, lego_bitfield, monkeypatch):
+    """Round 6: where the next batch's march was issued at the START of the previous step, the HOST waits for its event
+    (ngp_event_synchronize) instead of the main stream (a satisfied cross-queue event wait cost the stream ~10 us per step).  Same
+    ordering guarantee, so: identical parameters after a run of prefetched steps, in deterministic mode, with either form of the wait."""
+    from ngp_hip.trainer import FusedTrainer
+    n = 4096
+
+    def run(env):
+        if env:
+            monkeypatch.setenv("NGP_EXPERIMENT", env)
+        else:
+            monkeypatch.delenv("NGP_EXPERIMENT", raising=False)
+        m, o, d, target = _make(lego_bitfield, n=n)
+        tr = FusedTrainer(m, init_scale=2.0**10).set_deterministic(True)
+        early = []
+        for i in range(12):
+            tr.step(o, d, target, prefetch=(o, d))
+            torch.cuda.synchronize()                   # (the adaptive placement reads the previous march's count: make it arrive)
+            early.append(tr._march_sets(n)[tr._cur].issued_early)
+        tr.sync_master()
+        out = (tr.table.clone(), tr.mlp_flat.clone(), tr.prefetch_hits, tr._host_wait_ok, early)
+        tr.close()
+        return out
+    t_h, w_h, hits_h, ok_h, early_h = run("")
+    t_s, w_s, hits_s, ok_s, early_s = run("prefetch_host_wait=0")
+    assert ok_h and not ok_s and hits_h == hits_s == 11
+    assert any(early_h) and early_h == early_s          # light marches go to the start of the step: that is where the host may wait
+    assert torch.equal(t_h, t_s) and torch.equal(w_h, w_s)
+
+
 def test_host_word_and_finite_check_entries(hip_lib):
     """The small entry points of round 5 on their own: pinned host memory + asynchronous device-to-host copy, and the read-only
     multi-tensor inf / nan check GradScaler's decision rests on."""
