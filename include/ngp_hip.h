@@ -365,9 +365,9 @@ int ngp_event_create(void** event);
 int ngp_event_record(void* event, void* stream);
 int ngp_stream_wait_event(void* stream, void* event);
 int ngp_event_destroy(void* event);
-/* ... and the host-side wait for one (round 6): returns when the work recorded in front of the event has completed.  FusedTrainer waits
- * this way for a prefetched march that was issued a whole step earlier: a stream-side wait for an event of another queue costs the waiting
- * stream ~10 us even when the event completed long ago. */
+/* ... and the host-side wait for one (round 6): returns when the work recorded in front of the event has completed.  FusedTrainer can wait
+ * this way (NGP_EXPERIMENT prefetch_host_wait=1) for a prefetched march that was issued a whole step earlier: a stream-side wait for an
+ * event of another queue costs the waiting stream ~10 us even when the event completed long ago. */
 int ngp_event_synchronize(void* event);
 /* A non-blocking stream of the lowest priority the device offers (for the prefetched march: it should take only the CUs the step's
  * own kernels leave free); *least / *greatest (nullable) = hipDeviceGetStreamPriorityRange. */

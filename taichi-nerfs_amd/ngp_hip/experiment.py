@@ -15,7 +15,7 @@ KEYS = {
     "live_backward": "0: backward over every marched sample instead of the live ones",
     "march_fused": "0: the count / scan / write chain instead of the one-launch march",
     "march_rng": "torch: jitter from torch.rand instead of the march kernel's counter-based generator",
-    "prefetch_host_wait": "0: the main stream always waits for the prefetched march with a stream-side event wait (round 5); default: the host waits where the march was issued a step earlier",
+    "prefetch_host_wait": "1: the HOST waits for the prefetched march where it was issued a step earlier (no cross-queue wait packet on the main stream; default: the stream-side wait)",
     "prefetch_at": "0 / 1 / 2 / 2.5 / 2.75 / 3 / 4: where in the step the next batch's march goes on the side stream (unset: adaptive)",
     "side_priority": "low / default: stream priority of that march (unset: adaptive)",
     "march_shape": "'waves,idle_lds_bytes': launch shape of that march (unset: adaptive)",

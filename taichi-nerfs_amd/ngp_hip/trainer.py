@@ -230,7 +230,7 @@ class FusedTrainer:
                                and self.hash_bwd == "sliced")
         pinned = any(_exp.has(k) for k in ("prefetch_at", "march_shape", "side_priority"))
         self._adaptive_prefetch = self._one_gpu_flush and not pinned
-        self._host_wait_ok = _exp.get("prefetch_host_wait", "1") != "0"
+        self._host_wait_ok = _exp.get("prefetch_host_wait", "0") == "1"       # opt-in: see step()
         self._side_prio = None
         self._side_default = self._side
         self._side_low = None
@@ -507,11 +507,11 @@ class FusedTrainer:
             # whatever the side stream did to this set has to be finished before the main stream reads OR rewrites it (a stale
             # prefetch for other rays would otherwise race with the re-march below on M.stage / counts / xyzs).
             # Round 6: a stream-side wait for an event of ANOTHER queue is a barrier packet that costs the main stream ~10 us even when
-            # the event completed long ago (measured: 0.4745 -> 0.4635 ms per step without it).  Where the march was issued at the START of
-            # the previous step (narrow marches: it is done ~100 us into that step) the HOST waits for the event instead and no packet is
-            # queued: the host then runs at most one step ahead of the device, with ~130 us of launches to issue against ~370 us of that
-            # step still to run.  Marches placed late in the step (heavy ones) keep the stream-side wait: the host would stall for a
-            # whole step.  NGP_EXPERIMENT prefetch_host_wait=0: the stream-side wait always.
+            # the event completed long ago (timing run without it: 0.4745 -> 0.4635 ms per step).  NGP_EXPERIMENT prefetch_host_wait=1 lets
+            # the HOST wait instead where the march was issued at the START of the previous step (done ~100 us into that step): no packet,
+            # the host at most one step ahead.  Measured -5 us in three alternating pairs on one box, nothing (0.461 against 0.462 ms) in
+            # pairs on three other boxes, and one unexplained cluster of 0.51 ms runs on three boxes with it on: it couples the device to
+            # the host's pace for a gain inside the box-to-box spread, so it stays OFF by default (profiles/r06_scatter_add_valu_experiment.txt (15)).
             if self._host_wait_ok and M.issued_early and self._graph is None:
                 M.ready.synchronize()
             else:

@@ -566,8 +566,8 @@ def test_prefetched_march_placement_adapts_to_the_march_it_follows(hip_lib, lego
 
 
 def test_host_side_wait_for_the_prefetched_march_changes_nothing(hip_lib, lego_bitfield, monkeypatch):
-    """Round 6: where the next batch's march was issued at the START of the previous step, the HOST waits for its event
-    (ngp_event_synchronize) instead of the main stream (a satisfied cross-queue event wait cost the stream ~10 us per step).  Same
+    """Round 6, opt-in (NGP_EXPERIMENT prefetch_host_wait=1): where the next batch's march was issued at the START of the previous step, the
+    HOST waits for its event (ngp_event_synchronize) instead of the main stream (a satisfied cross-queue event wait costs it ~10 us).  Same
     ordering guarantee, so: identical parameters after a run of prefetched steps, in deterministic mode, with either form of the wait."""
     from ngp_hip.trainer import FusedTrainer
     n = 4096
@@ -588,8 +588,8 @@ def test_host_side_wait_for_the_prefetched_march_changes_nothing(hip_lib, lego_b
         out = (tr.table.clone(), tr.mlp_flat.clone(), tr.prefetch_hits, tr._host_wait_ok, early)
         tr.close()
         return out
-    t_h, w_h, hits_h, ok_h, early_h = run("")
-    t_s, w_s, hits_s, ok_s, early_s = run("prefetch_host_wait=0")
+    t_h, w_h, hits_h, ok_h, early_h = run("prefetch_host_wait=1")
+    t_s, w_s, hits_s, ok_s, early_s = run("")
     assert ok_h and not ok_s and hits_h == hits_s == 11
     assert any(early_h) and early_h == early_s          # light marches go to the start of the step: that is where the host may wait
     assert torch.equal(t_h, t_s) and torch.equal(w_h, w_s)
