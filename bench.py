@@ -449,7 +449,15 @@ def _isolated_leg(args, ctx, extra, timeout_s):
     import subprocess
     world, rank = ctx["world"], ctx["rank"]
     env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC") and k != "NGP_BENCH_ISOLATE"}
-    env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 17)      # (rank 0's child hosts this store itself)
+    # the children's rendezvous: a port rank 0 finds free now, told to every rank through the parents' group (rank 0's child hosts the store)
+    port = [0]
+    if rank == 0:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port[0] = sk.getsockname()[1]
+    dist.broadcast_object_list(port, src=0, device=ctx["dev"] if ctx.get("backend") == "nccl" else None)
+    env["MASTER_PORT"] = str(port[0])
     env["NGP_BENCH_CHILD"] = "1"
     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(world), "--steps", str(args.steps), "--warmup", str(args.warmup),
            "--condition", str(args.condition), "--kernel-events-every", str(args.kernel_events_every), "--no-cpu-baseline", "--no-configs"] + extra
